@@ -1,0 +1,450 @@
+"""TEST INFRASTRUCTURE ONLY (oracle).  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this file; the product path never does.
+
+CPU restatement ("port") of the reference hot path -- the GAN `Trainer.train / train_D / train_G`
+inner loop and the VAE `compute_batch` -- of shayneobrien/generative-models, written from its
+behaviour, not copied: ONE generic step loop plus a per-variant loss functor replaces the
+reference's twelve near-identical files (AST comparison).  The arithmetic
+itself lives in a third-party dependency of the reference, PyTorch (reference pins torch==0.4.1,
+requirements.txt:5; this oracle runs on the container's torch 2.10.0 CPU kernels), so the port calls
+the same torch CPU ops (nn.Linear, relu, sigmoid, autograd, optim.Adam, DataLoader, the global
+mt19937 generator) in the same order as the reference call sites cited on each function.
+
+PINNING: the reference ships no tests / golden vectors.  This port is pinned
+(a) bit-for-bit against the unmodified reference executed in the build container
+(tests/test_oracle_pin.py, needs /root/reference) and (b) against committed fixtures generated
+from the unmodified reference by oracle/gen_golden.py (tests/golden/*.npz, travel to the GPU box).
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+EPS = 1e-8
+
+F_METHODS = ("total_variation", "forward_kl", "reverse_kl", "pearson", "hellinger",
+             "jensen_shannon")
+
+
+# --------------------------------------------------------------------------------------------
+# Networks.  Attribute names = the reference's state_dict keys.
+# --------------------------------------------------------------------------------------------
+class TwoLayer(nn.Module):
+    """x -> relu(first(x)) -> out_act(second(.)).  ns_gan.py:35-60, w_gp_gan.py:59-62 (relu out),
+    be_gan.py:63-76 / info_gan.py:78-94 (identity out)."""
+
+    def __init__(self, names, n_in, n_hidden, n_out, out_act):
+        super().__init__()
+        self._names = names
+        setattr(self, names[0], nn.Linear(n_in, n_hidden))
+        setattr(self, names[1], nn.Linear(n_hidden, n_out))
+        self._out_act = out_act
+
+    def forward(self, x):
+        h = F.relu(getattr(self, self._names[0])(x))
+        y = getattr(self, self._names[1])(h)
+        if self._out_act == "sigmoid":
+            return torch.sigmoid(y)
+        if self._out_act == "relu":
+            return F.relu(y)
+        return y
+
+
+class GANModel(nn.Module):
+    """Container with .G .D (.Q), .z_dim, .shape -- ns_gan.py:63-74, info_gan.py:97-111.
+    Construction order G, D, (Q) fixes the order in which nn.Linear init consumes the global RNG
+    (SURVEY.md section 3.7)."""
+
+    def __init__(self, variant, image_size, hidden_dim, z_dim, output_dim=1, disc_dim=10,
+                 cont_dim=10):
+        super().__init__()
+        self.variant = variant
+        self.image_size, self.hidden_dim, self.z_dim, self.output_dim = \
+            image_size, hidden_dim, z_dim, output_dim
+        self.disc_dim, self.cont_dim = disc_dim, cont_dim
+        g_in = z_dim + (disc_dim + cont_dim if variant == "info" else 0)
+        self.G = TwoLayer(("linear", "generate"), g_in, hidden_dim, image_size, "sigmoid")
+        if variant == "be":
+            self.D = TwoLayer(("encoder", "decoder"), image_size, hidden_dim, image_size, "id")
+        elif variant == "info":
+            self.D = TwoLayer(("linear", "discriminator"), image_size, hidden_dim, output_dim,
+                              "sigmoid")
+            self.Q = TwoLayer(("linear", "inference"), image_size, hidden_dim,
+                              disc_dim + cont_dim, "id")
+        else:
+            self.D = TwoLayer(("linear", "discriminate"), image_size, hidden_dim, output_dim,
+                              "relu" if variant == "wgp" else "sigmoid")
+        self.shape = int(image_size ** 0.5)
+
+
+class VAEModel(nn.Module):
+    """vae.py:47-106.  Keys encoder.{linear,mu,log_var}, decoder.{linear,recon}."""
+
+    class Enc(nn.Module):
+        def __init__(self, image_size, hidden_dim, z_dim):
+            super().__init__()
+            self.linear = nn.Linear(image_size, hidden_dim)
+            self.mu = nn.Linear(hidden_dim, z_dim)
+            self.log_var = nn.Linear(hidden_dim, z_dim)
+
+        def forward(self, x):
+            h = F.relu(self.linear(x))
+            return self.mu(h), self.log_var(h)
+
+    def __init__(self, image_size=784, hidden_dim=400, z_dim=20):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim = image_size, hidden_dim, z_dim
+        self.encoder = VAEModel.Enc(image_size, hidden_dim, z_dim)
+        self.decoder = TwoLayer(("linear", "recon"), z_dim, hidden_dim, image_size, "sigmoid")
+        self.shape = int(image_size ** 0.5)
+
+    def forward(self, x):
+        mu, log_var = self.encoder(x)
+        eps = torch.randn(mu.shape)                       # vae.py:104 (global CPU generator)
+        z = mu + eps * torch.exp(log_var / 2)             # vae.py:105
+        return self.decoder(z), mu, log_var
+
+
+# --------------------------------------------------------------------------------------------
+# Per-variant defaults: (G_lr, D_lr, D_steps) of each train() signature.
+# --------------------------------------------------------------------------------------------
+DEFAULTS = {
+    "ns": (2e-4, 2e-4, 1), "mm": (2e-4, 2e-4, 1), "w": (5e-5, 5e-5, 5), "wgp": (1e-4, 1e-4, 5),
+    "ls": (1e-4, 1e-4, 1), "dra": (1e-4, 1e-4, 5), "be": (1e-4, 1e-4, 1), "ra": (2e-4, 2e-4, 1),
+    "f": (1e-4, 1e-4, 1), "fisher": (1e-4, 1e-4, 1), "info": (2e-4, 2e-4, 1),
+}
+# reference module / model class / trainer class per variant (used by the pin tests)
+REFERENCE_NAMES = {
+    "ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "mm": ("mm_gan", "MMGAN", "MMGANTrainer"),
+    "w": ("w_gan", "WGAN", "WGANTrainer"), "wgp": ("w_gp_gan", "WGPGAN", "WGPGANTrainer"),
+    "ls": ("ls_gan", "LSGAN", "LSGANTrainer"), "dra": ("dra_gan", "DRAGAN", "DRAGANTrainer"),
+    "be": ("be_gan", "BEGAN", "BEGANTrainer"), "ra": ("ra_gan", "RaNSGAN", "RaNSGANTrainer"),
+    "f": ("f_gan", "fGAN", "fGANTrainer"), "fisher": ("fisher_gan", "FisherGAN",
+                                                      "FisherGANTrainer"),
+    "info": ("info_gan", "InfoGAN", "InfoGANTrainer"), "vae": ("vae", "VAE", "VAETrainer"),
+}
+
+
+def f_div_D(method, sx, sg):
+    """f_gan.py:99-121."""
+    if method == "total_variation":
+        return -(torch.mean(0.5 * torch.tanh(sx)) - torch.mean(0.5 * torch.tanh(sg)))
+    if method == "forward_kl":
+        return -(torch.mean(sx) - torch.mean(torch.exp(sg - 1)))
+    if method == "reverse_kl":
+        return -(torch.mean(-torch.exp(sx)) - torch.mean(-1 - sg))
+    if method == "pearson":
+        return -(torch.mean(sx) - torch.mean(0.25 * sg ** 2 + sg))
+    if method == "hellinger":
+        return -(torch.mean(1 - torch.exp(sx)) - torch.mean((1 - torch.exp(sg)) / torch.exp(sg)))
+    if method == "jensen_shannon":
+        two = torch.tensor(2.)
+        return -(torch.mean(two - (1 + torch.exp(-sx))) - torch.mean(-(two - torch.exp(sg))))
+    raise AssertionError("Invalid divergence.")
+
+
+def f_div_G(method, sg):
+    """f_gan.py:123-142."""
+    if method == "total_variation":
+        return -torch.mean(0.5 * torch.tanh(sg))
+    if method == "forward_kl":
+        return -torch.mean(torch.exp(sg - 1))
+    if method == "reverse_kl":
+        return -torch.mean(-1 - sg)
+    if method == "pearson":
+        return -torch.mean(0.25 * sg ** 2 + sg)
+    if method == "hellinger":
+        return -torch.mean((1 - torch.exp(sg)) / torch.exp(sg))
+    if method == "jensen_shannon":
+        return -torch.mean(-(torch.tensor(2.) - torch.exp(sg)))
+    raise AssertionError("Invalid divergence.")
+
+
+class GANPort:
+    """Generic restatement of <Name>Trainer (ns_gan.py:77-226 and its ten siblings)."""
+
+    def __init__(self, variant, model, train_iter, method="jensen_shannon", tap=None):
+        assert variant in DEFAULTS
+        self.variant, self.model, self.train_iter, self.method = variant, model, train_iter, method
+        self.Glosses, self.Dlosses, self.MIlosses = [], [], []
+        self.num_epochs = 0
+        self.tap = tap          # tap(kind, trainer, info) after every optimizer step (tests)
+
+    # -- data / noise: ns_gan.py:218-226, info_gan.py:306-325 --------------------------------
+    def process_batch(self):
+        images, _ = next(iter(self.train_iter))          # fresh iterator => fresh permutation
+        return images.view(images.shape[0], -1)
+
+    def noise(self, B):
+        m = self.model
+        if self.variant != "info":
+            return torch.randn(B, m.z_dim)
+        z = torch.randn(B, m.z_dim)
+        onehot = torch.zeros((B, m.disc_dim))
+        cat = torch.randint(0, m.disc_dim, (B,), dtype=torch.long)
+        onehot[range(B), cat] = 1
+        cont = torch.randn(B, m.cont_dim)
+        return torch.cat((z, onehot, cont), dim=1)
+
+    # -- gradient penalty helper: w_gp_gan.py:205-215, dra_gan.py:208-220 --------------------
+    def _penalty(self, x_hat, lam=10.0, k=1.0):
+        d_hat = self.model.D(x_hat)
+        grads = torch.autograd.grad(outputs=d_hat, inputs=x_hat,
+                                    grad_outputs=torch.ones(d_hat.size()),
+                                    create_graph=True, retain_graph=True, only_inputs=True)[0]
+        return lam * torch.mean((grads.norm(2, dim=1) - k) ** 2)
+
+    # -- losses ------------------------------------------------------
+    def d_loss(self, images):
+        v, m = self.variant, self.model
+        B = images.shape[0]
+        if v in ("ns", "w", "ls", "wgp"):
+            # noise is drawn first: ns_gan.py:183-188, w_gan.py:200-205, ls_gan.py:183-189
+            g_out = m.G(self.noise(B))
+            sx, sg = m.D(images), m.D(g_out)
+        elif v == "be":
+            rx = m.D(images)                                              # be_gan.py:224-225
+            dx = torch.mean(torch.sum(torch.abs(rx - images), dim=1))
+            g_out = m.G(self.noise(B))
+            rg = m.D(g_out)
+            dg = torch.mean(torch.sum(torch.abs(rg - g_out), dim=1))      # be_gan.py:233
+            self._be_dx, self._be_dg = dx, dg
+            return dx - (self.K * dg)                                     # be_gan.py:236
+        else:
+            # D(x) evaluated before the noise draw: mm_gan.py:205-212, dra, ra, f, fisher, info
+            sx = m.D(images)
+            g_out = m.G(self.noise(B))
+            sg = m.D(g_out)
+        if v in ("ns", "mm", "info"):
+            return torch.sum(-torch.mean(torch.log(sx + EPS) + torch.log(1 - sg + EPS)))
+        if v == "w":
+            return -1 * torch.mean(sx) + torch.mean(sg)                   # w_gan.py:208
+        if v == "ls":
+            return 0.50 * torch.mean((sx - 1) ** 2) + 0.50 * torch.mean((sg - 0) ** 2)
+        if v == "wgp":
+            eps = torch.rand(B, 1).expand(images.size()).requires_grad_()  # w_gp_gan.py:197
+            x_hat = eps * images + (1 - eps) * g_out                       # w_gp_gan.py:201
+            return torch.mean(sg) - torch.mean(sx) + self._penalty(x_hat)  # w_gp_gan.py:218
+        if v == "dra":
+            loss = -torch.mean(torch.log(sx + EPS) + torch.log(1 - sg + EPS))
+            delta = torch.rand(B, 1).expand(images.size())                 # dra_gan.py:200
+            x_hat = (delta * images.data + (1 - delta) *
+                     (images.data + 1 * images.data.std() * torch.rand(images.size())))
+            return loss + self._penalty(x_hat.requires_grad_())            # dra_gan.py:203-223
+        if v == "ra":
+            return -torch.mean(torch.log(torch.sigmoid(sx - sg.mean()) + EPS)
+                               + torch.log(torch.sigmoid(1 - sg) + EPS)) / 2   # ra_gan.py:204
+        if v == "f":
+            return f_div_D(self.method, sx, sg)
+        if v == "fisher":
+            m1x, m1g = sx.mean(), sg.mean()                                # fisher_gan.py:214-223
+            m2x, m2g = (sx ** 2).mean(), (sg ** 2).mean()
+            omega = 1 - (0.5 * m2x + 0.5 * m2g)
+            return -((m1x - m1g) + self.LAMBDA * omega - (self.RHO / 2) * (omega ** 2))
+        raise AssertionError(v)
+
+    def g_loss(self, images):
+        v, m = self.variant, self.model
+        g_out = m.G(self.noise(images.shape[0]))
+        if v == "be":
+            rg = m.D(g_out)
+            return torch.mean(torch.sum(torch.abs(rg - g_out), dim=1))    # be_gan.py:256
+        sg = m.D(g_out)
+        if v in ("ns", "dra", "ra", "info"):
+            return -torch.mean(torch.log(sg + EPS))                       # ns_gan.py:214
+        if v == "mm":
+            return torch.mean(torch.log((1 - sg) + EPS))                  # mm_gan.py:235
+        if v in ("w", "wgp"):
+            return -1 * torch.mean(sg)                                    # w_gan.py:227
+        if v == "ls":
+            return 0.50 * torch.mean((sg - 1) ** 2)                       # ls_gan.py:213
+        if v == "f":
+            return f_div_G(self.method, sg)
+        if v == "fisher":
+            return -sg.mean()                                             # fisher_gan.py:246
+        raise AssertionError(v)
+
+    def q_loss(self, images):
+        """info_gan.py:269-304."""
+        m = self.model
+        noise = self.noise(images.shape[0])
+        out = m.Q(m.G(noise))
+        q_disc, q_cont = out[:, :m.disc_dim], out[:, m.disc_dim:]
+        target = noise[:, m.z_dim:m.z_dim + m.disc_dim]
+        disc = F.cross_entropy(q_disc, torch.max(target, 1)[1])
+        cont = F.mse_loss(q_cont, noise[:, m.z_dim + m.disc_dim:])
+        return 1 * (disc + cont)
+
+    # -- the step loop: ns_gan.py:94-170 and siblings ----------------------------------------
+    def train(self, num_epochs, G_lr=None, D_lr=None, D_steps=None, G_init=5, clip=0.01,
+              GAMMA=0.50, LAMBDA=1e-3, K=0.00, RHO=1e-6, max_steps=None):
+        v, m = self.variant, self.model
+        dflt = DEFAULTS[v]
+        G_lr = dflt[0] if G_lr is None else G_lr
+        D_lr = dflt[1] if D_lr is None else D_lr
+        D_steps = dflt[2] if D_steps is None else D_steps
+        if v == "fisher":                                                  # fisher_gan.py:117-118
+            self.LAMBDA = torch.zeros(1).requires_grad_()
+            self.RHO = torch.tensor(RHO).requires_grad_()
+        if v == "info":                                                    # info_gan.py:142-148
+            pD, pG, pQ = list(m.D.parameters()), list(m.G.parameters()), list(m.Q.parameters())
+            D_opt = optim.Adam(params=pD, lr=D_lr)
+            G_opt = optim.Adam(params=pG, lr=G_lr)
+            MI_opt = optim.Adam(params=(pG + pQ), lr=G_lr)
+        else:
+            G_opt = optim.Adam(params=list(m.G.parameters()), lr=G_lr)      # ns_gan.py:107-110
+            D_opt = optim.Adam(params=list(m.D.parameters()), lr=D_lr)
+        self.G_opt, self.D_opt = G_opt, D_opt
+        if v == "be":                                                      # be_gan.py:133-136
+            from torch.optim.lr_scheduler import ReduceLROnPlateau
+            pat = 5 * len(self.train_iter)
+            G_sched = ReduceLROnPlateau(G_opt, factor=0.50, threshold=0.01, patience=pat)
+            D_sched = ReduceLROnPlateau(D_opt, factor=0.50, threshold=0.01, patience=pat)
+            self.K = K
+        epoch_steps = int(np.ceil(len(self.train_iter) / D_steps))          # ns_gan.py:114
+        if max_steps is not None:
+            epoch_steps = min(epoch_steps, max_steps)
+        if v == "mm" and G_init > 0:                                        # mm_gan.py:121-136
+            for _ in range(G_init):
+                images = self.process_batch()
+                G_opt.zero_grad()
+                loss = self.g_loss(images)
+                loss.backward()
+                G_opt.step()
+                self._tap("G_init", loss)
+        for _epoch in range(1, num_epochs + 1):
+            m.train()
+            G_losses, D_losses, MI_losses = [], [], []
+            for _ in range(epoch_steps):
+                step_losses = []
+                for _ in range(D_steps):
+                    images = self.process_batch()
+                    D_opt.zero_grad()
+                    D_loss = self.d_loss(images)
+                    D_loss.backward()
+                    if v == "fisher":                                       # fisher_gan.py:155-156
+                        self.LAMBDA = self.LAMBDA + self.RHO * self.LAMBDA.grad
+                        self.LAMBDA = self.LAMBDA.detach().requires_grad_()
+                    D_opt.step()
+                    step_losses.append(D_loss.item())
+                    if v == "w":                                            # w_gan.py:158,241-243
+                        for p in m.D.parameters():
+                            p.data.clamp_(-clip, clip)
+                    self._tap("D", D_loss, images)
+                D_losses.append(np.mean(step_losses))                       # ns_gan.py:145
+                G_opt.zero_grad()
+                G_loss = self.g_loss(images)
+                G_losses.append(G_loss.item())
+                G_loss.backward()
+                G_opt.step()
+                self._tap("G", G_loss, images)
+                if v == "be":                                               # be_gan.py:189-195
+                    dx, dg = self._be_dx, self._be_dg
+                    convergence = (dx + torch.abs(GAMMA * dx - dg)).item()
+                    k_update = (self.K + LAMBDA * (GAMMA * dx - dg)).item()
+                    self.K = min(max(0, k_update), 1)
+                    D_sched.step(convergence)
+                    G_sched.step(convergence)
+                if v == "info":                                             # info_gan.py:198-207
+                    MI_opt.zero_grad()
+                    MI_loss = self.q_loss(images)
+                    MI_losses.append(MI_loss.item())
+                    MI_loss.backward()
+                    MI_opt.step()
+                    self._tap("Q", MI_loss, images)
+            self.Glosses.extend(G_losses)
+            self.Dlosses.extend(D_losses)
+            self.MIlosses.extend(MI_losses)
+            self.num_epochs += 1
+
+    def _tap(self, kind, loss, images=None):
+        if self.tap is not None:
+            self.tap(kind, self, {"loss": float(loss.item()), "images": images})
+
+
+class VAEPort:
+    """vae.py:109-223 (train loop, compute_batch, kl_divergence, evaluate)."""
+
+    def __init__(self, model, train_iter, val_iter, test_iter, tap=None):
+        self.model, self.train_iter, self.val_iter, self.test_iter = \
+            model, train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))       # vae.py:120 (2 RNG draws)
+        self.kl_loss, self.recon_loss, self.val_losses = [], [], []
+        self.num_epochs = 0
+        self.tap = tap
+
+    def compute_batch(self, batch):
+        images, _ = batch
+        images = images.view(images.shape[0], -1)
+        out, mu, log_var = self.model(images)
+        recon = torch.sum((images - out) ** 2)                                   # vae.py:203
+        kl = torch.sum(0.5 * (mu ** 2 + torch.exp(log_var) - log_var - 1))       # vae.py:212
+        return recon, kl
+
+    def evaluate(self, iterator):
+        losses = []
+        for batch in iterator:                      # no no_grad, still samples eps (vae.py:214)
+            r, k = self.compute_batch(batch)
+            losses.append((r + k).item())
+        return np.mean(losses)
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5, max_steps=None, do_eval=True):
+        opt = optim.Adam(params=list(self.model.parameters()), lr=lr, weight_decay=weight_decay)
+        self.opt = opt
+        for _epoch in range(1, num_epochs + 1):
+            self.model.train()
+            e_recon, e_kl = [], []
+            for i, batch in enumerate(self.train_iter):
+                if max_steps is not None and i >= max_steps:
+                    break
+                opt.zero_grad()
+                recon, kl = self.compute_batch(batch)
+                loss = recon + kl
+                loss.backward()
+                opt.step()
+                e_recon.append(recon.item())
+                e_kl.append(kl.item())
+                if self.tap is not None:
+                    self.tap("VAE", self, {"recon": e_recon[-1], "kl": e_kl[-1],
+                                           "images": batch[0]})
+            self.kl_loss.extend(e_kl)
+            self.recon_loss.extend(e_recon)
+            if do_eval:
+                self.model.eval()
+                val = self.evaluate(self.val_iter)
+                self.val_losses.append(val)
+                if val < self.best_val_loss:
+                    self.best_model = copy.deepcopy(self.model)
+                    self.best_val_loss = val
+            self.num_epochs += 1
+
+
+# --------------------------------------------------------------------------------------------
+# Synthetic data (same recipe as oracle/ref_harness.synthetic_loaders).
+# --------------------------------------------------------------------------------------------
+def synthetic_images(n, image_shape=(1, 28, 28), p=0.1307):
+    return torch.bernoulli(torch.full((n,) + tuple(image_shape), p))
+
+
+def synthetic_loaders(batch_size, n_train=50000, n_val=10000, n_test=10000,
+                      image_shape=(1, 28, 28), p=0.1307, seed=3435):
+    torch.manual_seed(seed)
+    def mk(n):
+        ds = torch.utils.data.TensorDataset(synthetic_images(n, image_shape, p),
+                                            torch.zeros(n, dtype=torch.int64))
+        return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True)
+    return mk(n_train), mk(n_val), mk(n_test)
+
+
+def build(variant, image_size=784, hidden_dim=400, z_dim=20, seed=1234, **kw):
+    """Model construction with the parity seed."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    if variant == "vae":
+        return VAEModel(image_size, hidden_dim, z_dim)
+    return GANModel(variant, image_size, hidden_dim, z_dim, **kw)

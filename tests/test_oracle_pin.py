@@ -1,0 +1,103 @@
+"""Pins oracle/port.py bit-for-bit against the UNMODIFIED reference executed on CPU.
+
+Runs only where /root/reference is mounted (the build container); on the GPU box these tests
+skip and the committed fixtures (tests/test_golden.py) carry the pin instead."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import port, ref_harness
+
+needs_ref = pytest.mark.skipif(not ref_harness.available(), reason="reference not mounted")
+
+IMG, HID, Z, B, N = 64, 48, 8, 16, 160       # small dims: same code path, seconds to run
+
+
+def _loaders(batch):
+    return ref_harness.synthetic_loaders(batch, n_train=N, n_val=48, n_test=48,
+                                         image_shape=(1, 8, 8))
+
+
+def _run_reference(variant, steps_kw):
+    mod_name, model_name, trainer_name = port.REFERENCE_NAMES[variant]
+    mod = ref_harness.load(mod_name)
+    train_iter, val_iter, test_iter = _loaders(B)
+    torch.manual_seed(1234)
+    if variant == "info":
+        model = getattr(mod, model_name)(image_size=IMG, hidden_dim=HID, z_dim=Z, disc_dim=10,
+                                         cont_dim=10)
+    else:
+        model = getattr(mod, model_name)(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    trainer = getattr(mod, trainer_name)(model, train_iter, val_iter, test_iter, viz=False)
+    with ref_harness.quiet():
+        trainer.train(**steps_kw)
+    return trainer, model
+
+
+def _run_port(variant, steps_kw):
+    train_iter, val_iter, test_iter = _loaders(B)
+    model = port.build(variant, IMG, HID, Z)
+    kw = dict(steps_kw)
+    method = kw.pop("method", "jensen_shannon")
+    trainer = port.GANPort(variant, model, train_iter, method=method)
+    trainer.train(**kw)
+    return trainer, model
+
+
+GAN_CASES = [
+    ("ns", dict(num_epochs=2)),
+    ("mm", dict(num_epochs=1, G_init=3)),
+    ("w", dict(num_epochs=1, D_steps=2)),
+    ("wgp", dict(num_epochs=1, D_steps=1)),
+    ("wgp", dict(num_epochs=1, D_steps=3)),
+    ("ls", dict(num_epochs=2)),
+    ("dra", dict(num_epochs=1, D_steps=1)),
+    ("be", dict(num_epochs=2)),
+    ("ra", dict(num_epochs=1)),
+    ("fisher", dict(num_epochs=1)),
+    ("info", dict(num_epochs=1)),
+] + [("f", dict(num_epochs=1, method=m)) for m in port.F_METHODS]
+
+
+@needs_ref
+@pytest.mark.parametrize("variant,kw", GAN_CASES, ids=[f"{v}-{i}" for i, (v, _) in enumerate(GAN_CASES)])
+def test_gan_port_bit_exact(variant, kw):
+    ref_tr, ref_model = _run_reference(variant, kw)
+    ref_rng = torch.get_rng_state()
+    my_tr, my_model = _run_port(variant, kw)
+    assert len(ref_tr.Glosses) == len(my_tr.Glosses) > 0
+    np.testing.assert_array_equal(np.array(ref_tr.Glosses), np.array(my_tr.Glosses))
+    np.testing.assert_array_equal(np.array(ref_tr.Dlosses), np.array(my_tr.Dlosses))
+    if variant == "info":
+        np.testing.assert_array_equal(np.array(ref_tr.MIlosses), np.array(my_tr.MIlosses))
+    ref_sd, my_sd = ref_model.state_dict(), my_model.state_dict()
+    assert list(ref_sd.keys()) == list(my_sd.keys())          # drop-in key names
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], my_sd[k]), k
+    # both consumed the global generator identically
+    assert torch.equal(ref_rng, torch.get_rng_state())
+
+
+@needs_ref
+def test_vae_port_bit_exact():
+    mod = ref_harness.load("vae")
+    tr_i, va_i, te_i = _loaders(B)
+    torch.manual_seed(1234)
+    ref_model = mod.VAE(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    ref_tr = mod.VAETrainer(ref_model, tr_i, va_i, te_i, viz=False)
+    with ref_harness.quiet():
+        ref_tr.train(num_epochs=2)
+    ref_state = torch.get_rng_state()
+
+    tr_i, va_i, te_i = _loaders(B)
+    my_model = port.build("vae", IMG, HID, Z)
+    my_tr = port.VAEPort(my_model, tr_i, va_i, te_i)
+    my_tr.train(num_epochs=2)
+    np.testing.assert_array_equal(np.array(ref_tr.recon_loss), np.array(my_tr.recon_loss))
+    np.testing.assert_array_equal(np.array(ref_tr.kl_loss), np.array(my_tr.kl_loss))
+    assert ref_tr.best_val_loss == my_tr.best_val_loss
+    ref_sd, my_sd = ref_model.state_dict(), my_model.state_dict()
+    assert list(ref_sd.keys()) == list(my_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], my_sd[k]), k
+    assert torch.equal(ref_state, torch.get_rng_state())
