@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by executing the UNMODIFIED reference
+(/root/reference/src/*.py, via oracle/ref_harness.py) on CPU.  Run in the build container:
+
+    python -m oracle.gen_golden
+
+The fixtures travel to the GPU box (where /root/reference does not exist) and pin both
+oracle/port.py (tests/test_golden.py, CPU) and the HIP path (tests/test_gpu_trainers.py).
+
+Every fixture is reproducible from seeds: dataset = ref_harness.synthetic_loaders(seed 3435),
+model = torch.manual_seed(1234) then the reference constructor, all later draws come from the
+global CPU generator in the reference's own order.  Stored: per-step loss lists, final
+parameters (small configs) or per-tensor digests (full-size configs), and the final RNG state
+digest.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import port, ref_harness
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+SMALL = dict(image_size=64, hidden_dim=48, z_dim=8, batch=16, n_train=160, n_val=48, n_test=48,
+             image_shape=(1, 8, 8))
+FULL = dict(image_size=784, hidden_dim=400, z_dim=20, n_train=50000, n_val=512, n_test=512,
+            image_shape=(1, 28, 28))
+
+
+def digest(t):
+    a = t.detach().cpu().numpy().astype(np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a[0], a[-1], a[a.size // 2]])
+
+
+def rng_digest():
+    return hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest()
+
+
+def run_reference(variant, cfg, batch, train_kw, steps_cap=None):
+    mod_name, model_name, trainer_name = port.REFERENCE_NAMES[variant]
+    mod = ref_harness.load(mod_name)
+    loaders = ref_harness.synthetic_loaders(batch, n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                            n_test=cfg["n_test"], image_shape=cfg["image_shape"])
+    torch.manual_seed(1234)
+    kw = dict(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+    if variant == "info":
+        kw.update(disc_dim=10, cont_dim=10)
+    model = getattr(mod, model_name)(**kw)
+    trainer = getattr(mod, trainer_name)(model, *loaders, viz=False)
+    if steps_cap is not None:
+        # Cap the number of steps WITHOUT touching the reference: len(train_iter) drives
+        # epoch_steps (ns_gan.py:114); a DataLoader subclass reporting a shorter length keeps
+        # sampling identical (fresh full permutation per step, first B rows).
+        class Capped(torch.utils.data.DataLoader):
+            def __len__(self):
+                return steps_cap
+        ds = loaders[0].dataset
+        trainer.train_iter = Capped(ds, batch_size=batch, shuffle=True)
+    with ref_harness.quiet():
+        trainer.train(**train_kw)
+    return trainer, model
+
+
+def save(name, arrays, meta):
+    arrays = dict(arrays)
+    arrays["meta"] = np.array(json.dumps(meta))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items() if k != "meta"})
+
+
+SMALL_CASES = {
+    "ns": dict(num_epochs=2), "mm": dict(num_epochs=1, G_init=3), "w": dict(num_epochs=1, D_steps=2),
+    "wgp": dict(num_epochs=1, D_steps=1), "ls": dict(num_epochs=2),
+    "dra": dict(num_epochs=1, D_steps=1), "be": dict(num_epochs=2), "ra": dict(num_epochs=1),
+    "fisher": dict(num_epochs=1), "info": dict(num_epochs=1),
+}
+
+FULL_CASES = {      # variant -> (batch, steps, train kwargs); BASELINE.json configs 2,3,5
+    "ns": (256, 24, dict(num_epochs=1)),
+    "ls": (1024, 12, dict(num_epochs=1)),
+    "wgp": (256, 16, dict(num_epochs=1, D_steps=1)),
+}
+
+
+def main():
+    if not ref_harness.available():
+        sys.exit("reference not mounted; fixtures can only be generated in the build container")
+    torch.set_num_threads(1)            # one thread: the most reproducible summation order
+    for variant, kw in SMALL_CASES.items():
+        tr, model = run_reference(variant, SMALL, SMALL["batch"], kw)
+        arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+        if variant == "info":
+            arrays["MIlosses"] = np.array(tr.MIlosses)
+        for k, v in model.state_dict().items():
+            arrays["param:" + k] = v.numpy()
+        save(variant + "_small", arrays, dict(variant=variant, cfg=SMALL, train_kw=kw,
+                                              rng=rng_digest(), torch=torch.__version__))
+    for method in port.F_METHODS:
+        kw = dict(num_epochs=1, method=method)
+        tr, model = run_reference("f", SMALL, SMALL["batch"], kw)
+        arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+        for k, v in model.state_dict().items():
+            arrays["param:" + k] = v.numpy()
+        save("f_%s_small" % method, arrays, dict(variant="f", cfg=SMALL, train_kw=kw,
+                                                 rng=rng_digest(), torch=torch.__version__))
+    # VAE small
+    mod = ref_harness.load("vae")
+    loaders = ref_harness.synthetic_loaders(SMALL["batch"], n_train=SMALL["n_train"],
+                                            n_val=SMALL["n_val"], n_test=SMALL["n_test"],
+                                            image_shape=SMALL["image_shape"])
+    torch.manual_seed(1234)
+    model = mod.VAE(image_size=SMALL["image_size"], hidden_dim=SMALL["hidden_dim"],
+                    z_dim=SMALL["z_dim"])
+    tr = mod.VAETrainer(model, *loaders, viz=False)
+    with ref_harness.quiet():
+        tr.train(num_epochs=2)
+    arrays = {"recon_loss": np.array(tr.recon_loss), "kl_loss": np.array(tr.kl_loss),
+              "best_val_loss": np.array(tr.best_val_loss)}
+    for k, v in model.state_dict().items():
+        arrays["param:" + k] = v.numpy()
+    save("vae_small", arrays, dict(variant="vae", cfg=SMALL, train_kw=dict(num_epochs=2),
+                                   rng=rng_digest(), torch=torch.__version__))
+    # full-size loss curves + digests
+    for variant, (batch, steps, kw) in FULL_CASES.items():
+        tr, model = run_reference(variant, FULL, batch, kw, steps_cap=steps)
+        arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+        for k, v in model.state_dict().items():
+            arrays["digest:" + k] = digest(v)
+        save("%s_full_b%d" % (variant, batch), arrays,
+             dict(variant=variant, cfg=FULL, batch=batch, steps=steps, train_kw=kw,
+                  rng=rng_digest(), torch=torch.__version__))
+    # VAE full size, B=512: one capped epoch (first `steps` batches of the real epoch order)
+    mod = ref_harness.load("vae")
+    steps = 12
+    loaders = ref_harness.synthetic_loaders(512, n_train=512 * steps, n_val=FULL["n_val"],
+                                            n_test=FULL["n_test"], image_shape=FULL["image_shape"])
+    torch.manual_seed(1234)
+    model = mod.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = mod.VAETrainer(model, *loaders, viz=False)
+    with ref_harness.quiet():
+        tr.train(num_epochs=1)
+    arrays = {"recon_loss": np.array(tr.recon_loss), "kl_loss": np.array(tr.kl_loss),
+              "best_val_loss": np.array(tr.best_val_loss)}
+    for k, v in model.state_dict().items():
+        arrays["digest:" + k] = digest(v)
+    save("vae_full_b512", arrays, dict(variant="vae", cfg=FULL, batch=512, steps=steps,
+                                       n_train=512 * steps, train_kw=dict(num_epochs=1),
+                                       rng=rng_digest(), torch=torch.__version__))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""oracle/port.py against the committed fixtures that oracle/gen_golden.py produced from the
+UNMODIFIED reference.  Runs on CPU everywhere (build container and GPU box): this is what pins
+the oracle where /root/reference is absent.  Same torch build => normally bit-identical; the
+tolerance only absorbs a different host ISA picking a different MKL sgemm kernel."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import port
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 2e-5, 2e-6          # fp32, <= 24 free-running steps (SURVEY.md section 4 horizon)
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
+               if not os.path.basename(p).startswith("vae"))
+FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256"]
+
+
+def run_port_gan(meta, batch, max_steps=None):
+    cfg = meta["cfg"]
+    loaders = port.synthetic_loaders(batch, n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    model = port.build(meta["variant"], cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    kw = dict(meta["train_kw"])
+    method = kw.pop("method", "jensen_shannon")
+    tr = port.GANPort(meta["variant"], model, loaders[0], method=method)
+    tr.train(max_steps=max_steps, **kw)
+    return tr, model
+
+
+def test_fixture_inventory():
+    assert len(SMALL) == 16, SMALL          # 10 variants + 6 f-divergences
+    for n in FULL + ["vae_small", "vae_full_b512"]:
+        assert os.path.isfile(os.path.join(GOLDEN, n + ".npz")), n
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_gan_small(name):
+    z, meta = load(name)
+    tr, model = run_port_gan(meta, meta["cfg"]["batch"])
+    np.testing.assert_allclose(np.array(tr.Glosses), z["Glosses"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(np.array(tr.Dlosses), z["Dlosses"], rtol=RTOL, atol=ATOL)
+    if "MIlosses" in z.files:
+        np.testing.assert_allclose(np.array(tr.MIlosses), z["MIlosses"], rtol=RTOL, atol=ATOL)
+    sd = model.state_dict()
+    keys = [k[6:] for k in z.files if k.startswith("param:")]
+    assert keys == list(sd.keys())
+    for k in keys:
+        np.testing.assert_allclose(sd[k].numpy(), z["param:" + k], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_gan_full(name):
+    z, meta = load(name)
+    tr, model = run_port_gan(meta, meta["batch"], max_steps=meta["steps"])
+    np.testing.assert_allclose(np.array(tr.Glosses), z["Glosses"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(np.array(tr.Dlosses), z["Dlosses"], rtol=RTOL, atol=ATOL)
+    from oracle.gen_golden import digest
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(digest(v), z["digest:" + k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512"])
+def test_vae(name):
+    z, meta = load(name)
+    cfg = meta["cfg"]
+    batch = meta.get("batch", cfg.get("batch"))
+    loaders = port.synthetic_loaders(batch, n_train=meta.get("n_train", cfg["n_train"]),
+                                     n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                     image_shape=tuple(cfg["image_shape"]))
+    model = port.build("vae", cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    tr = port.VAEPort(model, *loaders)
+    tr.train(**meta["train_kw"])
+    np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(tr.kl_loss), z["kl_loss"], rtol=RTOL)
+    np.testing.assert_allclose(tr.best_val_loss, float(z["best_val_loss"]), rtol=RTOL)
