@@ -1,0 +1,103 @@
+"""ctypes binding of libgm_hip.so (C-ABI declared in include/gm_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.  The product
+path never routes through torch eager kernels or the CPU oracle for the ops bound here."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgm_hip.so")
+
+GM_EINVAL = -10001
+ACT_ID, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT = {"id": ACT_ID, None: ACT_ID, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+LOSS = {"ns": 0, "mm": 1, "w": 2, "ls": 3, "ra": 4, "fisher": 5, "f_total_variation": 6,
+        "f_forward_kl": 7, "f_reverse_kl": 8, "f_pearson": 9, "f_hellinger": 10,
+        "f_jensen_shannon": 11}
+
+
+class Slot(ctypes.Structure):
+    """gm_slot: ((ctr ? *ctr : 0) * mul + add) % ring * stride."""
+    _fields_ = [("ctr", c_void_p), ("mul", c_int32), ("add", c_int32), ("ring", c_int32),
+                ("stride", c_int64)]
+
+
+def slot(ctr=0, mul=0, add=0, ring=0, stride=0):
+    return Slot(ctr or None, mul, add, ring, stride)
+
+
+NO_SLOT = Slot(None, 0, 0, 0, 0)
+
+_P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
+
+_SIGNATURES = {
+    "gm_version": (c_int, []),
+    "gm_arch": (c_char_p, []),
+    "gm_last_error": (c_char_p, []),
+    "gm_tick": (c_int, [_P, _P, c_int64]),
+    "gm_gather_rows": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
+    "gm_linear_fwd": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
+                              c_int]),
+    "gm_linear_bwd_dx": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
+                                 c_int, c_int]),
+    "gm_linear_bwd_dw": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
+                                 c_int]),
+    "gm_gan_loss": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, POINTER(c_float), c_int,
+                            c_float, _P, Slot, _P, _P, _P]),
+    "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, c_float, c_float, c_float, c_float,
+                        c_float]),
+    "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
+    "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
+    "gm_graph_begin": (c_int, [_P]),
+    "gm_graph_end": (c_int, [_P, POINTER(c_void_p)]),
+    "gm_graph_launch": (c_int, [_P, _P]),
+    "gm_graph_destroy": (c_int, [_P]),
+    "gm_event_create": (c_int, [POINTER(c_void_p)]),
+    "gm_event_record": (c_int, [_P, _P]),
+    "gm_event_sync": (c_int, [_P]),
+    "gm_event_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
+    "gm_event_destroy": (c_int, [_P]),
+}
+
+_lib = None
+
+
+class GMError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgm_hip.so; raise loudly if it is not there (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise GMError("HIP extension %s is missing -- run `python __graft_entry__.py build` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gm_last_error()
+        raise GMError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def declared_symbols():
+    """Every function declared in include/gm_hip.h (parsed), for the export test."""
+    import re
+    hdr = os.path.join(os.path.dirname(HERE), "include", "gm_hip.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,483 @@
+// gm_ops.hip -- non-GEMM kernels of the GAN/VAE step: batch gather, adversarial losses with their
+// score gradients, flat Adam (+WGAN clamp), the per-graph tick, and HIP-graph / event helpers.
+#include "gm_common.h"
+
+#include <string>
+
+// ------------------------------------------------------------------------------------------
+// library bookkeeping
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+extern "C" void gm_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+extern "C" const char* gm_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gm_version(void) { return 100; }
+extern "C" const char* gm_arch(void) { return "gfx950"; }
+
+// ------------------------------------------------------------------------------------------
+// tick
+// ------------------------------------------------------------------------------------------
+__global__ void tick_kernel(int64_t* ctr, int64_t inc) { *ctr += inc; }
+
+extern "C" int gm_tick(void* stream, int64_t* ctr, int64_t inc) {
+    GM_CHECK_ARG(ctr);
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 gather: out[b,:] = data[idx[b],:]   (process_batch, ns_gan.py:222-226)
+// One 3136-byte image row per wave: 196 float4 -> lanes issue coalesced 16-B loads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ data,
+                                                         int64_t n_rows,
+                                                         const int64_t* __restrict__ idx,
+                                                         gm_slot idx_slot, float* __restrict__ out,
+                                                         int64_t ld_out, int B, int row_elems,
+                                                         int vec) {
+    const int64_t* ix = idx + gm_slot_offset(idx_slot);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    int64_t r = ix[b];
+    if (r < 0 || r >= n_rows) r = 0;     // never fault on a corrupt index; parity tests catch it
+    const float* src = data + r * (int64_t)row_elems;
+    float* dst = out + (int64_t)b * ld_out;
+    if (vec) {
+        const int n4 = row_elems >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = lane; i < n4; i += 64) d4[i] = s4[i];
+    } else {
+        for (int i = lane; i < row_elems; i += 64) dst[i] = src[i];
+    }
+}
+
+extern "C" int gm_gather_rows(void* stream, const float* data, int64_t n_rows, const int64_t* idx,
+                              gm_slot idx_slot, float* out, int64_t ld_out, int B, int row_elems) {
+    GM_CHECK_ARG(data && idx && out && B > 0 && row_elems > 0 && ld_out >= row_elems);
+    const int vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(data) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       data, n_rows, idx, idx_slot, out, ld_out, B, row_elems, vec);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 adversarial losses.  One 256-thread workgroup: the score vectors are [B] (B <= a few
+// thousand), so a single workgroup with wave64 shuffle + LDS reductions is both the fastest
+// shape and bit-deterministic.  Sums are carried in fp64 and rounded once.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct LossP {
+    int variant, gen_mode, B, out_act;
+    const float* sx;
+    const float* sg;
+    float hyper[8];
+    float inv_b;
+    float* loss_out;
+    gm_slot loss_slot;
+    float* dax;
+    float* dag;
+    float* aux;
+};
+
+__device__ double block_sum(double v, double* sh) {
+    v = gm_wave_sum_d(v);
+    __syncthreads();                       // protect sh from the previous use
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__device__ __forceinline__ float act_grad(float g, float s, int out_act) {
+    if (out_act == GM_ACT_SIGMOID) return (g * (1.f - s)) * s;   // SigmoidBackward: grad*(1-y)*y
+    if (out_act == GM_ACT_RELU) return s > 0.f ? g : 0.f;
+    return g;
+}
+
+constexpr float EPS = 1e-8f;
+
+__global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
+    __shared__ double sh[4];
+    const int t = threadIdx.x, B = p.B;
+    const float ib = p.inv_b;
+    const bool D = !p.gen_mode;
+    double acc = 0.0;           // sum of per-sample loss terms (already signed)
+    float extra = 0.f;          // variant-specific scalar folded into the loss at the end
+
+    if (p.variant == GM_LOSS_RA && D) {
+        // ra_gan.py:204-205  L = -mean(log(sig(sx - mean(sg)) + eps) + log(sig(1 - sg) + eps)) / 2
+        double s1 = 0.0;
+        for (int i = t; i < B; i += 256) s1 += (double)p.sg[i];
+        const float mg = (float)(block_sum(s1, sh) * (double)ib);
+        double sq = 0.0;
+        for (int i = t; i < B; i += 256) {
+            const float u = gm_sigmoid(p.sx[i] - mg);
+            const float v = gm_sigmoid(1.f - p.sg[i]);
+            acc += (double)(logf(u + EPS) + logf(v + EPS));
+            const float gu = (-0.5f * ib) / (u + EPS);       // dL/du
+            const float du = (gu * (1.f - u)) * u;           // through the inner sigmoid
+            p.dax[i] = act_grad(du, p.sx[i], p.out_act);
+            sq += (double)du;
+        }
+        const float sum_du = (float)block_sum(sq, sh);        // d/dmg = -sum_du ; dmg/dsg_j = 1/B
+        for (int i = t; i < B; i += 256) {
+            const float v = gm_sigmoid(1.f - p.sg[i]);
+            const float gv = (-0.5f * ib) / (v + EPS);
+            const float dv = -((gv * (1.f - v)) * v);         // d(1 - sg)/dsg = -1
+            p.dag[i] = act_grad(dv - sum_du * ib, p.sg[i], p.out_act);
+        }
+        const double tot = block_sum(acc, sh);
+        if (t == 0) p.loss_out[gm_slot_index(p.loss_slot)] = -(float)(tot * (double)ib) / 2.f;
+        return;
+    }
+
+    if (p.variant == GM_LOSS_FISHER && D) {
+        // fisher_gan.py:214-223; aux[0] = lambda (updated in place: :155-156), aux[1..4] = moments
+        double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+        for (int i = t; i < B; i += 256) {
+            const float x = p.sx[i], g = p.sg[i];
+            a1 += x; a2 += (double)(x * x); b1 += g; b2 += (double)(g * g);
+        }
+        const float m1x = (float)(block_sum(a1, sh) * (double)ib);
+        const float m2x = (float)(block_sum(a2, sh) * (double)ib);
+        const float m1g = (float)(block_sum(b1, sh) * (double)ib);
+        const float m2g = (float)(block_sum(b2, sh) * (double)ib);
+        const float lam = p.aux[0], rho = p.hyper[0];
+        const float omega = 1.f - (0.5f * m2x + 0.5f * m2g);
+        const float loss = -((m1x - m1g) + lam * omega - (rho / 2.f) * (omega * omega));
+        const float dO = -(lam - rho * omega);               // dL/dOmega
+        for (int i = t; i < B; i += 256) {
+            // dOmega/dsx_i = -0.5 * 2 * sx_i / B
+            p.dax[i] = act_grad(-ib + dO * (-(p.sx[i] * ib)), p.sx[i], p.out_act);
+            p.dag[i] = act_grad(ib + dO * (-(p.sg[i] * ib)), p.sg[i], p.out_act);
+        }
+        __syncthreads();
+        if (t == 0) {
+            p.loss_out[gm_slot_index(p.loss_slot)] = loss;
+            p.aux[0] = lam + rho * (-omega);                  // lambda += rho * lambda.grad
+            p.aux[1] = m1x; p.aux[2] = m1g; p.aux[3] = m2x; p.aux[4] = m2g;
+        }
+        return;
+    }
+
+    // separable variants: per-sample term + per-sample gradient
+    for (int i = t; i < B; i += 256) {
+        const float g = p.sg[i];
+        const float x = D ? p.sx[i] : 0.f;
+        float lx = 0.f, lg = 0.f, dx = 0.f, dg = 0.f;      // loss terms (to be averaged), dL/ds
+        switch (p.variant) {
+        case GM_LOSS_NS:
+            if (D) {   // ns_gan.py:191-192
+                const float ux = x + EPS, ug = (1.f - g) + EPS;
+                lx = -logf(ux); lg = -logf(ug);
+                dx = (-ib) / ux; dg = -((-ib) / ug);
+            } else {   // ns_gan.py:214
+                const float ug = g + EPS;
+                lg = -logf(ug); dg = (-ib) / ug;
+            }
+            break;
+        case GM_LOSS_MM:
+            if (D) {
+                const float ux = x + EPS, ug = (1.f - g) + EPS;
+                lx = -logf(ux); lg = -logf(ug);
+                dx = (-ib) / ux; dg = -((-ib) / ug);
+            } else {   // mm_gan.py:235
+                const float ug = (1.f - g) + EPS;
+                lg = logf(ug); dg = -(ib / ug);
+            }
+            break;
+        case GM_LOSS_W:
+        case GM_LOSS_FISHER:   // generator mode only reaches here: -mean(sg)
+            if (D) { lx = -x; lg = g; dx = -ib; dg = ib; }
+            else   { lg = -g; dg = -ib; }
+            break;
+        case GM_LOSS_LS: {
+            const float a = p.hyper[0], b = p.hyper[1], c = p.hyper[2];
+            if (D) {   // ls_gan.py:192-193
+                lx = 0.5f * ((x - b) * (x - b)); lg = 0.5f * ((g - a) * (g - a));
+                dx = (0.5f * ib) * (2.f * (x - b)); dg = (0.5f * ib) * (2.f * (g - a));
+            } else {   // ls_gan.py:213
+                lg = 0.5f * ((g - c) * (g - c)); dg = (0.5f * ib) * (2.f * (g - c));
+            }
+            break;
+        }
+        case GM_LOSS_RA:       // generator mode: plain NS (ra_gan.py:227)
+        {
+            const float ug = g + EPS;
+            lg = -logf(ug); dg = (-ib) / ug;
+            break;
+        }
+        case GM_LOSS_F_TV: {
+            const float tg = tanhf(g);
+            if (D) { const float tx = tanhf(x);
+                     lx = -(0.5f * tx); lg = 0.5f * tg;
+                     dx = -(0.5f * ib) * (1.f - tx * tx); dg = (0.5f * ib) * (1.f - tg * tg); }
+            else   { lg = -(0.5f * tg); dg = -(0.5f * ib) * (1.f - tg * tg); }
+            break;
+        }
+        case GM_LOSS_F_FKL: {
+            const float e = expf(g - 1.f);
+            if (D) { lx = -x; lg = e; dx = -ib; dg = ib * e; }
+            else   { lg = -e; dg = -(ib * e); }
+            break;
+        }
+        case GM_LOSS_F_RKL:
+            if (D) { const float e = expf(x); lx = e; lg = -1.f - g; dx = ib * e; dg = -ib; }
+            else   { lg = -(-1.f - g); dg = ib; }
+            break;
+        case GM_LOSS_F_PEARSON: {
+            const float q = 0.25f * (g * g) + g;
+            if (D) { lx = -x; lg = q; dx = -ib; dg = ib * (0.5f * g + 1.f); }
+            else   { lg = -q; dg = -(ib * (0.5f * g + 1.f)); }
+            break;
+        }
+        case GM_LOSS_F_HELLINGER: {
+            const float eg = expf(g);
+            const float h = (1.f - eg) / eg;                    // = exp(-g) - 1
+            if (D) { const float ex = expf(x);
+                     lx = -(1.f - ex); lg = h; dx = ib * ex; dg = -(ib / eg); }
+            else   { lg = -h; dg = ib / eg; }
+            break;
+        }
+        case GM_LOSS_F_JS: {
+            const float eg = expf(g);
+            if (D) { const float enx = expf(-x);
+                     lx = -(2.f - (1.f + enx)); lg = -(2.f - eg);
+                     dx = -(ib * enx); dg = ib * eg; }
+            else   { lg = 2.f - eg; dg = -(ib * eg); }
+            break;
+        }
+        default: break;
+        }
+        acc += (double)lx + (double)lg;
+        if (D && p.dax) p.dax[i] = act_grad(dx, x, p.out_act);
+        if (p.dag) p.dag[i] = act_grad(dg, g, p.out_act);
+    }
+    (void)extra;
+    const double tot = block_sum(acc, sh);
+    if (t == 0) p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot * (double)ib);
+}
+
+}  // namespace
+
+extern "C" int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx,
+                           const float* sg, int B, int out_act, const float* hyper, int n_hyper,
+                           float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
+                           float* aux_io) {
+    GM_CHECK_ARG(sg && loss_out && B > 0 && n_hyper >= 0 && n_hyper <= 8);
+    GM_CHECK_ARG(variant >= GM_LOSS_NS && variant <= GM_LOSS_F_JS);
+    GM_CHECK_ARG(gen_mode || (sx && dax && dag));
+    GM_CHECK_ARG(!(variant == GM_LOSS_FISHER && !gen_mode) || aux_io);
+    LossP p{};
+    p.variant = variant; p.gen_mode = gen_mode; p.B = B; p.out_act = out_act;
+    p.sx = sx; p.sg = sg; p.inv_b = inv_b;
+    for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
+    p.loss_out = loss_out; p.loss_slot = loss_slot; p.dax = dax; p.dag = dag; p.aux = aux_io;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// K7 Adam on a flat buffer, arithmetic order of torch _single_tensor_adam:
+//   g = grad + wd*p ; m += (1-b1)*(g-m) ; v = v*b2 + (1-b2)*g*g ;
+//   denom = sqrt(v)/bc2_sqrt + eps ; p += (-step_size) * m / denom ; optional clamp (w_gan.py:241)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
+                                                  const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v,
+                                                  int64_t n, const float* __restrict__ sched,
+                                                  gm_slot sched_slot, float one_minus_b1, float b2,
+                                                  float one_minus_b2, float eps, float wd,
+                                                  float clamp) {
+    const int64_t si = gm_slot_index(sched_slot);
+    const float step_size = sched[2 * si], bc2_sqrt = sched[2 * si + 1];
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        if (wd != 0.f) gg = gg + wd * pp;
+        mm = mm + one_minus_b1 * (gg - mm);
+        vv = vv * b2;
+        vv = vv + (one_minus_b2 * gg) * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp = pp + ((-step_size) * mm) / denom;
+        if (clamp > 0.f) pp = fminf(fmaxf(pp, -clamp), clamp);
+    };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y);
+        upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        upd(p[i], g[i], m[i], v[i]);
+}
+
+extern "C" int gm_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                       const float* sched, gm_slot sched_slot, float beta1, float beta2, float eps,
+                       float weight_decay, float clamp) {
+    GM_CHECK_ARG(p && g && m && v && sched && n > 0);
+    GM_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                   reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    // python: 1 - beta1 evaluated in double, then cast to the op's fp32 scalar
+    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       sched, sched_slot, omb1, beta2, omb2, eps, weight_decay, clamp);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// activation backward (general autograd path)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dY,
+                                                     const float* __restrict__ Y,
+                                                     float* __restrict__ dA, int64_t n, int act) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dA[i] = act_grad(dY[i], Y[i], act);
+}
+
+extern "C" int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t n,
+                          int act) {
+    GM_CHECK_ARG(dY && Y && dA && n > 0);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dY, Y, dA,
+                       n, act);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// HOST: O(B) prefix of torch.randperm(n) for a freshly seeded CPU generator (see gm_hip.h)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Mt19937 {
+    uint32_t s[624];
+    int pos;
+    explicit Mt19937(uint32_t seed) {
+        s[0] = seed;
+        for (int j = 1; j < 624; ++j) s[j] = 1812433253u * (s[j - 1] ^ (s[j - 1] >> 30)) + j;
+        pos = 624;
+    }
+    void twist() {
+        for (int k = 0; k < 624; ++k) {
+            const uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
+            s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        pos = 0;
+    }
+    uint32_t next() {
+        if (pos >= 624) twist();
+        uint32_t y = s[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+};
+}  // namespace
+
+extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out) {
+    GM_CHECK_ARG(out && n > 0 && B > 0 && B <= n && n < (int64_t)(0xffffffffu / 20));
+    Mt19937 rng((uint32_t)(seed & 0xffffffffu));
+    // sparse view of the permutation array r[] (identity except for touched entries):
+    // open-addressing table of (key, value), capacity >= 4B, power of two.
+    size_t cap = 16;
+    while (cap < (size_t)B * 4) cap <<= 1;
+    std::string storage(cap * 2 * sizeof(int64_t), '\0');
+    int64_t* keys = reinterpret_cast<int64_t*>(&storage[0]);
+    int64_t* vals = keys + cap;
+    for (size_t i = 0; i < cap; ++i) keys[i] = -1;
+    auto find = [&](int64_t k) -> size_t {
+        size_t h = (size_t)((uint64_t)k * 0x9E3779B97F4A7C15ull) & (cap - 1);
+        while (keys[h] != -1 && keys[h] != k) h = (h + 1) & (cap - 1);
+        return h;
+    };
+    auto get = [&](int64_t k) -> int64_t { size_t h = find(k); return keys[h] == k ? vals[h] : k; };
+    auto put = [&](int64_t k, int64_t v) { size_t h = find(k); keys[h] = k; vals[h] = v; };
+    for (int64_t i = 0; i < B; ++i) {
+        if (i < n - 1) {
+            const int64_t z = (int64_t)(rng.next() % (uint64_t)(n - i));
+            const int64_t j = i + z;
+            const int64_t vi = get(i), vj = get(j);
+            put(i, vj);
+            put(j, vi);
+            out[i] = vj;
+        } else {
+            out[i] = get(i);          // last element of a full permutation: no draw
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// HIP graph + event helpers
+// ------------------------------------------------------------------------------------------
+#define GM_HIP(call)                                              \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) {                                  \
+            gm_set_error(hipGetErrorString(e__));                 \
+            return -(int)e__;                                     \
+        }                                                         \
+    } while (0)
+
+extern "C" int gm_graph_begin(void* stream) {
+    GM_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int gm_graph_end(void* stream, void** graph_exec_out) {
+    GM_CHECK_ARG(graph_exec_out);
+    hipGraph_t graph = nullptr;
+    GM_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { gm_set_error(hipGetErrorString(e)); return -(int)e; }
+    *graph_exec_out = (void*)exec;
+    return 0;
+}
+extern "C" int gm_graph_launch(void* graph_exec, void* stream) {
+    GM_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int gm_graph_destroy(void* graph_exec) {
+    if (graph_exec) GM_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+extern "C" int gm_event_create(void** ev_out) {
+    GM_CHECK_ARG(ev_out);
+    hipEvent_t ev;
+    GM_HIP(hipEventCreate(&ev));
+    *ev_out = (void*)ev;
+    return 0;
+}
+extern "C" int gm_event_record(void* ev, void* stream) {
+    GM_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int gm_event_sync(void* ev) {
+    GM_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
+extern "C" int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+    GM_CHECK_ARG(ms_out);
+    GM_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return 0;
+}
+extern "C" int gm_event_destroy(void* ev) {
+    if (ev) GM_HIP(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}

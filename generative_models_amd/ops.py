@@ -1,0 +1,266 @@
+"""Tensor-level wrappers over the C-ABI (include/gm_hip.h) + autograd Functions.
+
+Everything here launches hand-written gfx950 kernels from libgm_hip.so on torch's current HIP
+stream.  PyTorch only owns the memory.  No op has a torch-eager fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, LOSS, NO_SLOT, Slot, slot  # noqa: F401  (re-exported)
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise _lib.GMError("%s must be a float32 device tensor (got %s on %s)" %
+                           (name, t.dtype, t.device))
+    return t
+
+
+def _ld(t):
+    """Leading dimension of a 2-D (or 1-D treated as a column) row-major view."""
+    if t.dim() == 1:
+        return 1
+    if t.stride(1) != 1:
+        raise _lib.GMError("inner dimension must be contiguous")
+    return t.stride(0)
+
+
+# ---- raw ops (pointers may be offset views; M/K/N given explicitly) -------------------------
+def linear_fwd(x, W, b, y, act, M=None, x_slot=NO_SLOT, stream=None):
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b).  ns_gan.py:44-45,58-59."""
+    N, K = W.shape
+    M = x.shape[0] if M is None else M
+    _lib.call("gm_linear_fwd", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x), x_slot,
+              _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
+              _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act] if not isinstance(act, int) else act)
+    return y
+
+
+def linear_bwd_dx(dA, W, dX, below=None, epi="id", M=None, stream=None):
+    """dX[M,K] = dA[M,N] @ W[N,K] (* act'(below))."""
+    N, K = W.shape
+    M = dA.shape[0] if M is None else M
+    _lib.call("gm_linear_bwd_dx", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+              W.data_ptr(), _chk(dX, "dX").data_ptr(), _ld(dX),
+              below.data_ptr() if below is not None else None,
+              _ld(below) if below is not None else 0, M, K, N,
+              ACT[epi] if not isinstance(epi, int) else epi)
+    return dX
+
+
+def linear_bwd_dw(dA, X, dW, db, M=None, accumulate=False, x_slot=NO_SLOT, stream=None):
+    """dW[N,K] (+)= dA[M,N]^T @ X[M,K]; db[N] (+)= colsum(dA)."""
+    N, K = dW.shape
+    M = dA.shape[0] if M is None else M
+    _lib.call("gm_linear_bwd_dw", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+              _chk(X, "X").data_ptr(), _ld(X), x_slot, dW.data_ptr(),
+              db.data_ptr() if db is not None else None, M, K, N, 1 if accumulate else 0)
+
+
+def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
+    """out[b,:] = data[idx[b],:]  (process_batch, ns_gan.py:222-226)."""
+    n_rows, row = data.shape
+    B = out.shape[0] if B is None else B
+    assert idx.dtype == torch.int64 and idx.is_cuda
+    _lib.call("gm_gather_rows", stream or stream_ptr(), data.data_ptr(), n_rows, idx.data_ptr(),
+              idx_slot, out.data_ptr(), _ld(out), B, row)
+    return out
+
+
+def gan_loss(variant, gen_mode, sx, sg, B, out_act, loss_out, dax, dag, hyper=(), inv_b=None,
+             loss_slot=NO_SLOT, aux=None, stream=None):
+    """Adversarial loss + d(loss)/d(pre-activation score).  SURVEY.md appendix A.2."""
+    h = (ctypes.c_float * 8)(*([float(x) for x in hyper] + [0.0] * (8 - len(hyper))))
+    inv_b = float(np.float32(1.0) / np.float32(B)) if inv_b is None else float(inv_b)
+    _lib.call("gm_gan_loss", stream or stream_ptr(), LOSS[variant] if isinstance(variant, str) else variant,
+              1 if gen_mode else 0, sx.data_ptr() if sx is not None else None, sg.data_ptr(), B,
+              ACT[out_act] if not isinstance(out_act, int) else out_act, h, len(hyper), inv_b,
+              loss_out.data_ptr(), loss_slot, dax.data_ptr() if dax is not None else None,
+              dag.data_ptr() if dag is not None else None,
+              aux.data_ptr() if aux is not None else None)
+
+
+def adam(p, g, m, v, sched, sched_slot=NO_SLOT, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+         clamp=0.0, stream=None):
+    """Flat Adam step, torch _single_tensor_adam order."""
+    _lib.call("gm_adam", stream or stream_ptr(), p.data_ptr(), g.data_ptr(), m.data_ptr(),
+              v.data_ptr(), p.numel(), sched.data_ptr(), sched_slot, betas[0], betas[1], eps,
+              weight_decay, clamp)
+
+
+def act_bwd(dY, Y, dA, act, stream=None):
+    _lib.call("gm_act_bwd", stream or stream_ptr(), dY.data_ptr(), Y.data_ptr(), dA.data_ptr(),
+              dY.numel(), ACT[act])
+    return dA
+
+
+def tick(ctr, inc=1, stream=None):
+    _lib.call("gm_tick", stream or stream_ptr(), ctr.data_ptr(), inc)
+
+
+def adam_schedule(lr, n_steps, betas=(0.9, 0.999), start=1):
+    """Per-step scalars exactly as torch computes them in Python doubles (adam.py:531-536):
+    step_size = lr / (1 - b1**step), bc2_sqrt = (1 - b2**step) ** 0.5; cast to fp32 like the
+    scalar operands of addcdiv_/div.  Returns float32 [n_steps, 2]."""
+    out = np.empty((n_steps, 2), dtype=np.float32)
+    for i in range(n_steps):
+        step = start + i
+        bc1 = 1 - betas[0] ** step
+        bc2 = 1 - betas[1] ** step
+        out[i, 0] = lr / bc1
+        out[i, 1] = bc2 ** 0.5
+    return out
+
+
+def randperm_prefix(seed, n, B, out=None):
+    """HOST: first B entries of torch.randperm(n, generator=Generator().manual_seed(seed))."""
+    if out is None:
+        out = np.empty(B, dtype=np.int64)
+    _lib.call("gm_randperm_prefix", seed & 0xFFFFFFFFFFFFFFFF, n, B, out.ctypes.data)
+    return out
+
+
+# ---- HIP graph wrapper --------------------------------------------------------------------
+class Graph:
+    """A captured sequence of gm_* launches (hipGraph).  Capture happens on a side stream."""
+
+    def __init__(self):
+        self.exec = None
+        self._stream = torch.cuda.Stream()
+
+    def capture(self, fn):
+        s = self._stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            _lib.call("gm_graph_begin", s.cuda_stream)
+            try:
+                fn(s.cuda_stream)
+            finally:
+                out = ctypes.c_void_p()
+                _lib.call("gm_graph_end", s.cuda_stream, ctypes.byref(out))
+            self.exec = out
+        torch.cuda.current_stream().wait_stream(s)
+        return self
+
+    def launch(self, stream=None):
+        _lib.call("gm_graph_launch", self.exec, stream or stream_ptr())
+
+    def __del__(self):
+        try:
+            if self.exec:
+                _lib.load().gm_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    """HIP event on an explicit stream (bench.py roofline timing)."""
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        _lib.call("gm_event_create", ctypes.byref(self.h))
+
+    def record(self, stream=None):
+        _lib.call("gm_event_record", self.h, stream or stream_ptr())
+
+    def sync(self):
+        _lib.call("gm_event_sync", self.h)
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float()
+        _lib.call("gm_event_elapsed_ms", self.h, stop.h, ctypes.byref(ms))
+        return ms.value
+
+
+# ---- general autograd path (user-overridden train_D / train_G; README.md:29-31) -----------
+class _MM(torch.autograd.Function):
+    """C = op(A, B) for the three GEMM layouts; closed under differentiation, so arbitrary-order
+    autograd (WGAN-GP style create_graph=True) works on top of the HIP kernels.
+    kind: 'nt' A[M,K] B[N,K]^T ; 'nn' A[M,N] B[N,K] ; 'tn' A[M,N]^T B[M,K]."""
+
+    @staticmethod
+    def forward(ctx, A, B, kind):
+        A, B = A.contiguous(), B.contiguous()
+        ctx.kind = kind
+        ctx.save_for_backward(A, B)
+        if kind == "nt":
+            C = torch.empty(A.shape[0], B.shape[0], device=A.device)
+            linear_fwd(A, B, None, C, "id")
+        elif kind == "nn":
+            C = torch.empty(A.shape[0], B.shape[1], device=A.device)
+            linear_bwd_dx(A, B, C)
+        else:
+            C = torch.empty(A.shape[1], B.shape[1], device=A.device)
+            linear_bwd_dw(A, B, C, None)
+        return C
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        k = ctx.kind
+        gA = gB = None
+        if k == "nt":      # C = A B^T
+            if ctx.needs_input_grad[0]: gA = _MM.apply(G, B, "nn")
+            if ctx.needs_input_grad[1]: gB = _MM.apply(G, A, "tn")
+        elif k == "nn":    # C = A B
+            if ctx.needs_input_grad[0]: gA = _MM.apply(G, B, "nt")
+            if ctx.needs_input_grad[1]: gB = _MM.apply(A, G, "tn")
+        else:              # C = A^T B
+            if ctx.needs_input_grad[0]: gA = _MM.apply(B, G, "nt")
+            if ctx.needs_input_grad[1]: gB = _MM.apply(A, G, "nn")
+        return gA, gB, None
+
+
+class _FusedLinear(torch.autograd.Function):
+    """y = act(x W^T + b) with the fused forward kernel; first-order backward on HIP kernels,
+    higher-order through _MM."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        x = x.contiguous()
+        y = torch.empty(x.shape[0], W.shape[0], device=x.device)
+        linear_fwd(x, W, b, y, act)
+        ctx.act = act
+        ctx.save_for_backward(x, W, y)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        act = ctx.act
+        if torch.is_grad_enabled():        # create_graph=True: stay differentiable
+            if act == "relu":
+                dA = gy * (y > 0).to(gy.dtype)
+            elif act == "sigmoid":
+                dA = gy * (1 - y) * y
+            else:
+                dA = gy
+            gx = _MM.apply(dA, W, "nn") if ctx.needs_input_grad[0] else None
+            gW = _MM.apply(dA, x, "tn") if ctx.needs_input_grad[1] else None
+            gb = dA.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return gx, gW, gb, None
+        gy = gy.contiguous()
+        dA = gy if act in ("id", None) else act_bwd(gy, y, torch.empty_like(gy), act)
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            linear_bwd_dx(dA, W, gx)
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(W)
+            gb = torch.empty(W.shape[0], device=W.device) if ctx.has_bias else None
+            linear_bwd_dw(dA, x, gW, gb)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = dA.sum(0)
+        return gx, gW, gb, None
+
+
+def fused_linear(x, weight, bias, act):
+    """Drop-in for act(F.linear(x, weight, bias)) on device tensors."""
+    return _FusedLinear.apply(x, weight, bias, act)

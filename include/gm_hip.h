@@ -1,0 +1,134 @@
+/*
+ * gm_hip.h -- C-ABI of libgm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the hot
+ * path of shayneobrien/generative-models (GAN Trainer.train/train_D/train_G, VAE compute_batch).
+ *
+ * The reference has no FFI of its own: its hot path bottoms out in
+ * PyTorch ops.  Each entry point below therefore cites the reference call site whose torch op(s)
+ * it replaces.  Conventions (all entry points):
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     asynchronous on it and allocation-free, so it can be captured into a hipGraph;
+ *   - all pointers are raw DEVICE pointers owned by the caller (PyTorch), fp32 unless noted,
+ *     matrices row-major with explicit leading dimensions in elements;
+ *   - return 0 on success, a negative hipError_t on a launch error, GM_EINVAL on bad arguments;
+ *   - nothing here falls back to a CPU path.
+ *
+ * "slot" arguments (ctr, mul, add, ring, stride): graph-replayable addressing of per-step data.
+ * The effective pointer is  base + ((ctr ? *ctr : 0) * mul + add) % ring * stride  (ring <= 0
+ * means no modulo).  `ctr` is a device int64 advanced by gm_tick() once per replayed graph, so a
+ * captured graph walks through prefetched index / noise rings and the Adam step table without
+ * host involvement.
+ */
+#ifndef GM_HIP_H
+#define GM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_EINVAL (-10001)
+
+/* activations (Generator/Discriminator.forward: ns_gan.py:43-46,57-60; w_gp_gan.py:59-62;
+ * be_gan.py:73-76) */
+enum { GM_ACT_ID = 0, GM_ACT_RELU = 1, GM_ACT_SIGMOID = 2 };
+
+/* GAN loss variants */
+enum {
+    GM_LOSS_NS = 0,      /* ns_gan.py:191-192,214   (also InfoGAN D/G, DRAGAN first-order, RaGAN G) */
+    GM_LOSS_MM = 1,      /* mm_gan.py:215-216,235 */
+    GM_LOSS_W = 2,       /* w_gan.py:208,227 ; w_gp_gan.py:218 (first-order part),237 */
+    GM_LOSS_LS = 3,      /* ls_gan.py:192-193,213 */
+    GM_LOSS_RA = 4,      /* ra_gan.py:204-205 (D) ; :227 (G = NS) */
+    GM_LOSS_FISHER = 5,  /* fisher_gan.py:214-223 (D) ; :246 (G) */
+    GM_LOSS_F_TV = 6, GM_LOSS_F_FKL = 7, GM_LOSS_F_RKL = 8, GM_LOSS_F_PEARSON = 9,
+    GM_LOSS_F_HELLINGER = 10, GM_LOSS_F_JS = 11   /* f_gan.py:99-142 */
+};
+
+typedef struct gm_slot {
+    const int64_t* ctr;   /* device counter or NULL */
+    int32_t mul, add, ring;
+    int64_t stride;       /* elements */
+} gm_slot;
+
+/* ---- library ------------------------------------------------------------------------- */
+int gm_version(void);
+const char* gm_arch(void);                 /* "gfx950" */
+const char* gm_last_error(void);
+
+/* ---- per-graph tick: *ctr += inc (one thread).  Replaces the Python loop counters of
+ * Trainer.train (ns_gan.py:117-126). */
+int gm_tick(void* stream, int64_t* ctr, int64_t inc);
+
+/* ---- K1: batch gather.  Replaces DataLoader collate in process_batch (ns_gan.py:222-226):
+ * out[b,:] = data[idx[b],:].  idx is int64 [B] at slot `idx_slot`. */
+int gm_gather_rows(void* stream, const float* data, int64_t n_rows, const int64_t* idx,
+                   gm_slot idx_slot, float* out, int64_t ld_out, int B, int row_elems);
+
+/* ---- K2/K3: Y[M,N] = act(X[M,K] * W[N,K]^T + bias[N]).  Replaces nn.Linear + F.relu /
+ * torch.sigmoid (ns_gan.py:44-45,58-59).  X may live in a ring (noise: ns_gan.py:218-220). */
+int gm_linear_fwd(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                  const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act);
+
+/* ---- K5/K6: dX[M,K] = dA[M,N] * W[N,K], then times act'(below) where `below` is the output
+ * of the layer that produced X (epi: GM_ACT_ID none, GM_ACT_RELU mask below>0,
+ * GM_ACT_SIGMOID below*(1-below)).  Replaces autograd's AddmmBackward + Relu/SigmoidBackward
+ * inside Tensor.backward() (ns_gan.py:138,155). */
+int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
+                     int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
+                     int epi);
+
+/* ---- K5: dW[N,K] (=|+=) dA[M,N]^T * X[M,K];  db[N] (=|+=) sum_m dA[m,:] (db may be NULL).
+ * Replaces autograd's weight/bias gradient accumulation (ns_gan.py:138,155). */
+int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
+                     gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate);
+
+/* ---- K4: adversarial loss + its gradient w.r.t. the critic's PRE-activation output.
+ * sx,sg: [B] post-activation scores D(x), D(G(z)) (sx NULL in generator mode).
+ * out_act: activation that produced the scores (sigmoid, or relu for WGAN-GP).
+ * hyper: host array of up to 8 floats (LS: a,b,c ; Fisher: rho).
+ * inv_b: fp32 1/B used for every mean and its gradient (1/B_global under data parallelism).
+ * loss_out[slot]: scalar loss.  dax/dag: [B] gradients (dax NULL in generator mode).
+ * aux_io: device scratch/state (Fisher: lambda, moments; RaGAN: mean) or NULL.
+ * Replaces the torch elementwise/mean ops in train_D / train_G (appendix A.2 table). */
+int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx, const float* sg, int B,
+                int out_act, const float* hyper, int n_hyper, float inv_b, float* loss_out,
+                gm_slot loss_slot, float* dax, float* dag, float* aux_io);
+
+/* ---- K7 (+K8): Adam over one flat parameter buffer, exactly torch's _single_tensor_adam
+ * (SURVEY.md section 3.5).  sched: device float2 table {step_size = lr/bc1, bc2_sqrt} indexed by
+ * slot (the optimizer step number); clamp > 0 applies p = clamp(p, -clamp, clamp) afterwards
+ * (w_gan.py:241-243).  Replaces optim.Adam.step (ns_gan.py:139,156). */
+int gm_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+            const float* sched, gm_slot sched_slot, float beta1, float beta2, float eps,
+            float weight_decay, float clamp);
+
+/* ---- elementwise activation backward for the general autograd path:
+ * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */
+int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t n, int act);
+
+/* ---- HOST helper (no device work): first B entries of torch.randperm(n, generator=
+ * Generator().manual_seed(seed)) in O(B): RandomSampler.__iter__ (torch/utils/data/sampler.py:160-185)
+ * feeding process_batch (ns_gan.py:222-226).  mt19937 seeded with the low 32 bits of `seed`,
+ * forward Fisher-Yates `z = random() % (n-i); swap(r[i], r[i+z])` as in ATen randperm_cpu.
+ * Bit-exact sampling indices without materialising the 50 000-entry permutation. */
+int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out_host);
+
+/* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ------------------ */
+int gm_graph_begin(void* stream);
+int gm_graph_end(void* stream, void** graph_exec_out);
+int gm_graph_launch(void* graph_exec, void* stream);
+int gm_graph_destroy(void* graph_exec);
+
+/* ---- timing helpers for bench.py (HIP events on the launch stream) --------------------- */
+int gm_event_create(void** ev_out);
+int gm_event_record(void* ev, void* stream);
+int gm_event_sync(void* ev);
+int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
+int gm_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GM_HIP_H */
