@@ -45,8 +45,18 @@ _SIGNATURES = {
                                  c_int]),
     "gm_gan_loss": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, POINTER(c_float), c_int,
                             c_float, _P, Slot, _P, _P, _P]),
-    "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, c_float, c_float, c_float, c_float,
-                        c_float]),
+    "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, ctypes.c_double, ctypes.c_double,
+                        ctypes.c_double, ctypes.c_double, c_float]),
+    "gm_interp": (c_int, [_P, _P, Slot, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int]),
+    "gm_gp_u": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int]),
+    "gm_gp_norm": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_float, c_float, c_float, c_int,
+                           c_int]),
+    "gm_gp_dw2": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
+    "gm_vae_reparam": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, Slot, c_int, c_int]),
+    "gm_vae_reparam_bwd": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int64, c_int,
+                                   c_int]),
+    "gm_sqerr_sigmoid_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
+    "gm_sum_finalize": (c_int, [_P, _P, c_int, c_float, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_graph_begin": (c_int, [_P]),

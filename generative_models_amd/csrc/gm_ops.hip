@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
             break;
         case GM_LOSS_W:
         case GM_LOSS_FISHER:   // generator mode only reaches here: -mean(sg)
-            if (D) { lx = -x; lg = g; dx = -ib; dg = ib; }
+            if (D) { lx = -x; lg = g; dx = -ib; dg = ib;
+                     // WGAN-GP: + lambda * mean((||grad|| - 1)^2), per-row terms in aux
+                     // (w_gp_gan.py:215-218; rows produced by gm_gp_norm)
+                     if (p.aux) lx += p.hyper[0] * p.aux[i]; }
             else   { lg = -g; dg = -ib; }
             break;
         case GM_LOSS_LS: {
@@ -321,18 +324,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
 }
 
 extern "C" int gm_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
-                       const float* sched, gm_slot sched_slot, float beta1, float beta2, float eps,
-                       float weight_decay, float clamp) {
+                       const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                       double eps, double weight_decay, float clamp) {
     GM_CHECK_ARG(p && g && m && v && sched && n > 0);
     GM_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                    reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     // python: 1 - beta1 evaluated in double, then cast to the op's fp32 scalar
-    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       sched, sched_slot, omb1, beta2, omb2, eps, weight_decay, clamp);
+                       sched, sched_slot, omb1, (float)beta2, omb2, (float)eps, (float)weight_decay,
+                       clamp);
     GM_LAUNCH_RET();
 }
 

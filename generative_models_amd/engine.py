@@ -1,0 +1,383 @@
+"""Fused-step engines: the reference's Trainer.train inner loop (ns_gan.py:117-160 and siblings;
+vae.py:144-167) re-designed for MI355X.
+
+Reference per step: DataLoader reshuffle on the host, 3 H2D copies, ~60 tiny autograd ops,
+two `.item()` syncs.  Here, per iteration:
+
+  host   : replays the reference's global-CPU-generator draw order ahead
+           of time into pinned staging buffers -- sampler seed -> O(B) randperm prefix
+           (gm_randperm_prefix), noise/eps via the same torch CPU generator calls -- one H2D copy
+           per CHUNK of iterations;
+  device : one hipGraph replay per iteration (D_steps critic steps + 1 generator step): gather,
+           MFMA GEMMs with fused bias/activation/activation-gradient epilogues, loss + score
+           gradient, flat Adam.  A device counter advanced by the graph itself selects the ring
+           slot / Adam-schedule row / loss slot, so replays need no host-side arguments;
+  sync   : none until the epoch ends (losses are read back in one copy).
+
+Only the wasted work of the reference is skipped (G gradients during the D
+step, D gradients during the G step); every observable -- parameters, loss lists, RNG stream
+position -- matches the reference."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import GMError
+
+CHUNK = 64          # iterations prefetched per host->device upload
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatParams:
+    """Packs nn.Parameters into one flat fp32 device buffer (16-byte aligned segments) and
+    re-points `.data` at views of it, so one Adam launch / one all-reduce bucket covers the net.
+    The nn.Linear modules stay the parameter holders (state_dict keys)."""
+
+    def __init__(self, params, device):
+        self.params = list(params)
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += _align4(p.numel())
+        self.n = n
+        self.offsets = offs
+        self.flat = torch.zeros(n, device=device)
+        self.grad = torch.zeros(n, device=device)
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.views, self.gviews = [], []
+        for p, o in zip(self.params, offs):
+            v = self.flat[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.views.append(v)
+            self.gviews.append(self.grad[o:o + p.numel()].view(p.shape))
+
+    def still_bound(self):
+        return all(p.data.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def rebind(self):
+        """If the user replaced parameter storage (load_state_dict keeps it; .to() may not)."""
+        for p, v in zip(self.params, self.views):
+            if p.data.data_ptr() != v.data_ptr():
+                v.copy_(p.data)
+                p.data = v
+
+    def reset_state(self):
+        self.m.zero_()
+        self.v.zero_()
+
+    def expose_grads(self):
+        for p, g in zip(self.params, self.gviews):
+            p.grad = g
+
+
+class _Linear:
+    """Raw views of one nn.Linear inside a FlatParams (weights, bias, and their grads)."""
+
+    def __init__(self, fp, lin):
+        iw = [i for i, p in enumerate(fp.params) if p is lin.weight][0]
+        ib = [i for i, p in enumerate(fp.params) if p is lin.bias][0]
+        self.W, self.b = fp.views[iw], fp.views[ib]
+        self.gW, self.gb = fp.gviews[iw], fp.gviews[ib]
+
+
+# --------------------------------------------------------------------------------------------
+# Host RNG protocol (parity mode).  Every draw below comes from torch's GLOBAL CPU generator in
+# the reference's order, so after train() the generator is exactly where the reference leaves it.
+# --------------------------------------------------------------------------------------------
+def draw_sampler_indices(n, B, out):
+    """One `next(iter(DataLoader(shuffle=True)))`: dataloader.py:706-710 (base seed, unused),
+    sampler.py:163-165 (sampler seed), then the first B of randperm(n) on a private generator."""
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    ops.randperm_prefix(seed, n, B, out)
+    return seed
+
+
+class GANEngine:
+    """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
+    (ns, mm, w, ls, ra, f, fisher, wgp)."""
+
+    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp")
+
+    def __init__(self, variant, model, data, B, device, method=None, use_graph=True,
+                 world_size=1, rank=0, process_group=None):
+        assert variant in self.SUPPORTED, variant
+        self.variant, self.model, self.device = variant, model, device
+        self.method = method
+        self.loss_key = ("f_" + method) if variant == "f" else ("w" if variant == "wgp" else variant)
+        self.out_act = "relu" if variant == "wgp" else "sigmoid"
+        self.B = B                         # GLOBAL batch (reference semantics)
+        self.world, self.rank, self.pg = world_size, rank, process_group
+        assert B % world_size == 0, "global batch must divide across ranks"
+        self.Bl = B // world_size          # rows this rank computes
+        self.data = data                   # [N, I] fp32 on device
+        self.N, self.I = data.shape
+        G, D = model.G, model.D
+        self.fG = FlatParams(G.parameters(), device)
+        self.fD = FlatParams(D.parameters(), device)
+        g1, g2 = list(G.children())[:2]
+        d1, d2 = list(D.children())[:2]
+        self.G1, self.G2 = _Linear(self.fG, g1), _Linear(self.fG, g2)
+        self.D1, self.D2 = _Linear(self.fD, d1), _Linear(self.fD, d2)
+        self.Z = self.G1.W.shape[1]
+        self.H = self.G1.W.shape[0]
+        self.Hd_dim = self.D1.W.shape[0]
+        assert self.D2.W.shape[0] == 1, "score-based critics only"
+        self.use_graph = use_graph
+        Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
+        dev = device
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.X2 = z(2 * Bl, I)             # rows [0,Bl): real batch, [Bl,2Bl): G(z)
+        self.Hg = z(Bl, H)
+        self.Hd = z(2 * Bl, Hd)
+        self.S2 = z(2 * Bl)                # scores
+        self.dS = z(2 * Bl)                # d loss / d pre-activation score
+        self.dHd = z(2 * Bl, Hd)
+        self.dXg = z(Bl, I)
+        self.dHg = z(Bl, H)
+        self.aux = z(8)                    # Fisher lambda + moments
+        if variant == "wgp":
+            self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
+            self.U, self.Gr, self.Gam, self.T = z(Bl, Hd), z(Bl, I), z(Bl, I), z(Bl, Hd)
+            self.pen = z(Bl)
+        self.ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.graph = None
+        self._graph_key = None
+
+    # -- slots --------------------------------------------------------------------------------
+    def _slot(self, it, mul, add, ring, stride):
+        """Graph mode: resolved on device from the counter; eager mode: resolved here."""
+        if self.use_graph:
+            return ops.slot(self.ctr.data_ptr(), mul, add, ring, stride)
+        i = it * mul + add
+        if ring > 0:
+            i %= ring
+        return ops.slot(0, 0, i, 0, stride)
+
+    # -- one iteration = D_steps critic steps + one generator step -----------------------------
+    def _issue_iteration(self, st, it):
+        d = self.D_steps
+        for j in range(d):
+            self._issue_D(st, it, j)
+        self._issue_G(st, it)
+        if self.use_graph:
+            ops.tick(self.ctr, 1, stream=st)
+
+    def _allreduce(self, flat):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _issue_D(self, st, it, j):
+        Bl, d, R = self.Bl, self.D_steps, self.R
+        G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
+        X2, Hg, Hd, S2, dS, dHd = self.X2, self.Hg, self.Hd, self.S2, self.dS, self.dHd
+        r0 = self.rank * Bl                       # this rank's rows of the global batch
+        idx_slot = self._slot(it, d, j, R * d, self.B)
+        zD_slot = self._slot(it, d, j, R * d, self.B * self.Z)
+        ops.gather_rows(self.data, self.idx_ring.view(-1)[r0:], X2, B=Bl, idx_slot=idx_slot,
+                        stream=st)
+        zbase = self.zD_ring.view(-1)[r0 * self.Z:].view(-1, self.Z)
+        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=zD_slot, stream=st)
+        ops.linear_fwd(Hg, G2.W, G2.b, X2[Bl:], "sigmoid", M=Bl, stream=st)
+        ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
+        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
+        aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
+        if self.variant == "wgp":
+            self._issue_gp_forward(st, it, j)
+            aux, hyper = self.pen, (self.gp_lambda,)
+        ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
+                     dS[:Bl], dS[Bl:], hyper=hyper, inv_b=self.inv_b,
+                     loss_slot=self._slot(it, d, j, 0, 1), aux=aux, stream=st)
+        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
+        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
+        ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
+        if self.variant == "wgp":
+            self._issue_gp_backward(st)
+        self._allreduce(self.fD.grad)
+        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
+                 self._slot(it, d, j, 0, 1), clamp=self.clip, stream=st)
+
+    def _issue_G(self, st, it):
+        Bl, R = self.Bl, self.R
+        G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
+        Hg, Hd, S2, dS, dHd = self.Hg, self.Hd, self.S2, self.dS, self.dHd
+        Xg = self.X2[Bl:]
+        r0 = self.rank * Bl
+        zG_slot = self._slot(it, 1, 0, R, self.B * self.Z)
+        zbase = self.zG_ring.view(-1)[r0 * self.Z:].view(-1, self.Z)
+        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=zG_slot, stream=st)
+        ops.linear_fwd(Hg, G2.W, G2.b, Xg, "sigmoid", M=Bl, stream=st)
+        ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
+        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
+        ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
+                     hyper=self.hyper, inv_b=self.inv_b,
+                     loss_slot=self._slot(it, 1, self.g_off, 0, 1), stream=st)
+        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
+        ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
+        ops.linear_bwd_dw(self.dXg, Hg, G2.gW, G2.gb, M=Bl, stream=st)
+        ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
+        ops.linear_bwd_dw(self.dHg, zbase, G1.gW, G1.gb, M=Bl, x_slot=zG_slot, stream=st)
+        self._allreduce(self.fG.grad)
+        ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
+                 self._slot(it, 1, self.g_off, 0, 1), stream=st)
+
+    # -- WGAN-GP penalty: w_gp_gan.py:195-218, hand-derived second backward -----
+    def _issue_gp_forward(self, st, it, j):
+        from . import ops_fused as ops_gp
+        Bl, d, R = self.Bl, self.D_steps, self.R
+        D1, D2 = self.D1, self.D2
+        r0 = self.rank * Bl
+        eps_slot = self._slot(it, d, j, R * d, self.B)
+        ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
+                      stream=st)
+        ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
+        ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "relu", M=Bl, stream=st)
+        ops_gp.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)                  # u = m2*(m1.w2)
+        ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                # g = u W1
+        ops_gp.gp_norm(self.Gr, self.Gam, self.pen, self.gp_lambda, self.inv_b, stream=st)
+
+    def _issue_gp_backward(self, st):
+        from . import ops_fused as ops_gp
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        ops.linear_bwd_dw(self.U, self.Gam, D1.gW, None, M=Bl, accumulate=True, stream=st)
+        ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)      # gamma W1^T
+        ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
+
+    # -- host prefetch of one chunk of iterations ---------------------------------------------
+    def _alloc_rings(self, R):
+        d, B, Z, dev = self.D_steps, self.B, self.Z, self.device
+        self.R = R
+        self.idx_ring = torch.zeros(R * d, B, dtype=torch.int64, device=dev)
+        self.zD_ring = torch.zeros(R * d, B, Z, device=dev)
+        self.zG_ring = torch.zeros(R, B, Z, device=dev)
+        pin = lambda *s, **k: torch.zeros(*s, **k).pin_memory()
+        self.stage = []
+        for _ in range(2):
+            s = dict(idx=pin(R * d, B, dtype=torch.int64), zD=pin(R * d, B, Z), zG=pin(R, B, Z),
+                     event=None)
+            if self.variant == "wgp":
+                s["eps"] = pin(R * d, B)
+            self.stage.append(s)
+        if self.variant == "wgp":
+            self.eps_ring = torch.zeros(R * d, B, device=dev)
+
+    def _draw_D(self, s, k):
+        """Draws of one critic step in reference order (appendix A.4)."""
+        draw_sampler_indices(self.N, self.B, s["idx_np"][k])
+        s["zD"][k].normal_()                         # torch.randn(B, Z)   ns_gan.py:183,220
+        if self.variant == "wgp":
+            s["eps"][k].uniform_()                   # torch.rand(B, 1)    w_gp_gan.py:197
+
+    def _draw_G(self, s, k):
+        s["zG"][k].normal_()                         # ns_gan.py:208
+
+    def _prefetch(self, it0, n_it, which):
+        s = self.stage[which]
+        if s["event"] is not None:
+            s["event"].synchronize()                 # staging buffer free again?
+        if "idx_np" not in s:
+            s["idx_np"] = s["idx"].numpy()
+        d = self.D_steps
+        for i in range(n_it):
+            for j in range(d):
+                self._draw_D(s, i * d + j)
+            self._draw_G(s, i)
+        r = it0 % self.R                 # ring slot of the chunk's first iteration (n_it <= R - r)
+        self.idx_ring[r * d:(r + n_it) * d].copy_(s["idx"][:n_it * d], non_blocking=True)
+        self.zD_ring[r * d:(r + n_it) * d].copy_(s["zD"][:n_it * d], non_blocking=True)
+        self.zG_ring[r:r + n_it].copy_(s["zG"][:n_it], non_blocking=True)
+        if self.variant == "wgp":
+            self.eps_ring[r * d:(r + n_it) * d].copy_(s["eps"][:n_it * d], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        s["event"] = ev
+
+    # -- public: run `n_iters` iterations starting a fresh train() ----------------------------
+    def configure(self, n_iters, G_lr, D_lr, D_steps, clip=0.0, hyper=(), g_init=0,
+                  gp_lambda=10.0):
+        """Called once per train(): fresh Adam state (optimizers are locals of the reference's
+        train()), schedules, loss buffers, rings, graph."""
+        dev = self.device
+        self.D_steps, self.clip, self.hyper = D_steps, float(clip), tuple(hyper)
+        self.g_off = g_init
+        self.gp_lambda = float(gp_lambda)
+        self.inv_b = float(np.float32(1.0) / np.float32(self.B))
+        self.fG.rebind(); self.fD.rebind()
+        self.fG.reset_state(); self.fD.reset_state()
+        self.fG.grad.zero_(); self.fD.grad.zero_()
+        self.schedD = torch.from_numpy(ops.adam_schedule(D_lr, max(1, n_iters * D_steps))).to(dev)
+        self.schedG = torch.from_numpy(ops.adam_schedule(G_lr, n_iters + g_init)).to(dev)
+        self.lossD = torch.zeros(max(1, n_iters * D_steps), device=dev)
+        self.lossG = torch.zeros(n_iters + g_init, device=dev)
+        self.aux.zero_()
+        self.ctr.zero_()
+        R = max(1, min(CHUNK, n_iters))
+        key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph)
+        if getattr(self, "_ring_key", None) != (D_steps, R):
+            self._alloc_rings(R)
+            self._ring_key = (D_steps, R)
+            self._graph_key = None
+        # schedule / loss buffers are re-created per train(): pointers change => recapture
+        self._graph_key = None
+        self._key = key
+
+    def _ensure_graph(self):
+        if not self.use_graph or self._graph_key == self._key:
+            return
+        torch.cuda.synchronize()
+        self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
+        self._graph_key = self._key
+
+    def run(self, n_iters, it_start=0):
+        """Run iterations [it_start, it_start+n_iters) (chunked prefetch + graph replays)."""
+        if self.world > 1 and self.use_graph:
+            raise GMError("data-parallel runs use eager launches (RCCL collectives between ops)")
+        self._ensure_graph()
+        R = self.R
+        it, end, which = it_start, it_start + n_iters, 0
+        while it < end:
+            n = min(R - (it % R), end - it)
+            self._prefetch(it, n, which)
+            which ^= 1
+            if self.use_graph:
+                for _ in range(n):
+                    self.graph.launch()
+            else:
+                st = ops.stream_ptr()
+                for k in range(n):
+                    self._issue_iteration(st, it + k)
+            it += n
+
+    def g_init_steps(self, n):
+        """MMGAN pre-training (mm_gan.py:121-136): process_batch draws + G step, eager."""
+        s = self.stage[0]
+        if "idx_np" not in s:
+            s["idx_np"] = s["idx"].numpy()
+        saved_graph, saved_off = self.use_graph, self.g_off
+        self.use_graph = False
+        st = ops.stream_ptr()
+        for k in range(n):
+            draw_sampler_indices(self.N, self.B, s["idx_np"][0])    # images are unused by train_G
+            s["zG"][0].normal_()
+            self.zG_ring[0].copy_(s["zG"][0])
+            self.g_off = k
+            self._issue_G(st, 0)
+        torch.cuda.synchronize()
+        self.use_graph, self.g_off = saved_graph, saved_off
+
+    def losses(self, it0, it1):
+        """Per-iteration (G loss, mean D loss over D_steps) like ns_gan.py:142-154."""
+        d = self.D_steps
+        lg = self.lossG[self.g_off + it0:self.g_off + it1].cpu().numpy()
+        ld = self.lossD[it0 * d:it1 * d].cpu().numpy().reshape(-1, d)
+        G = [float(x) for x in lg]
+        D = [float(np.mean([float(v) for v in row])) for row in ld]
+        return G, D

@@ -1,0 +1,50 @@
+"""Tensor-level wrappers for the variant-specific fused kernels (csrc/gm_fused.hip)."""
+from . import _lib
+from ._lib import NO_SLOT
+from .ops import _ld, stream_ptr
+
+
+def interp(eps, eps_slot, x, g, out, stream=None):
+    """x_hat = eps*x + (1-eps)*g   (w_gp_gan.py:197-201)."""
+    B, I = out.shape
+    _lib.call("gm_interp", stream or stream_ptr(), eps.data_ptr(), eps_slot, x.data_ptr(), _ld(x),
+              g.data_ptr(), _ld(g), out.data_ptr(), _ld(out), B, I)
+
+
+def gp_u(s, h, w2, u, stream=None):
+    B, H = u.shape
+    _lib.call("gm_gp_u", stream or stream_ptr(), s.data_ptr(), h.data_ptr(), _ld(h), w2.data_ptr(),
+              u.data_ptr(), _ld(u), B, H)
+
+
+def gp_norm(g, gamma, pen, lam, inv_b, k=1.0, stream=None):
+    B, I = g.shape
+    _lib.call("gm_gp_norm", stream or stream_ptr(), g.data_ptr(), _ld(g), gamma.data_ptr(),
+              _ld(gamma), pen.data_ptr(), lam, inv_b, k, B, I)
+
+
+def gp_dw2(s, h, t, gw2, stream=None):
+    B, H = h.shape
+    _lib.call("gm_gp_dw2", stream or stream_ptr(), s.data_ptr(), h.data_ptr(), _ld(h), t.data_ptr(),
+              _ld(t), gw2.data_ptr(), B, H)
+
+
+def vae_reparam(ml, eps, z, kl_out, B, Z, eps_slot=NO_SLOT, kl_slot=NO_SLOT, stream=None):
+    _lib.call("gm_vae_reparam", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
+              eps_slot, z.data_ptr(), _ld(z), kl_out.data_ptr(), kl_slot, B, Z)
+
+
+def vae_reparam_bwd(ml, eps, dz, dml, B, Z, eps_slot=NO_SLOT, stream=None):
+    _lib.call("gm_vae_reparam_bwd", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
+              eps_slot, dz.data_ptr(), _ld(dz), dml.data_ptr(), _ld(dml), B, Z)
+
+
+def sqerr_sigmoid_bwd(x, xr, dA, partial, B, stream=None):
+    I = x.shape[1]
+    _lib.call("gm_sqerr_sigmoid_bwd", stream or stream_ptr(), x.data_ptr(), _ld(x), xr.data_ptr(),
+              _ld(xr), dA.data_ptr(), _ld(dA), partial.data_ptr(), B, I)
+
+
+def sum_finalize(partial, n, out, scale=1.0, out_slot=NO_SLOT, stream=None):
+    _lib.call("gm_sum_finalize", stream or stream_ptr(), partial.data_ptr(), n, scale,
+              out.data_ptr(), out_slot)

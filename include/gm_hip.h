@@ -99,10 +99,48 @@ int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx, const 
 /* ---- K7 (+K8): Adam over one flat parameter buffer, exactly torch's _single_tensor_adam
  * (SURVEY.md section 3.5).  sched: device float2 table {step_size = lr/bc1, bc2_sqrt} indexed by
  * slot (the optimizer step number); clamp > 0 applies p = clamp(p, -clamp, clamp) afterwards
- * (w_gan.py:241-243).  Replaces optim.Adam.step (ns_gan.py:139,156). */
+ * (w_gan.py:241-243).  betas/eps/weight_decay arrive as the Python doubles torch receives;
+ * 1-beta is formed in double and then cast to fp32, like torch's scalar operands.
+ * Replaces optim.Adam.step (ns_gan.py:139,156). */
 int gm_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
-            const float* sched, gm_slot sched_slot, float beta1, float beta2, float eps,
-            float weight_decay, float clamp);
+            const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
+            double weight_decay, float clamp);
+
+/* ---- K9: WGAN-GP interpolation  x_hat = eps*x + (1-eps)*G(z), eps [B] in a ring
+ * (w_gp_gan.py:197-201). */
+int gm_interp(void* stream, const float* eps, gm_slot eps_slot, const float* x, int64_t ldx,
+              const float* g, int64_t ldg, float* out, int64_t ldo, int B, int I);
+
+/* ---- K10 prologue: u[b,n] = [s_b>0]*[h[b,n]>0]*w2[n]: the vector that autograd.grad(D(x_hat),
+ * x_hat) (w_gp_gan.py:207-212) pushes through the ReLU critic; grad = u * W1 is then one
+ * gm_linear_bwd_dx call. */
+int gm_gp_u(void* stream, const float* s, const float* h, int64_t ldh, const float* w2, float* u,
+            int64_t ldu, int B, int H);
+
+/* ---- K11: per-row ||g||_2, penalty rows pen[b] = (n_b - k)^2 and
+ * gamma = d(lambda*mean((n-k)^2))/dg (0 where n_b == 0)  (w_gp_gan.py:215, dra_gan.py:220). */
+int gm_gp_norm(void* stream, const float* g, int64_t ldg, float* gamma, int64_t ldm, float* pen,
+               float lambda, float inv_b, float k, int B, int I);
+
+/* ---- K12 tail: gw2[n] += sum_b [s_b>0][h[b,n]>0]*t[b,n]  (second backward into w2; the dW1 term
+ * is gm_linear_bwd_dw(u, gamma, accumulate) and t = gamma*W1^T is gm_linear_fwd). */
+int gm_gp_dw2(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
+              int64_t ldt, float* gw2, int B, int H);
+
+/* ---- K14: VAE.  ml = [mu | log_var] (B x 2Z, the two encoder heads packed side by side).
+ * reparam: z = mu + eps*exp(lv/2) (vae.py:100-106), kl_out[slot] = sum 0.5*(mu^2+exp(lv)-lv-1)
+ * (vae.py:210-212).  reparam_bwd: d(recon+kl)/d[mu|lv] from dz.  sqerr: per-row sums of
+ * (x-xr)^2 (vae.py:203) + gradient w.r.t. the decoder's pre-sigmoid output. */
+int gm_vae_reparam(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
+                   float* z, int64_t ldz, float* kl_out, gm_slot kl_slot, int B, int Z);
+int gm_vae_reparam_bwd(void* stream, const float* ml, int64_t ldml, const float* eps,
+                       gm_slot eps_slot, const float* dz, int64_t lddz, float* dml, int64_t ldd,
+                       int B, int Z);
+int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, const float* xr, int64_t ldr,
+                         float* dA, int64_t lda, float* partial, int B, int I);
+/* out[slot] = scale * sum(partial[0..n)) in a fixed order (deterministic loss reductions). */
+int gm_sum_finalize(void* stream, const float* partial, int n, float scale, float* out,
+                    gm_slot out_slot);
 
 /* ---- elementwise activation backward for the general autograd path:
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */

@@ -1,0 +1,218 @@
+"""Trainer-level parity on the MI355X: the drop-in <Name>Trainer.train() (fused hipGraph engine)
+against (a) the CPU oracle (oracle/port.py) run here on identical seeds and (b) the committed
+golden fixtures generated from the unmodified reference.  Checked: per-step loss lists, final
+parameters, and that the global CPU generator ends in the same state (bit-exact draw protocol).
+
+Tolerance: 1e-5 (north_star) on losses relative to max(1,|loss|) over the free-running horizon
+used here (<= 24 steps; SURVEY.md section 4 explains why longer free-running horizons diverge
+chaotically even between two CPU summation orders); parameters 1e-5 absolute on O(0.1) weights.
+"""
+import glob
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(os.path.dirname(HERE), "generative_models_amd", "src")
+GOLDEN = os.path.join(HERE, "golden")
+sys.path.insert(0, SRC)
+
+from oracle import port  # noqa: E402
+
+MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "mm": ("mm_gan", "MMGAN", "MMGANTrainer"),
+        "w": ("w_gan", "WGAN", "WGANTrainer"), "wgp": ("w_gp_gan", "WGPGAN", "WGPGANTrainer"),
+        "ls": ("ls_gan", "LSGAN", "LSGANTrainer"), "ra": ("ra_gan", "RaNSGAN", "RaNSGANTrainer"),
+        "fisher": ("fisher_gan", "FisherGAN", "FisherGANTrainer"),
+        "f": ("f_gan", "fGAN", "fGANTrainer")}
+TOL = 1e-5
+
+
+def lclose(got, ref, what, tol=TOL):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= tol, "%s: max err %.3e at step %d\n got %s\n ref %s" % (
+        what, err.max(), int(err.argmax()), got[:6], ref[:6])
+
+
+def build_product(variant, cfg, batch, loaders=None, use_graph=True):
+    mod_name, model_name, trainer_name = MODS[variant]
+    mod = importlib.import_module(mod_name)
+    if loaders is None:
+        loaders = port.synthetic_loaders(batch, n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                         n_test=cfg["n_test"],
+                                         image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    model = getattr(mod, model_name)(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
+                                     z_dim=cfg["z_dim"])
+    tr = getattr(mod, trainer_name)(model, *loaders, viz=False)
+    tr.use_graph = use_graph
+    return tr, model
+
+
+def run_product(variant, cfg, batch, train_kw, use_graph=True, capped=None):
+    tr, model = build_product(variant, cfg, batch, use_graph=use_graph)
+    if capped is not None:
+        class Capped(torch.utils.data.DataLoader):
+            def __len__(self):
+                return capped
+        tr.train_iter = Capped(tr.train_iter.dataset, batch_size=batch, shuffle=True)
+    kw = dict(train_kw)
+    if variant == "f":
+        kw["method"] = kw.get("method", "jensen_shannon")
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**kw)
+    torch.cuda.synchronize()
+    return tr, model, torch.get_rng_state()
+
+
+def run_oracle(variant, cfg, batch, train_kw, max_steps=None):
+    loaders = port.synthetic_loaders(batch, n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    model = port.build(variant, cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    kw = dict(train_kw)
+    method = kw.pop("method", "jensen_shannon")
+    tr = port.GANPort(variant, model, loaders[0], method=method)
+    tr.train(max_steps=max_steps, **kw)
+    return tr, model, torch.get_rng_state()
+
+
+SMALL = dict(image_size=64, hidden_dim=48, z_dim=8, batch=16, n_train=160, n_val=48, n_test=48,
+             image_shape=(1, 8, 8))
+RAGGED = dict(image_size=100, hidden_dim=70, z_dim=10, batch=24, n_train=200, n_val=48, n_test=48,
+              image_shape=(1, 10, 10))
+
+CASES = [("ns", dict(num_epochs=2)), ("mm", dict(num_epochs=1, G_init=3)),
+         ("w", dict(num_epochs=1, D_steps=2)), ("ls", dict(num_epochs=2)),
+         ("ra", dict(num_epochs=1)), ("fisher", dict(num_epochs=1)),
+         ("wgp", dict(num_epochs=1, D_steps=1)), ("wgp", dict(num_epochs=1, D_steps=3))]
+
+
+@pytest.mark.parametrize("cfg", [SMALL, RAGGED], ids=["small", "ragged"])
+@pytest.mark.parametrize("variant,kw", CASES, ids=["%s%d" % (v, i) for i, (v, _) in enumerate(CASES)])
+def test_engine_vs_oracle(variant, kw, cfg):
+    o_tr, o_model, o_rng = run_oracle(variant, cfg, cfg["batch"], kw)
+    p_tr, p_model, p_rng = run_product(variant, cfg, cfg["batch"], kw)
+    lclose(p_tr.Dlosses, o_tr.Dlosses, "%s Dlosses" % variant)
+    lclose(p_tr.Glosses, o_tr.Glosses, "%s Glosses" % variant)
+    assert torch.equal(o_rng, p_rng), "global CPU generator must end in the reference's state"
+    osd, psd = o_model.state_dict(), p_model.state_dict()
+    assert list(osd.keys()) == list(psd.keys())
+    for k in osd:
+        err = (psd[k].cpu() - osd[k]).abs().max().item()
+        assert err <= 2e-5, (k, err)
+    assert p_tr.num_epochs == kw["num_epochs"]
+
+
+def test_eager_equals_graph():
+    """The hipGraph replay and the eager launch sequence are the same kernels: bitwise equal."""
+    a = run_product("ns", SMALL, 16, dict(num_epochs=2), use_graph=True)
+    b = run_product("ns", SMALL, 16, dict(num_epochs=2), use_graph=False)
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
+
+
+def test_run_to_run_determinism():
+    a = run_product("ls", SMALL, 16, dict(num_epochs=1))
+    b = run_product("ls", SMALL, 16, dict(num_epochs=1))
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses
+
+
+def test_two_train_calls_reset_adam():
+    """Optimizers are locals of the reference's train(): Adam state resets per call."""
+    cfg = SMALL
+    loaders = port.synthetic_loaders(16, n_train=cfg["n_train"], n_val=48, n_test=48,
+                                     image_shape=cfg["image_shape"])
+    model = port.build("ns", cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    o = port.GANPort("ns", model, loaders[0])
+    o.train(1); o.train(1)
+    tr, pm = build_product("ns", cfg, 16)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(1); tr.train(1)
+    lclose(tr.Glosses, o.Glosses, "two-call Glosses")
+    lclose(tr.Dlosses, o.Dlosses, "two-call Dlosses")
+    assert tr.num_epochs == 2
+
+
+@pytest.mark.parametrize("name", sorted(
+    os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+    if os.path.basename(p).split("_")[0] in ("ns", "mm", "w", "wgp", "ls", "ra", "fisher")))
+def test_engine_vs_reference_golden(name):
+    """HIP path vs fixtures produced by the UNMODIFIED reference (oracle/gen_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg, variant = meta["cfg"], meta["variant"]
+    full = "steps" in meta
+    batch = meta["batch"] if full else cfg["batch"]
+    p_tr, p_model, _ = run_product(variant, cfg, batch, meta["train_kw"],
+                                   capped=meta["steps"] if full else None)
+    lclose(p_tr.Glosses, z["Glosses"], name + " Glosses")
+    lclose(p_tr.Dlosses, z["Dlosses"], name + " Dlosses")
+    sd = p_model.state_dict()
+    if full:
+        from oracle.gen_golden import digest
+        for k, v in sd.items():
+            np.testing.assert_allclose(digest(v), z["digest:" + k], rtol=2e-4, atol=2e-4)
+    else:
+        for k, v in sd.items():
+            np.testing.assert_allclose(v.cpu().numpy(), z["param:" + k], rtol=0, atol=2e-5)
+
+
+def test_sampling_indices_bit_exact():
+    """process_batch replacement: gathered rows == the reference DataLoader's batch, bit for bit."""
+    from generative_models_amd import engine, ops
+    loaders = port.synthetic_loaders(32, n_train=500, n_val=48, n_test=48, image_shape=(1, 8, 8))
+    ds = loaders[0].dataset.tensors[0]
+    data = ds.reshape(500, -1).cuda()
+    torch.manual_seed(77)
+    ref_batches = [next(iter(loaders[0]))[0].view(32, -1) for _ in range(5)]
+    torch.manual_seed(77)
+    out = torch.empty(32, 64, device="cuda")
+    idx = np.empty(32, dtype=np.int64)
+    for rb in ref_batches:
+        engine.draw_sampler_indices(500, 32, idx)
+        ops.gather_rows(data, torch.from_numpy(idx).cuda(), out)
+        assert torch.equal(out.cpu(), rb)
+
+
+def test_user_override_takes_general_path():
+    """README.md:33-65: NSGAN -> LSGAN by overriding train_D/train_G only."""
+    import ns_gan
+    from generative_models_amd.trainers import to_cuda
+
+    class MyLS(ns_gan.NSGANTrainer):
+        def train_D(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            G_output = self.model.G(noise)
+            DX, DG = self.model.D(images), self.model.D(G_output)
+            return 0.5 * torch.mean((DX - 1) ** 2) + 0.5 * torch.mean((DG - 0) ** 2)
+
+        def train_G(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            DG = self.model.D(self.model.G(noise))
+            return 0.5 * torch.mean((DG - 1) ** 2)
+
+    cfg = SMALL
+    o_tr, o_model, o_rng = run_oracle("ls", cfg, 16, dict(num_epochs=1, G_lr=2e-4, D_lr=2e-4))
+    loaders = port.synthetic_loaders(16, n_train=cfg["n_train"], n_val=48, n_test=48,
+                                     image_shape=cfg["image_shape"])
+    torch.manual_seed(1234)
+    model = ns_gan.NSGAN(cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    tr = MyLS(model, *loaders)
+    assert not tr._stock()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(1)
+    lclose(tr.Glosses, o_tr.Glosses, "override Glosses")
+    lclose(tr.Dlosses, o_tr.Dlosses, "override Dlosses")
+    assert torch.equal(o_rng, torch.get_rng_state())
