@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the NSGAN D+G step (BASELINE.json metric), bs=256 per GPU, fp32.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one full reference iteration (ns_gan.py:122-156): process_batch -> train_D ->
+backward -> Adam(D) -> train_G -> backward -> Adam(G), in PARITY mode (reference RNG protocol,
+bit-exact sampling indices).  The dataset (synthetic 50 000 x 28x28 Bernoulli images, seed 3435)
+is resident in HBM before the timed region; the host-side RNG prefetch is inside it.
+Weak scaling: every rank runs bs=256 (global batch 256*N), gradients all-reduced over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "generative_models_amd", "src"))
+
+FLOP_PER_IMAGE = 6_326_400        # 10 U GEMMs + small, algorithmic (no wasted bwd)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md:41
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
+B_PER_GPU = 256
+IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
+
+
+def synthetic_dataset():
+    torch.manual_seed(3435)
+    img = torch.bernoulli(torch.full((N_TRAIN, 1, 28, 28), 0.1307))
+    ds = torch.utils.data.TensorDataset(img, torch.zeros(N_TRAIN, dtype=torch.int64))
+    return ds
+
+
+def gemm_shapes(B):
+    """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms."""
+    return [
+        # D step
+        ("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", 2 * B, IMG, HID), ("fwd", 2 * B, HID, 1),
+        ("dw", 2 * B, HID, 1), ("dx", 2 * B, HID, 1), ("dw", 2 * B, IMG, HID),
+        # G step
+        ("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", B, IMG, HID), ("fwd", B, HID, 1),
+        ("dx", B, HID, 1), ("dx", B, IMG, HID), ("dw", B, HID, IMG), ("dx", B, HID, IMG),
+        ("dw", B, Z, HID),
+    ]
+
+
+def time_kernels_isolated(B, reps=200):
+    """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
+    back `reps` times.  Returns {kind: (total_us_per_step, total_flop_per_step, n_launches)}."""
+    from generative_models_amd import ops
+    dev = "cuda"
+    out = {}
+    st = ops.stream_ptr()
+    for kind, M, K, N in gemm_shapes(B):
+        x = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        dA = torch.randn(M, N, device=dev)
+        y = torch.empty(M, N, device=dev)
+        dX = torch.empty(M, K, device=dev)
+        dW = torch.empty(N, K, device=dev)
+        db = torch.empty(N, device=dev)
+        b = torch.zeros(N, device=dev)
+        if kind == "fwd":
+            fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st)
+        elif kind == "dx":
+            fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
+        else:
+            fn = lambda: ops.linear_bwd_dw(dA, x, dW, db, stream=st)
+        for _ in range(10):
+            fn()
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        e1.sync()
+        us = e0.elapsed_ms(e1) * 1e3 / reps
+        t, f, n = out.get(kind, (0.0, 0.0, 0))
+        out[kind] = (t + us, f + 2.0 * M * K * N, n + 1)
+    return out
+
+
+def cpu_baseline(seconds_target=15.0):
+    """Oracle port (CPU restatement of the reference trainer, oracle/port.py) timed as-written
+    (DataLoader reshuffle included) on this host's cores: NSGAN bs=256, same synthetic data."""
+    from oracle import port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ds = synthetic_dataset()
+    loader = torch.utils.data.DataLoader(ds, batch_size=B_PER_GPU, shuffle=True)
+    model = port.build("ns", IMG, HID, Z)
+    tr = port.GANPort("ns", model, loader)
+    tr.train(1, max_steps=20)                       # warm-up
+    t0 = time.perf_counter()
+    tr.train(1, max_steps=50)
+    per_step = (time.perf_counter() - t0) / 50
+    steps = int(max(50, min(3000, seconds_target / per_step)))
+    t0 = time.perf_counter()
+    tr.train(1, max_steps=steps)
+    dt = time.perf_counter() - t0
+    return {"value": steps * B_PER_GPU / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d NSGAN bs=256 D+G steps of oracle/port.py (torch %s CPU, %d threads), "
+                      "as-written incl. DataLoader reshuffle, %.1f s" % (steps, torch.__version__,
+                                                                          cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node "
+                     "%d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from generative_models_amd import engine as gm_engine, ops
+    import ns_gan
+
+    ds = synthetic_dataset()
+    B_global = B_PER_GPU * world
+    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, shuffle=True)
+    torch.manual_seed(1234)
+    model = ns_gan.NSGAN(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    trainer = ns_gan.NSGANTrainer(model, loader, None, None, viz=False)
+    dev = torch.device("cuda", local_rank)
+    data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
+    eng = gm_engine.GANEngine("ns", trainer.model, data, B_global, dev,
+                              use_graph=(world == 1 and not args.no_graph),
+                              world_size=world, rank=rank)
+    W, K = args.warmup, args.steps
+    eng.configure(W + K, 2e-4, 2e-4, 1)
+    eng.run(W, it_start=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    eng.run(K, it_start=W)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    G, D = eng.losses(W, W + K)
+    assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
+    img_s = K * B_global / dt
+
+    if rank == 0:
+        kt = time_kernels_isolated(B_PER_GPU)
+        dom = max(kt, key=lambda k: kt[k][0])
+        t_us, flop, n = kt[dom]
+        names = {"fwd": "gemm_kernel<0,32,*> (linear fwd)", "dx": "gemm_kernel<1,32,*> (linear dX)",
+                 "dw": "gemm_kernel<2,32,*> (linear dW)"}
+        achieved = flop / (t_us * 1e-6) / 1e12
+        line = {
+            "metric": "images/sec (28x28 MNIST) per D+G step, NSGAN bs=256",
+            "value": img_s, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NSGAN MNIST bs=256 fp32 per GPU (BASELINE.json configs[1]); "
+                                   "784-400-20 MLPs, N=50000 synthetic Bernoulli images, parity-mode "
+                                   "RNG protocol, Adam 2e-4, D_steps=1",
+                       "global_batch": B_global,
+                       "launch": "hipGraph/iteration" if eng.use_graph else "eager+RCCL all-reduce",
+                       "parallelism": "dp%d" % world},
+            "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "launches_per_step": n, "avg_launch_us": t_us / n,
+                         "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "gm_linear_bwd_dw": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                  c_int]),
     "gm_gan_loss": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, POINTER(c_float), c_int,
-                            c_float, _P, Slot, _P, _P, _P]),
+                            c_float, _P, Slot, _P, _P, _P, _P]),
     "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, ctypes.c_double, ctypes.c_double,
                         ctypes.c_double, ctypes.c_double, c_float]),
     "gm_interp": (c_int, [_P, _P, Slot, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int]),

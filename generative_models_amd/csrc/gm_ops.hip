@@ -81,6 +81,7 @@ struct LossP {
     float* dax;
     float* dag;
     float* aux;
+    float* db;      // optional: d loss / d (head bias) = sum(dax) + sum(dag), fp64-accumulated
 };
 
 __device__ double block_sum(double v, double* sh) {
@@ -112,14 +113,16 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
         double s1 = 0.0;
         for (int i = t; i < B; i += 256) s1 += (double)p.sg[i];
         const float mg = (float)(block_sum(s1, sh) * (double)ib);
-        double sq = 0.0;
+        double sq = 0.0, sbx = 0.0, sbg = 0.0;
         for (int i = t; i < B; i += 256) {
             const float u = gm_sigmoid(p.sx[i] - mg);
             const float v = gm_sigmoid(1.f - p.sg[i]);
             acc += (double)(logf(u + EPS) + logf(v + EPS));
             const float gu = (-0.5f * ib) / (u + EPS);       // dL/du
             const float du = (gu * (1.f - u)) * u;           // through the inner sigmoid
-            p.dax[i] = act_grad(du, p.sx[i], p.out_act);
+            const float ax = act_grad(du, p.sx[i], p.out_act);
+            p.dax[i] = ax;
+            sbx += (double)ax;
             sq += (double)du;
         }
         const float sum_du = (float)block_sum(sq, sh);        // d/dmg = -sum_du ; dmg/dsg_j = 1/B
@@ -127,10 +130,16 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
             const float v = gm_sigmoid(1.f - p.sg[i]);
             const float gv = (-0.5f * ib) / (v + EPS);
             const float dv = -((gv * (1.f - v)) * v);         // d(1 - sg)/dsg = -1
-            p.dag[i] = act_grad(dv - sum_du * ib, p.sg[i], p.out_act);
+            const float ag = act_grad(dv - sum_du * ib, p.sg[i], p.out_act);
+            p.dag[i] = ag;
+            sbg += (double)ag;
         }
         const double tot = block_sum(acc, sh);
-        if (t == 0) p.loss_out[gm_slot_index(p.loss_slot)] = -(float)(tot * (double)ib) / 2.f;
+        const float bx = (float)block_sum(sbx, sh), bg = (float)block_sum(sbg, sh);
+        if (t == 0) {
+            p.loss_out[gm_slot_index(p.loss_slot)] = -(float)(tot * (double)ib) / 2.f;
+            if (p.db) p.db[0] = bx + bg;
+        }
         return;
     }
 
@@ -149,13 +158,18 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
         const float omega = 1.f - (0.5f * m2x + 0.5f * m2g);
         const float loss = -((m1x - m1g) + lam * omega - (rho / 2.f) * (omega * omega));
         const float dO = -(lam - rho * omega);               // dL/dOmega
+        double sbx = 0.0, sbg = 0.0;
         for (int i = t; i < B; i += 256) {
             // dOmega/dsx_i = -0.5 * 2 * sx_i / B
-            p.dax[i] = act_grad(-ib + dO * (-(p.sx[i] * ib)), p.sx[i], p.out_act);
-            p.dag[i] = act_grad(ib + dO * (-(p.sg[i] * ib)), p.sg[i], p.out_act);
+            const float ax = act_grad(-ib + dO * (-(p.sx[i] * ib)), p.sx[i], p.out_act);
+            const float ag = act_grad(ib + dO * (-(p.sg[i] * ib)), p.sg[i], p.out_act);
+            p.dax[i] = ax; p.dag[i] = ag;
+            sbx += (double)ax; sbg += (double)ag;
         }
+        const float bx = (float)block_sum(sbx, sh), bg = (float)block_sum(sbg, sh);
         __syncthreads();
         if (t == 0) {
+            if (p.db) p.db[0] = bx + bg;
             p.loss_out[gm_slot_index(p.loss_slot)] = loss;
             p.aux[0] = lam + rho * (-omega);                  // lambda += rho * lambda.grad
             p.aux[1] = m1x; p.aux[2] = m1g; p.aux[3] = m2x; p.aux[4] = m2g;
@@ -164,6 +178,7 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
     }
 
     // separable variants: per-sample term + per-sample gradient
+    double sbx = 0.0, sbg = 0.0;
     for (int i = t; i < B; i += 256) {
         const float g = p.sg[i];
         const float x = D ? p.sx[i] : 0.f;
@@ -256,12 +271,19 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
         default: break;
         }
         acc += (double)lx + (double)lg;
-        if (D && p.dax) p.dax[i] = act_grad(dx, x, p.out_act);
-        if (p.dag) p.dag[i] = act_grad(dg, g, p.out_act);
+        if (D && p.dax) { const float ax = act_grad(dx, x, p.out_act); p.dax[i] = ax; sbx += (double)ax; }
+        if (p.dag) { const float ag = act_grad(dg, g, p.out_act); p.dag[i] = ag; sbg += (double)ag; }
     }
     (void)extra;
     const double tot = block_sum(acc, sh);
-    if (t == 0) p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot * (double)ib);
+    // head-bias gradient: the two halves are summed separately (as autograd accumulates the
+    // D(x) and D(G(z)) paths) in fp64, so an exactly-cancelling gradient stays exactly zero
+    // (Adam would amplify a 1e-9 residue into an O(0.1*lr) step).
+    const float bx = (float)block_sum(sbx, sh), bg = (float)block_sum(sbg, sh);
+    if (t == 0) {
+        p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot * (double)ib);
+        if (p.db) p.db[0] = bx + bg;
+    }
 }
 
 }  // namespace
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
 extern "C" int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx,
                            const float* sg, int B, int out_act, const float* hyper, int n_hyper,
                            float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
-                           float* aux_io) {
+                           float* aux_io, float* db_out) {
     GM_CHECK_ARG(sg && loss_out && B > 0 && n_hyper >= 0 && n_hyper <= 8);
     GM_CHECK_ARG(variant >= GM_LOSS_NS && variant <= GM_LOSS_F_JS);
     GM_CHECK_ARG(gen_mode || (sx && dax && dag));
@@ -279,6 +301,7 @@ extern "C" int gm_gan_loss(void* stream, int variant, int gen_mode, const float*
     p.sx = sx; p.sg = sg; p.inv_b = inv_b;
     for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
     p.loss_out = loss_out; p.loss_slot = loss_slot; p.dax = dax; p.dag = dag; p.aux = aux_io;
+    p.db = db_out;
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }

@@ -194,8 +194,8 @@ class GANEngine:
             aux, hyper = self.pen, (self.gp_lambda,)
         ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
                      dS[:Bl], dS[Bl:], hyper=hyper, inv_b=self.inv_b,
-                     loss_slot=self._slot(it, d, j, 0, 1), aux=aux, stream=st)
-        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
+                     loss_slot=self._slot(it, d, j, 0, 1), aux=aux, db=D2.gb, stream=st)
+        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
         ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
         ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp":

@@ -74,7 +74,7 @@ def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
 
 
 def gan_loss(variant, gen_mode, sx, sg, B, out_act, loss_out, dax, dag, hyper=(), inv_b=None,
-             loss_slot=NO_SLOT, aux=None, stream=None):
+             loss_slot=NO_SLOT, aux=None, db=None, stream=None):
     """Adversarial loss + d(loss)/d(pre-activation score).  SURVEY.md appendix A.2."""
     h = (ctypes.c_float * 8)(*([float(x) for x in hyper] + [0.0] * (8 - len(hyper))))
     inv_b = float(np.float32(1.0) / np.float32(B)) if inv_b is None else float(inv_b)
@@ -83,7 +83,8 @@ def gan_loss(variant, gen_mode, sx, sg, B, out_act, loss_out, dax, dag, hyper=()
               ACT[out_act] if not isinstance(out_act, int) else out_act, h, len(hyper), inv_b,
               loss_out.data_ptr(), loss_slot, dax.data_ptr() if dax is not None else None,
               dag.data_ptr() if dag is not None else None,
-              aux.data_ptr() if aux is not None else None)
+              aux.data_ptr() if aux is not None else None,
+              db.data_ptr() if db is not None else None)
 
 
 def adam(p, g, m, v, sched, sched_slot=NO_SLOT, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

@@ -90,11 +90,13 @@ int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X,
  * hyper: host array of up to 8 floats (LS: a,b,c ; Fisher: rho).
  * inv_b: fp32 1/B used for every mean and its gradient (1/B_global under data parallelism).
  * loss_out[slot]: scalar loss.  dax/dag: [B] gradients (dax NULL in generator mode).
- * aux_io: device scratch/state (Fisher: lambda, moments; RaGAN: mean) or NULL.
+ * aux_io: device state/extra terms (Fisher: lambda, moments; WGAN-GP: penalty rows) or NULL.
+ * db_out: optional [1] gradient of the critic's output bias (sum of dax + sum of dag, each half
+ *   accumulated in fp64 so that exactly-cancelling gradients stay exactly zero).
  * Replaces the torch elementwise/mean ops in train_D / train_G (appendix A.2 table). */
 int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx, const float* sg, int B,
                 int out_act, const float* hyper, int n_hyper, float inv_b, float* loss_out,
-                gm_slot loss_slot, float* dax, float* dag, float* aux_io);
+                gm_slot loss_slot, float* dax, float* dag, float* aux_io, float* db_out);
 
 /* ---- K7 (+K8): Adam over one flat parameter buffer, exactly torch's _single_tensor_adam
  * (SURVEY.md section 3.5).  sched: device float2 table {step_size = lr/bc1, bc2_sqrt} indexed by
