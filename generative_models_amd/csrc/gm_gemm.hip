@@ -5,20 +5,24 @@
 //   dx   (NN): dX[M,K] = dA[M,N] * W[N,K] (* act'(below))   autograd of the above, ns_gan.py:138,155
 //   dw   (TN): dW[N,K] = dA[M,N]^T * X[M,K], db = colsum(dA)
 //
-// Design for this problem (tiny, L2-resident, latency-bound -- SURVEY.md section 7 "hard parts"):
-//   * 32x32 output tile per 256-thread workgroup so that even B=256 launches >= 200 workgroups;
-//   * the reduction dimension of every K-step is SPLIT ACROSS THE FOUR WAVES of the workgroup
-//     (wave w owns k in [w*BK/4,(w+1)*BK/4)): each wave keeps one 32x32 accumulator and issues
-//     v_mfma_f32_32x32x2_f32 back to back (64-cycle issue == dependent latency, so one accumulator
-//     runs the matrix pipe at full rate), then the four partial tiles are summed through LDS.
-//     This cuts the dependent MFMA chain for K=784 from 392 to 98 instructions per wave;
-//   * operands are staged global -> registers -> LDS in a [k][x] layout with row stride 36 floats:
-//     the MFMA fragment reads (32 consecutive floats of one k row per half-wave) and the
-//     transposing ds_write_b32 stores are both bank-conflict free; global loads of tile t+1 are in
-//     flight while tile t is multiplied (register prefetch + double-buffered LDS, one barrier per
-//     K-step);
-//   * exact fp32: MFMA f32 is a k-ordered fmaf chain, no reduced-precision path exists on gfx950.
-//   * db falls out of the dW GEMM for free: X is given a virtual ones-column at index K.
+// Design for this problem (B=256: every GEMM is ~0.1-0.3 GFLOP, L2/MALL-resident, and the step is
+// a chain of ~16 dependent GEMMs -- latency, not bandwidth or FLOPs, is the enemy):
+//   * 32x32 output tile per workgroup so that even B=256 launches 100-325 workgroups;
+//   * the reduction dimension is SPLIT ACROSS THE 16 WAVES of a 1024-thread workgroup in
+//     round-robin 8-deep chunks.  Because no two waves of a workgroup touch the same k, there is
+//     NO operand reuse inside the workgroup, so operands are NOT staged through LDS: each wave
+//     loads its chunks straight into v_mfma_f32_32x32x2_f32 fragment registers (the M=small
+//     "load straight to VGPRs, deep unroll, late vmcnt" regime of the CDNA guide), with a whole
+//     group of 4 chunks (8-32 loads) in flight before the first MFMA.  The dependent chain for
+//     K=784 is 28 MFMAs per wave instead of 392, with no barrier inside it;
+//   * fragment trick: lane (row r = lane&31, half h = lane>>5) loads 4 consecutive k
+//     (k = 8c+4h+j) of its row with ONE 16-byte load; MFMA j consumes element j, i.e. the k-order
+//     inside a chunk is permuted identically for A and B -- legal because a sum does not care;
+//   * the 16 partial tiles are combined through 64 KB of LDS (conflict-free row writes/reads),
+//     then bias / activation / activation-gradient epilogues are applied and rows are stored as
+//     coalesced 128-byte segments;
+//   * exact fp32 (MFMA f32 == fmaf chain); deterministic (no atomics);
+//   * db falls out of the dW GEMM for free: X gets a virtual ones-column at index K.
 #include "gm_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int TM = 32, TN = 32;
-constexpr int LD = 36;
+constexpr int WAVES = 16;
+constexpr int G = 4;          // chunks (of 8 k) in flight per wave per pipeline stage
 
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
@@ -46,182 +51,143 @@ struct GemmP {
     gm_slot a_slot, b_slot;
 };
 
-// Operand element (x, k) lives at P[x*ld + k]  (k contiguous).
-template <int BK, bool VEC>
-struct LoaderKC {
-    float4 r[BK / 32];
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int x0, int X,
-                                         int k0, int K, int t) {
-        const int x = x0 + (t & 31);
-#pragma unroll
-        for (int i = 0; i < BK / 32; ++i) {
-            const int k = k0 + 4 * ((t >> 5) + 8 * i);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x < X) {
-                const float* q = P + (int64_t)x * ld + k;
-                if (VEC && k + 3 < K) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (k + 0 < K) v.x = q[0];
-                    if (k + 1 < K) v.y = q[1];
-                    if (k + 2 < K) v.z = q[2];
-                    if (k + 3 < K) v.w = q[3];
-                }
-            }
-            r[i] = v;
+// k-contiguous operand: element (x, k) at P[x*ld + k].  Returns the 4 values k = kb..kb+3.
+template <bool VEC>
+__device__ __forceinline__ float4 load_kc(const float* __restrict__ P, int64_t ld, int x, int X,
+                                          int kb, int K) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < X) {
+        const float* q = P + (int64_t)x * ld + kb;
+        if (VEC && kb + 3 < K) {
+            v = *reinterpret_cast<const float4*>(q);
+        } else {
+            if (kb + 0 < K) v.x = q[0];
+            if (kb + 1 < K) v.y = q[1];
+            if (kb + 2 < K) v.z = q[2];
+            if (kb + 3 < K) v.w = q[3];
         }
     }
-    __device__ __forceinline__ void store(float* S, int t) const {
-#pragma unroll
-        for (int i = 0; i < BK / 32; ++i) {
-            const int kr = 4 * ((t >> 5) + 8 * i);
-            float* s = S + kr * LD + (t & 31);
-            s[0 * LD] = r[i].x;
-            s[1 * LD] = r[i].y;
-            s[2 * LD] = r[i].z;
-            s[3 * LD] = r[i].w;
-        }
-    }
-};
+    return v;
+}
 
-// Operand element (x, k) lives at P[k*ld + x]  (x contiguous).  ones_col: virtual column of 1s.
-template <int BK, bool VEC>
-struct LoaderXC {
-    float4 r[BK / 32];
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int x0, int X,
-                                         int k0, int K, int t, int ones_col) {
-        const int x = x0 + 4 * (t & 7);
-#pragma unroll
-        for (int i = 0; i < BK / 32; ++i) {
-            const int k = k0 + (t >> 3) + 32 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < K) {
-                const float* q = P + (int64_t)k * ld + x;
-                if (VEC && x + 3 < X) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (x + 0 < X) v.x = q[0];
-                    if (x + 1 < X) v.y = q[1];
-                    if (x + 2 < X) v.z = q[2];
-                    if (x + 3 < X) v.w = q[3];
-                    if (ones_col >= 0) {
-                        if (x + 0 == ones_col) v.x = 1.f;
-                        if (x + 1 == ones_col) v.y = 1.f;
-                        if (x + 2 == ones_col) v.z = 1.f;
-                        if (x + 3 == ones_col) v.w = 1.f;
-                    }
-                }
-            }
-            r[i] = v;
-        }
+// x-contiguous operand: element (x, k) at P[k*ld + x]; 4 coalesced dword loads (one per k).
+__device__ __forceinline__ float4 load_xc(const float* __restrict__ P, int64_t ld, int x, int X,
+                                          int kb, int K, int ones_col) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < X) {
+        const float* q = P + (int64_t)kb * ld + x;
+        if (kb + 0 < K) v.x = q[0];
+        if (kb + 1 < K) v.y = q[ld];
+        if (kb + 2 < K) v.z = q[2 * ld];
+        if (kb + 3 < K) v.w = q[3 * ld];
+    } else if (x == ones_col) {
+        if (kb + 0 < K) v.x = 1.f;
+        if (kb + 1 < K) v.y = 1.f;
+        if (kb + 2 < K) v.z = 1.f;
+        if (kb + 3 < K) v.w = 1.f;
     }
-    __device__ __forceinline__ void store(float* S, int t) const {
-#pragma unroll
-        for (int i = 0; i < BK / 32; ++i) {
-            const int kr = (t >> 3) + 32 * i;
-            *reinterpret_cast<float4*>(S + kr * LD + 4 * (t & 7)) = r[i];
-        }
-    }
-};
+    return v;
+}
 
-template <int MODE, int BK, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    // [buf][operand][BK][LD]; the cross-wave reduction buffer (4*32*33 floats) aliases it.
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LD];
-    static_assert(2 * 2 * BK * LD >= 4 * 32 * 33, "reduction buffer must fit");
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
+    __shared__ float red[WAVES * 32 * 32];      // 64 KB: one 32x32 partial tile per wave
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
 
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
-
-    // A is k-contiguous for fwd/dx, m-contiguous for dw; B is k-contiguous for fwd only.
-    LoaderKC<BK, VEC> a_kc;
-    LoaderXC<BK, VEC> a_xc;
-    LoaderKC<BK, VEC> b_kc;
-    LoaderXC<BK, VEC> b_xc;
-    const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;      // real columns of B
+    const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;       // real columns of B
     const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
+    const int nchunks = (p.K + 7) >> 3;
 
-    auto load_tiles = [&](int k0) {
-        if (MODE == MODE_DW) a_xc.load(A, p.lda, m0, p.M, k0, p.K, t, -1);
-        else                 a_kc.load(A, p.lda, m0, p.M, k0, p.K, t);
-        if (MODE == MODE_FWD) b_kc.load(B, p.ldb, n0, p.N, k0, p.K, t);
-        else                  b_xc.load(B, p.ldb, n0, b_cols, k0, p.K, t, ones_col);
+    auto load_a = [&](int c) -> float4 {
+        const int kb = 8 * c + 4 * h;
+        if (MODE == MODE_DW) return load_xc(A, p.lda, m0 + r, p.M, kb, p.K, -1);
+        return load_kc<VEC>(A, p.lda, m0 + r, p.M, kb, p.K);
     };
-    auto store_tiles = [&](int buf) {
-        float* As = smem + buf * (2 * BK * LD);
-        float* Bs = As + BK * LD;
-        if (MODE == MODE_DW) a_xc.store(As, t); else a_kc.store(As, t);
-        if (MODE == MODE_FWD) b_kc.store(Bs, t); else b_xc.store(Bs, t);
+    auto load_b = [&](int c) -> float4 {
+        const int kb = 8 * c + 4 * h;
+        if (MODE == MODE_FWD) return load_kc<VEC>(B, p.ldb, n0 + r, p.N, kb, p.K);
+        return load_xc(B, p.ldb, n0 + r, b_cols, kb, p.K, ones_col);
     };
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    const int nt = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int it = 0; it < nt; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nt) load_tiles((it + 1) * BK);
-        const float* As = smem + buf * (2 * BK * LD);
-        const float* Bs = As + BK * LD;
-        const int kw = w * (BK / 4) + (lane >> 5);
+    float4 a0[G], b0[G], a1[G], b1[G];
+    auto load_group = [&](float4 (&a)[G], float4 (&b)[G], int c) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const float a = As[(kw + 2 * kk) * LD + (lane & 31)];
-            const float b = Bs[(kw + 2 * kk) * LD + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < G; ++i) {
+            const int cc = c + i * WAVES;
+            if (cc < nchunks) { a[i] = load_a(cc); b[i] = load_b(cc); }
         }
-        if (it + 1 < nt) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+    auto mfma_group = [&](const float4 (&a)[G], const float4 (&b)[G], int c) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (c + i * WAVES < nchunks) {       // wave-uniform
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+            }
+        }
+    };
+
+    // two-stage register pipeline over this wave's chunks  w, w+16, w+32, ...
+    int c = w;
+    if (c < nchunks) {
+        load_group(a0, b0, c);
+        while (true) {
+            int cn = c + G * WAVES;
+            if (cn < nchunks) load_group(a1, b1, cn);
+            mfma_group(a0, b0, c);
+            if (cn >= nchunks) break;
+            c = cn;
+            cn = c + G * WAVES;
+            if (cn < nchunks) load_group(a0, b0, cn);
+            mfma_group(a1, b1, c);
+            if (cn >= nchunks) break;
+            c = cn;
+        }
     }
 
-    // cross-wave reduction through LDS (aliases the tile buffers; all reads are done)
-    float* red = smem;
+    // cross-wave reduction through LDS
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        red[(w * 32 + row) * 33 + (lane & 31)] = acc[r];
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[(w * 32 + row) * 32 + r] = acc[i];
     }
     __syncthreads();
-    const int row = t >> 3, c4 = 4 * (t & 7);
-    const int m = m0 + row;
-    if (m >= p.M) return;
-    float v[4];
+    const int row = t >> 5, col = t & 31;
+    float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int o = row * 33 + c4 + j;
-        v[j] = (red[o] + red[32 * 33 + o]) + (red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + c4 + j;
-        if (n >= p.N) continue;
-        float x = v[j];
-        if (MODE == MODE_FWD) {
-            if (p.bias) x += p.bias[n];
-            if (p.epi == GM_ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.epi == GM_ACT_SIGMOID) x = gm_sigmoid(x);
-            p.C[(int64_t)m * p.ldc + n] = x;
-        } else if (MODE == MODE_DX) {
-            if (p.epi == GM_ACT_RELU) {
-                x = (p.aux[(int64_t)m * p.ldaux + n] > 0.f) ? x : 0.f;
-            } else if (p.epi == GM_ACT_SIGMOID) {
-                const float y = p.aux[(int64_t)m * p.ldaux + n];
-                x = x * (y * (1.f - y));
-            }
-            float* c = p.C + (int64_t)m * p.ldc + n;
-            *c = p.accumulate ? (*c + x) : x;
-        } else {
-            float* c = (n == p.n_real) ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
-            *c = p.accumulate ? (*c + x) : x;
+    for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+
+    const int m = m0 + row, n = n0 + col;
+    if (m >= p.M || n >= p.N) return;
+    if (MODE == MODE_FWD) {
+        if (p.bias) v += p.bias[n];
+        if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
+        p.C[(int64_t)m * p.ldc + n] = v;
+    } else if (MODE == MODE_DX) {
+        if (p.epi == GM_ACT_RELU) {
+            v = (p.aux[(int64_t)m * p.ldaux + n] > 0.f) ? v : 0.f;
+        } else if (p.epi == GM_ACT_SIGMOID) {
+            const float y = p.aux[(int64_t)m * p.ldaux + n];
+            v = v * (y * (1.f - y));
         }
+        float* cp = p.C + (int64_t)m * p.ldc + n;
+        *cp = p.accumulate ? (*cp + v) : v;
+    } else {
+        float* cp = (n == p.n_real) ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
+        *cp = p.accumulate ? (*cp + v) : v;
     }
 }
 
@@ -230,8 +196,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int MODE>
 int launch(hipStream_t s, const GemmP& p, bool vec) {
     dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM);
-    if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, 32, true>), grid, dim3(256), 0, s, p);
-    else     hipLaunchKernelGGL((gemm_kernel<MODE, 32, false>), grid, dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true>), grid, dim3(WAVES * 64), 0, s, p);
+    else     hipLaunchKernelGGL((gemm_kernel<MODE, false>), grid, dim3(WAVES * 64), 0, s, p);
     GM_LAUNCH_RET();
 }
 
@@ -263,7 +229,7 @@ extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, cons
     p.A = dA; p.B = W; p.C = dX; p.M = M; p.N = K; p.K = N;
     p.lda = lda; p.ldb = K; p.ldc = ldx; p.aux = below; p.ldaux = ld_below; p.epi = epi;
     p.a_slot = no_slot(); p.b_slot = no_slot();
-    const bool vec = aligned16(dA) && aligned16(W) && (lda % 4 == 0) && (K % 4 == 0);
+    const bool vec = aligned16(dA) && (lda % 4 == 0);
     return launch<MODE_DX>((hipStream_t)stream, p, vec);
 }
 
@@ -276,7 +242,5 @@ extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, cons
     p.A = dA; p.B = X; p.C = dW; p.M = N; p.N = K + (db ? 1 : 0); p.K = M;
     p.lda = lda; p.ldb = ldx; p.ldc = K; p.db = db; p.n_real = K; p.accumulate = accumulate;
     p.a_slot = no_slot(); p.b_slot = x_slot;
-    const bool vec = aligned16(dA) && aligned16(X) && (lda % 4 == 0) && (ldx % 4 == 0) &&
-                     (x_slot.stride % 4 == 0);
-    return launch<MODE_DW>((hipStream_t)stream, p, vec);
+    return launch<MODE_DW>((hipStream_t)stream, p, false);     // both operands use dword loads
 }

@@ -38,11 +38,16 @@ class FlatParams:
     The nn.Linear modules stay the parameter holders (state_dict keys)."""
 
     def __init__(self, params, device):
-        self.params = list(params)
-        offs, n = [], 0
-        for p in self.params:
-            offs.append(n)
-            n += _align4(p.numel())
+        # an element may be a tuple of parameters: packed back to back with no padding between
+        # them (e.g. the VAE's mu / log_var heads, used as ONE [2Z, H] matrix by the kernels)
+        self.params, offs, n = [], [], 0
+        for item in params:
+            group = item if isinstance(item, (tuple, list)) else (item,)
+            for p in group:
+                self.params.append(p)
+                offs.append(n)
+                n += p.numel()
+            n = _align4(n)
         self.n = n
         self.offsets = offs
         self.flat = torch.zeros(n, device=device)
@@ -381,3 +386,158 @@ class GANEngine:
         G = [float(x) for x in lg]
         D = [float(np.mean([float(v) for v in row])) for row in ld]
         return G, D
+
+
+class VAEEngine:
+    """vae.py:144-167 (train loop) + :214-223 (evaluate) as hipGraphs: one graph per distinct
+    batch size (full batches and the ragged last one, 50 000 mod 512 = 336), a device step counter
+    selecting index rows / eps rows / Adam-schedule rows / loss slots."""
+
+    def __init__(self, model, device, use_graph=True):
+        self.model, self.device, self.use_graph = model, device, use_graph
+        enc, dec = model.encoder, model.decoder
+        self.fp = FlatParams([enc.linear.weight, enc.linear.bias,
+                              (enc.mu.weight, enc.log_var.weight), (enc.mu.bias, enc.log_var.bias),
+                              dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias],
+                             device)
+        fp = self.fp
+        self.E1, self.D1, self.D2 = _Linear(fp, enc.linear), _Linear(fp, dec.linear), \
+            _Linear(fp, dec.recon)
+        Z, H = enc.mu.weight.shape
+        self.Z, self.H, self.I = Z, H, enc.linear.weight.shape[1]
+        i_w = [i for i, p in enumerate(fp.params) if p is enc.mu.weight][0]
+        i_b = [i for i, p in enumerate(fp.params) if p is enc.mu.bias][0]
+        o_w, o_b = fp.offsets[i_w], fp.offsets[i_b]
+
+        class _Packed:          # [mu ; log_var] as one 2Z x H layer
+            W = fp.flat[o_w:o_w + 2 * Z * H].view(2 * Z, H)
+            b = fp.flat[o_b:o_b + 2 * Z]
+            gW = fp.grad[o_w:o_w + 2 * Z * H].view(2 * Z, H)
+            gb = fp.grad[o_b:o_b + 2 * Z]
+        self.ML = _Packed
+        self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        self.graphs = {}
+        self._bufB = None
+
+    def _alloc(self, B):
+        if self._bufB == B:
+            return
+        dev, I, H, Z = self.device, self.I, self.H, self.Z
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.X, self.He, self.ml, self.Zs = z(B, I), z(B, H), z(B, 2 * Z), z(B, Z)
+        self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
+        self.dHdec, self.dZ, self.dml, self.dHe = z(B, H), z(B, Z), z(B, 2 * Z), z(B, H)
+        self.part = z(B)
+        self._bufB = B
+        self.graphs = {}
+
+    def _slot(self, t, mul, add, ring, stride):
+        if self.use_graph:
+            return ops.slot(self.ctr.data_ptr(), mul, add, ring, stride)
+        i = t * mul + add
+        if ring > 0:
+            i %= ring
+        return ops.slot(0, 0, i, 0, stride)
+
+    def _issue(self, st, t, b, train):
+        """One batch of size b: forward + losses (+ backward + Adam when train)."""
+        from . import ops_fused as of
+        R, B, Z = self.R, self.B, self.Z
+        E1, ML, D1, D2 = self.E1, self.ML, self.D1, self.D2
+        idx_slot = self._slot(t, 1, 0, R, B)
+        eps_slot = self._slot(t, 1, 0, R, B * Z)
+        loss_slot = self._slot(t, 1, 0, 0, 1)
+        recon_out, kl_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
+        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
+        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        ops.linear_fwd(self.He, ML.W, ML.b, self.ml, "id", M=b, stream=st)
+        of.vae_reparam(self.ml, self.eps_ring.view(-1), self.Zs, kl_out, b, Z, eps_slot=eps_slot,
+                       kl_slot=loss_slot, stream=st)
+        ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
+        ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
+        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
+        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
+        if train:
+            ops.linear_bwd_dw(self.dA, self.Hdec, D2.gW, D2.gb, M=b, stream=st)
+            ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
+            ops.linear_bwd_dw(self.dHdec, self.Zs, D1.gW, D1.gb, M=b, stream=st)
+            ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
+            of.vae_reparam_bwd(self.ml, self.eps_ring.view(-1), self.dZ, self.dml, b, Z,
+                               eps_slot=eps_slot, stream=st)
+            ops.linear_bwd_dw(self.dml, self.He, ML.gW, ML.gb, M=b, stream=st)
+            ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
+            ops.linear_bwd_dw(self.dHe, self.X, E1.gW, E1.gb, M=b, stream=st)
+            ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched,
+                     self._slot(t, 1, 0, 0, 1), weight_decay=self.wd, stream=st)
+        if self.use_graph:
+            ops.tick(self.ctr, 1, stream=st)
+
+    def configure(self, B, n_train_steps, lr, weight_decay):
+        dev = self.device
+        self._alloc(B)
+        self.B, self.wd = B, float(weight_decay)
+        self.fp.rebind()
+        self.fp.reset_state()
+        self.fp.grad.zero_()
+        self.sched = torch.from_numpy(ops.adam_schedule(lr, max(1, n_train_steps))).to(dev)
+        self.recon = torch.zeros(max(1, n_train_steps), device=dev)
+        self.kl = torch.zeros(max(1, n_train_steps), device=dev)
+        self.R = CHUNK
+        self.idx_ring = torch.zeros(self.R, B, dtype=torch.int64, device=dev)
+        self.eps_ring = torch.zeros(self.R, B, self.Z, device=dev)
+        self.stage = [dict(idx=torch.zeros(self.R, B, dtype=torch.int64).pin_memory(),
+                           eps=torch.zeros(self.R, B, self.Z).pin_memory(), event=None)
+                      for _ in range(2)]
+        self.graphs = {}
+        self.t_train = 0
+
+    def _graph(self, b, train):
+        key = (b, train, self.data.data_ptr())
+        if key not in self.graphs:
+            torch.cuda.synchronize()
+            self.graphs[key] = ops.Graph().capture(lambda st: self._issue(st, 0, b, train))
+        return self.graphs[key]
+
+    def run_pass(self, data, perm, train, t0):
+        """One pass over `data` in the order `perm` (host int64 tensor): batches of B rows, last
+        one ragged.  Global eps draws (vae.py:104) happen here, batch by batch, in order.
+        t0: first loss/schedule slot.  Returns number of batches."""
+        self.data = data
+        B, R, Z = self.B, self.R, self.Z
+        n = perm.numel()
+        nb = (n + B - 1) // B
+        self.ctr.fill_(t0)
+        done, which = 0, 0
+        while done < nb:
+            t = t0 + done
+            cnt = min(R - (t % R), nb - done)
+            s = self.stage[which]
+            which ^= 1
+            if s["event"] is not None:
+                s["event"].synchronize()
+            sizes = []
+            for k in range(cnt):
+                lo = (done + k) * B
+                b = min(B, n - lo)
+                sizes.append(b)
+                s["idx"][k, :b].copy_(perm[lo:lo + b])
+                s["eps"][k].view(-1)[:b * Z].normal_()        # torch.randn(mu.shape), vae.py:104
+            r = t % R
+            self.idx_ring[r:r + cnt].copy_(s["idx"][:cnt], non_blocking=True)
+            self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            s["event"] = ev
+            for k, b in enumerate(sizes):
+                if self.use_graph:
+                    self._graph(b, train).launch()
+                else:
+                    self._issue(ops.stream_ptr(), t + k, b, train)
+            done += cnt
+        return nb
+
+    def alloc_val(self, n):
+        if getattr(self, "vrecon", None) is None or self.vrecon.numel() < n:
+            self.vrecon = torch.zeros(n, device=self.device)
+            self.vkl = torch.zeros(n, device=self.device)
+            self.graphs = {k: g for k, g in self.graphs.items() if k[1]}   # drop eval graphs

@@ -1,0 +1,25 @@
+"""Drop-in for the reference's src/dra_gan.py (dra_gan.py:32-245).  DRAGAN's penalty needs the
+second derivative through the sigmoid critic; it runs on the general path (autograd over the HIP
+GEMM Functions, ops._MM is closed under differentiation)."""
+import _bootstrap  # noqa: F401
+import numpy as np  # noqa: F401
+import torch  # noqa: F401
+import torch.nn as nn  # noqa: F401
+
+from utils import *  # noqa: F401,F403
+from generative_models_amd import trainers as _t
+from generative_models_amd.trainers import Generator, Discriminator  # noqa: F401
+
+
+class DRAGAN(_t.GANModel):
+    """dra_gan.py:63-74"""
+
+
+@_t.stock
+class DRAGANTrainer(_t.GANTrainer):
+    """dra_gan.py:77-245"""
+    variant = "dra"
+
+    def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=5):
+        """dra_gan.py:94."""
+        self._train(num_epochs, G_lr, D_lr, D_steps)

@@ -23,6 +23,8 @@ class FisherGANTrainer(_t.GANTrainer):
     def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=1, RHO=1e-6):
         """fisher_gan.py:101; lambda lives on the device and is updated by the loss kernel
         (:155-156); self.LAMBDA mirrors it after train()."""
+        self.LAMBDA = to_var(torch.zeros(1))          # fisher_gan.py:117-118
+        self.RHO = to_var(torch.tensor(RHO))
         self._train(num_epochs, G_lr, D_lr, D_steps, hyper=(RHO,))
         if self._engine is not None:
             self.LAMBDA = self._engine.aux[0:1].clone()

@@ -121,34 +121,51 @@ class GANModel(nn.Module):
         self.shape = int(image_size ** 0.5)
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam stand-in for the general path: same math (ops.adam = SURVEY.md 3.5), one
-    launch over a flat buffer.  zero_grad() sets grads to None like torch >= 2.0."""
+    launch over a private flat copy of the parameters.  It is a torch Optimizer so that
+    lr schedulers (BEGAN's ReduceLROnPlateau, be_gan.py:133-136) can drive param_groups[0]['lr'].
+    Parameters whose grad is None are skipped like torch does (their moments do not advance):
+    handled by keeping one (flat, step) pair per "has grad" pattern is overkill here -- the
+    reference never mixes patterns within one optimizer, so a None grad means "all None"."""
 
     def __init__(self, params, lr, weight_decay=0.0, clamp=0.0):
-        from .engine import FlatParams
-        self.params = [p for p in params if p.requires_grad]
-        self.lr, self.wd, self.clamp = lr, weight_decay, clamp
-        dev = self.params[0].device
-        self.fp = FlatParams(self.params, dev)
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr))
+        self.wd, self.clamp = weight_decay, clamp
+        self._ps = params
+        dev = params[0].device
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)
+        z = lambda: torch.zeros(n, device=dev)
+        self.flat, self.grad, self.m, self.v = z(), z(), z(), z()
+        self.offs, o = [], 0
+        for p in params:
+            self.offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
         self.t = 0
-        self._sched = None
 
-    def zero_grad(self):
-        for p in self.params:
+    def zero_grad(self, set_to_none=True):
+        for p in self._ps:
             p.grad = None
 
-    def step(self):
-        fp = self.fp
-        fp.rebind()
-        for p, g in zip(self.params, fp.gviews):
+    @torch.no_grad()
+    def step(self, closure=None):
+        if all(p.grad is None for p in self._ps):
+            return
+        for p, o in zip(self._ps, self.offs):
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
             if p.grad is None:
-                g.zero_()
-            elif p.grad.data_ptr() != g.data_ptr():
-                g.copy_(p.grad)
+                self.grad[o:o + k].zero_()
+            else:
+                self.grad[o:o + k].copy_(p.grad.reshape(-1))
         self.t += 1
-        sched = torch.from_numpy(ops.adam_schedule(self.lr, 1, start=self.t)).to(fp.flat.device)
-        ops.adam(fp.flat, fp.grad, fp.m, fp.v, sched, weight_decay=self.wd, clamp=self.clamp)
+        lr = self.param_groups[0]["lr"]
+        sched = torch.from_numpy(ops.adam_schedule(lr, 1, start=self.t)).to(self.flat.device)
+        ops.adam(self.flat, self.grad, self.m, self.v, sched, weight_decay=self.wd,
+                 clamp=self.clamp)
+        for p, o in zip(self._ps, self.offs):
+            p.data.copy_(self.flat[o:o + p.numel()].view(p.shape))
 
 
 class GANTrainer:
@@ -201,6 +218,24 @@ class GANTrainer:
         if v == "ra":
             return -torch.mean(torch.log(torch.sigmoid(sx - sg.mean()) + EPS)
                                + torch.log(torch.sigmoid(1 - sg) + EPS)) / 2
+        if v == "f":
+            return self.loss_fnc.D_loss(sx, sg)
+        if v == "fisher":
+            m1x, m1g = sx.mean(), sg.mean()
+            m2x, m2g = (sx ** 2).mean(), (sg ** 2).mean()
+            omega = 1 - (0.5 * m2x + 0.5 * m2g)
+            return -((m1x - m1g) + self.LAMBDA * omega - (self.RHO / 2) * (omega ** 2))
+        if v == "dra":
+            lam, K, C = kw.get("LAMBDA", 10), kw.get("K", 1), kw.get("C", 1)
+            loss = -torch.mean(torch.log(sx + EPS) + torch.log(1 - sg + EPS))
+            delta = to_cuda(torch.rand(images.shape[0], 1).expand(images.size()))
+            x_hat = to_var(delta * images.data + (1 - delta) *
+                           (images.data + C * images.data.std() * to_cuda(torch.rand(images.size()))))
+            d_hat = self.model.D(x_hat)
+            grads = torch.autograd.grad(outputs=d_hat, inputs=x_hat,
+                                        grad_outputs=to_cuda(torch.ones(d_hat.shape)),
+                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
+            return loss + lam * torch.mean((grads.norm(2, dim=1) - K) ** 2)
         if v == "wgp":
             lam = kw.get("LAMBDA", 10)
             eps = to_var(torch.rand(images.shape[0], 1).expand(images.size()))
@@ -215,8 +250,12 @@ class GANTrainer:
     def train_G(self, images, **kw):
         v, m = self.variant, self.model
         sg = m.D(m.G(self.compute_noise(images.shape[0], m.z_dim)))
-        if v in ("ns", "ra"):
+        if v in ("ns", "ra", "dra"):
             return -torch.mean(torch.log(sg + EPS))
+        if v == "f":
+            return self.loss_fnc.G_loss(sg)
+        if v == "fisher":
+            return -sg.mean()
         if v == "mm":
             return torch.mean(torch.log((1 - sg) + EPS))
         if v in ("w", "wgp"):
@@ -299,7 +338,10 @@ class GANTrainer:
                     images = self.process_batch(self.train_iter)
                     D_opt.zero_grad()
                     D_loss = self.train_D(images, **kwD)
+                    if isinstance(D_loss, tuple):       # Fisher returns (D_loss, IPM_ratio)
+                        D_loss = D_loss[0]
                     D_loss.backward()
+                    self._after_D_backward()
                     D_opt.step()
                     step.append(D_loss.item())
                 D_losses.append(np.mean(step))
@@ -309,6 +351,12 @@ class GANTrainer:
                 G_loss.backward()
                 G_opt.step()
             self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+
+    def _after_D_backward(self):
+        """Fisher GAN's hand-rolled lambda ascent (fisher_gan.py:155-156); no-op otherwise."""
+        if self.variant == "fisher":
+            self.LAMBDA = self.LAMBDA + self.RHO * self.LAMBDA.grad
+            self.LAMBDA = to_var(self.LAMBDA.detach())
 
     def _end_epoch(self, epoch, num_epochs, G_losses, D_losses, quiet=False):
         self.Glosses.extend(G_losses)
@@ -338,3 +386,438 @@ def stock(cls):
     """Marks a trainer class shipped by this package (fast-path eligible when not overridden)."""
     cls._gm_stock_class = True
     return cls
+
+
+# ============================================================================================
+# VAE (vae.py:47-223)
+# ============================================================================================
+class Encoder(nn.Module):
+    """vae.py:47-61."""
+
+    def __init__(self, image_size, hidden_dim, z_dim):
+        super().__init__()
+        self.linear = nn.Linear(image_size, hidden_dim)
+        self.mu = nn.Linear(hidden_dim, z_dim)
+        self.log_var = nn.Linear(hidden_dim, z_dim)
+
+    def forward(self, x):
+        h = _lin(self.linear, x, "relu")
+        return _lin(self.mu, h, "id"), _lin(self.log_var, h, "id")
+
+
+class Decoder(_TwoLayer):
+    """vae.py:64-77."""
+    _names = ("linear", "recon")
+
+    def __init__(self, z_dim, hidden_dim, image_size):
+        super().__init__()
+        self._build(z_dim, hidden_dim, image_size)
+
+
+class VAE(nn.Module):
+    """vae.py:80-106."""
+
+    def __init__(self, image_size=784, hidden_dim=400, z_dim=20):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim = image_size, hidden_dim, z_dim
+        self.encoder = Encoder(image_size=image_size, hidden_dim=hidden_dim, z_dim=z_dim)
+        self.decoder = Decoder(z_dim=z_dim, hidden_dim=hidden_dim, image_size=image_size)
+        self.shape = int(image_size ** 0.5)
+
+    def forward(self, x):
+        mu, log_var = self.encoder(x)
+        z = self.reparameterize(mu, log_var)
+        return self.decoder(z), mu, log_var
+
+    def reparameterize(self, mu, log_var):
+        epsilon = to_cuda(torch.randn(mu.shape))
+        return mu + epsilon * torch.exp(log_var / 2)
+
+
+def _epoch_order(loader):
+    """The permutation one `for batch in loader` pass uses, drawn exactly like the reference's
+    DataLoader does: base seed at iterator creation (dataloader.py:706-710), sampler seed at the
+    first next() (sampler.py:163-165), then randperm(n) on a private generator."""
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(len(loader.dataset), generator=g)
+
+
+@stock
+class VAETrainer:
+    """vae.py:109-223."""
+    _gm_stock_class = True
+
+    def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
+        self.model = to_cuda(model)
+        self.name = model.__class__.__name__
+        self.train_iter, self.val_iter, self.test_iter = train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))          # vae.py:120 (consumes RNG)
+        self.viz = viz
+        self.kl_loss, self.recon_loss = [], []
+        self.num_epochs = 0
+        self._engine = None
+        self.use_graph = True
+
+    def compute_batch(self, batch):
+        """vae.py:193-208 (general path: autograd over the fused linear kernels)."""
+        images, _ = batch
+        images = to_cuda(images.view(images.shape[0], -1))
+        outputs, mu, log_var = self.model(images)
+        recon_loss = torch.sum((images - outputs) ** 2)
+        return recon_loss, self.kl_divergence(mu, log_var)
+
+    def kl_divergence(self, mu, log_var):
+        """vae.py:210-212."""
+        return torch.sum(0.5 * (mu ** 2 + torch.exp(log_var) - log_var - 1))
+
+    def evaluate(self, iterator):
+        """vae.py:214-223."""
+        loss = []
+        for batch in iterator:
+            r, k = self.compute_batch(batch)
+            loss.append((r + k).item())
+        return np.mean(loss)
+
+    def _loader_ok(self, it):
+        return (isinstance(it, torch.utils.data.DataLoader)
+                and isinstance(it.dataset, torch.utils.data.TensorDataset)
+                and isinstance(it.sampler, torch.utils.data.RandomSampler)
+                and it.sampler.generator is None and it.generator is None
+                and not it.sampler.replacement and it.num_workers == 0 and not it.drop_last
+                and it.batch_size is not None)
+
+    def _stock(self):
+        cls = type(self)
+        for name in ("compute_batch", "kl_divergence", "evaluate"):
+            if name in self.__dict__:
+                return False
+            for base in cls.__mro__:
+                if name in base.__dict__:
+                    if not base.__dict__.get("_gm_stock_class", False):
+                        return False
+                    break
+        return (self._loader_ok(self.train_iter) and self._loader_ok(self.val_iter)
+                and self.train_iter.batch_size == self.val_iter.batch_size)
+
+    def _device_data(self, loader):
+        cache = self.__dict__.setdefault("_data_cache", {})
+        key = id(loader.dataset)
+        if key not in cache:
+            imgs = loader.dataset.tensors[0]
+            dev = next(self.model.parameters()).device
+            cache[key] = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
+        return cache[key]
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5, quiet=False):
+        """vae.py:127-191."""
+        from copy import deepcopy
+        if self._stock():
+            if not torch.cuda.is_available():
+                raise GMError("no MI355X visible: the fused step engine has no CPU fallback")
+            from .engine import VAEEngine
+            dev = next(self.model.parameters()).device
+            if self._engine is None:
+                self._engine = VAEEngine(self.model, dev, use_graph=self.use_graph)
+            eng = self._engine
+            eng.use_graph = self.use_graph
+            B = self.train_iter.batch_size
+            steps = len(self.train_iter)
+            eng.configure(B, num_epochs * steps, lr, weight_decay)
+            tdata, vdata = self._device_data(self.train_iter), self._device_data(self.val_iter)
+            nval = len(self.val_iter)
+            eng.alloc_val(nval)
+            for epoch in range(1, num_epochs + 1):
+                self.model.train()
+                t0 = (epoch - 1) * steps
+                eng.run_pass(tdata, _epoch_order(self.train_iter), True, t0)
+                self.model.eval()
+                eng.run_pass(vdata, _epoch_order(self.val_iter), False, 0)
+                recon = [float(x) for x in eng.recon[t0:t0 + steps].cpu().numpy()]   # one sync
+                kl = [float(x) for x in eng.kl[t0:t0 + steps].cpu().numpy()]
+                vr, vk = eng.vrecon[:nval].cpu().numpy(), eng.vkl[:nval].cpu().numpy()
+                val_loss = np.mean([float(a + b) for a, b in zip(vr, vk)])
+                self._end_epoch(epoch, num_epochs, recon, kl, val_loss, deepcopy, quiet)
+            return
+        # GENERAL path (compute_batch / evaluate overridden)
+        opt = FlatAdam(self.model.parameters(), lr, weight_decay=weight_decay)
+        for epoch in range(1, num_epochs + 1):
+            self.model.train()
+            recon, kl = [], []
+            for batch in self.train_iter:
+                opt.zero_grad()
+                r, k = self.compute_batch(batch)
+                (r + k).backward()
+                opt.step()
+                recon.append(r.item())
+                kl.append(k.item())
+            self.model.eval()
+            val_loss = self.evaluate(self.val_iter)
+            self._end_epoch(epoch, num_epochs, recon, kl, val_loss, deepcopy, quiet)
+
+    def _end_epoch(self, epoch, num_epochs, recon, kl, val_loss, deepcopy, quiet):
+        self.kl_loss.extend(kl)
+        self.recon_loss.extend(recon)
+        if val_loss < self.best_val_loss:
+            self.best_model = deepcopy(self.model)
+            self.best_val_loss = val_loss
+        if not quiet:
+            tot = [float(np.float32(a) + np.float32(b)) for a, b in zip(recon, kl)]
+            print("Epoch[%d/%d], Total Loss: %.4f, Reconst Loss: %.4f, KL Div: %.7f, Val Loss: %.4f"
+                  % (epoch, num_epochs, np.mean(tot), np.mean(recon), np.mean(kl), val_loss))
+        self.num_epochs += 1
+
+    def save_model(self, savepath):
+        torch.save(self.model.state_dict(), savepath)
+
+    def load_model(self, loadpath):
+        self.model.load_state_dict(torch.load(loadpath))
+
+
+# ============================================================================================
+# f-GAN divergences (f_gan.py:85-142) -- used by the general path and exposed as a drop-in name
+# ============================================================================================
+class Divergence:
+    METHODS = ("total_variation", "forward_kl", "reverse_kl", "pearson", "hellinger",
+               "jensen_shannon")
+
+    def __init__(self, method):
+        self.method = method.lower().strip()
+        assert self.method in self.METHODS, "Invalid divergence."
+
+    def D_loss(self, DX_score, DG_score):
+        m, x, g = self.method, DX_score, DG_score
+        if m == "total_variation":
+            return -(torch.mean(0.5 * torch.tanh(x)) - torch.mean(0.5 * torch.tanh(g)))
+        if m == "forward_kl":
+            return -(torch.mean(x) - torch.mean(torch.exp(g - 1)))
+        if m == "reverse_kl":
+            return -(torch.mean(-torch.exp(x)) - torch.mean(-1 - g))
+        if m == "pearson":
+            return -(torch.mean(x) - torch.mean(0.25 * g ** 2 + g))
+        if m == "hellinger":
+            return -(torch.mean(1 - torch.exp(x)) - torch.mean((1 - torch.exp(g)) / torch.exp(g)))
+        return -(torch.mean(torch.tensor(2.) - (1 + torch.exp(-x)))
+                 - torch.mean(-(torch.tensor(2.) - torch.exp(g))))
+
+    def G_loss(self, DG_score):
+        m, g = self.method, DG_score
+        if m == "total_variation":
+            return -torch.mean(0.5 * torch.tanh(g))
+        if m == "forward_kl":
+            return -torch.mean(torch.exp(g - 1))
+        if m == "reverse_kl":
+            return -torch.mean(-1 - g)
+        if m == "pearson":
+            return -torch.mean(0.25 * g ** 2 + g)
+        if m == "hellinger":
+            return -torch.mean((1 - torch.exp(g)) / torch.exp(g))
+        return -torch.mean(-(torch.tensor(2.) - torch.exp(g)))
+
+
+# ============================================================================================
+# BEGAN (be_gan.py:48-258): autoencoder critic, proportional control of K, plateau schedulers.
+# General path only: K and the schedulers are host-side scalars updated from per-step losses
+# (be_gan.py:189-195), which is a host sync per step by construction of the algorithm.
+# ============================================================================================
+class AEDiscriminator(_TwoLayer):
+    """be_gan.py:63-76."""
+    _names = ("encoder", "decoder")
+    _out_act = "id"
+
+    def __init__(self, image_size, hidden_dim):
+        super().__init__()
+        self._build(image_size, hidden_dim, image_size)
+
+
+class BEGANModel(nn.Module):
+    """be_gan.py:79-90."""
+
+    def __init__(self, image_size, hidden_dim, z_dim):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim = image_size, hidden_dim, z_dim
+        self.G = Generator(image_size, hidden_dim, z_dim)
+        self.D = AEDiscriminator(image_size, hidden_dim)
+        self.shape = int(image_size ** 0.5)
+
+
+class BEGANTrainerBase(GANTrainer):
+    variant = "be"
+
+    def train_D(self, images, K):
+        """be_gan.py:212-238."""
+        m = self.model
+        DX_loss = torch.mean(torch.sum(torch.abs(m.D(images) - images), dim=1))
+        G_output = m.G(self.compute_noise(images.shape[0], m.z_dim))
+        DG_loss = torch.mean(torch.sum(torch.abs(m.D(G_output) - G_output), dim=1))
+        return DX_loss - (K * DG_loss), DX_loss, DG_loss
+
+    def train_G(self, images):
+        """be_gan.py:240-258."""
+        m = self.model
+        G_output = m.G(self.compute_noise(images.shape[0], m.z_dim))
+        return torch.mean(torch.sum(torch.abs(m.D(G_output) - G_output), dim=1))
+
+    def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=1, GAMMA=0.50, LAMBDA=1e-3, K=0.00,
+              quiet=False):
+        """be_gan.py:109-210."""
+        from torch.optim.lr_scheduler import ReduceLROnPlateau
+        m = self.model
+        G_opt, D_opt = FlatAdam(m.G.parameters(), G_lr), FlatAdam(m.D.parameters(), D_lr)
+        pat = 5 * len(self.train_iter)
+        G_sch = ReduceLROnPlateau(G_opt, factor=0.50, threshold=0.01, patience=pat)
+        D_sch = ReduceLROnPlateau(D_opt, factor=0.50, threshold=0.01, patience=pat)
+        epoch_steps = int(np.ceil(len(self.train_iter) / D_steps))
+        for epoch in range(1, num_epochs + 1):
+            m.train()
+            G_losses, D_losses = [], []
+            for _ in range(epoch_steps):
+                step = []
+                for _ in range(D_steps):
+                    images = self.process_batch(self.train_iter)
+                    D_opt.zero_grad()
+                    D_loss, DX_loss, DG_loss = self.train_D(images, K)
+                    D_loss.backward()
+                    D_opt.step()
+                    step.append(D_loss.item())
+                D_losses.append(np.mean(step))
+                G_opt.zero_grad()
+                G_loss = self.train_G(images)
+                G_loss.backward()
+                G_opt.step()
+                G_losses.append(G_loss.item())
+                convergence = (DX_loss + torch.abs(GAMMA * DX_loss - DG_loss)).item()
+                K_update = (K + LAMBDA * (GAMMA * DX_loss - DG_loss)).item()
+                K = min(max(0, K_update), 1)
+                D_sch.step(convergence)
+                G_sch.step(convergence)
+            self.K = K
+            self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+
+
+# ============================================================================================
+# InfoGAN (info_gan.py:45-325).  General path (three optimizers, G updated by two of them).
+# ============================================================================================
+class InfoGenerator(_TwoLayer):
+    _names = ("linear", "generate")
+
+    def __init__(self, image_size, hidden_dim, z_dim, disc_dim, cont_dim):
+        super().__init__()
+        self._build(z_dim + disc_dim + cont_dim, hidden_dim, image_size)
+
+
+class InfoDiscriminator(_TwoLayer):
+    _names = ("linear", "discriminator")
+
+    def __init__(self, image_size, hidden_dim, output_dim):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.output_dim = image_size, hidden_dim, output_dim
+        self._build(image_size, hidden_dim, output_dim)
+
+
+class InfoQ(_TwoLayer):
+    _names = ("linear", "inference")
+    _out_act = "id"
+
+    def __init__(self, image_size, hidden_dim, disc_dim, cont_dim):
+        super().__init__()
+        self.image_size, self.hidden_dim = image_size, hidden_dim
+        self.disc_dim, self.cont_dim = disc_dim, cont_dim
+        self._build(image_size, hidden_dim, disc_dim + cont_dim)
+
+    def forward(self, x):
+        out = super().forward(x)
+        return out[:, :self.disc_dim], out[:, self.disc_dim:]
+
+
+class InfoGANModel(nn.Module):
+    """info_gan.py:97-110."""
+
+    def __init__(self, image_size, hidden_dim, z_dim, disc_dim, cont_dim, output_dim=1):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim = image_size, hidden_dim, z_dim
+        self.disc_dim, self.cont_dim, self.output_dim = disc_dim, cont_dim, output_dim
+        self.G = InfoGenerator(image_size, hidden_dim, z_dim, disc_dim, cont_dim)
+        self.D = InfoDiscriminator(image_size, hidden_dim, output_dim)
+        self.Q = InfoQ(image_size, hidden_dim, disc_dim, cont_dim)
+        self.shape = int(image_size ** 0.5)
+
+
+class InfoGANTrainerBase(GANTrainer):
+    variant = "info"
+
+    def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
+        super().__init__(model, train_iter, val_iter, test_iter, viz)
+        self.MIlosses = []
+
+    def compute_noise(self, batch_size, z_dim, disc_dim, cont_dim, c=None):
+        """info_gan.py:306-325."""
+        z = torch.randn(batch_size, z_dim)
+        disc_c = torch.zeros((batch_size, disc_dim))
+        if c is not None:
+            categorical = int(c) * torch.ones((batch_size,), dtype=torch.long)
+        else:
+            categorical = torch.randint(0, disc_dim, (batch_size,), dtype=torch.long)
+        disc_c[range(batch_size), categorical] = 1
+        cont_c = torch.randn(batch_size, cont_dim)
+        return to_cuda(torch.cat((z, disc_c, cont_c), dim=1))
+
+    def _noise(self, images):
+        m = self.model
+        return self.compute_noise(images.shape[0], m.z_dim, m.disc_dim, m.cont_dim)
+
+    def train_D(self, images):
+        m = self.model
+        sx = m.D(images)
+        sg = m.D(m.G(self._noise(images)))
+        return torch.sum(-torch.mean(torch.log(sx + EPS) + torch.log(1 - sg + EPS)))
+
+    def train_G(self, images):
+        m = self.model
+        return -torch.mean(torch.log(m.D(m.G(self._noise(images))) + EPS))
+
+    def train_Q(self, images, LAMBDA=1):
+        """info_gan.py:269-304."""
+        import torch.nn.functional as F
+        m = self.model
+        noise = self._noise(images)
+        q_disc, q_cont = m.Q(m.G(noise))
+        target = noise[:, m.z_dim:m.z_dim + m.disc_dim]
+        disc_loss = F.cross_entropy(q_disc, torch.max(target, 1)[1])
+        cont_loss = F.mse_loss(q_cont, noise[:, m.z_dim + m.disc_dim:])
+        return LAMBDA * (disc_loss + cont_loss)
+
+    def train(self, num_epochs, G_lr=2e-4, D_lr=2e-4, D_steps=1, quiet=False):
+        """info_gan.py:130-221."""
+        m = self.model
+        pD, pG, pQ = list(m.D.parameters()), list(m.G.parameters()), list(m.Q.parameters())
+        D_opt, G_opt, MI_opt = FlatAdam(pD, D_lr), FlatAdam(pG, G_lr), FlatAdam(pG + pQ, G_lr)
+        epoch_steps = int(np.ceil(len(self.train_iter) / D_steps))
+        for epoch in range(1, num_epochs + 1):
+            m.train()
+            G_losses, D_losses, MI_losses = [], [], []
+            for _ in range(epoch_steps):
+                step = []
+                for _ in range(D_steps):
+                    images = self.process_batch(self.train_iter)
+                    D_opt.zero_grad()
+                    D_loss = self.train_D(images)
+                    D_loss.backward()
+                    D_opt.step()
+                    step.append(D_loss.item())
+                D_losses.append(np.mean(step))
+                G_opt.zero_grad()
+                G_loss = self.train_G(images)
+                G_losses.append(G_loss.item())
+                G_loss.backward()
+                G_opt.step()
+                MI_opt.zero_grad()
+                MI_loss = self.train_Q(images)
+                MI_losses.append(MI_loss.item())
+                MI_loss.backward()
+                MI_opt.step()
+            self.MIlosses.extend(MI_losses)
+            self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)

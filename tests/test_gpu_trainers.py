@@ -30,7 +30,8 @@ MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "mm": ("mm_gan", "MMGAN", "MM
         "w": ("w_gan", "WGAN", "WGANTrainer"), "wgp": ("w_gp_gan", "WGPGAN", "WGPGANTrainer"),
         "ls": ("ls_gan", "LSGAN", "LSGANTrainer"), "ra": ("ra_gan", "RaNSGAN", "RaNSGANTrainer"),
         "fisher": ("fisher_gan", "FisherGAN", "FisherGANTrainer"),
-        "f": ("f_gan", "fGAN", "fGANTrainer")}
+        "f": ("f_gan", "fGAN", "fGANTrainer"), "dra": ("dra_gan", "DRAGAN", "DRAGANTrainer"),
+        "be": ("be_gan", "BEGAN", "BEGANTrainer"), "info": ("info_gan", "InfoGAN", "InfoGANTrainer")}
 TOL = 1e-5
 
 
@@ -50,8 +51,10 @@ def build_product(variant, cfg, batch, loaders=None, use_graph=True):
                                          n_test=cfg["n_test"],
                                          image_shape=tuple(cfg["image_shape"]))
     torch.manual_seed(1234)
-    model = getattr(mod, model_name)(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
-                                     z_dim=cfg["z_dim"])
+    kw = dict(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+    if variant == "info":
+        kw.update(disc_dim=10, cont_dim=10)
+    model = getattr(mod, model_name)(**kw)
     tr = getattr(mod, trainer_name)(model, *loaders, viz=False)
     tr.use_graph = use_graph
     return tr, model
@@ -93,7 +96,11 @@ RAGGED = dict(image_size=100, hidden_dim=70, z_dim=10, batch=24, n_train=200, n_
 CASES = [("ns", dict(num_epochs=2)), ("mm", dict(num_epochs=1, G_init=3)),
          ("w", dict(num_epochs=1, D_steps=2)), ("ls", dict(num_epochs=2)),
          ("ra", dict(num_epochs=1)), ("fisher", dict(num_epochs=1)),
-         ("wgp", dict(num_epochs=1, D_steps=1)), ("wgp", dict(num_epochs=1, D_steps=3))]
+         ("wgp", dict(num_epochs=1, D_steps=1)), ("wgp", dict(num_epochs=1, D_steps=3)),
+         # general path (autograd over the HIP GEMM Functions + flat HIP Adam)
+         ("dra", dict(num_epochs=1, D_steps=1)), ("be", dict(num_epochs=2)),
+         ("info", dict(num_epochs=1))] + \
+        [("f", dict(num_epochs=1, method=m)) for m in port.F_METHODS]
 
 
 @pytest.mark.parametrize("cfg", [SMALL, RAGGED], ids=["small", "ragged"])
@@ -110,6 +117,8 @@ def test_engine_vs_oracle(variant, kw, cfg):
         err = (psd[k].cpu() - osd[k]).abs().max().item()
         assert err <= 2e-5, (k, err)
     assert p_tr.num_epochs == kw["num_epochs"]
+    if variant == "info":
+        lclose(p_tr.MIlosses, o_tr.MIlosses, "info MIlosses")
 
 
 def test_eager_equals_graph():
@@ -146,7 +155,8 @@ def test_two_train_calls_reset_adam():
 
 @pytest.mark.parametrize("name", sorted(
     os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-    if os.path.basename(p).split("_")[0] in ("ns", "mm", "w", "wgp", "ls", "ra", "fisher")))
+    if os.path.basename(p).split("_")[0] in ("ns", "mm", "w", "wgp", "ls", "ra", "fisher", "f",
+                                             "dra", "be", "info")))
 def test_engine_vs_reference_golden(name):
     """HIP path vs fixtures produced by the UNMODIFIED reference (oracle/gen_golden.py)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -216,3 +226,55 @@ def test_user_override_takes_general_path():
     lclose(tr.Glosses, o_tr.Glosses, "override Glosses")
     lclose(tr.Dlosses, o_tr.Dlosses, "override Dlosses")
     assert torch.equal(o_rng, torch.get_rng_state())
+
+
+# ---------------------------------------------------------------------------------------------
+# VAE (config 4): fused engine vs oracle and vs reference fixtures, incl. the ragged last batch
+# ---------------------------------------------------------------------------------------------
+def run_vae_product(cfg, batch, n_train, epochs, use_graph=True):
+    import vae
+    loaders = port.synthetic_loaders(batch, n_train=n_train, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    model = vae.VAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+    tr = vae.VAETrainer(model, *loaders, viz=False)
+    tr.use_graph = use_graph
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=epochs)
+    torch.cuda.synchronize()
+    return tr, model, torch.get_rng_state()
+
+
+@pytest.mark.parametrize("cfg,n_train", [(SMALL, 160), (RAGGED, 200), (SMALL, 150)],
+                         ids=["small", "ragged", "partial-batch"])
+def test_vae_engine_vs_oracle(cfg, n_train):
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=n_train, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build("vae", cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    o = port.VAEPort(o_model, *loaders)
+    o.train(2)
+    o_rng = torch.get_rng_state()
+    p, p_model, p_rng = run_vae_product(cfg, cfg["batch"], n_train, 2)
+    lclose(np.array(p.recon_loss) / 100, np.array(o.recon_loss) / 100, "vae recon")   # sums ~1e3
+    lclose(p.kl_loss, o.kl_loss, "vae kl", tol=2e-5)
+    assert abs(p.best_val_loss - o.best_val_loss) <= 1e-5 * max(1, abs(o.best_val_loss))
+    assert torch.equal(o_rng, p_rng)
+    for (k, a), (_, b) in zip(p_model.state_dict().items(), o_model.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5, k
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512"])
+def test_vae_engine_vs_reference_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    batch = meta.get("batch", cfg.get("batch"))
+    p, p_model, _ = run_vae_product(cfg, batch, meta.get("n_train", cfg["n_train"]),
+                                    meta["train_kw"]["num_epochs"])
+    ref = z["recon_loss"]
+    got = np.array(p.recon_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
+    ref, got = z["kl_loss"], np.array(p.kl_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 2e-5, (got[:4], ref[:4])
+    assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
