@@ -162,7 +162,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
     eng = gm_engine.GANEngine("ns", trainer.model, data, B_global, dev,
-                              use_graph=(world == 1 and not args.no_graph),
+                              use_graph=not args.no_graph,
                               world_size=world, rank=rank)
     W, K = args.warmup, args.steps
     log('engine built')
@@ -207,7 +207,7 @@ def main():
                                    "784-400-20 MLPs, N=50000 synthetic Bernoulli images, parity-mode "
                                    "RNG protocol, Adam 2e-4, D_steps=1",
                        "global_batch": B_global,
-                       "launch": "hipGraph/iteration" if eng.use_graph else "eager+RCCL all-reduce",
+                       "launch": ("hipGraph/iteration" if world == 1 else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world},
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": achieved,

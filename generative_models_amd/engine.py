@@ -135,6 +135,7 @@ class GANEngine:
         self.Hd_dim = self.D1.W.shape[0]
         assert self.D2.W.shape[0] == 1, "score-based critics only"
         self.use_graph = use_graph
+        self.force_segments = False    # tests: exercise the DP launch structure on one rank
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
         z = lambda *s: torch.zeros(*s, device=dev)
@@ -166,20 +167,54 @@ class GANEngine:
         return ops.slot(0, 0, i, 0, stride)
 
     # -- one iteration = D_steps critic steps + one generator step -----------------------------
-    def _issue_iteration(self, st, it):
+    def _segments(self):
+        """The iteration as launch segments separated by the gradient all-reduces (SURVEY.md 8e:
+        exactly two collectives per D+G step at D_steps=1):
+            [D fwd+bwd] AR(D) [Adam D | next D fwd+bwd] AR(D) ... [Adam D | G fwd+bwd] AR(G) [Adam G | tick]
+        Returns [(fn(st, it), flat_grad_to_allreduce_after_or_None), ...]."""
         d = self.D_steps
+        segs = []
+        def seg(parts, ar):
+            def run(st, it, parts=parts):
+                for f in parts:
+                    f(st, it)
+            segs.append((run, ar))
+        pending = []
         for j in range(d):
-            self._issue_D(st, it, j)
-        self._issue_G(st, it)
+            pending.append(lambda st, it, j=j: self._issue_D_pre(st, it, j))
+            seg(pending, self.fD.grad)
+            pending = [lambda st, it, j=j: self._issue_D_post(st, it, j)]
+        pending.append(lambda st, it: self._issue_G_pre(st, it))
+        seg(pending, self.fG.grad)
+        tail = [lambda st, it: self._issue_G_post(st, it)]
         if self.use_graph:
-            ops.tick(self.ctr, 1, stream=st)
+            tail.append(lambda st, it: ops.tick(self.ctr, 1, stream=st))
+        seg(tail, None)
+        return segs
+
+    def _issue_iteration(self, st, it):
+        """Single-process form: all segments back to back (one hipGraph when use_graph)."""
+        for run, ar in self._segments():
+            run(st, it)
+            if ar is not None:
+                self._allreduce(ar)
 
     def _allreduce(self, flat):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world > 1 or self.force_segments:
+            from . import dp
+            dp.allreduce_sum_(flat, self.pg)
 
     def _issue_D(self, st, it, j):
+        self._issue_D_pre(st, it, j)
+        self._allreduce(self.fD.grad)
+        self._issue_D_post(st, it, j)
+
+    def _issue_G(self, st, it):
+        self._issue_G_pre(st, it)
+        self._allreduce(self.fG.grad)
+        self._issue_G_post(st, it)
+
+    def _issue_D_pre(self, st, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
         G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
         X2, Hg, Hd, S2, dS, dHd = self.X2, self.Hg, self.Hd, self.S2, self.dS, self.dHd
@@ -205,11 +240,12 @@ class GANEngine:
         ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp":
             self._issue_gp_backward(st)
-        self._allreduce(self.fD.grad)
-        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
-                 self._slot(it, d, j, 0, 1), clamp=self.clip, stream=st)
 
-    def _issue_G(self, st, it):
+    def _issue_D_post(self, st, it, j):
+        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
+                 self._slot(it, self.D_steps, j, 0, 1), clamp=self.clip, stream=st)
+
+    def _issue_G_pre(self, st, it):
         Bl, R = self.Bl, self.R
         G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
         Hg, Hd, S2, dS, dHd = self.Hg, self.Hd, self.S2, self.dS, self.dHd
@@ -229,7 +265,8 @@ class GANEngine:
         ops.linear_bwd_dw(self.dXg, Hg, G2.gW, G2.gb, M=Bl, stream=st)
         ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
         ops.linear_bwd_dw(self.dHg, zbase, G1.gW, G1.gb, M=Bl, x_slot=zG_slot, stream=st)
-        self._allreduce(self.fG.grad)
+
+    def _issue_G_post(self, st, it):
         ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
                  self._slot(it, 1, self.g_off, 0, 1), stream=st)
 
@@ -338,13 +375,21 @@ class GANEngine:
         if not self.use_graph or self._graph_key == self._key:
             return
         torch.cuda.synchronize()
-        self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
+        if self.world == 1 and not self.force_segments:
+            self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
+            self.seg_graphs = None
+        else:
+            # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
+            self.seg_graphs = [(ops.Graph().capture(lambda st, run=run: run(st, 0)), ar)
+                               for run, ar in self._segments()]
         self._graph_key = self._key
 
     def run(self, n_iters, it_start=0):
         """Run iterations [it_start, it_start+n_iters) (chunked prefetch + graph replays)."""
-        if self.world > 1 and self.use_graph:
-            raise GMError("data-parallel runs use eager launches (RCCL collectives between ops)")
+        if self.world > 1 and self.variant in ("ra", "fisher"):
+            raise GMError("RaGAN / FisherGAN losses are not a mean of per-sample terms; their "
+                          "data-parallel form needs a scalar pre-all-reduce (SURVEY.md 8e) and is "
+                          "not implemented: run them on one GPU")
         self._ensure_graph()
         R = self.R
         it, end, which = it_start, it_start + n_iters, 0
@@ -352,9 +397,15 @@ class GANEngine:
             n = min(R - (it % R), end - it)
             self._prefetch(it, n, which)
             which ^= 1
-            if self.use_graph:
+            if self.use_graph and self.world == 1 and not self.force_segments:
                 for _ in range(n):
                     self.graph.launch()
+            elif self.use_graph:
+                for _ in range(n):
+                    for g, ar in self.seg_graphs:
+                        g.launch()
+                        if ar is not None:
+                            self._allreduce(ar)
             else:
                 st = ops.stream_ptr()
                 for k in range(n):
@@ -381,8 +432,15 @@ class GANEngine:
     def losses(self, it0, it1):
         """Per-iteration (G loss, mean D loss over D_steps) like ns_gan.py:142-154."""
         d = self.D_steps
-        lg = self.lossG[self.g_off + it0:self.g_off + it1].cpu().numpy()
-        ld = self.lossD[it0 * d:it1 * d].cpu().numpy().reshape(-1, d)
+        lg_t = self.lossG[self.g_off + it0:self.g_off + it1]
+        ld_t = self.lossD[it0 * d:it1 * d]
+        if self.world > 1:       # per-rank partial means (1/B_global scaling) -> global means
+            from . import dp
+            lg_t, ld_t = lg_t.clone(), ld_t.clone()
+            dp.allreduce_sum_(lg_t, self.pg)
+            dp.allreduce_sum_(ld_t, self.pg)
+        lg = lg_t.cpu().numpy()
+        ld = ld_t.cpu().numpy().reshape(-1, d)
         G = [float(x) for x in lg]
         D = [float(np.mean([float(v) for v in row])) for row in ld]
         return G, D

@@ -297,8 +297,11 @@ class GANTrainer:
             dev = next(self.model.parameters()).device
             imgs = it.dataset.tensors[0]
             data = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
+            from . import dp
+            world, rank, group = dp.current()
             self._engine = GANEngine(self.variant, self.model, data, it.batch_size, dev,
-                                     method=self.method, use_graph=self.use_graph)
+                                     method=self.method, use_graph=self.use_graph,
+                                     world_size=world, rank=rank, process_group=group)
             self._engine_key = key
         return self._engine
 

@@ -1,0 +1,104 @@
+"""Data-parallel semantics on CPU: world_size=2 over gloo (the GPU path uses RCCL with the same
+calls).  The compute here is the ORACLE's math (tests may use it); what is under test is the
+product's sharding + flat-bucket all-reduce plumbing (generative_models_amd/dp.py, engine host
+protocol): N ranks == 1 rank up to fp32 summation order, identical sampling on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from generative_models_amd import dp, engine
+from oracle import port
+
+B, I, H, Z, N = 32, 64, 48, 8, 400
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat(params):
+    return torch.cat([p.grad.reshape(-1) for p in params])
+
+
+def _d_loss_rows(model, images, noise, inv_b, variant):
+    """Per-shard critic loss with GLOBAL 1/B scaling (what each rank's loss kernel computes)."""
+    sx, sg = model.D(images), model.D(model.G(noise))
+    if variant == "ns":
+        return -(torch.log(sx + 1e-8) + torch.log(1 - sg + 1e-8)).sum() * inv_b
+    return (0.5 * (sx - 1) ** 2 + 0.5 * (sg - 0) ** 2).sum() * inv_b        # ls
+
+
+def _worker(rank, world, port_no, variant, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_no)
+    os.environ["WORLD_SIZE"], os.environ["RANK"], os.environ["LOCAL_RANK"] = \
+        str(world), str(rank), str(rank)
+    torch.set_num_threads(1)
+    w, r, _ = dp.init_from_env(backend="gloo")
+    assert (w, r) == (world, rank) and dp.current()[:2] == (world, rank)
+    # identical host RNG protocol on every rank -> identical global index batch and noise
+    torch.manual_seed(3435)
+    data = torch.bernoulli(torch.full((N, I), 0.1307))
+    model = port.build("ns" if variant == "ns" else "ls", I, H, Z)
+    torch.manual_seed(99)
+    idx = np.empty(B, dtype=np.int64)
+    engine.draw_sampler_indices(N, B, idx)
+    noise = torch.randn(B, Z)
+    lo, hi = dp.shard_range(B, world, rank)
+    images = data[torch.from_numpy(idx)]
+    inv_b = 1.0 / B
+    loss_local = _d_loss_rows(model, images[lo:hi], noise[lo:hi], inv_b, variant)
+    model.zero_grad()
+    loss_local.backward()
+    dparams = list(model.D.parameters())
+    bucket = _flat(dparams).clone()
+    dp.allreduce_sum_(bucket)                       # ONE flat bucket per optimizer
+    loss_t = loss_local.detach().clone().reshape(1)
+    dp.allreduce_sum_(loss_t)
+    # single-process reference on the full batch
+    model.zero_grad()
+    full = _d_loss_rows(model, images, noise, inv_b, variant)
+    full.backward()
+    ref = _flat(dparams)
+    out_q.put((rank, idx.copy(), float((bucket - ref).abs().max()), float(ref.abs().max()),
+               float(loss_t.item()), float(full.item()), lo, hi))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["ns", "ls"])
+def test_two_rank_gradients_match_single_process(variant):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_no = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port_no, variant, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert np.array_equal(res[0][1], res[1][1]), "ranks must sample the same global batch"
+    covered = sorted((r[6], r[7]) for r in res)
+    assert covered == [(0, B // 2), (B // 2, B)]
+    for r in res:
+        assert r[2] <= 1e-6 * max(1.0, r[3]), "all-reduced shard grads != full-batch grads: %r" % (r,)
+        assert abs(r[4] - r[5]) <= 1e-6 * max(1.0, abs(r[5]))
+
+
+def test_shard_range_and_errors():
+    assert dp.shard_range(1024, 8, 3) == (384, 512)
+    assert [dp.shard_range(256, 4, r) for r in range(4)] == [(0, 64), (64, 128), (128, 192), (192, 256)]
+    with pytest.raises(ValueError):
+        dp.shard_range(100, 8, 0)
+    assert dp.current() == (1, 0, None)

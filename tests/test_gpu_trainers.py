@@ -113,9 +113,12 @@ def test_engine_vs_oracle(variant, kw, cfg):
     assert torch.equal(o_rng, p_rng), "global CPU generator must end in the reference's state"
     osd, psd = o_model.state_dict(), p_model.state_dict()
     assert list(osd.keys()) == list(psd.keys())
+    # BEGAN's L1 loss has sign() gradients: a sign flip near |D(x)-x| = 0 moves a parameter by a
+    # full Adam step (lr = 1e-4), so its parameters get a one-step allowance
+    ptol = 1.5e-4 if variant == "be" else 2e-5
     for k in osd:
         err = (psd[k].cpu() - osd[k]).abs().max().item()
-        assert err <= 2e-5, (k, err)
+        assert err <= ptol, (k, err)
     assert p_tr.num_epochs == kw["num_epochs"]
     if variant == "info":
         lclose(p_tr.MIlosses, o_tr.MIlosses, "info MIlosses")
@@ -278,3 +281,29 @@ def test_vae_engine_vs_reference_golden(name):
     ref, got = z["kl_loss"], np.array(p.kl_loss)
     assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 2e-5, (got[:4], ref[:4])
     assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
+
+
+def test_dp_launch_structure_single_rank_rccl():
+    """The data-parallel launch structure (one hipGraph per segment, RCCL all-reduce of the flat
+    gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run bitwise
+    (an all-reduce over one rank is the identity)."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port_no = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_no)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ref = run_product("ls", SMALL, 16, dict(num_epochs=2))
+        tr, model = build_product("ls", SMALL, 16)
+        eng = tr._get_engine()
+        eng.force_segments = True
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(num_epochs=2)
+        torch.cuda.synchronize()
+        assert eng.seg_graphs is not None and len(eng.seg_graphs) == 3
+        assert tr.Glosses == ref[0].Glosses and tr.Dlosses == ref[0].Dlosses
+        for (k, a), (_, b) in zip(model.state_dict().items(), ref[1].state_dict().items()):
+            assert torch.equal(a, b), k
+    finally:
+        dist.destroy_process_group()
