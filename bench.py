@@ -52,7 +52,7 @@ def gemm_shapes(B):
     ]
 
 
-def time_kernels_isolated(B, reps=200):
+def time_kernels_isolated(B, reps=100):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kind: (total_us_per_step, total_flop_per_step, n_launches)}."""
     from generative_models_amd import ops
@@ -74,15 +74,25 @@ def time_kernels_isolated(B, reps=200):
             fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
         else:
             fn = lambda: ops.linear_bwd_dw(dA, x, dW, db, stream=st)
-        for _ in range(10):
-            fn()
+        fn()
+        torch.cuda.synchronize()
+        # capture `reps` back-to-back launches into one hipGraph so that the host-side launch
+        # cost (python+ctypes, ~8 us) is not what the events measure
+        def body(gst, fn=fn, kind=kind):
+            nonlocal st
+            st = gst
+            for _ in range(reps):
+                fn()
+        g = ops.Graph().capture(body)
+        st = ops.stream_ptr()
+        g.launch(); g.launch()
         e0, e1 = ops.Event(), ops.Event()
         e0.record(st)
-        for _ in range(reps):
-            fn()
+        g.launch()
         e1.record(st)
         e1.sync()
         us = e0.elapsed_ms(e1) * 1e3 / reps
+        log('  %-3s M=%4d K=%4d N=%4d : %7.2f us  %6.2f TFLOP/s' % (kind, M, K, N, us, 2.0*M*K*N/us/1e6))
         t, f, n = out.get(kind, (0.0, 0.0, 0))
         out[kind] = (t + us, f + 2.0 * M * K * N, n + 1)
     return out

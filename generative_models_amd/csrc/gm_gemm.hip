@@ -25,6 +25,8 @@
 //   * db falls out of the dW GEMM for free: X gets a virtual ones-column at index K.
 #include "gm_common.h"
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -49,6 +51,10 @@ struct GemmP {
     int epi;
     int accumulate;
     gm_slot a_slot, b_slot;
+    // XCD-aware tile mapping (0 = plain 2-D grid).  The 8 XCDs form an xr x xc grid; XCD (i,j)
+    // owns m-tiles [i*tm/xr, (i+1)*tm/xr) x n-tiles [j*tn/xc, (j+1)*tn/xc), so the operand rows a
+    // private L2 has to pull over the fabric shrink from "all of A and B" to 1/xr of A + 1/xc of B.
+    int xr, xc, tm, tn;
 };
 
 // k-contiguous operand: element (x, k) at P[x*ld + k].  Returns the 4 values k = kb..kb+3.
@@ -96,7 +102,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (p.xr > 0) {
+        // block b is dispatched to XCD b % 8 (observed placement; only speed depends on it)
+        const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
+        const int xi = xcd / p.xc, xj = xcd % p.xc;
+        const int mlo = (xi * p.tm) / p.xr, mhi = ((xi + 1) * p.tm) / p.xr;
+        const int nlo = (xj * p.tn) / p.xc, nhi = ((xj + 1) * p.tn) / p.xc;
+        const int nn = nhi - nlo;
+        if (nn <= 0 || l >= (mhi - mlo) * nn) return;
+        tile_m = mlo + l / nn;
+        tile_n = nlo + l % nn;
+    }
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
 
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
@@ -193,9 +211,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int xcd_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("GM_XCD_MAP");
+        mode = e ? atoi(e) : 1;
+    }
+    return mode;
+}
+
 template <int MODE>
-int launch(hipStream_t s, const GemmP& p, bool vec) {
-    dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM);
+int launch(hipStream_t s, const GemmP& p_in, bool vec) {
+    GemmP p = p_in;
+    const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
+    dim3 grid(tn, tm);
+    p.xr = 0;
+    if (xcd_mode() && tm * tn >= 16) {
+        // pick the XCD grid xr x xc (xr*xc == 8) minimising per-XCD operand rows tm/xr + tn/xc
+        int best = 1 << 30, bxr = 8;
+        for (int xr = 1; xr <= 8; xr <<= 1) {
+            const int xc = 8 / xr;
+            if (xr > tm || xc > tn) continue;
+            const int cost = (tm + xr - 1) / xr + (tn + xc - 1) / xc;
+            if (cost < best) { best = cost; bxr = xr; }
+        }
+        if (best < (1 << 30)) {
+            p.xr = bxr; p.xc = 8 / bxr; p.tm = tm; p.tn = tn;
+            const int per = ((tm + p.xr - 1) / p.xr) * ((tn + p.xc - 1) / p.xc);
+            grid = dim3(8 * per, 1);
+        }
+    }
     if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true>), grid, dim3(WAVES * 64), 0, s, p);
     else     hipLaunchKernelGGL((gemm_kernel<MODE, false>), grid, dim3(WAVES * 64), 0, s, p);
     GM_LAUNCH_RET();
