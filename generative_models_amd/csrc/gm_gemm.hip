@@ -55,6 +55,7 @@ struct GemmP {
     // owns m-tiles [i*tm/xr, (i+1)*tm/xr) x n-tiles [j*tn/xc, (j+1)*tn/xc), so the operand rows a
     // private L2 has to pull over the fabric shrink from "all of A and B" to 1/xr of A + 1/xc of B.
     int xr, xc, tm, tn;
+    int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
 };
 
 // k-contiguous operand: element (x, k) at P[x*ld + k].  Returns the 4 values k = kb..kb+3.
@@ -137,18 +138,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // chunk schedule of this wave: position q = 0,1,2,... -> chunk id.  Round-robin (q*16 + w)
+    // spreads adjacent chunks over waves; blocked (w*cpw + q) gives each wave a contiguous k-range
+    // so that its consecutive 16-byte loads fall into the same 128-byte lines.
+    const int cstep = p.cpw > 0 ? 1 : WAVES;
+    const int cbase = p.cpw > 0 ? w * p.cpw : w;
+    const int cend = p.cpw > 0 ? min(nchunks, (w + 1) * p.cpw) : nchunks;
     float4 a0[G], b0[G], a1[G], b1[G];
     auto load_group = [&](float4 (&a)[G], float4 (&b)[G], int c) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int cc = c + i * WAVES;
-            if (cc < nchunks) { a[i] = load_a(cc); b[i] = load_b(cc); }
+            const int cc = c + i * cstep;
+            if (cc < cend) { a[i] = load_a(cc); b[i] = load_b(cc); }
         }
     };
     auto mfma_group = [&](const float4 (&a)[G], const float4 (&b)[G], int c) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            if (c + i * WAVES < nchunks) {       // wave-uniform
+            if (c + i * cstep < cend) {       // wave-uniform
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
@@ -158,19 +165,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     };
 
     // two-stage register pipeline over this wave's chunks  w, w+16, w+32, ...
-    int c = w;
-    if (c < nchunks) {
+    int c = cbase;
+    if (c < cend) {
         load_group(a0, b0, c);
         while (true) {
-            int cn = c + G * WAVES;
-            if (cn < nchunks) load_group(a1, b1, cn);
+            int cn = c + G * cstep;
+            if (cn < cend) load_group(a1, b1, cn);
             mfma_group(a0, b0, c);
-            if (cn >= nchunks) break;
+            if (cn >= cend) break;
             c = cn;
-            cn = c + G * WAVES;
-            if (cn < nchunks) load_group(a0, b0, cn);
+            cn = c + G * cstep;
+            if (cn < cend) load_group(a0, b0, cn);
             mfma_group(a1, b1, c);
-            if (cn >= nchunks) break;
+            if (cn >= cend) break;
             c = cn;
         }
     }
@@ -215,7 +222,7 @@ int xcd_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("GM_XCD_MAP");
-        mode = e ? atoi(e) : 1;
+        mode = e ? atoi(e) : 0;
     }
     return mode;
 }
@@ -226,6 +233,12 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec) {
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
+    {
+        static int blocked = -1;
+        if (blocked < 0) { const char* e = getenv("GM_CHUNK_BLOCKED"); blocked = e ? atoi(e) : 0; }
+        const int nchunks = (p.K + 7) / 8;
+        p.cpw = blocked ? (nchunks + WAVES - 1) / WAVES : 0;
+    }
     if (xcd_mode() && tm * tn >= 16) {
         // pick the XCD grid xr x xc (xr*xc == 8) minimising per-XCD operand rows tm/xr + tn/xc
         int best = 1 << 30, bxr = 8;
