@@ -57,6 +57,13 @@ _SIGNATURES = {
                                    c_int]),
     "gm_sqerr_sigmoid_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
     "gm_sum_finalize": (c_int, [_P, _P, c_int, c_float, _P, Slot]),
+    "gm_head_fwd_loss": (c_int, [_P, c_int, c_int, _P, c_int64, _P, _P, c_int, c_int, c_int,
+                                 POINTER(c_float), c_int, c_float, _P, _P, _P, _P]),
+    "gm_head_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot, c_float,
+                            c_int, c_int, c_int]),
+    "gm_stream_create": (c_int, [POINTER(c_void_p)]),
+    "gm_stream_destroy": (c_int, [_P]),
+    "gm_stream_wait_event": (c_int, [_P, _P]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_graph_begin": (c_int, [_P]),

@@ -48,3 +48,106 @@ __device__ __forceinline__ double gm_wave_sum_d(double v) {
 }
 
 __device__ __forceinline__ float gm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- shared by the loss kernels (gm_ops.hip) and the fused critic-head kernels (gm_fused.hip) ----
+constexpr float EPS = 1e-8f;
+
+static __device__ __forceinline__ float act_grad(float g, float s, int out_act) {
+    if (out_act == GM_ACT_SIGMOID) return (g * (1.f - s)) * s;   // SigmoidBackward: grad*(1-y)*y
+    if (out_act == GM_ACT_RELU) return s > 0.f ? g : 0.f;
+    return g;
+}
+
+// Per-sample loss terms and d loss / d score for the separable variants (appendix A.2):
+// lx/dx for a real-sample score x, lg/dg for a generated-sample score g; `D` = critic mode.
+static __device__ __forceinline__ void sample_terms(int variant, bool D, float x, float g, float ib,
+                                             const float* hyper, float& lx, float& lg, float& dx,
+                                             float& dg) {
+    lx = lg = dx = dg = 0.f;
+    switch (variant) {
+    case GM_LOSS_NS:
+        if (D) {   // ns_gan.py:191-192
+            const float ux = x + EPS, ug = (1.f - g) + EPS;
+            lx = -logf(ux); lg = -logf(ug);
+            dx = (-ib) / ux; dg = -((-ib) / ug);
+        } else {   // ns_gan.py:214
+            const float ug = g + EPS;
+            lg = -logf(ug); dg = (-ib) / ug;
+        }
+        break;
+    case GM_LOSS_MM:
+        if (D) {
+            const float ux = x + EPS, ug = (1.f - g) + EPS;
+            lx = -logf(ux); lg = -logf(ug);
+            dx = (-ib) / ux; dg = -((-ib) / ug);
+        } else {   // mm_gan.py:235
+            const float ug = (1.f - g) + EPS;
+            lg = logf(ug); dg = -(ib / ug);
+        }
+        break;
+    case GM_LOSS_W:
+    case GM_LOSS_FISHER:   // generator mode only reaches here: -mean(sg)
+        if (D) { lx = -x; lg = g; dx = -ib; dg = ib;
+ }
+        else   { lg = -g; dg = -ib; }
+        break;
+    case GM_LOSS_LS: {
+        const float a = hyper[0], b = hyper[1], c = hyper[2];
+        if (D) {   // ls_gan.py:192-193
+            lx = 0.5f * ((x - b) * (x - b)); lg = 0.5f * ((g - a) * (g - a));
+            dx = (0.5f * ib) * (2.f * (x - b)); dg = (0.5f * ib) * (2.f * (g - a));
+        } else {   // ls_gan.py:213
+            lg = 0.5f * ((g - c) * (g - c)); dg = (0.5f * ib) * (2.f * (g - c));
+        }
+        break;
+    }
+    case GM_LOSS_RA:       // generator mode: plain NS (ra_gan.py:227)
+    {
+        const float ug = g + EPS;
+        lg = -logf(ug); dg = (-ib) / ug;
+        break;
+    }
+    case GM_LOSS_F_TV: {
+        const float tg = tanhf(g);
+        if (D) { const float tx = tanhf(x);
+                 lx = -(0.5f * tx); lg = 0.5f * tg;
+                 dx = -(0.5f * ib) * (1.f - tx * tx); dg = (0.5f * ib) * (1.f - tg * tg); }
+        else   { lg = -(0.5f * tg); dg = -(0.5f * ib) * (1.f - tg * tg); }
+        break;
+    }
+    case GM_LOSS_F_FKL: {
+        const float e = expf(g - 1.f);
+        if (D) { lx = -x; lg = e; dx = -ib; dg = ib * e; }
+        else   { lg = -e; dg = -(ib * e); }
+        break;
+    }
+    case GM_LOSS_F_RKL:
+        if (D) { const float e = expf(x); lx = e; lg = -1.f - g; dx = ib * e; dg = -ib; }
+        else   { lg = -(-1.f - g); dg = ib; }
+        break;
+    case GM_LOSS_F_PEARSON: {
+        const float q = 0.25f * (g * g) + g;
+        if (D) { lx = -x; lg = q; dx = -ib; dg = ib * (0.5f * g + 1.f); }
+        else   { lg = -q; dg = -(ib * (0.5f * g + 1.f)); }
+        break;
+    }
+    case GM_LOSS_F_HELLINGER: {
+        const float eg = expf(g);
+        const float h = (1.f - eg) / eg;                    // = exp(-g) - 1
+        if (D) { const float ex = expf(x);
+                 lx = -(1.f - ex); lg = h; dx = ib * ex; dg = -(ib / eg); }
+        else   { lg = -h; dg = ib / eg; }
+        break;
+    }
+    case GM_LOSS_F_JS: {
+        const float eg = expf(g);
+        if (D) { const float enx = expf(-x);
+                 lx = -(2.f - (1.f + enx)); lg = -(2.f - eg);
+                 dx = -(ib * enx); dg = ib * eg; }
+        else   { lg = 2.f - eg; dg = -(ib * eg); }
+        break;
+    }
+    default: break;
+    }
+}
+

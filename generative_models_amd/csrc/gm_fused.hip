@@ -245,3 +245,136 @@ extern "C" int gm_sum_finalize(void* stream, const float* partial, int n, float 
                        scale, out, out_slot);
     GM_LAUNCH_RET();
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused critic head (output_dim == 1; ns_gan.py:59 + the loss lines of train_D / train_G):
+//   head_fwd_loss : s_r = act(h_r . w2 + b2)  ->  per-row loss term l_r and dS_r = d loss/d a2_r
+//                   (separable variants only; one wave per row, 400-wide dot by wave64 shuffle)
+//   head_bwd      : dH[r,n] = dS_r * w2[n] * [h[r,n] > 0]   (ReluBackward of the hidden layer)
+//                   gw2[n]  = sum_r dS_r * h[r,n],  gb2 = fl(sum_{x rows} dS) + fl(sum_{g rows} dS)
+//                   loss    = inv_b * sum_r l_r  (block 0, fp64, fixed order)
+// They replace four launches of the generic path (N=1 GEMV, loss, N=1 dW, K=1 dX).
+// ------------------------------------------------------------------------------------------
+struct HeadP {
+    const float* H; int64_t ldh;
+    const float* w2; const float* b2;
+    int variant, gen_mode, out_act, R, B, Hd;     // R rows: D mode 2B (x rows then g rows), G mode B
+    float hyper[8];
+    float inv_b;
+    const float* pen;                             // WGAN-GP penalty rows (x rows) or null
+    float* S; float* dS; float* rowloss;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= p.R) return;
+    const float* h = p.H + (int64_t)r * p.ldh;
+    float acc = 0.f;
+    for (int i = lane; i < p.Hd; i += 64) acc = fmaf(h[i], p.w2[i], acc);
+    acc = gm_wave_sum(acc);
+    float a2 = acc + p.b2[0];
+    float s = a2;
+    if (p.out_act == GM_ACT_SIGMOID) s = gm_sigmoid(a2);
+    else if (p.out_act == GM_ACT_RELU) s = fmaxf(a2, 0.f);
+    if (lane == 0) {
+        const bool D = !p.gen_mode;
+        const bool is_x = D && r < p.B;
+        float lx, lg, dx, dg;
+        sample_terms(p.variant, D, is_x ? s : 0.5f, is_x ? 0.5f : s, p.inv_b, p.hyper, lx, lg, dx, dg);
+        float l = is_x ? lx : lg;
+        if (is_x && p.pen && p.variant == GM_LOSS_W) l += p.hyper[0] * p.pen[r];
+        p.S[r] = s;
+        p.dS[r] = act_grad(is_x ? dx : dg, s, p.out_act);
+        p.rowloss[r] = l;
+    }
+}
+
+extern "C" int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const float* H,
+                                int64_t ldh, const float* w2, const float* b2, int out_act, int B,
+                                int Hd, const float* hyper, int n_hyper, float inv_b,
+                                const float* pen, float* S, float* dS, float* rowloss) {
+    GM_CHECK_ARG(H && w2 && b2 && S && dS && rowloss && B > 0 && Hd > 0 && n_hyper >= 0 && n_hyper <= 8);
+    GM_CHECK_ARG(variant != GM_LOSS_RA || gen_mode);
+    GM_CHECK_ARG(variant != GM_LOSS_FISHER || gen_mode);
+    HeadP p{};
+    p.H = H; p.ldh = ldh; p.w2 = w2; p.b2 = b2; p.variant = variant; p.gen_mode = gen_mode;
+    p.out_act = out_act; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd; p.inv_b = inv_b;
+    for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
+    p.pen = pen; p.S = S; p.dS = dS; p.rowloss = rowloss;
+    hipLaunchKernelGGL(head_fwd_loss_kernel, dim3((p.R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    GM_LAUNCH_RET();
+}
+
+struct HeadBwdP {
+    const float* H; int64_t ldh;
+    const float* dS; const float* w2; const float* rowloss;
+    float* dH; int64_t lddh;
+    float* gw2; float* gb2;                 // null in generator mode (D grads are not needed)
+    float* loss_out; gm_slot loss_slot;
+    float inv_b;
+    int R, B, Hd, gen_mode;
+};
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdP p) {
+    __shared__ float sh[8][33];
+    __shared__ double shd[4];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float acc = 0.f;
+    if (c < p.Hd) {
+        const float w = p.w2[c];
+        for (int r = rg; r < p.R; r += 8) {
+            const float h = p.H[(int64_t)r * p.ldh + c];
+            const float d = p.dS[r];
+            p.dH[(int64_t)r * p.lddh + c] = (h > 0.f) ? d * w : 0.f;
+            acc = fmaf(d, h, acc);
+        }
+    }
+    if (p.gw2) {
+        sh[rg][cl] = acc;
+        __syncthreads();
+        if (rg == 0 && c < p.Hd) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += sh[q][cl];
+            p.gw2[c] = v;
+        }
+    }
+    if (blockIdx.x == 0) {
+        // scalars: loss = inv_b * sum l_r ; gb2 = fl(sum over x rows) + fl(sum over g rows)
+        double sl = 0.0, sx = 0.0, sg = 0.0;
+        for (int r = threadIdx.x; r < p.R; r += 256) {
+            sl += (double)p.rowloss[r];
+            const double d = (double)p.dS[r];
+            if (!p.gen_mode && r < p.B) sx += d; else sg += d;
+        }
+        double v[3] = {sl, sx, sg};
+        float outv[3];
+        for (int k = 0; k < 3; ++k) {
+            double a = gm_wave_sum_d(v[k]);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = a;
+            __syncthreads();
+            outv[k] = (k == 0) ? (float)(((shd[0] + shd[1]) + (shd[2] + shd[3])) * (double)p.inv_b)
+                               : (float)((shd[0] + shd[1]) + (shd[2] + shd[3]));
+        }
+        if (threadIdx.x == 0) {
+            p.loss_out[gm_slot_index(p.loss_slot)] = outv[0];
+            if (p.gb2) p.gb2[0] = outv[1] + outv[2];
+        }
+    }
+}
+
+extern "C" int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS,
+                           const float* w2, const float* rowloss, float* dH, int64_t lddh,
+                           float* gw2, float* gb2, float* loss_out, gm_slot loss_slot, float inv_b,
+                           int gen_mode, int B, int Hd) {
+    GM_CHECK_ARG(H && dS && w2 && rowloss && dH && loss_out && B > 0 && Hd > 0);
+    HeadBwdP p{};
+    p.H = H; p.ldh = ldh; p.dS = dS; p.w2 = w2; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
+    p.gw2 = gw2; p.gb2 = gb2; p.loss_out = loss_out; p.loss_slot = loss_slot; p.inv_b = inv_b;
+    p.gen_mode = gen_mode; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((Hd + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
+    GM_LAUNCH_RET();
+}

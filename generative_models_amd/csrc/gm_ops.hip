@@ -92,13 +92,7 @@ __device__ double block_sum(double v, double* sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__device__ __forceinline__ float act_grad(float g, float s, int out_act) {
-    if (out_act == GM_ACT_SIGMOID) return (g * (1.f - s)) * s;   // SigmoidBackward: grad*(1-y)*y
-    if (out_act == GM_ACT_RELU) return s > 0.f ? g : 0.f;
-    return g;
-}
 
-constexpr float EPS = 1e-8f;
 
 __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
     __shared__ double sh[4];
@@ -181,95 +175,12 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
     double sbx = 0.0, sbg = 0.0;
     for (int i = t; i < B; i += 256) {
         const float g = p.sg[i];
-        const float x = D ? p.sx[i] : 0.f;
-        float lx = 0.f, lg = 0.f, dx = 0.f, dg = 0.f;      // loss terms (to be averaged), dL/ds
-        switch (p.variant) {
-        case GM_LOSS_NS:
-            if (D) {   // ns_gan.py:191-192
-                const float ux = x + EPS, ug = (1.f - g) + EPS;
-                lx = -logf(ux); lg = -logf(ug);
-                dx = (-ib) / ux; dg = -((-ib) / ug);
-            } else {   // ns_gan.py:214
-                const float ug = g + EPS;
-                lg = -logf(ug); dg = (-ib) / ug;
-            }
-            break;
-        case GM_LOSS_MM:
-            if (D) {
-                const float ux = x + EPS, ug = (1.f - g) + EPS;
-                lx = -logf(ux); lg = -logf(ug);
-                dx = (-ib) / ux; dg = -((-ib) / ug);
-            } else {   // mm_gan.py:235
-                const float ug = (1.f - g) + EPS;
-                lg = logf(ug); dg = -(ib / ug);
-            }
-            break;
-        case GM_LOSS_W:
-        case GM_LOSS_FISHER:   // generator mode only reaches here: -mean(sg)
-            if (D) { lx = -x; lg = g; dx = -ib; dg = ib;
-                     // WGAN-GP: + lambda * mean((||grad|| - 1)^2), per-row terms in aux
-                     // (w_gp_gan.py:215-218; rows produced by gm_gp_norm)
-                     if (p.aux) lx += p.hyper[0] * p.aux[i]; }
-            else   { lg = -g; dg = -ib; }
-            break;
-        case GM_LOSS_LS: {
-            const float a = p.hyper[0], b = p.hyper[1], c = p.hyper[2];
-            if (D) {   // ls_gan.py:192-193
-                lx = 0.5f * ((x - b) * (x - b)); lg = 0.5f * ((g - a) * (g - a));
-                dx = (0.5f * ib) * (2.f * (x - b)); dg = (0.5f * ib) * (2.f * (g - a));
-            } else {   // ls_gan.py:213
-                lg = 0.5f * ((g - c) * (g - c)); dg = (0.5f * ib) * (2.f * (g - c));
-            }
-            break;
-        }
-        case GM_LOSS_RA:       // generator mode: plain NS (ra_gan.py:227)
-        {
-            const float ug = g + EPS;
-            lg = -logf(ug); dg = (-ib) / ug;
-            break;
-        }
-        case GM_LOSS_F_TV: {
-            const float tg = tanhf(g);
-            if (D) { const float tx = tanhf(x);
-                     lx = -(0.5f * tx); lg = 0.5f * tg;
-                     dx = -(0.5f * ib) * (1.f - tx * tx); dg = (0.5f * ib) * (1.f - tg * tg); }
-            else   { lg = -(0.5f * tg); dg = -(0.5f * ib) * (1.f - tg * tg); }
-            break;
-        }
-        case GM_LOSS_F_FKL: {
-            const float e = expf(g - 1.f);
-            if (D) { lx = -x; lg = e; dx = -ib; dg = ib * e; }
-            else   { lg = -e; dg = -(ib * e); }
-            break;
-        }
-        case GM_LOSS_F_RKL:
-            if (D) { const float e = expf(x); lx = e; lg = -1.f - g; dx = ib * e; dg = -ib; }
-            else   { lg = -(-1.f - g); dg = ib; }
-            break;
-        case GM_LOSS_F_PEARSON: {
-            const float q = 0.25f * (g * g) + g;
-            if (D) { lx = -x; lg = q; dx = -ib; dg = ib * (0.5f * g + 1.f); }
-            else   { lg = -q; dg = -(ib * (0.5f * g + 1.f)); }
-            break;
-        }
-        case GM_LOSS_F_HELLINGER: {
-            const float eg = expf(g);
-            const float h = (1.f - eg) / eg;                    // = exp(-g) - 1
-            if (D) { const float ex = expf(x);
-                     lx = -(1.f - ex); lg = h; dx = ib * ex; dg = -(ib / eg); }
-            else   { lg = -h; dg = ib / eg; }
-            break;
-        }
-        case GM_LOSS_F_JS: {
-            const float eg = expf(g);
-            if (D) { const float enx = expf(-x);
-                     lx = -(2.f - (1.f + enx)); lg = -(2.f - eg);
-                     dx = -(ib * enx); dg = ib * eg; }
-            else   { lg = 2.f - eg; dg = -(ib * eg); }
-            break;
-        }
-        default: break;
-        }
+        const float x = D ? p.sx[i] : 0.5f;
+        float lx, lg, dx, dg;
+        sample_terms(p.variant, D, x, g, ib, p.hyper, lx, lg, dx, dg);
+        // WGAN-GP: + lambda * mean((||grad|| - 1)^2), per-row terms in aux
+        // (w_gp_gan.py:215-218; rows produced by gm_gp_norm)
+        if (D && p.aux && p.variant == GM_LOSS_W) lx += p.hyper[0] * p.aux[i];
         acc += (double)lx + (double)lg;
         if (D && p.dax) { const float ax = act_grad(dx, x, p.out_act); p.dax[i] = ax; sbx += (double)ax; }
         if (p.dag) { const float ag = act_grad(dg, g, p.out_act); p.dag[i] = ag; sbg += (double)ag; }
@@ -481,6 +392,22 @@ extern "C" int gm_graph_launch(void* graph_exec, void* stream) {
 }
 extern "C" int gm_graph_destroy(void* graph_exec) {
     if (graph_exec) GM_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+extern "C" int gm_stream_create(void** stream_out) {
+    GM_CHECK_ARG(stream_out);
+    hipStream_t st;
+    GM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream_out = (void*)st;
+    return 0;
+}
+extern "C" int gm_stream_destroy(void* stream) {
+    if (stream) GM_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+extern "C" int gm_stream_wait_event(void* stream, void* ev) {
+    GM_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
     return 0;
 }
 

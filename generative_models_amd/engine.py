@@ -136,6 +136,10 @@ class GANEngine:
         assert self.D2.W.shape[0] == 1, "score-based critics only"
         self.use_graph = use_graph
         self.force_segments = False    # tests: exercise the DP launch structure on one rank
+        import os
+        self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
+        self.dag = os.environ.get("GM_DAG", "1") != "0"
+        self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
         z = lambda *s: torch.zeros(*s, device=dev)
@@ -147,6 +151,8 @@ class GANEngine:
         self.dHd = z(2 * Bl, Hd)
         self.dXg = z(Bl, I)
         self.dHg = z(Bl, H)
+        self.Hg2, self.Xg2 = z(Bl, H), z(Bl, I)     # generator step's own G(z) buffers
+        self.rowloss = z(2 * Bl)
         self.aux = z(8)                    # Fisher lambda + moments
         if variant == "wgp":
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
@@ -214,61 +220,135 @@ class GANEngine:
         self._allreduce(self.fG.grad)
         self._issue_G_post(st, it)
 
-    def _issue_D_pre(self, st, it, j):
+    # ---- pieces of one critic step (composed sequentially, or as parallel graph branches) -----
+    def _D_gather(self, st, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
-        G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
-        X2, Hg, Hd, S2, dS, dHd = self.X2, self.Hg, self.Hd, self.S2, self.dS, self.dHd
         r0 = self.rank * Bl                       # this rank's rows of the global batch
-        idx_slot = self._slot(it, d, j, R * d, self.B)
+        ops.gather_rows(self.data, self.idx_ring.view(-1)[r0:], self.X2, B=Bl,
+                        idx_slot=self._slot(it, d, j, R * d, self.B), stream=st)
+
+    def _D_gen(self, st, it, j):
+        Bl, d, R = self.Bl, self.D_steps, self.R
+        G1, G2 = self.G1, self.G2
         zD_slot = self._slot(it, d, j, R * d, self.B * self.Z)
-        ops.gather_rows(self.data, self.idx_ring.view(-1)[r0:], X2, B=Bl, idx_slot=idx_slot,
-                        stream=st)
-        zbase = self.zD_ring.view(-1)[r0 * self.Z:].view(-1, self.Z)
-        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=zD_slot, stream=st)
-        ops.linear_fwd(Hg, G2.W, G2.b, X2[Bl:], "sigmoid", M=Bl, stream=st)
+        zbase = self.zD_ring.view(-1)[self.rank * Bl * self.Z:].view(-1, self.Z)
+        ops.linear_fwd(zbase, G1.W, G1.b, self.Hg, "relu", M=Bl, x_slot=zD_slot, stream=st)
+        ops.linear_fwd(self.Hg, G2.W, G2.b, self.X2[Bl:], "sigmoid", M=Bl, stream=st)
+
+    def _D_rest(self, st, it, j):
+        Bl, d = self.Bl, self.D_steps
+        D1, D2 = self.D1, self.D2
+        X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
+        loss_slot = self._slot(it, d, j, 0, 1)
         ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
-        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
             self._issue_gp_forward(st, it, j)
             aux, hyper = self.pen, (self.gp_lambda,)
-        ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
-                     dS[:Bl], dS[Bl:], hyper=hyper, inv_b=self.inv_b,
-                     loss_slot=self._slot(it, d, j, 0, 1), aux=aux, db=D2.gb, stream=st)
-        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
-        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
+        if self.fuse_head and self.variant not in ("ra", "fisher"):
+            from . import ops_fused as of
+            of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
+                             self.inv_b, aux, S2, dS, self.rowloss, stream=st)
+            of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, D2.gW, D2.gb, self.lossD, loss_slot,
+                        self.inv_b, False, Bl, stream=st)
+        else:
+            ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
+            ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
+                         dS[:Bl], dS[Bl:], hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot,
+                         aux=aux, db=D2.gb, stream=st)
+            ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
+            ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
         ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp":
             self._issue_gp_backward(st)
+
+    def _issue_D_pre(self, st, it, j):
+        self._D_gather(st, it, j)
+        self._D_gen(st, it, j)
+        self._D_rest(st, it, j)
 
     def _issue_D_post(self, st, it, j):
         ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
                  self._slot(it, self.D_steps, j, 0, 1), clamp=self.clip, stream=st)
 
-    def _issue_G_pre(self, st, it):
-        Bl, R = self.Bl, self.R
-        G1, G2, D1, D2 = self.G1, self.G2, self.D1, self.D2
-        Hg, Hd, S2, dS, dHd = self.Hg, self.Hd, self.S2, self.dS, self.dHd
-        Xg = self.X2[Bl:]
-        r0 = self.rank * Bl
-        zG_slot = self._slot(it, 1, 0, R, self.B * self.Z)
-        zbase = self.zG_ring.view(-1)[r0 * self.Z:].view(-1, self.Z)
-        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=zG_slot, stream=st)
-        ops.linear_fwd(Hg, G2.W, G2.b, Xg, "sigmoid", M=Bl, stream=st)
+    # ---- pieces of the generator step (own Hg2/Xg2 buffers: its generator forward only needs G's
+    # parameters, so it can run as a parallel branch of the critic step) ----------------------
+    def _G_zslot(self, it):
+        zbase = self.zG_ring.view(-1)[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        return zbase, self._slot(it, 1, 0, self.R, self.B * self.Z)
+
+    def _G_gen(self, st, it):
+        G1, G2 = self.G1, self.G2
+        zbase, zG_slot = self._G_zslot(it)
+        ops.linear_fwd(zbase, G1.W, G1.b, self.Hg2, "relu", M=self.Bl, x_slot=zG_slot, stream=st)
+        ops.linear_fwd(self.Hg2, G2.W, G2.b, self.Xg2, "sigmoid", M=self.Bl, stream=st)
+
+    def _G_critic(self, st, it):
+        """D(G(z)) forward, loss, and the backward through D down to d loss / d (pre-sigmoid G)."""
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        Hd, S2, dS, dHd, Xg = self.Hd, self.S2, self.dS, self.dHd, self.Xg2
+        loss_slot = self._slot(it, 1, self.g_off, 0, 1)
         ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
-        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
-        ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
-                     hyper=self.hyper, inv_b=self.inv_b,
-                     loss_slot=self._slot(it, 1, self.g_off, 0, 1), stream=st)
-        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
+        if self.fuse_head:
+            from . import ops_fused as of
+            of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
+                             self.inv_b, None, S2, dS, self.rowloss, stream=st)
+            of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, None, None, self.lossG, loss_slot,
+                        self.inv_b, True, Bl, stream=st)
+        else:
+            ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
+            ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
+                         hyper=self.hyper, inv_b=self.inv_b, loss_slot=loss_slot, stream=st)
+            ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
         ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
-        ops.linear_bwd_dw(self.dXg, Hg, G2.gW, G2.gb, M=Bl, stream=st)
-        ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
-        ops.linear_bwd_dw(self.dHg, zbase, G1.gW, G1.gb, M=Bl, x_slot=zG_slot, stream=st)
+
+    def _G_dw2(self, st, it):
+        ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
+
+    def _G_dh_dw1(self, st, it):
+        zbase, zG_slot = self._G_zslot(it)
+        ops.linear_bwd_dx(self.dXg, self.G2.W, self.dHg, below=self.Hg2, epi="relu", M=self.Bl,
+                          stream=st)
+        ops.linear_bwd_dw(self.dHg, zbase, self.G1.gW, self.G1.gb, M=self.Bl, x_slot=zG_slot,
+                          stream=st)
+
+    def _issue_G_pre(self, st, it):
+        self._G_gen(st, it)
+        self._G_critic(st, it)
+        self._G_dw2(st, it)
+        self._G_dh_dw1(st, it)
 
     def _issue_G_post(self, st, it):
         ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
                  self._slot(it, 1, self.g_off, 0, 1), stream=st)
+
+    # ---- the same iteration as a DAG: independent pieces become parallel hipGraph branches ----
+    def _issue_iteration_dag(self, st, it):
+        from . import _lib
+        s1, s2 = self.side
+        ev = iter(self.events)
+        def fork(src, dst):
+            e = next(ev)
+            e.record(src)
+            _lib.call("gm_stream_wait_event", dst, e.h)
+        fork(st, s1)
+        self._G_gen(s1, it)                       # generator step's G(z): needs only G's params
+        for j in range(self.D_steps):
+            fork(st, s2)
+            self._D_gather(s2, it, j)             # gather || critic step's G(z)
+            self._D_gen(st, it, j)
+            fork(s2, st)
+            self._D_rest(st, it, j)
+            self._issue_D_post(st, it, j)
+        fork(s1, st)                              # join: Xg2/Hg2 ready, D updated
+        self._G_critic(st, it)
+        fork(st, s1)
+        self._G_dw2(s1, it)                       # dW2 || (dH -> dW1)
+        self._G_dh_dw1(st, it)
+        fork(s1, st)
+        self._issue_G_post(st, it)
+        ops.tick(self.ctr, 1, stream=st)
 
     # -- WGAN-GP penalty: w_gp_gan.py:195-218, hand-derived second backward (SURVEY.md A.3) -----
     def _issue_gp_forward(self, st, it, j):
@@ -362,7 +442,8 @@ class GANEngine:
         self.aux.zero_()
         self.ctr.zero_()
         R = max(1, min(CHUNK, n_iters))
-        key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph)
+        key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
+               self.fuse_head, self.dag)
         if getattr(self, "_ring_key", None) != (D_steps, R):
             self._alloc_rings(R)
             self._ring_key = (D_steps, R)
@@ -376,7 +457,19 @@ class GANEngine:
             return
         torch.cuda.synchronize()
         if self.world == 1 and not self.force_segments:
-            self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
+            if self.dag:
+                import ctypes
+                from . import _lib
+                if self.side is None:
+                    self.side = []
+                    for _ in range(2):
+                        h = ctypes.c_void_p()
+                        _lib.call("gm_stream_create", ctypes.byref(h))
+                        self.side.append(h)
+                self.events = [ops.Event() for _ in range(4 + 2 * self.D_steps)]
+                self.graph = ops.Graph().capture(lambda st: self._issue_iteration_dag(st, 0))
+            else:
+                self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them

@@ -48,3 +48,24 @@ def sqerr_sigmoid_bwd(x, xr, dA, partial, B, stream=None):
 def sum_finalize(partial, n, out, scale=1.0, out_slot=NO_SLOT, stream=None):
     _lib.call("gm_sum_finalize", stream or stream_ptr(), partial.data_ptr(), n, scale,
               out.data_ptr(), out_slot)
+
+
+def head_fwd_loss(variant, gen_mode, H, w2, b2, out_act, B, hyper, inv_b, pen, S, dS, rowloss,
+                  stream=None):
+    """Fused critic head forward + per-row loss + d loss/d pre-activation (separable variants)."""
+    import ctypes
+    from ._lib import ACT, LOSS
+    h = (ctypes.c_float * 8)(*([float(x) for x in hyper] + [0.0] * (8 - len(hyper))))
+    _lib.call("gm_head_fwd_loss", stream or stream_ptr(), LOSS[variant], 1 if gen_mode else 0,
+              H.data_ptr(), _ld(H), w2.data_ptr(), b2.data_ptr(), ACT[out_act], B, H.shape[1], h,
+              len(hyper), inv_b, pen.data_ptr() if pen is not None else None, S.data_ptr(),
+              dS.data_ptr(), rowloss.data_ptr())
+
+
+def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_mode, B, stream=None):
+    """dH = dS (x) w2 masked by H>0; gw2 = dS^T H; gb2; loss scalar (see gm_hip.h)."""
+    _lib.call("gm_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
+              w2.data_ptr(), rowloss.data_ptr(), dH.data_ptr(), _ld(dH),
+              gw2.data_ptr() if gw2 is not None else None,
+              gb2.data_ptr() if gb2 is not None else None, loss_out.data_ptr(), loss_slot, inv_b,
+              1 if gen_mode else 0, B, H.shape[1])

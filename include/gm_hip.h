@@ -144,6 +144,20 @@ int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, const float*
 int gm_sum_finalize(void* stream, const float* partial, int n, float scale, float* out,
                     gm_slot out_slot);
 
+/* ---- fused critic head (output_dim == 1, separable loss variants): replaces the N=1 GEMV
+ * (`self.discriminate`, ns_gan.py:59), the loss lines of train_D / train_G (appendix A.2) and, in
+ * the backward, the N=1 dW + K=1 dX launches.  H: hidden activations [R,Hd] (critic mode R=2B,
+ * rows 0..B-1 real then B generated; generator mode R=B).  head_fwd_loss writes scores S[R],
+ * dS[R] = d loss / d pre-activation and per-row loss terms; head_bwd writes
+ * dH = dS (x) w2 masked by H>0, gw2 = dS^T H, gb2 (fp64 half-sums) and the loss scalar. */
+int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const float* H, int64_t ldh,
+                     const float* w2, const float* b2, int out_act, int B, int Hd,
+                     const float* hyper, int n_hyper, float inv_b, const float* pen, float* S,
+                     float* dS, float* rowloss);
+int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS, const float* w2,
+                const float* rowloss, float* dH, int64_t lddh, float* gw2, float* gb2,
+                float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode, int B, int Hd);
+
 /* ---- elementwise activation backward for the general autograd path:
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */
 int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t n, int act);
@@ -160,6 +174,12 @@ int gm_graph_begin(void* stream);
 int gm_graph_end(void* stream, void** graph_exec_out);
 int gm_graph_launch(void* graph_exec, void* stream);
 int gm_graph_destroy(void* graph_exec);
+
+/* ---- side streams + cross-stream dependencies, so independent kernels of one iteration become
+ * parallel branches of the captured hipGraph */
+int gm_stream_create(void** stream_out);
+int gm_stream_destroy(void* stream);
+int gm_stream_wait_event(void* stream, void* ev);
 
 /* ---- timing helpers for bench.py (HIP events on the launch stream) --------------------- */
 int gm_event_create(void** ev_out);

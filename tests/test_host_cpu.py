@@ -1,0 +1,141 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, host
+helpers are bit-exact against torch, drop-in modules expose the reference's surface, fast-path
+selection logic, and the product fails loudly instead of computing on CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(os.path.dirname(HERE), "generative_models_amd", "src")
+sys.path.insert(0, SRC)
+
+from generative_models_amd import _lib, engine, ops, trainers  # noqa: E402
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 29
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _lib._SIGNATURES, "declared in gm_hip.h but not bound: " + name
+    for name in _lib._SIGNATURES:
+        assert name in declared, "bound but not declared in gm_hip.h: " + name
+    assert lib.gm_arch() == b"gfx950" and lib.gm_version() >= 100
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    lib = _lib.load()
+    rc = lib.gm_linear_fwd(None, None, 0, _lib.NO_SLOT, None, None, None, 0, 0, 0, 0, 0)
+    assert rc == _lib.GM_EINVAL and b"bad argument" in lib.gm_last_error()
+    with pytest.raises(_lib.GMError):
+        _lib.call("gm_adam", None, None, None, None, None, 0, None, _lib.NO_SLOT, 0.9, 0.999, 1e-8,
+                  0.0, 0.0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345, 2 ** 40 + 17, 2 ** 63 - 5])
+@pytest.mark.parametrize("n,B", [(50000, 256), (50000, 1024), (160, 16), (1000, 1000), (10, 10), (7, 1)])
+def test_randperm_prefix_bit_exact(seed, n, B):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    ref = torch.randperm(n, generator=g)[:B].numpy()
+    assert np.array_equal(ops.randperm_prefix(seed, n, B), ref)
+
+
+def test_sampler_protocol_matches_dataloader_bit_exact():
+    """engine.draw_sampler_indices == the batch the reference's DataLoader would yield, and it
+    leaves the global generator in the same state."""
+    data = torch.arange(500, dtype=torch.float32).reshape(500, 1)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, torch.zeros(500)),
+                                         batch_size=32, shuffle=True)
+    torch.manual_seed(11)
+    ref = [next(iter(loader))[0].reshape(-1).long().numpy() for _ in range(4)]
+    ref_state = torch.get_rng_state()
+    torch.manual_seed(11)
+    idx = np.empty(32, dtype=np.int64)
+    for r in ref:
+        engine.draw_sampler_indices(500, 32, idx)
+        assert np.array_equal(idx, r)
+    assert torch.equal(ref_state, torch.get_rng_state())
+
+
+def test_epoch_order_matches_dataloader():
+    data = torch.arange(100, dtype=torch.float32).reshape(100, 1)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, torch.zeros(100)),
+                                         batch_size=16, shuffle=True)
+    torch.manual_seed(5)
+    ref = torch.cat([b[0].reshape(-1) for b in loader]).long()
+    st = torch.get_rng_state()
+    torch.manual_seed(5)
+    assert torch.equal(trainers._epoch_order(loader), ref)
+    assert torch.equal(st, torch.get_rng_state())
+
+
+def test_adam_schedule_matches_torch_scalars():
+    s = ops.adam_schedule(2e-4, 5)
+    for i, step in enumerate(range(1, 6)):
+        bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+        assert s[i, 0] == np.float32(2e-4 / bc1) and s[i, 1] == np.float32(bc2 ** 0.5)
+
+
+def test_dropin_surface_and_state_dict_keys():
+    import ns_gan, w_gp_gan, be_gan, info_gan, vae, f_gan, utils  # noqa: F401
+    m = ns_gan.NSGAN(784, 400, 20)
+    assert list(m.state_dict()) == ["G.linear.weight", "G.linear.bias", "G.generate.weight",
+                                    "G.generate.bias", "D.linear.weight", "D.linear.bias",
+                                    "D.discriminate.weight", "D.discriminate.bias"]
+    assert (m.z_dim, m.shape, m.image_size, m.hidden_dim, m.output_dim) == (20, 28, 784, 400, 1)
+    assert sum(p.numel() for p in m.parameters()) == 637185
+    assert list(be_gan.BEGAN(784, 400, 20).state_dict())[4:] == [
+        "D.encoder.weight", "D.encoder.bias", "D.decoder.weight", "D.decoder.bias"]
+    assert "D.discriminator.weight" in info_gan.InfoGAN(784, 400, 20, 10, 10).state_dict()
+    assert sum(p.numel() for p in vae.VAE().parameters()) == 652824
+    for name in ("Generator", "Discriminator", "NSGAN", "NSGANTrainer", "to_cuda", "to_var", "get_data"):
+        assert hasattr(ns_gan, name)
+    assert hasattr(f_gan, "Divergence") and hasattr(info_gan, "Q")
+    with pytest.raises(AssertionError):
+        f_gan.Divergence("not-a-divergence")
+
+
+def test_same_seed_gives_reference_initial_weights():
+    """nn.Linear construction order == the reference's (G.linear, G.generate, D.linear, D...)."""
+    import ns_gan
+    from oracle import port
+    torch.manual_seed(1234)
+    a = ns_gan.NSGAN(64, 48, 8).state_dict()
+    b = port.build("ns", 64, 48, 8).state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_fast_path_selection_and_no_cpu_compute():
+    import ns_gan
+    from oracle import port
+    loaders = port.synthetic_loaders(16, n_train=160, n_val=48, n_test=48, image_shape=(1, 8, 8))
+    tr = ns_gan.NSGANTrainer(ns_gan.NSGAN(64, 48, 8), *loaders)
+    assert tr._stock()
+
+    class Mine(ns_gan.NSGANTrainer):
+        def train_G(self, images):
+            return super().train_G(images)
+    assert not Mine(ns_gan.NSGAN(64, 48, 8), *loaders)._stock()
+    seq = torch.utils.data.DataLoader(loaders[0].dataset, batch_size=16, shuffle=False)
+    assert not ns_gan.NSGANTrainer(ns_gan.NSGAN(64, 48, 8), seq, None, None)._stock()
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.GMError):
+            tr.train(1)                                   # no GPU -> loud failure, never CPU math
+        with pytest.raises(_lib.GMError):
+            tr.model.G(torch.zeros(2, 8))
+
+
+def test_flat_params_pack_and_alias():
+    lin_a, lin_b = torch.nn.Linear(5, 3), torch.nn.Linear(3, 7)
+    w0 = lin_a.weight.detach().clone()
+    fp = engine.FlatParams([lin_a.weight, lin_a.bias, (lin_b.weight, lin_b.bias)], "cpu")
+    assert fp.offsets == [0, 16, 20, 41] and fp.n == 48
+    assert torch.equal(lin_a.weight.data, w0)
+    fp.flat[0] = 42.0
+    assert lin_a.weight.data[0, 0].item() == 42.0 and fp.still_bound()
