@@ -316,15 +316,19 @@ struct HeadBwdP {
     int R, B, Hd, gen_mode;
 };
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdP p) {
-    __shared__ float sh[8][33];
-    __shared__ double shd[4];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+// 16 columns x 64 row-groups per 1024-thread workgroup: 25 workgroups for Hd=400, 8 rows per thread
+// at R=512 -- enough parallelism that the 800 KB read + 800 KB write is not a serial row walk.
+constexpr int HB_COLS = 16, HB_RG = 64;
+
+__global__ __launch_bounds__(1024) void head_bwd_kernel(HeadBwdP p) {
+    __shared__ float sh[HB_RG][HB_COLS + 1];
+    __shared__ double shd[16];
+    const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
+    const int c = blockIdx.x * HB_COLS + cl;
     float acc = 0.f;
     if (c < p.Hd) {
         const float w = p.w2[c];
-        for (int r = rg; r < p.R; r += 8) {
+        for (int r = rg; r < p.R; r += HB_RG) {
             const float h = p.H[(int64_t)r * p.ldh + c];
             const float d = p.dS[r];
             p.dH[(int64_t)r * p.lddh + c] = (h > 0.f) ? d * w : 0.f;
@@ -336,15 +340,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdP p) {
         __syncthreads();
         if (rg == 0 && c < p.Hd) {
             float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v += sh[q][cl];
+            for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
             p.gw2[c] = v;
         }
     }
     if (blockIdx.x == 0) {
         // scalars: loss = inv_b * sum l_r ; gb2 = fl(sum over x rows) + fl(sum over g rows)
         double sl = 0.0, sx = 0.0, sg = 0.0;
-        for (int r = threadIdx.x; r < p.R; r += 256) {
+        for (int r = threadIdx.x; r < p.R; r += 1024) {
             sl += (double)p.rowloss[r];
             const double d = (double)p.dS[r];
             if (!p.gen_mode && r < p.B) sx += d; else sg += d;
@@ -356,8 +359,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdP p) {
             __syncthreads();
             if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = a;
             __syncthreads();
-            outv[k] = (k == 0) ? (float)(((shd[0] + shd[1]) + (shd[2] + shd[3])) * (double)p.inv_b)
-                               : (float)((shd[0] + shd[1]) + (shd[2] + shd[3]));
+            double tot = 0.0;
+            for (int q = 0; q < 16; ++q) tot += shd[q];
+            outv[k] = (k == 0) ? (float)(tot * (double)p.inv_b) : (float)tot;
         }
         if (threadIdx.x == 0) {
             p.loss_out[gm_slot_index(p.loss_slot)] = outv[0];
@@ -375,6 +379,7 @@ extern "C" int gm_head_bwd(void* stream, const float* H, int64_t ldh, const floa
     p.H = H; p.ldh = ldh; p.dS = dS; p.w2 = w2; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
     p.gw2 = gw2; p.gb2 = gb2; p.loss_out = loss_out; p.loss_slot = loss_slot; p.inv_b = inv_b;
     p.gen_mode = gen_mode; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((Hd + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((Hd + HB_COLS - 1) / HB_COLS), dim3(1024), 0,
+                       (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }

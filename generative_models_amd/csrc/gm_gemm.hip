@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int TM = 32, TN = 32;
-constexpr int WAVES = 16;
+constexpr int MAXW = 16;      // waves per workgroup: 16 (one workgroup per CU) or 8 (two per CU)
 constexpr int G = 4;          // chunks (of 8 k) in flight per wave per pipeline stage
 
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
@@ -96,9 +96,9 @@ __device__ __forceinline__ float4 load_xc(const float* __restrict__ P, int64_t l
     return v;
 }
 
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
-    __shared__ float red[WAVES * 32 * 32];      // 64 KB: one 32x32 partial tile per wave
+    __shared__ float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -189,13 +189,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
         red[(w * 32 + row) * 32 + r] = acc[i];
     }
     __syncthreads();
-    const int row = t >> 5, col = t & 31;
+#pragma unroll
+    for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
+    const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
     float v = 0.f;
 #pragma unroll
     for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
 
     const int m = m0 + row, n = n0 + col;
-    if (m >= p.M || n >= p.N) return;
+    if (m >= p.M || n >= p.N) continue;
     if (MODE == MODE_FWD) {
         if (p.bias) v += p.bias[n];
         if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     } else {
         float* cp = (n == p.n_real) ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
         *cp = p.accumulate ? (*cp + v) : v;
+    }
     }
 }
 
@@ -237,8 +240,13 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec) {
         static int blocked = -1;
         if (blocked < 0) { const char* e = getenv("GM_CHUNK_BLOCKED"); blocked = e ? atoi(e) : 0; }
         const int nchunks = (p.K + 7) / 8;
-        p.cpw = blocked ? (nchunks + WAVES - 1) / WAVES : 0;
+        p.cpw = blocked ? (nchunks + MAXW - 1) / MAXW : 0;
     }
+    // More tiles than CUs: 8-wave workgroups (107 VGPRs -> 4 waves/SIMD -> TWO workgroups per CU)
+    // run all tiles in one round instead of two; otherwise 16 waves halve the MFMA chain.
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("GM_WAVES8"); w8 = e ? atoi(e) : 1; }
+    const bool use8 = w8 && (tm * tn > 256) && p.cpw == 0;
     if (xcd_mode() && tm * tn >= 16) {
         // pick the XCD grid xr x xc (xr*xc == 8) minimising per-XCD operand rows tm/xr + tn/xc
         int best = 1 << 30, bxr = 8;
@@ -254,8 +262,13 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec) {
             grid = dim3(8 * per, 1);
         }
     }
-    if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true>), grid, dim3(WAVES * 64), 0, s, p);
-    else     hipLaunchKernelGGL((gemm_kernel<MODE, false>), grid, dim3(WAVES * 64), 0, s, p);
+    if (use8) {
+        if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true, 8>), grid, dim3(512), 0, s, p);
+        else     hipLaunchKernelGGL((gemm_kernel<MODE, false, 8>), grid, dim3(512), 0, s, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true, 16>), grid, dim3(1024), 0, s, p);
+        else     hipLaunchKernelGGL((gemm_kernel<MODE, false, 16>), grid, dim3(1024), 0, s, p);
+    }
     GM_LAUNCH_RET();
 }
 

@@ -138,7 +138,7 @@ class GANEngine:
         self.force_segments = False    # tests: exercise the DP launch structure on one rank
         import os
         self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
-        self.dag = os.environ.get("GM_DAG", "1") != "0"
+        self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
