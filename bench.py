@@ -39,27 +39,37 @@ def synthetic_dataset():
     return ds
 
 
-def gemm_shapes(B):
-    """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms."""
-    return [
-        # D step
-        ("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", 2 * B, IMG, HID), ("fwd", 2 * B, HID, 1),
-        ("dw", 2 * B, HID, 1), ("dx", 2 * B, HID, 1), ("dw", 2 * B, IMG, HID),
-        # G step
-        ("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", B, IMG, HID), ("fwd", B, HID, 1),
-        ("dx", B, HID, 1), ("dx", B, IMG, HID), ("dw", B, HID, IMG), ("dx", B, HID, IMG),
-        ("dw", B, Z, HID),
-    ]
+def gemm_shapes(B, fused_head=True):
+    """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
+    critic-head kernels (default) the N=1 layer is not a GEMM launch any more."""
+    d_head = [] if fused_head else [("fwd", 2 * B, HID, 1), ("dw", 2 * B, HID, 1), ("dx", 2 * B, HID, 1)]
+    g_head = [] if fused_head else [("fwd", B, HID, 1), ("dx", B, HID, 1)]
+    return ([("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", 2 * B, IMG, HID)] + d_head +
+            [("dw", 2 * B, IMG, HID)] +
+            [("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", B, IMG, HID)] + g_head +
+            [("dx", B, IMG, HID), ("dw", B, HID, IMG), ("dx", B, HID, IMG), ("dw", B, Z, HID)])
 
 
-def time_kernels_isolated(B, reps=100):
+def clock_probe():
+    """Effective shader clock (MHz) while every CU runs a dependent fp32-MFMA chain."""
+    from generative_models_amd import _lib, ops
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    sink = torch.zeros(1, device="cuda")
+    for _ in range(3):
+        _lib.call("gm_clock_probe", ops.stream_ptr(), 4000, out.data_ptr(), sink.data_ptr())
+    torch.cuda.synchronize()
+    cyc, wall = [int(x) for x in out.cpu()]
+    return cyc / max(wall, 1) * 100.0, cyc / 4000.0
+
+
+def time_kernels_isolated(B, reps=100, fused_head=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kind: (total_us_per_step, total_flop_per_step, n_launches)}."""
     from generative_models_amd import ops
     dev = "cuda"
     out = {}
     st = ops.stream_ptr()
-    for kind, M, K, N in gemm_shapes(B):
+    for kind, M, K, N in gemm_shapes(B, fused_head):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -208,12 +218,25 @@ def main():
     img_s = K * B_global / dt
 
     if rank == 0:
-        kt = time_kernels_isolated(B_PER_GPU)
+        kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head)
+        mhz, cyc_per_mfma = clock_probe()
+        log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         log('isolated kernel timing done')
         dom = max(kt, key=lambda k: kt[k][0])
         t_us, flop, n = kt[dom]
-        names = {"fwd": "gemm_kernel<0,32,*> (linear fwd)", "dx": "gemm_kernel<1,32,*> (linear dX)",
-                 "dw": "gemm_kernel<2,32,*> (linear dW)"}
+        names = {"fwd": "gemm_kernel<0,*,*> (linear fwd)", "dx": "gemm_kernel<1,*,*> (linear dX)",
+                 "dw": "gemm_kernel<2,*,*> (linear dW)"}
+        # HBM/fabric bytes per launch of that kernel family from the committed PMC pass
+        # (profiles/r01_pmc_fetch_write.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            mode = {"fwd": "<0,", "dx": "<1,", "dw": "<2,"}[dom]
+            rows = [v for k, v in pmc.items() if "gemm_kernel" + mode in k and v["read_bytes"] > 2e6]
+            if rows:
+                traffic = sum(v["read_bytes"] + v["write_bytes"] for v in rows) / len(rows)
+        except Exception:
+            traffic = None
         achieved = flop / (t_us * 1e-6) / 1e12
         line = {
             "metric": "images/sec (28x28 MNIST) per D+G step, NSGAN bs=256",
@@ -229,7 +252,8 @@ def main():
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "shader_clock_mhz": round(mhz),
                          "launches_per_step": n, "avg_launch_us": t_us / n,
                          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
         }

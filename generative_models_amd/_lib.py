@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgm_hip.so")
+LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(HERE, "libgm_hip.so")
 
 GM_EINVAL = -10001
 ACT_ID, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -61,6 +61,7 @@ _SIGNATURES = {
                                  POINTER(c_float), c_int, c_float, _P, _P, _P, _P]),
     "gm_head_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot, c_float,
                             c_int, c_int, c_int]),
+    "gm_clock_probe": (c_int, [_P, c_int, _P, _P]),
     "gm_stream_create": (c_int, [POINTER(c_void_p)]),
     "gm_stream_destroy": (c_int, [_P]),
     "gm_stream_wait_event": (c_int, [_P, _P]),

@@ -33,7 +33,7 @@ namespace {
 
 constexpr int TM = 32, TN = 32;
 constexpr int MAXW = 16;      // waves per workgroup: 16 (one workgroup per CU) or 8 (two per CU)
-constexpr int G = 4;          // chunks (of 8 k) in flight per wave per pipeline stage
+constexpr int G = 7;          // chunks (of 8 k) in flight per wave (rolling window)
 
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
@@ -144,41 +144,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     const int cstep = p.cpw > 0 ? 1 : WAVES;
     const int cbase = p.cpw > 0 ? w * p.cpw : w;
     const int cend = p.cpw > 0 ? min(nchunks, (w + 1) * p.cpw) : nchunks;
-    float4 a0[G], b0[G], a1[G], b1[G];
-    auto load_group = [&](float4 (&a)[G], float4 (&b)[G], int c) {
+    // Rolling register window of G chunks per wave: all G chunk-loads are issued up front (for
+    // K = 784 and 16 waves that is the wave's whole k-range), MFMAs consume them in order as they
+    // land, and each slot is refilled with the chunk G positions ahead right after its MFMAs are
+    // issued.  Measured (profiles/r01_experiments.md): with the former two-group ping-pong the
+    // load phase (3.5 us) and the MFMA chain (2.75 us) of the K=784 GEMM ran back to back.
+    const int nq = (cend - cbase + cstep - 1) / cstep;      // chunk positions owned by this wave
+    float4 ra[G], rb[G];
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int cc = c + i * cstep;
-            if (cc < cend) { a[i] = load_a(cc); b[i] = load_b(cc); }
+    for (int i = 0; i < G; ++i) {
+        if (i < nq) {
+            const int cc = cbase + i * cstep;
+#if defined(GM_ABLATE) && GM_ABLATE == 2      // experiment: no operand loads (MFMA chain only)
+            ra[i] = make_float4(1.f, 2.f, 3.f, 4.f); rb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+            ra[i] = load_a(cc); rb[i] = load_b(cc);
+#endif
         }
-    };
-    auto mfma_group = [&](const float4 (&a)[G], const float4 (&b)[G], int c) {
+    }
+    for (int q0 = 0; q0 < nq; q0 += G) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            if (c + i * cstep < cend) {       // wave-uniform
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+            const int q = q0 + i;
+            if (q < nq) {                                    // wave-uniform
+#if defined(GM_ABLATE) && GM_ABLATE == 1      // experiment: loads only (keep them live, no MFMA)
+                asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w),
+                             "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+#else
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].x, rb[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].y, rb[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].z, rb[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].w, rb[i].w, acc, 0, 0, 0);
+#endif
+                if (q + G < nq) {
+                    const int cc = cbase + (q + G) * cstep;
+#if !(defined(GM_ABLATE) && GM_ABLATE == 2)
+                    ra[i] = load_a(cc); rb[i] = load_b(cc);
+#endif
+                }
             }
-        }
-    };
-
-    // two-stage register pipeline over this wave's chunks  w, w+16, w+32, ...
-    int c = cbase;
-    if (c < cend) {
-        load_group(a0, b0, c);
-        while (true) {
-            int cn = c + G * cstep;
-            if (cn < cend) load_group(a1, b1, cn);
-            mfma_group(a0, b0, c);
-            if (cn >= cend) break;
-            c = cn;
-            cn = c + G * cstep;
-            if (cn < cend) load_group(a0, b0, cn);
-            mfma_group(a1, b1, c);
-            if (cn >= cend) break;
-            c = cn;
         }
     }
 

@@ -395,6 +395,28 @@ extern "C" int gm_graph_destroy(void* graph_exec) {
     return 0;
 }
 
+// Shader-clock probe: runs a dependent MFMA chain for `iters` instructions in every wave of a
+// full grid and reports shader cycles (s_memtime) and the 100 MHz wall clock spanned by block 0,
+// so bench.py can state the effective engine clock the roofline is quoted against.
+typedef float f32x16_probe __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, unsigned long long* out, float* sink) {
+    f32x16_probe acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float a = (float)threadIdx.x, b = 1.0f;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (acc[0] == 123.456f) sink[0] = acc[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+
+extern "C" int gm_clock_probe(void* stream, int iters, unsigned long long* out2, float* sink) {
+    GM_CHECK_ARG(out2 && sink && iters > 0);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, iters, out2,
+                       sink);
+    GM_LAUNCH_RET();
+}
+
 extern "C" int gm_stream_create(void** stream_out) {
     GM_CHECK_ARG(stream_out);
     hipStream_t st;

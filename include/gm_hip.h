@@ -181,6 +181,10 @@ int gm_stream_create(void** stream_out);
 int gm_stream_destroy(void* stream);
 int gm_stream_wait_event(void* stream, void* ev);
 
+/* ---- diagnostics: dependent v_mfma_f32_32x32x2_f32 chain on 256 workgroups; out2[0] = shader
+ * cycles (s_memtime), out2[1] = 100 MHz wall-clock ticks spanned by block 0. */
+int gm_clock_probe(void* stream, int iters, unsigned long long* out2, float* sink);
+
 /* ---- timing helpers for bench.py (HIP events on the launch stream) --------------------- */
 int gm_event_create(void** ev_out);
 int gm_event_record(void* ev, void* stream);
