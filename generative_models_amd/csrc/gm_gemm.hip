@@ -33,7 +33,7 @@ namespace {
 
 constexpr int TM = 32, TN = 32;
 constexpr int MAXW = 16;      // waves per workgroup: 16 (one workgroup per CU) or 8 (two per CU)
-constexpr int G = 7;          // chunks (of 8 k) in flight per wave (rolling window)
+constexpr int G = 7;          // chunks (of 8 k) loaded back to back per wave and batch
 
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
@@ -58,41 +58,48 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
 };
 
-// k-contiguous operand: element (x, k) at P[x*ld + k].  Returns the 4 values k = kb..kb+3.
+// Operand loads are BRANCH-FREE: out-of-range rows / k are clamped to a valid address and the
+// value is zeroed by a select afterwards.  (With `if (in range) load` hipcc branches around every
+// load and puts an s_waitcnt vmcnt(0) behind each one -- 14 serialized L2 round trips per wave,
+// measured as a 3.5 us load phase that did not overlap the MFMA chain.)
+
+// The load (raw_*) and the zeroing (fix_*) are separate functions: the selects run in the consume
+// stage, right before the MFMAs, so that nothing forces a wait while the loads are in flight.
+
+// k-contiguous operand: element (x, k) at P[x*ld + k]; the 4 values k = kb..kb+3.
 template <bool VEC>
-__device__ __forceinline__ float4 load_kc(const float* __restrict__ P, int64_t ld, int x, int X,
-                                          int kb, int K) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x < X) {
-        const float* q = P + (int64_t)x * ld + kb;
-        if (VEC && kb + 3 < K) {
-            v = *reinterpret_cast<const float4*>(q);
-        } else {
-            if (kb + 0 < K) v.x = q[0];
-            if (kb + 1 < K) v.y = q[1];
-            if (kb + 2 < K) v.z = q[2];
-            if (kb + 3 < K) v.w = q[3];
-        }
-    }
+__device__ __forceinline__ float4 raw_kc(const float* __restrict__ P, int64_t ld, int x, int X,
+                                         int kb, int K) {
+    const float* row = P + (int64_t)min(x, X - 1) * ld;
+    if (VEC)                        // K % 4 == 0 and 16-byte aligned rows: kb < K <=> kb+3 < K
+        return *reinterpret_cast<const float4*>(row + min(kb, K - 4));
+    return make_float4(row[min(kb + 0, K - 1)], row[min(kb + 1, K - 1)], row[min(kb + 2, K - 1)],
+                       row[min(kb + 3, K - 1)]);
+}
+__device__ __forceinline__ float4 fix_kc(float4 v, int x, int X, int kb, int K) {
+    const bool okx = x < X;
+    v.x = (okx && kb + 0 < K) ? v.x : 0.f;
+    v.y = (okx && kb + 1 < K) ? v.y : 0.f;
+    v.z = (okx && kb + 2 < K) ? v.z : 0.f;
+    v.w = (okx && kb + 3 < K) ? v.w : 0.f;
     return v;
 }
 
 // x-contiguous operand: element (x, k) at P[k*ld + x]; 4 coalesced dword loads (one per k).
-__device__ __forceinline__ float4 load_xc(const float* __restrict__ P, int64_t ld, int x, int X,
-                                          int kb, int K, int ones_col) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x < X) {
-        const float* q = P + (int64_t)kb * ld + x;
-        if (kb + 0 < K) v.x = q[0];
-        if (kb + 1 < K) v.y = q[ld];
-        if (kb + 2 < K) v.z = q[2 * ld];
-        if (kb + 3 < K) v.w = q[3 * ld];
-    } else if (x == ones_col) {
-        if (kb + 0 < K) v.x = 1.f;
-        if (kb + 1 < K) v.y = 1.f;
-        if (kb + 2 < K) v.z = 1.f;
-        if (kb + 3 < K) v.w = 1.f;
-    }
+// ones_col: virtual column of 1s (bias gradient through the dW GEMM).
+__device__ __forceinline__ float4 raw_xc(const float* __restrict__ P, int64_t ld, int x, int X,
+                                         int kb, int K) {
+    const float* col = P + min(x, X - 1);
+    return make_float4(col[(int64_t)min(kb + 0, K - 1) * ld], col[(int64_t)min(kb + 1, K - 1) * ld],
+                       col[(int64_t)min(kb + 2, K - 1) * ld], col[(int64_t)min(kb + 3, K - 1) * ld]);
+}
+__device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, int ones_col) {
+    const bool okx = x < X;
+    const float fill = (x == ones_col) ? 1.f : 0.f;
+    v.x = (kb + 0 < K) ? (okx ? v.x : fill) : 0.f;
+    v.y = (kb + 1 < K) ? (okx ? v.y : fill) : 0.f;
+    v.z = (kb + 2 < K) ? (okx ? v.z : fill) : 0.f;
+    v.w = (kb + 3 < K) ? (okx ? v.w : fill) : 0.f;
     return v;
 }
 
@@ -125,13 +132,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
 
     auto load_a = [&](int c) -> float4 {
         const int kb = 8 * c + 4 * h;
-        if (MODE == MODE_DW) return load_xc(A, p.lda, m0 + r, p.M, kb, p.K, -1);
-        return load_kc<VEC>(A, p.lda, m0 + r, p.M, kb, p.K);
+        if (MODE == MODE_DW) return raw_xc(A, p.lda, m0 + r, p.M, kb, p.K);
+        return raw_kc<VEC>(A, p.lda, m0 + r, p.M, kb, p.K);
     };
     auto load_b = [&](int c) -> float4 {
         const int kb = 8 * c + 4 * h;
-        if (MODE == MODE_FWD) return load_kc<VEC>(B, p.ldb, n0 + r, p.N, kb, p.K);
-        return load_xc(B, p.ldb, n0 + r, b_cols, kb, p.K, ones_col);
+        if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, n0 + r, p.N, kb, p.K);
+        return raw_xc(B, p.ldb, n0 + r, b_cols, kb, p.K);
+    };
+    auto fix_a = [&](float4 v, int c) -> float4 {
+        const int kb = 8 * c + 4 * h;
+        if (MODE == MODE_DW) return fix_xc(v, m0 + r, p.M, kb, p.K, -1);
+        return fix_kc(v, m0 + r, p.M, kb, p.K);
+    };
+    auto fix_b = [&](float4 v, int c) -> float4 {
+        const int kb = 8 * c + 4 * h;
+        if (MODE == MODE_FWD) return fix_kc(v, n0 + r, p.N, kb, p.K);
+        return fix_xc(v, n0 + r, b_cols, kb, p.K, ones_col);
     };
 
     f32x16 acc;
@@ -144,25 +161,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     const int cstep = p.cpw > 0 ? 1 : WAVES;
     const int cbase = p.cpw > 0 ? w * p.cpw : w;
     const int cend = p.cpw > 0 ? min(nchunks, (w + 1) * p.cpw) : nchunks;
-    // Rolling register window of G chunks per wave: all G chunk-loads are issued up front (for
-    // K = 784 and 16 waves that is the wave's whole k-range), MFMAs consume them in order as they
-    // land, and each slot is refilled with the chunk G positions ahead right after its MFMAs are
-    // issued.  Measured (profiles/r01_experiments.md): with the former two-group ping-pong the
-    // load phase (3.5 us) and the MFMA chain (2.75 us) of the K=784 GEMM ran back to back.
+    // Batches of G chunks per wave: G UNCONDITIONAL loads back to back (positions past the wave's
+    // range re-read its last chunk; addresses are always valid), then the MFMAs consume them in
+    // order as they land (the compiler emits counted s_waitcnt vmcnt(2*(G-1-i))).  For K = 784 and
+    // 16 waves one batch is the wave's whole k-range.  History (profiles/r01_experiments.md): with
+    // guarded loads hipcc put s_waitcnt vmcnt(0) behind every load -- a 3.5 us load phase made of
+    // 14 serialized round trips that did not overlap the 2.75 us MFMA chain.
     const int nq = (cend - cbase + cstep - 1) / cstep;      // chunk positions owned by this wave
-    float4 ra[G], rb[G];
+    for (int q0 = 0; q0 < nq; q0 += G) {
+        float4 ra[G], rb[G];
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
-        if (i < nq) {
-            const int cc = cbase + i * cstep;
+        for (int i = 0; i < G; ++i) {
+            const int cc = cbase + min(q0 + i, nq - 1) * cstep;
 #if defined(GM_ABLATE) && GM_ABLATE == 2      // experiment: no operand loads (MFMA chain only)
             ra[i] = make_float4(1.f, 2.f, 3.f, 4.f); rb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
 #else
             ra[i] = load_a(cc); rb[i] = load_b(cc);
 #endif
         }
-    }
-    for (int q0 = 0; q0 < nq; q0 += G) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int q = q0 + i;
@@ -171,17 +187,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
                 asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w),
                              "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
 #else
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].x, rb[i].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].y, rb[i].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].z, rb[i].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i].w, rb[i].w, acc, 0, 0, 0);
+                const int cq = cbase + q * cstep;
+                const float4 fa = fix_a(ra[i], cq), fb = fix_b(rb[i], cq);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
 #endif
-                if (q + G < nq) {
-                    const int cc = cbase + (q + G) * cstep;
-#if !(defined(GM_ABLATE) && GM_ABLATE == 2)
-                    ra[i] = load_a(cc); rb[i] = load_b(cc);
-#endif
-                }
             }
         }
     }
