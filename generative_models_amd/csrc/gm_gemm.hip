@@ -33,7 +33,8 @@ namespace {
 
 constexpr int TM = 32, TN = 32;
 constexpr int MAXW = 16;      // waves per workgroup: 16 (one workgroup per CU) or 8 (two per CU)
-constexpr int G = 7;          // chunks (of 8 k) loaded back to back per wave and batch
+// G = chunks (of 8 k) loaded back to back per wave and batch: template parameter, chosen per launch
+// as the smallest of {2, 4, 7} covering the wave's k-range (no redundant loads for short K).
 
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
@@ -103,7 +104,7 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
     return v;
 }
 
-template <int MODE, bool VEC, int WAVES>
+template <int MODE, bool VEC, int WAVES, int G>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
 
@@ -278,13 +279,15 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec) {
             grid = dim3(8 * per, 1);
         }
     }
-    if (use8) {
-        if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true, 8>), grid, dim3(512), 0, s, p);
-        else     hipLaunchKernelGGL((gemm_kernel<MODE, false, 8>), grid, dim3(512), 0, s, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((gemm_kernel<MODE, true, 16>), grid, dim3(1024), 0, s, p);
-        else     hipLaunchKernelGGL((gemm_kernel<MODE, false, 16>), grid, dim3(1024), 0, s, p);
-    }
+    const int nw = use8 ? 8 : 16;
+    const int per_wave = ((p.K + 7) / 8 + nw - 1) / nw;      // chunk positions of the busiest wave
+    const int g = per_wave <= 2 ? 2 : (per_wave <= 4 ? 4 : 7);
+#define GM_LAUNCH(V, W, GG) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG>), grid, dim3(W * 64), 0, s, p)
+#define GM_LAUNCH_G(V, W) do { if (g == 2) GM_LAUNCH(V, W, 2); else if (g == 4) GM_LAUNCH(V, W, 4); else GM_LAUNCH(V, W, 7); } while (0)
+    if (use8) { if (vec) GM_LAUNCH_G(true, 8); else GM_LAUNCH_G(false, 8); }
+    else      { if (vec) GM_LAUNCH_G(true, 16); else GM_LAUNCH_G(false, 16); }
+#undef GM_LAUNCH_G
+#undef GM_LAUNCH
     GM_LAUNCH_RET();
 }
 
