@@ -94,6 +94,36 @@ __device__ __forceinline__ float4 raw_xc(const float* __restrict__ P, int64_t ld
     return make_float4(col[(int64_t)min(kb + 0, K - 1) * ld], col[(int64_t)min(kb + 1, K - 1) * ld],
                        col[(int64_t)min(kb + 2, K - 1) * ld], col[(int64_t)min(kb + 3, K - 1) * ld]);
 }
+// Vector form for x-contiguous operands (ld % 4 == 0, X % 4 == 0, 16-byte aligned): ONE 16-byte load
+// per lane instead of four dword loads.  Lane l = e + 4q + 32m fetches x = x0+4q..4q+3 of row
+// k = 8c+4m+e (8 k-rows x 128 contiguous bytes per instruction); a 4x4 transpose inside each lane
+// quad (two DPP quad_perm exchange steps, no LDS) then gives lane (r = 4q+e, m) its four k values
+// -- exactly the MFMA fragment layout.
+__device__ __forceinline__ float4 raw_xc4(const float* __restrict__ P, int64_t ld, int x0, int X,
+                                          int c, int K, int lane) {
+    const int e = lane & 3, q = (lane >> 2) & 7, m = lane >> 5;
+    const int k = min(8 * c + 4 * m + e, K - 1);
+    const int x = min(x0 + 4 * q, X - 4);
+    return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
+}
+__device__ __forceinline__ float dpp_xor2(float v) {   // lane ^ 2 within the quad
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor1(float v) {   // lane ^ 1 within the quad
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// new[lane e][reg j] = old[lane j][reg e] over the 4 lanes of a quad
+__device__ __forceinline__ float4 quad_transpose(float4 v, int lane) {
+    const bool b1 = lane & 2, b0 = lane & 1;
+    // step 1: exchange 2x2 blocks with lane^2
+    const float s0 = dpp_xor2(b1 ? v.x : v.z), s1 = dpp_xor2(b1 ? v.y : v.w);
+    if (b1) { v.x = s0; v.y = s1; } else { v.z = s0; v.w = s1; }
+    // step 2: exchange inside the 2x2 blocks with lane^1
+    const float t0 = dpp_xor1(b0 ? v.x : v.y), t1 = dpp_xor1(b0 ? v.z : v.w);
+    if (b0) { v.x = t0; v.z = t1; } else { v.y = t0; v.w = t1; }
+    return v;
+}
+
 __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, int ones_col) {
     const bool okx = x < X;
     const float fill = (x == ones_col) ? 1.f : 0.f;
@@ -104,7 +134,7 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
     return v;
 }
 
-template <int MODE, bool VEC, int WAVES, int G>
+template <int MODE, bool VEC, int WAVES, int G, bool XV>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
 
@@ -133,23 +163,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
 
     auto load_a = [&](int c) -> float4 {
         const int kb = 8 * c + 4 * h;
-        if (MODE == MODE_DW) return raw_xc(A, p.lda, m0 + r, p.M, kb, p.K);
+        if (MODE == MODE_DW) {
+            if (XV) return raw_xc4(A, p.lda, m0, p.M, c, p.K, lane);
+            return raw_xc(A, p.lda, m0 + r, p.M, kb, p.K);
+        }
         return raw_kc<VEC>(A, p.lda, m0 + r, p.M, kb, p.K);
     };
     auto load_b = [&](int c) -> float4 {
         const int kb = 8 * c + 4 * h;
         if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, n0 + r, p.N, kb, p.K);
+        if (XV) return raw_xc4(B, p.ldb, n0, b_cols, c, p.K, lane);
         return raw_xc(B, p.ldb, n0 + r, b_cols, kb, p.K);
     };
     auto fix_a = [&](float4 v, int c) -> float4 {
         const int kb = 8 * c + 4 * h;
-        if (MODE == MODE_DW) return fix_xc(v, m0 + r, p.M, kb, p.K, -1);
+        if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, m0 + r, p.M, kb, p.K, -1);
         return fix_kc(v, m0 + r, p.M, kb, p.K);
     };
     auto fix_b = [&](float4 v, int c) -> float4 {
         const int kb = 8 * c + 4 * h;
         if (MODE == MODE_FWD) return fix_kc(v, n0 + r, p.N, kb, p.K);
-        return fix_xc(v, n0 + r, b_cols, kb, p.K, ones_col);
+        return fix_xc(XV ? quad_transpose(v, lane) : v, n0 + r, b_cols, kb, p.K, ones_col);
     };
 
     f32x16 acc;
@@ -248,7 +282,7 @@ int xcd_mode() {
 }
 
 template <int MODE>
-int launch(hipStream_t s, const GemmP& p_in, bool vec) {
+int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
     GemmP p = p_in;
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
@@ -281,11 +315,23 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec) {
     }
     const int nw = use8 ? 8 : 16;
     const int per_wave = ((p.K + 7) / 8 + nw - 1) / nw;      // chunk positions of the busiest wave
-    const int g = per_wave <= 2 ? 2 : (per_wave <= 4 ? 4 : 7);
-#define GM_LAUNCH(V, W, GG) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG>), grid, dim3(W * 64), 0, s, p)
-#define GM_LAUNCH_G(V, W) do { if (g == 2) GM_LAUNCH(V, W, 2); else if (g == 4) GM_LAUNCH(V, W, 4); else GM_LAUNCH(V, W, 7); } while (0)
-    if (use8) { if (vec) GM_LAUNCH_G(true, 8); else GM_LAUNCH_G(false, 8); }
-    else      { if (vec) GM_LAUNCH_G(true, 16); else GM_LAUNCH_G(false, 16); }
+    // batch depth: fewest loaded chunks, with a penalty per extra (serialized) batch
+    int g = 7, best_cost = 1 << 30;
+    for (int cand : {2, 4, 7}) {
+        const int batches = (per_wave + cand - 1) / cand;
+        const int cost = batches * cand + 2 * (batches - 1);
+        if (cost <= best_cost) { best_cost = cost; g = cand; }
+    }
+    static int xv_on = -1;
+    if (xv_on < 0) { const char* e = getenv("GM_XVEC"); xv_on = e ? atoi(e) : 1; }
+    const bool xv = xvec && xv_on && MODE != MODE_FWD;
+#define GM_LAUNCH(V, W, GG, X) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
+#define GM_LAUNCH_G(V, W, X) do { if (g == 2) GM_LAUNCH(V, W, 2, X); else if (g == 4) GM_LAUNCH(V, W, 4, X); else GM_LAUNCH(V, W, 7, X); } while (0)
+#define GM_LAUNCH_W(V, X) do { if (use8) GM_LAUNCH_G(V, 8, X); else GM_LAUNCH_G(V, 16, X); } while (0)
+    if (MODE == MODE_FWD) { if (vec) GM_LAUNCH_W(true, false); else GM_LAUNCH_W(false, false); }
+    else if (xv)          { if (vec) GM_LAUNCH_W(true, true); else GM_LAUNCH_W(false, true); }
+    else                  { if (vec) GM_LAUNCH_W(true, false); else GM_LAUNCH_W(false, false); }
+#undef GM_LAUNCH_W
 #undef GM_LAUNCH_G
 #undef GM_LAUNCH
     GM_LAUNCH_RET();
@@ -319,8 +365,9 @@ extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, cons
     p.A = dA; p.B = W; p.C = dX; p.M = M; p.N = K; p.K = N;
     p.lda = lda; p.ldb = K; p.ldc = ldx; p.aux = below; p.ldaux = ld_below; p.epi = epi;
     p.a_slot = no_slot(); p.b_slot = no_slot();
-    const bool vec = aligned16(dA) && (lda % 4 == 0);
-    return launch<MODE_DX>((hipStream_t)stream, p, vec);
+    const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0);
+    const bool xvec = aligned16(W) && (K % 4 == 0);
+    return launch<MODE_DX>((hipStream_t)stream, p, vec, xvec);
 }
 
 extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X,
@@ -332,5 +379,9 @@ extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, cons
     p.A = dA; p.B = X; p.C = dW; p.M = N; p.N = K + (db ? 1 : 0); p.K = M;
     p.lda = lda; p.ldb = ldx; p.ldc = K; p.db = db; p.n_real = K; p.accumulate = accumulate;
     p.a_slot = no_slot(); p.b_slot = x_slot;
-    return launch<MODE_DW>((hipStream_t)stream, p, false);     // both operands use dword loads
+    // both operands are x-contiguous; the 16-byte + quad-transpose path needs every row start and
+    // the tile edges on 4-element boundaries (the virtual ones-column sits at x == K, K % 4 == 0)
+    const bool xvec = aligned16(dA) && aligned16(X) && (lda % 4 == 0) && (ldx % 4 == 0) &&
+                      (N % 4 == 0) && (K % 4 == 0) && (x_slot.stride % 4 == 0) && N >= 4 && K >= 4;
+    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec);
 }
