@@ -57,6 +57,13 @@ _SIGNATURES = {
                                    c_int]),
     "gm_sqerr_sigmoid_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
     "gm_sum_finalize": (c_int, [_P, _P, c_int, c_float, _P, Slot]),
+    "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
+                                      _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
+    "gm_head_bwd_fused": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot,
+                                  c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, Slot,
+                                  ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, c_float, _P]),
     "gm_head_fwd_loss": (c_int, [_P, c_int, c_int, _P, c_int64, _P, _P, c_int, c_int, c_int,
                                  POINTER(c_float), c_int, c_float, _P, _P, _P, _P]),
     "gm_head_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot, c_float,

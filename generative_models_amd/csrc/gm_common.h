@@ -151,3 +151,25 @@ static __device__ __forceinline__ void sample_terms(int variant, bool D, float x
     }
 }
 
+
+// ---- Adam arithmetic shared by adam_kernel and the fused dW / head epilogues ----
+struct gm_adam_epi {          // optional "optimizer in the gradient epilogue" descriptor
+    float* pW; float* mW; float* vW;      // parameter / moments of the weight the GEMM produces dW for
+    float* pb; float* mb; float* vb;      // same for the bias (db)
+    const float* sched; gm_slot sched_slot;
+    float omb1, b2, omb2, eps, wd, clamp;
+    int enabled;
+};
+
+static __device__ __forceinline__ void adam_update(float& pp, float gg, float& mm, float& vv,
+                                                    float step_size, float bc2_sqrt, float omb1,
+                                                    float b2, float omb2, float eps, float wd,
+                                                    float clamp) {
+    if (wd != 0.f) gg = gg + wd * pp;
+    mm = mm + omb1 * (gg - mm);
+    vv = vv * b2;
+    vv = vv + (omb2 * gg) * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp = pp + ((-step_size) * mm) / denom;
+    if (clamp > 0.f) pp = fminf(fmaxf(pp, -clamp), clamp);
+}

@@ -314,6 +314,8 @@ struct HeadBwdP {
     float* loss_out; gm_slot loss_slot;
     float inv_b;
     int R, B, Hd, gen_mode;
+    gm_adam_epi adam;                       // optional: Adam on (w2, b2) right here (pW=w2, pb=b2)
+    int64_t* tick;                          // optional: *tick += 1 after the loss slot is written
 };
 
 // 16 columns x 64 row-groups per 1024-thread workgroup: 25 workgroups for Hd=400, 8 rows per thread
@@ -342,6 +344,13 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadBwdP p) {
             float v = 0.f;
             for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
             p.gw2[c] = v;
+            if (p.adam.enabled) {          // every thread of this block read w2[c] before the barrier
+                const int64_t si = gm_slot_index(p.adam.sched_slot);
+                float P = p.adam.pW[c], M = p.adam.mW[c], V = p.adam.vW[c];
+                adam_update(P, v, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1], p.adam.omb1,
+                            p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+                p.adam.pW[c] = P; p.adam.mW[c] = M; p.adam.vW[c] = V;
+            }
         }
     }
     if (blockIdx.x == 0) {
@@ -365,17 +374,66 @@ __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadBwdP p) {
         }
         if (threadIdx.x == 0) {
             p.loss_out[gm_slot_index(p.loss_slot)] = outv[0];
-            if (p.gb2) p.gb2[0] = outv[1] + outv[2];
+            if (p.gb2) {
+                const float gb = outv[1] + outv[2];
+                p.gb2[0] = gb;
+                if (p.adam.enabled) {
+                    const int64_t si = gm_slot_index(p.adam.sched_slot);
+                    float P = p.adam.pb[0], M = p.adam.mb[0], V = p.adam.vb[0];
+                    adam_update(P, gb, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1],
+                                p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd,
+                                p.adam.clamp);
+                    p.adam.pb[0] = P; p.adam.mb[0] = M; p.adam.vb[0] = V;
+                }
+            }
+            // the per-graph tick folded into this single-writer point: kernels later in the same
+            // iteration address their slots with add - mul (engine), the next iteration sees ctr+1
+            if (p.tick) *p.tick += 1;
         }
     }
 }
+
+static int head_bwd_impl(void* stream, const float* H, int64_t ldh, const float* dS,
+                         const float* w2, const float* rowloss, float* dH, int64_t lddh, float* gw2,
+                         float* gb2, float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode,
+                         int B, int Hd, const gm_adam_epi* adam, int64_t* tick);
 
 extern "C" int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS,
                            const float* w2, const float* rowloss, float* dH, int64_t lddh,
                            float* gw2, float* gb2, float* loss_out, gm_slot loss_slot, float inv_b,
                            int gen_mode, int B, int Hd) {
+    return head_bwd_impl(stream, H, ldh, dS, w2, rowloss, dH, lddh, gw2, gb2, loss_out, loss_slot,
+                         inv_b, gen_mode, B, Hd, nullptr, nullptr);
+}
+
+// head_bwd with the optimizer step for (w2, b2) and/or the per-graph tick folded in.
+extern "C" int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, const float* dS,
+                                 float* w2, float* b2, const float* rowloss, float* dH,
+                                 int64_t lddh, float* gw2, float* gb2, float* loss_out,
+                                 gm_slot loss_slot, float inv_b, int gen_mode, int B, int Hd,
+                                 int with_adam, float* mW, float* vW, float* mb, float* vb,
+                                 const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                                 double eps, double weight_decay, float clamp, int64_t* tick) {
+    gm_adam_epi a{};
+    if (with_adam) {
+        GM_CHECK_ARG(gw2 && gb2 && b2 && mW && vW && mb && vb && sched && !gen_mode);
+        a.pW = w2; a.mW = mW; a.vW = vW; a.pb = b2; a.mb = mb; a.vb = vb; a.sched = sched;
+        a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+        a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay;
+        a.clamp = clamp; a.enabled = 1;
+    }
+    return head_bwd_impl(stream, H, ldh, dS, w2, rowloss, dH, lddh, gw2, gb2, loss_out, loss_slot,
+                         inv_b, gen_mode, B, Hd, with_adam ? &a : nullptr, tick);
+}
+
+static int head_bwd_impl(void* stream, const float* H, int64_t ldh, const float* dS,
+                         const float* w2, const float* rowloss, float* dH, int64_t lddh, float* gw2,
+                         float* gb2, float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode,
+                         int B, int Hd, const gm_adam_epi* adam, int64_t* tick) {
     GM_CHECK_ARG(H && dS && w2 && rowloss && dH && loss_out && B > 0 && Hd > 0);
     HeadBwdP p{};
+    if (adam) p.adam = *adam;
+    p.tick = tick;
     p.H = H; p.ldh = ldh; p.dS = dS; p.w2 = w2; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
     p.gw2 = gw2; p.gb2 = gb2; p.loss_out = loss_out; p.loss_slot = loss_slot; p.inv_b = inv_b;
     p.gen_mode = gen_mode; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd;

@@ -57,6 +57,7 @@ struct GemmP {
     // private L2 has to pull over the fabric shrink from "all of A and B" to 1/xr of A + 1/xc of B.
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
+    gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
 };
 
 // Operand loads are BRANCH-FREE: out-of-range rows / k are clamped to a valid address and the
@@ -264,8 +265,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
         float* cp = p.C + (int64_t)m * p.ldc + n;
         *cp = p.accumulate ? (*cp + v) : v;
     } else {
-        float* cp = (n == p.n_real) ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
-        *cp = p.accumulate ? (*cp + v) : v;
+        const bool is_b = (n == p.n_real);
+        float* cp = is_b ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
+        if (p.accumulate) v += *cp;
+        *cp = v;
+        if (p.adam.enabled) {
+            // optimizer fused into the gradient epilogue: every gradient element is produced by
+            // exactly one thread, so Adam can run here and the separate launch disappears
+            const int64_t si = gm_slot_index(p.adam.sched_slot);
+            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
+            const int64_t o = is_b ? (int64_t)m : ((int64_t)m * p.ldc + n);
+            float* pp = (is_b ? p.adam.pb : p.adam.pW) + o;
+            float* mm = (is_b ? p.adam.mb : p.adam.mW) + o;
+            float* vv = (is_b ? p.adam.vb : p.adam.vW) + o;
+            float P = *pp, M = *mm, V = *vv;
+            adam_update(P, v, M, V, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
+                        p.adam.eps, p.adam.wd, p.adam.clamp);
+            *pp = P; *mm = M; *vv = V;
+        }
     }
     }
 }
@@ -370,11 +387,37 @@ extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, cons
     return launch<MODE_DX>((hipStream_t)stream, p, vec, xvec);
 }
 
+static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
+                   gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
+                   const gm_adam_epi* adam);
+
 extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X,
                                 int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K,
                                 int N, int accumulate) {
+    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, accumulate, nullptr);
+}
+
+extern "C" int gm_linear_bwd_dw_adam(void* stream, const float* dA, int64_t lda, const float* X,
+                                     int64_t ldx, gm_slot x_slot, float* dW, float* db, int M,
+                                     int K, int N, float* pW, float* mW, float* vW, float* pb,
+                                     float* mb, float* vb, const float* sched, gm_slot sched_slot,
+                                     double beta1, double beta2, double eps, double weight_decay,
+                                     float clamp) {
+    GM_CHECK_ARG(db && pW && mW && vW && pb && mb && vb && sched);
+    gm_adam_epi a{};
+    a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
+    a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+    a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
+    a.enabled = 1;
+    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, &a);
+}
+
+static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
+                   gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
+                   const gm_adam_epi* adam) {
     GM_CHECK_ARG(dA && X && dW && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GemmP p{};
+    if (adam) p.adam = *adam;
     // C[N_layer, K_layer(+1)] = sum_{m} dA[m,n] * X[m,k]  => GEMM dims (M=N_layer, N=K_layer(+1), K=batch)
     p.A = dA; p.B = X; p.C = dW; p.M = N; p.N = K + (db ? 1 : 0); p.K = M;
     p.lda = lda; p.ldb = ldx; p.ldc = K; p.db = db; p.n_real = K; p.accumulate = accumulate;

@@ -234,13 +234,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-        if (wd != 0.f) gg = gg + wd * pp;
-        mm = mm + one_minus_b1 * (gg - mm);
-        vv = vv * b2;
-        vv = vv + (one_minus_b2 * gg) * gg;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        pp = pp + ((-step_size) * mm) / denom;
-        if (clamp > 0.f) pp = fminf(fmaxf(pp, -clamp), clamp);
+        adam_update(pp, gg, mm, vv, step_size, bc2_sqrt, one_minus_b1, b2, one_minus_b2, eps, wd,
+                    clamp);
     };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 P = reinterpret_cast<float4*>(p)[i];

@@ -89,6 +89,9 @@ class _Linear:
         ib = [i for i, p in enumerate(fp.params) if p is lin.bias][0]
         self.W, self.b = fp.views[iw], fp.views[ib]
         self.gW, self.gb = fp.gviews[iw], fp.gviews[ib]
+        ow, ob, nw, nb = fp.offsets[iw], fp.offsets[ib], lin.weight.numel(), lin.bias.numel()
+        self.mW, self.vW = fp.m[ow:ow + nw], fp.v[ow:ow + nw]        # Adam moments (flat views)
+        self.mb, self.vb = fp.m[ob:ob + nb], fp.v[ob:ob + nb]
 
 
 # --------------------------------------------------------------------------------------------
@@ -139,6 +142,8 @@ class GANEngine:
         import os
         self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
+        self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
+        self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
@@ -163,9 +168,29 @@ class GANEngine:
         self._graph_key = None
 
     # -- slots --------------------------------------------------------------------------------
-    def _slot(self, it, mul, add, ring, stride):
-        """Graph mode: resolved on device from the counter; eager mode: resolved here."""
+    # -- which fusions apply to this run ---------------------------------------------------------
+    def _single(self):
+        return self.world == 1 and not self.force_segments
+
+    def _tick_in_head(self):
+        """The per-graph tick rides in the generator step's head_bwd kernel."""
+        return self.use_graph and self.fold_tick and self.fuse_head and not self.dag
+
+    def _adam_in_epilogue(self, net):
+        """Adam folded into the gradient-producing kernels (single GPU; not when later kernels
+        still accumulate into the gradients, i.e. WGAN-GP's critic)."""
+        if not (self.fuse_adam and self._single()) or self.dag:
+            return False
+        if net == "D":
+            return self.fuse_head and self.variant not in ("ra", "fisher", "wgp")
+        return True
+
+    def _slot(self, it, mul, add, ring, stride, post=False):
+        """Graph mode: resolved on device from the counter; eager mode: resolved here.
+        post=True: the consumer runs after the folded tick of this iteration (ctr already +1)."""
         if self.use_graph:
+            if post and self._tick_in_head():
+                add -= mul
             return ops.slot(self.ctr.data_ptr(), mul, add, ring, stride)
         i = it * mul + add
         if ring > 0:
@@ -193,7 +218,7 @@ class GANEngine:
         pending.append(lambda st, it: self._issue_G_pre(st, it))
         seg(pending, self.fG.grad)
         tail = [lambda st, it: self._issue_G_post(st, it)]
-        if self.use_graph:
+        if self.use_graph and not self._tick_in_head():
             tail.append(lambda st, it: ops.tick(self.ctr, 1, stream=st))
         seg(tail, None)
         return segs
@@ -249,8 +274,9 @@ class GANEngine:
             from . import ops_fused as of
             of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
                              self.inv_b, aux, S2, dS, self.rowloss, stream=st)
+            adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
             of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, D2.gW, D2.gb, self.lossD, loss_slot,
-                        self.inv_b, False, Bl, stream=st)
+                        self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
             ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
@@ -258,7 +284,11 @@ class GANEngine:
                          aux=aux, db=D2.gb, stream=st)
             ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
             ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
+        if self._adam_in_epilogue("D"):
+            ops.linear_bwd_dw_adam(dHd, X2, D1, self._adam_args("D", self._slot(it, d, j, 0, 1)),
+                                   M=2 * Bl, stream=st)
+        else:
+            ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp":
             self._issue_gp_backward(st)
 
@@ -267,7 +297,13 @@ class GANEngine:
         self._D_gen(st, it, j)
         self._D_rest(st, it, j)
 
+    def _adam_args(self, net, sched_slot):
+        return dict(sched=self.schedD if net == "D" else self.schedG, sched_slot=sched_slot,
+                    clamp=self.clip if net == "D" else 0.0)
+
     def _issue_D_post(self, st, it, j):
+        if self._adam_in_epilogue("D"):
+            return                                  # already applied by head_bwd / dW1 epilogues
         ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
                  self._slot(it, self.D_steps, j, 0, 1), clamp=self.clip, stream=st)
 
@@ -295,7 +331,8 @@ class GANEngine:
             of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
                              self.inv_b, None, S2, dS, self.rowloss, stream=st)
             of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, None, None, self.lossG, loss_slot,
-                        self.inv_b, True, Bl, stream=st)
+                        self.inv_b, True, Bl, tick=self.ctr if self._tick_in_head() else None,
+                        stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
             ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
@@ -303,25 +340,48 @@ class GANEngine:
             ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
         ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
 
-    def _G_dw2(self, st, it):
-        ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
+    # everything below runs AFTER the generator step's head kernel, i.e. after the folded tick
+    def _G_sched_slot(self, it):
+        return self._slot(it, 1, self.g_off, 0, 1, post=True)
 
-    def _G_dh_dw1(self, st, it):
-        zbase, zG_slot = self._G_zslot(it)
+    def _G_dh(self, st, it):
         ops.linear_bwd_dx(self.dXg, self.G2.W, self.dHg, below=self.Hg2, epi="relu", M=self.Bl,
                           stream=st)
-        ops.linear_bwd_dw(self.dHg, zbase, self.G1.gW, self.G1.gb, M=self.Bl, x_slot=zG_slot,
-                          stream=st)
+
+    def _G_dw2(self, st, it):
+        if self._adam_in_epilogue("G"):             # updates G2.W: must come after _G_dh read it
+            ops.linear_bwd_dw_adam(self.dXg, self.Hg2, self.G2,
+                                   self._adam_args("G", self._G_sched_slot(it)), M=self.Bl, stream=st)
+        else:
+            ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
+
+    def _G_dw1(self, st, it):
+        zbase = self.zG_ring.view(-1)[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        zG_slot = self._slot(it, 1, 0, self.R, self.B * self.Z, post=True)
+        if self._adam_in_epilogue("G"):
+            ops.linear_bwd_dw_adam(self.dHg, zbase, self.G1,
+                                   self._adam_args("G", self._G_sched_slot(it)), M=self.Bl,
+                                   x_slot=zG_slot, stream=st)
+        else:
+            ops.linear_bwd_dw(self.dHg, zbase, self.G1.gW, self.G1.gb, M=self.Bl, x_slot=zG_slot,
+                              stream=st)
+
+    def _G_dh_dw1(self, st, it):
+        self._G_dh(st, it)
+        self._G_dw1(st, it)
 
     def _issue_G_pre(self, st, it):
         self._G_gen(st, it)
         self._G_critic(st, it)
+        self._G_dh(st, it)                          # reads G2.W before _G_dw2 may update it
         self._G_dw2(st, it)
-        self._G_dh_dw1(st, it)
+        self._G_dw1(st, it)
 
     def _issue_G_post(self, st, it):
+        if self._adam_in_epilogue("G"):
+            return
         ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
-                 self._slot(it, 1, self.g_off, 0, 1), stream=st)
+                 self._G_sched_slot(it), stream=st)
 
     # ---- the same iteration as a DAG: independent pieces become parallel hipGraph branches ----
     def _issue_iteration_dag(self, st, it):
@@ -443,7 +503,7 @@ class GANEngine:
         self.ctr.zero_()
         R = max(1, min(CHUNK, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
-               self.fuse_head, self.dag)
+               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick)
         if getattr(self, "_ring_key", None) != (D_steps, R):
             self._alloc_rings(R)
             self._ring_key = (D_steps, R)

@@ -63,6 +63,20 @@ def linear_bwd_dw(dA, X, dW, db, M=None, accumulate=False, x_slot=NO_SLOT, strea
               db.data_ptr() if db is not None else None, M, K, N, 1 if accumulate else 0)
 
 
+def linear_bwd_dw_adam(dA, X, lin, adam, M=None, x_slot=NO_SLOT, betas=(0.9, 0.999), eps=1e-8,
+                       weight_decay=0.0, stream=None):
+    """dW/db as linear_bwd_dw (written into lin.gW/lin.gb) with Adam applied to the layer's
+    parameters in the same kernel.  lin: engine._Linear (W, b, gW, gb, mW, vW, mb, vb views);
+    adam: dict(sched, sched_slot, clamp)."""
+    N, K = lin.gW.shape
+    M = dA.shape[0] if M is None else M
+    _lib.call("gm_linear_bwd_dw_adam", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+              _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(), lin.gb.data_ptr(), M, K, N,
+              lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(), lin.b.data_ptr(),
+              lin.mb.data_ptr(), lin.vb.data_ptr(), adam["sched"].data_ptr(), adam["sched_slot"],
+              betas[0], betas[1], eps, weight_decay, adam.get("clamp", 0.0))
+
+
 def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
     """out[b,:] = data[idx[b],:]  (process_batch, ns_gan.py:222-226)."""
     n_rows, row = data.shape

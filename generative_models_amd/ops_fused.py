@@ -62,10 +62,24 @@ def head_fwd_loss(variant, gen_mode, H, w2, b2, out_act, B, hyper, inv_b, pen, S
               dS.data_ptr(), rowloss.data_ptr())
 
 
-def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_mode, B, stream=None):
-    """dH = dS (x) w2 masked by H>0; gw2 = dS^T H; gb2; loss scalar (see gm_hip.h)."""
-    _lib.call("gm_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
-              w2.data_ptr(), rowloss.data_ptr(), dH.data_ptr(), _ld(dH),
-              gw2.data_ptr() if gw2 is not None else None,
-              gb2.data_ptr() if gb2 is not None else None, loss_out.data_ptr(), loss_slot, inv_b,
-              1 if gen_mode else 0, B, H.shape[1])
+def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_mode, B, lin=None,
+             adam=None, tick=None, betas=(0.9, 0.999), eps=1e-8, stream=None):
+    """dH = dS (x) w2 masked by H>0; gw2 = dS^T H; gb2; loss scalar (see gm_hip.h).
+    adam (dict(sched, sched_slot, clamp)) + lin (engine._Linear of the head): also apply Adam to
+    (w2, b2) here.  tick: device int64 counter to advance once the loss slot is written."""
+    g = lambda t: t.data_ptr() if t is not None else None
+    if adam is None and tick is None:
+        _lib.call("gm_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
+                  w2.data_ptr(), rowloss.data_ptr(), dH.data_ptr(), _ld(dH), g(gw2), g(gb2),
+                  loss_out.data_ptr(), loss_slot, inv_b, 1 if gen_mode else 0, B, H.shape[1])
+        return
+    with_adam = adam is not None
+    _lib.call("gm_head_bwd_fused", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
+              w2.data_ptr(), lin.b.data_ptr() if with_adam else None, rowloss.data_ptr(),
+              dH.data_ptr(), _ld(dH), g(gw2), g(gb2), loss_out.data_ptr(), loss_slot, inv_b,
+              1 if gen_mode else 0, B, H.shape[1], 1 if with_adam else 0,
+              lin.mW.data_ptr() if with_adam else None, lin.vW.data_ptr() if with_adam else None,
+              lin.mb.data_ptr() if with_adam else None, lin.vb.data_ptr() if with_adam else None,
+              adam["sched"].data_ptr() if with_adam else None,
+              adam["sched_slot"] if with_adam else NO_SLOT, betas[0], betas[1], eps, 0.0,
+              adam.get("clamp", 0.0) if with_adam else 0.0, g(tick))

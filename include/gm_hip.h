@@ -84,6 +84,17 @@ int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, const float* W,
 int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                      gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate);
 
+/* gm_linear_bwd_dw with the optimizer folded into the gradient epilogue: dW/db are written as
+ * usual and Adam (same arithmetic as gm_adam) is applied to (pW,mW,vW)/(pb,mb,vb)
+ * by the thread that produced the gradient element -- optim.Adam.step (ns_gan.py:139,156) without
+ * its own launch.  Single-GPU fast path only (under data parallelism the all-reduce sits between
+ * gradient and optimizer). */
+int gm_linear_bwd_dw_adam(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
+                          gm_slot x_slot, float* dW, float* db, int M, int K, int N, float* pW,
+                          float* mW, float* vW, float* pb, float* mb, float* vb, const float* sched,
+                          gm_slot sched_slot, double beta1, double beta2, double eps,
+                          double weight_decay, float clamp);
+
 /* ---- K4: adversarial loss + its gradient w.r.t. the critic's PRE-activation output.
  * sx,sg: [B] post-activation scores D(x), D(G(z)) (sx NULL in generator mode).
  * out_act: activation that produced the scores (sigmoid, or relu for WGAN-GP).
@@ -157,6 +168,15 @@ int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const float* H, in
 int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS, const float* w2,
                 const float* rowloss, float* dH, int64_t lddh, float* gw2, float* gb2,
                 float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode, int B, int Hd);
+
+/* gm_head_bwd + optional Adam on (w2, b2) + optional per-graph tick (*tick += 1 once the loss
+ * slot is written; later kernels of the same iteration then address slots with add - mul). */
+int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, const float* dS, float* w2,
+                      float* b2, const float* rowloss, float* dH, int64_t lddh, float* gw2,
+                      float* gb2, float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode,
+                      int B, int Hd, int with_adam, float* mW, float* vW, float* mb, float* vb,
+                      const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
+                      double weight_decay, float clamp, int64_t* tick);
 
 /* ---- elementwise activation backward for the general autograd path:
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */
