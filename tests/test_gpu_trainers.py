@@ -285,7 +285,7 @@ def test_vae_engine_vs_reference_golden(name):
 
 def test_dp_launch_structure_single_rank_rccl():
     """The data-parallel launch structure (one hipGraph per segment, RCCL all-reduce of the flat
-    gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run bitwise
+    gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run
     (an all-reduce over one rank is the identity)."""
     import socket
     import torch.distributed as dist
@@ -302,8 +302,11 @@ def test_dp_launch_structure_single_rank_rccl():
             tr.train(num_epochs=2)
         torch.cuda.synchronize()
         assert eng.seg_graphs is not None and len(eng.seg_graphs) == 3
-        assert tr.Glosses == ref[0].Glosses and tr.Dlosses == ref[0].Dlosses
+        # same kernels except Adam (separate launch here, gradient-epilogue fusion in the
+        # single-graph run): identical up to fp32 contraction differences
+        lclose(tr.Glosses, ref[0].Glosses, "dp-structure Glosses", tol=1e-6)
+        lclose(tr.Dlosses, ref[0].Dlosses, "dp-structure Dlosses", tol=1e-6)
         for (k, a), (_, b) in zip(model.state_dict().items(), ref[1].state_dict().items()):
-            assert torch.equal(a, b), k
+            assert (a - b).abs().max().item() <= 1e-6, k
     finally:
         dist.destroy_process_group()
