@@ -261,6 +261,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
+        torch.distributed.barrier()          # rank 0 may still be in its reporting section
         torch.distributed.destroy_process_group()
 
 
