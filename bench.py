@@ -50,6 +50,30 @@ def gemm_shapes(B, fused_head=True):
             [("dx", B, IMG, HID), ("dw", B, HID, IMG), ("dx", B, HID, IMG), ("dw", B, Z, HID)])
 
 
+def gemm_variant(kind, M, K, N):
+    """Name of the gemm_kernel instantiation csrc/gm_gemm.hip launches for this layer shape
+    (mirrors launch<MODE>(): 8 waves when the grid has more than 256 tiles, batch depth G from the
+    chunks per wave, 16-byte paths by alignment) -- the name rocprofv3 reports."""
+    if kind == "fwd":
+        mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
+    elif kind == "dx":
+        mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
+    else:
+        mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
+        xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
+    tiles = -(-Mg // 32) * -(-Ng // 32)
+    nw = 8 if tiles > 256 else 16
+    per_wave = -(--(-Kr // 8) // nw)
+    g, best = 7, 1 << 30
+    for cand in (2, 4, 7):
+        batches = -(-per_wave // cand)
+        cost = batches * cand + 2 * (batches - 1)
+        if cost <= best:
+            best, g = cost, cand
+    b = lambda v: "true" if v else "false"
+    return "gemm_kernel<%d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv))
+
+
 def clock_probe():
     """Effective shader clock (MHz) while every CU runs a dependent fp32-MFMA chain."""
     from generative_models_amd import _lib, ops
@@ -64,7 +88,8 @@ def clock_probe():
 
 def time_kernels_isolated(B, reps=100, fused_head=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
-    back `reps` times.  Returns {kind: (total_us_per_step, total_flop_per_step, n_launches)}."""
+    back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
+    total_flop_per_step, n_launches_per_step)}."""
     from generative_models_amd import ops
     dev = "cuda"
     out = {}
@@ -103,8 +128,9 @@ def time_kernels_isolated(B, reps=100, fused_head=True):
         e1.sync()
         us = e0.elapsed_ms(e1) * 1e3 / reps
         log('  %-3s M=%4d K=%4d N=%4d : %7.2f us  %6.2f TFLOP/s' % (kind, M, K, N, us, 2.0*M*K*N/us/1e6))
-        t, f, n = out.get(kind, (0.0, 0.0, 0))
-        out[kind] = (t + us, f + 2.0 * M * K * N, n + 1)
+        name = gemm_variant(kind, M, K, N)
+        t, f, n = out.get(name, (0.0, 0.0, 0))
+        out[name] = (t + us, f + 2.0 * M * K * N, n + 1)
     return out
 
 
@@ -119,7 +145,7 @@ _T0 = time.perf_counter()
 def cpu_baseline(seconds_target=12.0):
     """Oracle port (CPU restatement of the reference trainer, oracle/port.py) timed as-written
     (DataLoader reshuffle included) on this host's cores: NSGAN bs=256, same synthetic data.
-    Thread count: the fastest of {4,8,16,32,64} in a short probe (hundreds of OpenMP threads on
+    Thread count: the fastest of {8,16,32} in a short probe (hundreds of OpenMP threads on
     256x400 GEMMs only add barrier time); the count used is reported as `cores`."""
     from oracle import port
     ds = synthetic_dataset()
@@ -128,12 +154,12 @@ def cpu_baseline(seconds_target=12.0):
     tr = port.GANPort("ns", model, loader)
     ncpu = os.cpu_count() or 1
     best = None
-    for cand in [c for c in (4, 8, 16, 32, 64) if c <= ncpu] or [1]:
+    for cand in [c for c in (8, 16, 32) if c <= ncpu] or [min(ncpu, 4)]:
         torch.set_num_threads(cand)
-        tr.train(1, max_steps=2)                    # warm-up at this thread count
+        tr.train(1, max_steps=3)                    # warm-up at this thread count
         t0 = time.perf_counter()
-        tr.train(1, max_steps=4)
-        ps = (time.perf_counter() - t0) / 4
+        tr.train(1, max_steps=12)
+        ps = (time.perf_counter() - t0) / 12
         log("cpu probe %.1f ms/step on %d threads" % (ps * 1e3, cand))
         if best is None or ps < best[0]:
             best = (ps, cand)
@@ -224,17 +250,16 @@ def main():
         log('isolated kernel timing done')
         dom = max(kt, key=lambda k: kt[k][0])
         t_us, flop, n = kt[dom]
-        names = {"fwd": "gemm_kernel<0,*,*> (linear fwd)", "dx": "gemm_kernel<1,*,*> (linear dX)",
-                 "dw": "gemm_kernel<2,*,*> (linear dW)"}
-        # HBM/fabric bytes per launch of that kernel family from the committed PMC pass
-        # (profiles/r01_pmc_fetch_write.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        # HBM/fabric bytes per launch of that kernel from the committed PMC pass
+        # (profiles/r01_pmc_fetch_write.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; PMC counters
+        # cannot be read from inside this process, so the per-dispatch averages are loaded)
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            mode = {"fwd": "<0,", "dx": "<1,", "dw": "<2,"}[dom]
-            rows = [v for k, v in pmc.items() if "gemm_kernel" + mode in k and v["read_bytes"] > 2e6]
+            rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]
             if rows:
-                traffic = sum(v["read_bytes"] + v["write_bytes"] for v in rows) / len(rows)
+                nd = sum(v["dispatches"] for v in rows)
+                traffic = sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in rows) / nd
         except Exception:
             traffic = None
         achieved = flop / (t_us * 1e-6) / 1e12
@@ -250,7 +275,7 @@ def main():
                        "launch": ("hipGraph/iteration" if world == 1 else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world},
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "shader_clock_mhz": round(mhz),
