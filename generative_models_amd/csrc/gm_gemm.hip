@@ -6,23 +6,32 @@
 //   dw   (TN): dW[N,K] = dA[M,N]^T * X[M,K], db = colsum(dA)
 //
 // Design for this problem (B=256: every GEMM is ~0.1-0.3 GFLOP, L2/MALL-resident, and the step is
-// a chain of ~16 dependent GEMMs -- latency, not bandwidth or FLOPs, is the enemy):
+// a chain of ~11 dependent GEMMs -- latency, not bandwidth or FLOPs, is the enemy):
 //   * 32x32 output tile per workgroup so that even B=256 launches 100-325 workgroups;
-//   * the reduction dimension is SPLIT ACROSS THE 16 WAVES of a 1024-thread workgroup in
-//     round-robin 8-deep chunks.  Because no two waves of a workgroup touch the same k, there is
-//     NO operand reuse inside the workgroup, so operands are NOT staged through LDS: each wave
-//     loads its chunks straight into v_mfma_f32_32x32x2_f32 fragment registers (the M=small
-//     "load straight to VGPRs, deep unroll, late vmcnt" regime of the CDNA guide), with a whole
-//     group of 4 chunks (8-32 loads) in flight before the first MFMA.  The dependent chain for
-//     K=784 is 28 MFMAs per wave instead of 392, with no barrier inside it;
+//   * the reduction dimension is SPLIT ACROSS THE WAVES of the workgroup in round-robin 8-deep
+//     chunks: 16 waves (1024 threads, one workgroup per CU) when the grid has <= 256 tiles, 8 waves
+//     (two workgroups per CU) when it has more, so every launch runs in a single round.  No two
+//     waves of a workgroup touch the same k => there is NO operand reuse inside the workgroup, so
+//     operands are NOT staged through LDS: each wave loads its chunks straight into
+//     v_mfma_f32_32x32x2_f32 fragment registers (the "load straight to VGPRs, deep unroll, late
+//     vmcnt" regime of the CDNA guide).  The dependent chain for K=784 is 28 MFMAs per wave
+//     instead of 392, with no barrier inside it;
+//   * loads are branch-free (clamped addresses, zeroing selects deferred to the consume stage) and
+//     issued G at a time back to back (G in {2,4,7} per launch = the wave's whole k-range for the
+//     shapes of this model), so hipcc emits counted s_waitcnt vmcnt(n) between the MFMA groups
+//     instead of a full drain behind every guarded load;
 //   * fragment trick: lane (row r = lane&31, half h = lane>>5) loads 4 consecutive k
 //     (k = 8c+4h+j) of its row with ONE 16-byte load; MFMA j consumes element j, i.e. the k-order
-//     inside a chunk is permuted identically for A and B -- legal because a sum does not care;
-//   * the 16 partial tiles are combined through 64 KB of LDS (conflict-free row writes/reads),
-//     then bias / activation / activation-gradient epilogues are applied and rows are stored as
-//     coalesced 128-byte segments;
+//     inside a chunk is permuted identically for A and B -- legal because a sum does not care.
+//     x-contiguous operands (dX's W, dW's dA and X) use one 16-byte load of 4 consecutive x at one
+//     k plus a 4x4 transpose inside each lane quad (two DPP quad_perm steps, no LDS);
+//   * the partial tiles are combined through 64/32 KB of LDS (conflict-free row writes/reads), then
+//     bias / activation / activation-gradient / accumulate / Adam epilogues are applied and rows
+//     are stored as coalesced 128-byte segments;
 //   * exact fp32 (MFMA f32 == fmaf chain); deterministic (no atomics);
-//   * db falls out of the dW GEMM for free: X gets a virtual ones-column at index K.
+//   * db falls out of the dW GEMM for free: X gets a virtual ones-column at index K;
+//   * optional optimizer-in-epilogue: the thread that produces a gradient element also applies
+//     Adam to the parameter (single-GPU fast path), removing the separate Adam launches.
 #include "gm_common.h"
 
 #include <cstdlib>
