@@ -144,19 +144,24 @@ class GANEngine:
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
+        self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
+        self._standalone_G = False
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
         z = lambda *s: torch.zeros(*s, device=dev)
-        self.X2 = z(2 * Bl, I)             # rows [0,Bl): real batch, [Bl,2Bl): G(z)
-        self.Hg = z(Bl, H)
+        # rows [0,Bl): real batch, [Bl,2Bl): G(z) of the critic step, [2Bl,3Bl): G(z) of the
+        # generator step -- contiguous so that both generator forwards can be ONE 2Bl-row launch
+        self.XX = z(3 * Bl, I)
+        self.X2, self.Xg2 = self.XX[:2 * Bl], self.XX[2 * Bl:]
+        self.HG = z(2 * Bl, H)
+        self.Hg, self.Hg2 = self.HG[:Bl], self.HG[Bl:]
         self.Hd = z(2 * Bl, Hd)
         self.S2 = z(2 * Bl)                # scores
         self.dS = z(2 * Bl)                # d loss / d pre-activation score
         self.dHd = z(2 * Bl, Hd)
         self.dXg = z(Bl, I)
         self.dHg = z(Bl, H)
-        self.Hg2, self.Xg2 = z(Bl, H), z(Bl, I)     # generator step's own G(z) buffers
         self.rowloss = z(2 * Bl)
         self.aux = z(8)                    # Fisher lambda + moments
         if variant == "wgp":
@@ -252,13 +257,20 @@ class GANEngine:
         ops.gather_rows(self.data, self.idx_ring.view(-1)[r0:], self.X2, B=Bl,
                         idx_slot=self._slot(it, d, j, R * d, self.B), stream=st)
 
+    def _batch_gen(self):
+        """Both generator forwards of an iteration (critic step's G(zD), generator step's G(zG))
+        read the same G parameters: with D_steps == 1 on one GPU they run as ONE launch pair on
+        2B rows (the noise ring stores [zD; zG] back to back)."""
+        return self.batch_gen_env and self.D_steps == 1 and self.world == 1 and not self.dag
+
     def _D_gen(self, st, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
         G1, G2 = self.G1, self.G2
-        zD_slot = self._slot(it, d, j, R * d, self.B * self.Z)
-        zbase = self.zD_ring.view(-1)[self.rank * Bl * self.Z:].view(-1, self.Z)
-        ops.linear_fwd(zbase, G1.W, G1.b, self.Hg, "relu", M=Bl, x_slot=zD_slot, stream=st)
-        ops.linear_fwd(self.Hg, G2.W, G2.b, self.X2[Bl:], "sigmoid", M=Bl, stream=st)
+        zD_slot = self._slot(it, d, j, R * d, self.zD_stride)
+        zbase = self.zD_base[self.rank * Bl * self.Z:].view(-1, self.Z)
+        rows = 2 * Bl if (self._batch_gen() and not self._standalone_G) else Bl
+        ops.linear_fwd(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot, stream=st)
+        ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
 
     def _D_rest(self, st, it, j):
         Bl, d = self.Bl, self.D_steps
@@ -310,10 +322,12 @@ class GANEngine:
     # ---- pieces of the generator step (own Hg2/Xg2 buffers: its generator forward only needs G's
     # parameters, so it can run as a parallel branch of the critic step) ----------------------
     def _G_zslot(self, it):
-        zbase = self.zG_ring.view(-1)[self.rank * self.Bl * self.Z:].view(-1, self.Z)
-        return zbase, self._slot(it, 1, 0, self.R, self.B * self.Z)
+        zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        return zbase, self._slot(it, 1, 0, self.R, self.zG_stride)
 
     def _G_gen(self, st, it):
+        if self._batch_gen() and not self._standalone_G:
+            return                                  # done together with the critic step's G(z)
         G1, G2 = self.G1, self.G2
         zbase, zG_slot = self._G_zslot(it)
         ops.linear_fwd(zbase, G1.W, G1.b, self.Hg2, "relu", M=self.Bl, x_slot=zG_slot, stream=st)
@@ -356,8 +370,8 @@ class GANEngine:
             ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
 
     def _G_dw1(self, st, it):
-        zbase = self.zG_ring.view(-1)[self.rank * self.Bl * self.Z:].view(-1, self.Z)
-        zG_slot = self._slot(it, 1, 0, self.R, self.B * self.Z, post=True)
+        zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
         if self._adam_in_epilogue("G"):
             ops.linear_bwd_dw_adam(self.dHg, zbase, self.G1,
                                    self._adam_args("G", self._G_sched_slot(it)), M=self.Bl,
@@ -438,13 +452,28 @@ class GANEngine:
         d, B, Z, dev = self.D_steps, self.B, self.Z, self.device
         self.R = R
         self.idx_ring = torch.zeros(R * d, B, dtype=torch.int64, device=dev)
-        self.zD_ring = torch.zeros(R * d, B, Z, device=dev)
-        self.zG_ring = torch.zeros(R, B, Z, device=dev)
         pin = lambda *s, **k: torch.zeros(*s, **k).pin_memory()
         self.stage = []
+        self.z_joint = self._batch_gen()
+        if self.z_joint:          # one ring of [zD; zG] pairs: slot stride 2*B*Z
+            self.z_ring = torch.zeros(R, 2, B, Z, device=dev)
+            self.zD_ring, self.zG_ring = self.z_ring[:, 0], self.z_ring[:, 1]
+            flat = self.z_ring.view(-1)
+            self.zD_base, self.zG_base = flat, flat[B * Z:]
+            self.zD_stride = self.zG_stride = 2 * B * Z
+        else:
+            self.zD_ring = torch.zeros(R * d, B, Z, device=dev)
+            self.zG_ring = torch.zeros(R, B, Z, device=dev)
+            self.zD_base, self.zG_base = self.zD_ring.view(-1), self.zG_ring.view(-1)
+            self.zD_stride = self.zG_stride = B * Z
         for _ in range(2):
-            s = dict(idx=pin(R * d, B, dtype=torch.int64), zD=pin(R * d, B, Z), zG=pin(R, B, Z),
-                     event=None)
+            if self.z_joint:
+                zz = pin(R, 2, B, Z)
+                s = dict(idx=pin(R * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1],
+                         event=None)
+            else:
+                s = dict(idx=pin(R * d, B, dtype=torch.int64), zD=pin(R * d, B, Z), zG=pin(R, B, Z),
+                         event=None)
             if self.variant == "wgp":
                 s["eps"] = pin(R * d, B)
             self.stage.append(s)
@@ -474,8 +503,11 @@ class GANEngine:
             self._draw_G(s, i)
         r = it0 % self.R                 # ring slot of the chunk's first iteration (n_it <= R - r)
         self.idx_ring[r * d:(r + n_it) * d].copy_(s["idx"][:n_it * d], non_blocking=True)
-        self.zD_ring[r * d:(r + n_it) * d].copy_(s["zD"][:n_it * d], non_blocking=True)
-        self.zG_ring[r:r + n_it].copy_(s["zG"][:n_it], non_blocking=True)
+        if self.z_joint:
+            self.z_ring[r:r + n_it].copy_(s["z"][:n_it], non_blocking=True)
+        else:
+            self.zD_ring[r * d:(r + n_it) * d].copy_(s["zD"][:n_it * d], non_blocking=True)
+            self.zG_ring[r:r + n_it].copy_(s["zG"][:n_it], non_blocking=True)
         if self.variant == "wgp":
             self.eps_ring[r * d:(r + n_it) * d].copy_(s["eps"][:n_it * d], non_blocking=True)
         ev = torch.cuda.Event()
@@ -503,10 +535,11 @@ class GANEngine:
         self.ctr.zero_()
         R = max(1, min(CHUNK, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
-               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick)
-        if getattr(self, "_ring_key", None) != (D_steps, R):
+               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen())
+        self.D_steps = D_steps
+        if getattr(self, "_ring_key", None) != (D_steps, R, self._batch_gen()):
             self._alloc_rings(R)
-            self._ring_key = (D_steps, R)
+            self._ring_key = (D_steps, R, self._batch_gen())
             self._graph_key = None
         # schedule / loss buffers are re-created per train(): pointers change => recapture
         self._graph_key = None
@@ -572,6 +605,7 @@ class GANEngine:
             s["idx_np"] = s["idx"].numpy()
         saved_graph, saved_off = self.use_graph, self.g_off
         self.use_graph = False
+        self._standalone_G = True
         st = ops.stream_ptr()
         for k in range(n):
             draw_sampler_indices(self.N, self.B, s["idx_np"][0])    # images are unused by train_G
@@ -581,6 +615,7 @@ class GANEngine:
             self._issue_G(st, 0)
         torch.cuda.synchronize()
         self.use_graph, self.g_off = saved_graph, saved_off
+        self._standalone_G = False
 
     def losses(self, it0, it1):
         """Per-iteration (G loss, mean D loss over D_steps) like ns_gan.py:142-154."""
