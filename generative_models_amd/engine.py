@@ -145,6 +145,7 @@ class GANEngine:
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
+        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "1")))   # iterations / graph
         self._standalone_G = False
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
@@ -563,6 +564,11 @@ class GANEngine:
                 self.graph = ops.Graph().capture(lambda st: self._issue_iteration_dag(st, 0))
             else:
                 self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
+                self.graph_k = None
+                if self.graph_iters > 1 and self._tick_in_head():
+                    k = self.graph_iters          # the device counter advances inside each iteration
+                    self.graph_k = ops.Graph().capture(
+                        lambda st: [self._issue_iteration(st, 0) for _ in range(k)])
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
@@ -584,7 +590,12 @@ class GANEngine:
             self._prefetch(it, n, which)
             which ^= 1
             if self.use_graph and self.world == 1 and not self.force_segments:
-                for _ in range(n):
+                left = n
+                gk = getattr(self, "graph_k", None)
+                while gk is not None and left >= self.graph_iters:
+                    gk.launch()
+                    left -= self.graph_iters
+                for _ in range(left):
                     self.graph.launch()
             elif self.use_graph:
                 for _ in range(n):
