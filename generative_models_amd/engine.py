@@ -145,7 +145,7 @@ class GANEngine:
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
-        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "1")))   # iterations / graph
+        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))   # iterations / graph
         self._standalone_G = False
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
