@@ -671,10 +671,15 @@ class VAEEngine:
             b = fp.flat[o_b:o_b + 2 * Z]
             gW = fp.grad[o_w:o_w + 2 * Z * H].view(2 * Z, H)
             gb = fp.grad[o_b:o_b + 2 * Z]
+            mW, vW = fp.m[o_w:o_w + 2 * Z * H], fp.v[o_w:o_w + 2 * Z * H]
+            mb, vb = fp.m[o_b:o_b + 2 * Z], fp.v[o_b:o_b + 2 * Z]
         self.ML = _Packed
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
         self.graphs = {}
         self._bufB = None
+        import os
+        self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
+        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))
 
     def _alloc(self, B):
         if self._bufB == B:
@@ -715,17 +720,27 @@ class VAEEngine:
         of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
         of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
         if train:
-            ops.linear_bwd_dw(self.dA, self.Hdec, D2.gW, D2.gb, M=b, stream=st)
+            sched_slot = self._slot(t, 1, 0, 0, 1)
+            if self.fuse_adam:
+                # Adam (weight_decay 1e-5, vae.py:139-142) folded into every dW epilogue; each dX
+                # GEMM reads a layer's weights BEFORE that layer's dW launch updates them
+                adam = dict(sched=self.sched, sched_slot=sched_slot)
+                dw = lambda dA, X, lin: ops.linear_bwd_dw_adam(dA, X, lin, adam, M=b,
+                                                               weight_decay=self.wd, stream=st)
+            else:
+                dw = lambda dA, X, lin: ops.linear_bwd_dw(dA, X, lin.gW, lin.gb, M=b, stream=st)
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            ops.linear_bwd_dw(self.dHdec, self.Zs, D1.gW, D1.gb, M=b, stream=st)
+            dw(self.dA, self.Hdec, D2)
             ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
+            dw(self.dHdec, self.Zs, D1)
             of.vae_reparam_bwd(self.ml, self.eps_ring.view(-1), self.dZ, self.dml, b, Z,
                                eps_slot=eps_slot, stream=st)
-            ops.linear_bwd_dw(self.dml, self.He, ML.gW, ML.gb, M=b, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            ops.linear_bwd_dw(self.dHe, self.X, E1.gW, E1.gb, M=b, stream=st)
-            ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched,
-                     self._slot(t, 1, 0, 0, 1), weight_decay=self.wd, stream=st)
+            dw(self.dml, self.He, ML)
+            dw(self.dHe, self.X, E1)
+            if not self.fuse_adam:
+                ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
+                         weight_decay=self.wd, stream=st)
         if self.use_graph:
             ops.tick(self.ctr, 1, stream=st)
 
@@ -748,11 +763,13 @@ class VAEEngine:
         self.graphs = {}
         self.t_train = 0
 
-    def _graph(self, b, train):
-        key = (b, train, self.data.data_ptr())
+    def _graph(self, b, train, k=1):
+        """hipGraph of k consecutive batches of size b (the device counter advances per batch)."""
+        key = (b, train, self.data.data_ptr(), k)
         if key not in self.graphs:
             torch.cuda.synchronize()
-            self.graphs[key] = ops.Graph().capture(lambda st: self._issue(st, 0, b, train))
+            self.graphs[key] = ops.Graph().capture(
+                lambda st: [self._issue(st, 0, b, train) for _ in range(k)])
         return self.graphs[key]
 
     def run_pass(self, data, perm, train, t0):
@@ -785,11 +802,22 @@ class VAEEngine:
             ev = torch.cuda.Event()
             ev.record()
             s["event"] = ev
-            for k, b in enumerate(sizes):
-                if self.use_graph:
-                    self._graph(b, train).launch()
-                else:
+            k = 0
+            while k < len(sizes):
+                b = sizes[k]
+                if not self.use_graph:
                     self._issue(ops.stream_ptr(), t + k, b, train)
+                    k += 1
+                    continue
+                run = 1
+                while k + run < len(sizes) and sizes[k + run] == b and run < self.graph_iters:
+                    run += 1
+                if run == self.graph_iters and run > 1:
+                    self._graph(b, train, run).launch()
+                    k += run
+                else:
+                    self._graph(b, train).launch()
+                    k += 1
             done += cnt
         return nb
 

@@ -32,7 +32,7 @@ def loaders(batch, n_val=10000):
     return mk(N_TRAIN), mk(n_val), mk(2048)
 
 
-def run(name, module, model_cls, trainer_cls, batch, train_kw, epochs=2):
+def run(name, module, model_cls, trainer_cls, batch, train_kw, epochs=6):
     import importlib
     mod = importlib.import_module(module)
     ld = loaders(batch)
