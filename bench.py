@@ -39,15 +39,17 @@ def synthetic_dataset():
     return ds
 
 
-def gemm_shapes(B, fused_head=True):
+def gemm_shapes(B, fused_head=True, batch_gen=True):
     """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
-    critic-head kernels (default) the N=1 layer is not a GEMM launch any more."""
+    critic-head kernels (default) the N=1 layer is not a GEMM launch any more; with the batched
+    generator forward (default at D_steps=1) G(zD) and G(zG) are one 2B-row launch pair."""
     d_head = [] if fused_head else [("fwd", 2 * B, HID, 1), ("dw", 2 * B, HID, 1), ("dx", 2 * B, HID, 1)]
     g_head = [] if fused_head else [("fwd", B, HID, 1), ("dx", B, HID, 1)]
-    return ([("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", 2 * B, IMG, HID)] + d_head +
-            [("dw", 2 * B, IMG, HID)] +
-            [("fwd", B, Z, HID), ("fwd", B, HID, IMG), ("fwd", B, IMG, HID)] + g_head +
-            [("dx", B, IMG, HID), ("dw", B, HID, IMG), ("dx", B, HID, IMG), ("dw", B, Z, HID)])
+    gen = [("fwd", 2 * B, Z, HID), ("fwd", 2 * B, HID, IMG)] if batch_gen else \
+        [("fwd", B, Z, HID), ("fwd", B, HID, IMG)] * 2
+    return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [("dw", 2 * B, IMG, HID)] +
+            [("fwd", B, IMG, HID)] + g_head +
+            [("dx", B, IMG, HID), ("dx", B, HID, IMG), ("dw", B, HID, IMG), ("dw", B, Z, HID)])
 
 
 def gemm_variant(kind, M, K, N):
@@ -86,7 +88,7 @@ def clock_probe():
     return cyc / max(wall, 1) * 100.0, cyc / 4000.0
 
 
-def time_kernels_isolated(B, reps=100, fused_head=True):
+def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -94,7 +96,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True):
     dev = "cuda"
     out = {}
     st = ops.stream_ptr()
-    for kind, M, K, N in gemm_shapes(B, fused_head):
+    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -244,7 +246,7 @@ def main():
     img_s = K * B_global / dt
 
     if rank == 0:
-        kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head)
+        kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen())
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         log('isolated kernel timing done')
