@@ -72,6 +72,8 @@ _SIGNATURES = {
     "gm_stream_create": (c_int, [POINTER(c_void_p)]),
     "gm_stream_destroy": (c_int, [_P]),
     "gm_stream_wait_event": (c_int, [_P, _P]),
+    "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,
+                               _P, c_int64, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_graph_begin": (c_int, [_P]),

@@ -441,3 +441,70 @@ static int head_bwd_impl(void* stream, const float* H, int64_t ldh, const float*
                        (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }
+
+// ------------------------------------------------------------------------------------------
+// K15 InfoGAN mutual-information loss (info_gan.py:295-302):
+//   disc = F.cross_entropy(q[:, :nd], argmax(onehot))      (mean over B of logsumexp - q[target])
+//   cont = F.mse_loss(q[:, nd:], c2)                       (mean over B*nc elements)
+//   loss = lambda * (disc + cont);  dq = d loss / d q
+// q: [B, nd+nc] (Q's identity output); noise: [B, zd+nd+nc] rows = [z | one-hot c1 | c2] (the G
+// input of this step, info_gan.py:306-325), read through a ring slot.  One workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restrict__ q, int64_t ldq,
+                                                         const float* __restrict__ noise,
+                                                         gm_slot noise_slot, int64_t ldn, int B,
+                                                         int zd, int nd, int nc, float lambda,
+                                                         float* __restrict__ dq, int64_t lddq,
+                                                         float* __restrict__ loss_out,
+                                                         gm_slot loss_slot) {
+    __shared__ double sh[4];
+    const float* nz = noise + gm_slot_offset(noise_slot);
+    const float inv_b = 1.0f / (float)B, inv_bc = 1.0f / (float)(B * nc);
+    double acc_d = 0.0, acc_c = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* qr = q + (int64_t)b * ldq;
+        const float* nr = nz + (int64_t)b * ldn;
+        // target = argmax of the one-hot block (torch.max(...,1)[1]: first maximal index)
+        int tgt = 0;
+        float best = nr[zd];
+        for (int j = 1; j < nd; ++j) { const float v = nr[zd + j]; if (v > best) { best = v; tgt = j; } }
+        // log_softmax (max-shifted, like at::log_softmax)
+        float mx = qr[0];
+        for (int j = 1; j < nd; ++j) mx = fmaxf(mx, qr[j]);
+        float se = 0.f;
+        for (int j = 0; j < nd; ++j) se += expf(qr[j] - mx);
+        const float lse = logf(se);
+        acc_d += (double)(-((qr[tgt] - mx) - lse));
+        float* dr = dq + (int64_t)b * lddq;
+        for (int j = 0; j < nd; ++j) {
+            const float sm = expf((qr[j] - mx) - lse);
+            dr[j] = lambda * ((sm - (j == tgt ? 1.f : 0.f)) * inv_b);
+        }
+        for (int j = 0; j < nc; ++j) {
+            const float d = qr[nd + j] - nr[zd + nd + j];
+            acc_c += (double)(d * d);
+            dr[nd + j] = lambda * ((2.f * d) * inv_bc);
+        }
+    }
+    double v[2] = {acc_d, acc_c};
+    float outv[2];
+    for (int k = 0; k < 2; ++k) {
+        const double a = gm_wave_sum_d(v[k]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+        __syncthreads();
+        outv[k] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * (double)(k == 0 ? inv_b : inv_bc));
+    }
+    if (threadIdx.x == 0) loss_out[gm_slot_index(loss_slot)] = lambda * (outv[0] + outv[1]);
+}
+
+extern "C" int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise,
+                              gm_slot noise_slot, int64_t ldn, int B, int z_dim, int disc_dim,
+                              int cont_dim, float lambda, float* dq, int64_t lddq, float* loss_out,
+                              gm_slot loss_slot) {
+    GM_CHECK_ARG(q && noise && dq && loss_out && B > 0 && disc_dim > 0 && cont_dim > 0 && z_dim >= 0);
+    hipLaunchKernelGGL(info_q_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
+                       noise_slot, ldn, B, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
+                       loss_slot);
+    GM_LAUNCH_RET();
+}

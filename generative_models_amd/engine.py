@@ -84,14 +84,16 @@ class FlatParams:
 class _Linear:
     """Raw views of one nn.Linear inside a FlatParams (weights, bias, and their grads)."""
 
-    def __init__(self, fp, lin):
+    def __init__(self, fp, lin, m=None, v=None):
+        m = fp.m if m is None else m            # alternative Adam moments (InfoGAN's MI optimizer)
+        v = fp.v if v is None else v
         iw = [i for i, p in enumerate(fp.params) if p is lin.weight][0]
         ib = [i for i, p in enumerate(fp.params) if p is lin.bias][0]
         self.W, self.b = fp.views[iw], fp.views[ib]
         self.gW, self.gb = fp.gviews[iw], fp.gviews[ib]
         ow, ob, nw, nb = fp.offsets[iw], fp.offsets[ib], lin.weight.numel(), lin.bias.numel()
-        self.mW, self.vW = fp.m[ow:ow + nw], fp.v[ow:ow + nw]        # Adam moments (flat views)
-        self.mb, self.vb = fp.m[ob:ob + nb], fp.v[ob:ob + nb]
+        self.mW, self.vW = m[ow:ow + nw], v[ow:ow + nw]              # Adam moments (flat views)
+        self.mb, self.vb = m[ob:ob + nb], v[ob:ob + nb]
 
 
 # --------------------------------------------------------------------------------------------
@@ -111,14 +113,15 @@ class GANEngine:
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
     (ns, mm, w, ls, ra, f, fisher, wgp)."""
 
-    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp")
+    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info")
 
     def __init__(self, variant, model, data, B, device, method=None, use_graph=True,
                  world_size=1, rank=0, process_group=None):
         assert variant in self.SUPPORTED, variant
         self.variant, self.model, self.device = variant, model, device
         self.method = method
-        self.loss_key = ("f_" + method) if variant == "f" else ("w" if variant == "wgp" else variant)
+        self.loss_key = ("f_" + method) if variant == "f" else \
+            {"wgp": "w", "info": "ns"}.get(variant, variant)
         self.out_act = "relu" if variant == "wgp" else "sigmoid"
         self.B = B                         # GLOBAL batch (reference semantics)
         self.world, self.rank, self.pg = world_size, rank, process_group
@@ -169,6 +172,20 @@ class GANEngine:
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
             self.U, self.Gr, self.Gam, self.T = z(Bl, Hd), z(Bl, I), z(Bl, I), z(Bl, Hd)
             self.pen = z(Bl)
+        if variant == "info":
+            # InfoGAN (info_gan.py:78-148): auxiliary net Q and a third optimizer over G u Q that
+            # keeps its OWN Adam moments for G's parameters
+            Q = model.Q
+            self.fQ = FlatParams(Q.parameters(), device)
+            q1, q2 = list(Q.children())[:2]
+            self.Q1, self.Q2 = _Linear(self.fQ, q1), _Linear(self.fQ, q2)
+            self.mi_m, self.mi_v = torch.zeros_like(self.fG.m), torch.zeros_like(self.fG.v)
+            self.G1mi = _Linear(self.fG, g1, m=self.mi_m, v=self.mi_v)
+            self.G2mi = _Linear(self.fG, g2, m=self.mi_m, v=self.mi_v)
+            self.zd, self.nd, self.nc = model.z_dim, model.disc_dim, model.cont_dim
+            nq = self.Q2.W.shape[0]
+            self.Hq, self.Qo, self.dQo, self.dHq = z(Bl, self.Q1.W.shape[0]), z(Bl, nq), z(Bl, nq), \
+                z(Bl, self.Q1.W.shape[0])
         self.ctr = torch.zeros(1, dtype=torch.int64, device=dev)
         self.graph = None
         self._graph_key = None
@@ -224,6 +241,8 @@ class GANEngine:
         pending.append(lambda st, it: self._issue_G_pre(st, it))
         seg(pending, self.fG.grad)
         tail = [lambda st, it: self._issue_G_post(st, it)]
+        if self.variant == "info":
+            tail.append(lambda st, it: self._issue_Q(st, it))
         if self.use_graph and not self._tick_in_head():
             tail.append(lambda st, it: ops.tick(self.ctr, 1, stream=st))
         seg(tail, None)
@@ -311,8 +330,46 @@ class GANEngine:
         self._D_rest(st, it, j)
 
     def _adam_args(self, net, sched_slot):
-        return dict(sched=self.schedD if net == "D" else self.schedG, sched_slot=sched_slot,
-                    clamp=self.clip if net == "D" else 0.0)
+        sched = {"D": self.schedD, "G": self.schedG}.get(net)
+        if net == "MI":
+            sched = self.schedMI
+        return dict(sched=sched, sched_slot=sched_slot, clamp=self.clip if net == "D" else 0.0)
+
+    # ---- InfoGAN train_Q (info_gan.py:269-304) + MI_optimizer.step: runs after the generator
+    # step, i.e. after the folded tick -> every slot is addressed with post=True ---------------
+    def _issue_Q(self, st, it):
+        from . import ops_fused as of
+        Bl, R = self.Bl, self.R
+        G1, G2, Q1, Q2 = self.G1, self.G2, self.Q1, self.Q2
+        Hg, Xg = self.Hg2, self.Xg2                   # free again: the generator step is done
+        zbase = self.zQ_ring.view(-1)[self.rank * Bl * self.Z:].view(-1, self.Z)
+        z_slot = self._slot(it, 1, 0, R, self.B * self.Z, post=True)
+        s_slot = self._slot(it, 1, 0, 0, 1, post=True)
+        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=z_slot, stream=st)
+        ops.linear_fwd(Hg, G2.W, G2.b, Xg, "sigmoid", M=Bl, stream=st)
+        ops.linear_fwd(Xg, Q1.W, Q1.b, self.Hq, "relu", M=Bl, stream=st)
+        ops.linear_fwd(self.Hq, Q2.W, Q2.b, self.Qo, "id", M=Bl, stream=st)
+        of.info_q_loss(self.Qo, zbase, z_slot, Bl, self.zd, self.nd, self.nc, self.dQo, self.lossMI,
+                       s_slot, stream=st)
+        fused = self.fuse_adam and self._single()
+        if fused:
+            adam = self._adam_args("MI", s_slot)
+            dw = lambda dA, X, lin, **kw: ops.linear_bwd_dw_adam(dA, X, lin, adam, M=Bl, stream=st, **kw)
+            g1, g2 = self.G1mi, self.G2mi
+        else:
+            dw = lambda dA, X, lin, **kw: ops.linear_bwd_dw(dA, X, lin.gW, lin.gb, M=Bl, stream=st, **kw)
+            g1, g2 = G1, G2
+        # every dX reads a layer's weights before that layer's dW(+Adam) launch
+        ops.linear_bwd_dx(self.dQo, Q2.W, self.dHq, below=self.Hq, epi="relu", M=Bl, stream=st)
+        dw(self.dQo, self.Hq, Q2)
+        ops.linear_bwd_dx(self.dHq, Q1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
+        dw(self.dHq, Xg, Q1)
+        ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
+        dw(self.dXg, Hg, g2)
+        dw(self.dHg, zbase, g1, x_slot=z_slot)
+        if not fused:
+            ops.adam(self.fG.flat, self.fG.grad, self.mi_m, self.mi_v, self.schedMI, s_slot, stream=st)
+            ops.adam(self.fQ.flat, self.fQ.grad, self.fQ.m, self.fQ.v, self.schedMI, s_slot, stream=st)
 
     def _issue_D_post(self, st, it, j):
         if self._adam_in_epilogue("D"):
@@ -477,18 +534,42 @@ class GANEngine:
                          event=None)
             if self.variant == "wgp":
                 s["eps"] = pin(R * d, B)
+            if self.variant == "info":
+                s["zQ"] = pin(R, B, Z)
             self.stage.append(s)
         if self.variant == "wgp":
             self.eps_ring = torch.zeros(R * d, B, device=dev)
+        if self.variant == "info":
+            self.zQ_ring = torch.zeros(R, B, Z, device=dev)
+
+    def _draw_info_noise(self, dst):
+        """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
+        three draws are made on contiguous tensors exactly like the reference's (normal_ on a
+        strided view would consume the generator differently), then packed into dst [B, z+nd+nc]."""
+        B, zd, nd, nc = self.B, self.zd, self.nd, self.nc
+        zz = torch.randn(B, zd)
+        cat = torch.randint(0, nd, (B,), dtype=torch.long)
+        cc = torch.randn(B, nc)
+        dst[:, :zd] = zz
+        dst[:, zd:zd + nd] = 0
+        dst[torch.arange(B), zd + cat] = 1
+        dst[:, zd + nd:] = cc
 
     def _draw_D(self, s, k):
         """Draws of one critic step in reference order (appendix A.4)."""
         draw_sampler_indices(self.N, self.B, s["idx_np"][k])
+        if self.variant == "info":
+            self._draw_info_noise(s["zD"][k])
+            return
         s["zD"][k].normal_()                         # torch.randn(B, Z)   ns_gan.py:183,220
         if self.variant == "wgp":
             s["eps"][k].uniform_()                   # torch.rand(B, 1)    w_gp_gan.py:197
 
     def _draw_G(self, s, k):
+        if self.variant == "info":
+            self._draw_info_noise(s["zG"][k])        # train_G: info_gan.py:258-260
+            self._draw_info_noise(s["zQ"][k])        # train_Q: info_gan.py:283-284
+            return
         s["zG"][k].normal_()                         # ns_gan.py:208
 
     def _prefetch(self, it0, n_it, which):
@@ -511,6 +592,8 @@ class GANEngine:
             self.zG_ring[r:r + n_it].copy_(s["zG"][:n_it], non_blocking=True)
         if self.variant == "wgp":
             self.eps_ring[r * d:(r + n_it) * d].copy_(s["eps"][:n_it * d], non_blocking=True)
+        if self.variant == "info":
+            self.zQ_ring[r:r + n_it].copy_(s["zQ"][:n_it], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         s["event"] = ev
@@ -532,6 +615,11 @@ class GANEngine:
         self.schedG = torch.from_numpy(ops.adam_schedule(G_lr, n_iters + g_init)).to(dev)
         self.lossD = torch.zeros(max(1, n_iters * D_steps), device=dev)
         self.lossG = torch.zeros(n_iters + g_init, device=dev)
+        if self.variant == "info":
+            self.fQ.rebind(); self.fQ.reset_state(); self.fQ.grad.zero_()
+            self.mi_m.zero_(); self.mi_v.zero_()
+            self.schedMI = torch.from_numpy(ops.adam_schedule(G_lr, max(1, n_iters))).to(dev)
+            self.lossMI = torch.zeros(max(1, n_iters), device=dev)
         self.aux.zero_()
         self.ctr.zero_()
         R = max(1, min(CHUNK, n_iters))
@@ -578,6 +666,8 @@ class GANEngine:
 
     def run(self, n_iters, it_start=0):
         """Run iterations [it_start, it_start+n_iters) (chunked prefetch + graph replays)."""
+        if self.world > 1 and self.variant == "info":
+            raise GMError("InfoGAN's three-optimizer step is not wired for data parallelism yet")
         if self.world > 1 and self.variant in ("ra", "fisher"):
             raise GMError("RaGAN / FisherGAN losses are not a mean of per-sample terms; their "
                           "data-parallel form needs a scalar pre-all-reduce (SURVEY.md 8e) and is "
@@ -643,6 +733,9 @@ class GANEngine:
         G = [float(x) for x in lg]
         D = [float(np.mean([float(v) for v in row])) for row in ld]
         return G, D
+
+    def mi_losses(self, it0, it1):
+        return [float(x) for x in self.lossMI[it0:it1].cpu().numpy()]
 
 
 class VAEEngine:

@@ -83,3 +83,11 @@ def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_m
               adam["sched"].data_ptr() if with_adam else None,
               adam["sched_slot"] if with_adam else NO_SLOT, betas[0], betas[1], eps, 0.0,
               adam.get("clamp", 0.0) if with_adam else 0.0, g(tick))
+
+
+def info_q_loss(q, noise, noise_slot, B, z_dim, disc_dim, cont_dim, dq, loss_out, loss_slot,
+                lam=1.0, stream=None):
+    """InfoGAN train_Q loss (info_gan.py:295-302) + d loss / d q."""
+    _lib.call("gm_info_q_loss", stream or stream_ptr(), q.data_ptr(), _ld(q), noise.data_ptr(),
+              noise_slot, z_dim + disc_dim + cont_dim, B, z_dim, disc_dim, cont_dim, lam,
+              dq.data_ptr(), _ld(dq), loss_out.data_ptr(), loss_slot)

@@ -320,6 +320,8 @@ class GANTrainer:
                 it0 = (epoch - 1) * epoch_steps
                 eng.run(epoch_steps, it_start=it0)
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)     # one sync per epoch
+                if self.variant == "info":
+                    self.MIlosses.extend(eng.mi_losses(it0, it0 + epoch_steps))
                 self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
             return
         # GENERAL path: user-overridden hooks, same loop as the reference
@@ -751,6 +753,8 @@ class InfoGANModel(nn.Module):
 
 class InfoGANTrainerBase(GANTrainer):
     variant = "info"
+    _gm_stock_class = True
+    _STOCK = GANTrainer._STOCK + ("train_Q",)
 
     def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
         super().__init__(model, train_iter, val_iter, test_iter, viz)
@@ -795,6 +799,8 @@ class InfoGANTrainerBase(GANTrainer):
 
     def train(self, num_epochs, G_lr=2e-4, D_lr=2e-4, D_steps=1, quiet=False):
         """info_gan.py:130-221."""
+        if self._stock():
+            return self._train(num_epochs, G_lr, D_lr, D_steps, quiet=quiet)     # fused engine
         m = self.model
         pD, pG, pQ = list(m.D.parameters()), list(m.G.parameters()), list(m.Q.parameters())
         D_opt, G_opt, MI_opt = FlatAdam(pD, D_lr), FlatAdam(pG, G_lr), FlatAdam(pG + pQ, G_lr)

@@ -178,6 +178,13 @@ int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, const float* dS
                       const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
                       double weight_decay, float clamp, int64_t* tick);
 
+/* ---- K15: InfoGAN mutual-information loss (train_Q, info_gan.py:269-304): cross-entropy of the
+ * categorical code + mean-squared error of the continuous code, and d loss / d q.  noise rows are
+ * [z | one-hot c1 | c2] as built by compute_noise (info_gan.py:306-325). */
+int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise, gm_slot noise_slot,
+                   int64_t ldn, int B, int z_dim, int disc_dim, int cont_dim, float lambda, float* dq,
+                   int64_t lddq, float* loss_out, gm_slot loss_slot);
+
 /* ---- elementwise activation backward for the general autograd path:
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */
 int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t n, int act);
