@@ -72,6 +72,13 @@ _SIGNATURES = {
     "gm_stream_create": (c_int, [POINTER(c_void_p)]),
     "gm_stream_destroy": (c_int, [_P]),
     "gm_stream_wait_event": (c_int, [_P, _P]),
+    "gm_l1_rows": (c_int, [_P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, _P, c_int64, _P]),
+    "gm_began_dloss": (c_int, [_P, _P, c_int, _P, _P, Slot]),
+    "gm_began_update": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int64, _P]),
+    "gm_adam_scaled": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, ctypes.c_double, ctypes.c_double,
+                               ctypes.c_double, ctypes.c_double, c_float, _P]),
+    "gm_linear_bwd_dx_add": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
+                                     c_int, c_int, _P, c_int64, c_float]),
     "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,
                                _P, c_int64, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),

@@ -508,3 +508,107 @@ extern "C" int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const f
                        loss_slot);
     GM_LAUNCH_RET();
 }
+
+// ------------------------------------------------------------------------------------------
+// K16 BEGAN (be_gan.py:212-258, 189-195).  The critic is an autoencoder; losses are per-row L1
+// reconstruction errors.  Device-resident state (float unless noted), so that the proportional
+// controller and the two ReduceLROnPlateau schedulers need no host sync:
+//   st[0]=K  st[1]=DX  st[2]=DG  st[3]=convergence  st[4]=scaleD  st[5]=scaleG
+//   dst (double): [0]=best [1]=lrD [2]=lrG [3]=lrD0 [4]=lrG0 ; ist (int64): [0]=num_bad
+// ------------------------------------------------------------------------------------------
+// rowsum[r] = sum_i |Y[r,i] - X[r,i]| ;  dY[r,i] = coef_r * sign(Y - X), coef_r = 1/B for the first B
+// rows (or all rows when K is null), -K/B for the rest (d(DX - K*DG)/dY, be_gan.py:225-236).
+__global__ __launch_bounds__(256) void l1_rows_kernel(const float* __restrict__ Y, int64_t ldy,
+                                                     const float* __restrict__ X, int64_t ldx,
+                                                     int R, int I, int B, const float* __restrict__ K,
+                                                     float* __restrict__ dY, int64_t lddy,
+                                                     float* __restrict__ rowsum) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const float coef = (K != nullptr && r >= B) ? (-K[0]) / (float)B : 1.0f / (float)B;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        const float d = Y[(int64_t)r * ldy + i] - X[(int64_t)r * ldx + i];
+        acc += fabsf(d);
+        dY[(int64_t)r * lddy + i] = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
+    }
+    acc = gm_wave_sum(acc);
+    if (lane == 0) rowsum[r] = acc;
+}
+
+extern "C" int gm_l1_rows(void* stream, const float* Y, int64_t ldy, const float* X, int64_t ldx,
+                          int R, int I, int B, const float* K_dev, float* dY, int64_t lddy,
+                          float* rowsum) {
+    GM_CHECK_ARG(Y && X && dY && rowsum && R > 0 && I > 0 && B > 0);
+    hipLaunchKernelGGL(l1_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, Y, ldy, X,
+                       ldx, R, I, B, K_dev, dY, lddy, rowsum);
+    GM_LAUNCH_RET();
+}
+
+// DX = mean(rows[0:B]), DG = mean(rows[B:2B]), D_loss = DX - K*DG  (be_gan.py:225-236)
+__global__ __launch_bounds__(256) void began_dloss_kernel(const float* __restrict__ rows, int B,
+                                                         float* __restrict__ st,
+                                                         float* __restrict__ loss_out,
+                                                         gm_slot loss_slot) {
+    __shared__ double sh[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) { a += (double)rows[i]; b += (double)rows[B + i]; }
+    double v[2] = {a, b};
+    float m[2];
+    for (int k = 0; k < 2; ++k) {
+        const double w = gm_wave_sum_d(v[k]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+        __syncthreads();
+        m[k] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)B);
+    }
+    if (threadIdx.x == 0) {
+        st[1] = m[0];
+        st[2] = m[1];
+        loss_out[gm_slot_index(loss_slot)] = m[0] - (st[0] * m[1]);
+    }
+}
+
+extern "C" int gm_began_dloss(void* stream, const float* rows, int B, float* state, float* loss_out,
+                              gm_slot loss_slot) {
+    GM_CHECK_ARG(rows && state && loss_out && B > 0);
+    hipLaunchKernelGGL(began_dloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, B, state,
+                       loss_out, loss_slot);
+    GM_LAUNCH_RET();
+}
+
+// End of a BEGAN iteration (be_gan.py:189-195): convergence measure, K <- clip(K + lambda*(gamma*DX
+// - DG), 0, 1), both ReduceLROnPlateau(mode=min, factor=.5, threshold=.01 rel, patience) steps
+// (torch/optim/lr_scheduler.py), learning-rate scales for the Adam kernels, and the graph tick.
+__global__ void began_update_kernel(float* st, double* dst, int64_t* ist, float gamma, float lambda,
+                                    int64_t patience, int64_t* tick) {
+    const float DX = st[1], DG = st[2], K = st[0];
+    const float diff = gamma * DX - DG;
+    const float conv = DX + fabsf(diff);
+    st[3] = conv;
+    const float ku = K + lambda * diff;
+    st[0] = fminf(fmaxf(0.f, ku), 1.f);
+    const double cur = (double)conv;
+    if (cur < dst[0] * (1.0 - 0.01)) { dst[0] = cur; ist[0] = 0; }
+    else ist[0] += 1;
+    if (ist[0] > patience) {
+        for (int k = 1; k <= 2; ++k) {
+            const double old_lr = dst[k];
+            const double new_lr = fmax(old_lr * 0.5, 0.0);
+            if (old_lr - new_lr > 1e-8) dst[k] = new_lr;
+        }
+        ist[0] = 0;
+    }
+    st[4] = (float)(dst[1] / dst[3]);
+    st[5] = (float)(dst[2] / dst[4]);
+    if (tick) *tick += 1;
+}
+
+extern "C" int gm_began_update(void* stream, float* state, double* dstate, int64_t* istate,
+                               float gamma, float lambda, int64_t patience, int64_t* tick) {
+    GM_CHECK_ARG(state && dstate && istate);
+    hipLaunchKernelGGL(began_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, dstate,
+                       istate, gamma, lambda, patience, tick);
+    GM_LAUNCH_RET();
+}

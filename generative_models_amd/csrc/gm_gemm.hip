@@ -67,6 +67,9 @@ struct GemmP {
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
+    const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
+    int64_t ldadd;
+    float add_scale;
 };
 
 // Operand loads are BRANCH-FREE: out-of-range rows / k are clamped to a valid address and the
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
         else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
         p.C[(int64_t)m * p.ldc + n] = v;
     } else if (MODE == MODE_DX) {
+        if (p.add) v += p.add_scale * p.add[(int64_t)m * p.ldadd + n];
         if (p.epi == GM_ACT_RELU) {
             v = (p.aux[(int64_t)m * p.ldaux + n] > 0.f) ? v : 0.f;
         } else if (p.epi == GM_ACT_SIGMOID) {
@@ -381,15 +385,34 @@ extern "C" int gm_linear_fwd(void* stream, const float* X, int64_t ldx, gm_slot 
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);
 }
 
+static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
+                   const float* below, int64_t ld_below, int M, int K, int N, int epi,
+                   const float* add, int64_t ldadd, float add_scale);
+
 extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, const float* W,
                                 float* dX, int64_t ldx, const float* below, int64_t ld_below,
                                 int M, int K, int N, int epi) {
+    return dx_impl(stream, dA, lda, W, dX, ldx, below, ld_below, M, K, N, epi, nullptr, 0, 0.f);
+}
+
+extern "C" int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, const float* W,
+                                    float* dX, int64_t ldx, const float* below, int64_t ld_below,
+                                    int M, int K, int N, int epi, const float* add, int64_t ldadd,
+                                    float add_scale) {
+    GM_CHECK_ARG(add && ldadd >= K);
+    return dx_impl(stream, dA, lda, W, dX, ldx, below, ld_below, M, K, N, epi, add, ldadd, add_scale);
+}
+
+static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
+                   const float* below, int64_t ld_below, int M, int K, int N, int epi,
+                   const float* add, int64_t ldadd, float add_scale) {
     GM_CHECK_ARG(dA && W && dX && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GM_CHECK_ARG(epi == GM_ACT_ID || (below && ld_below >= K));
     GemmP p{};
     // C[M, K_layer] = sum_{n} dA[m,n] * W[n,k]  => GEMM dims (M, N=K_layer, K=N_layer)
     p.A = dA; p.B = W; p.C = dX; p.M = M; p.N = K; p.K = N;
     p.lda = lda; p.ldb = K; p.ldc = ldx; p.aux = below; p.ldaux = ld_below; p.epi = epi;
+    p.add = add; p.ldadd = ldadd; p.add_scale = add_scale;
     p.a_slot = no_slot(); p.b_slot = no_slot();
     const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0);
     const bool xvec = aligned16(W) && (K % 4 == 0);

@@ -228,9 +228,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
                                                   int64_t n, const float* __restrict__ sched,
                                                   gm_slot sched_slot, float one_minus_b1, float b2,
                                                   float one_minus_b2, float eps, float wd,
-                                                  float clamp) {
+                                                  float clamp, const float* __restrict__ lr_scale) {
     const int64_t si = gm_slot_index(sched_slot);
-    const float step_size = sched[2 * si], bc2_sqrt = sched[2 * si + 1];
+    // lr_scale (BEGAN's ReduceLROnPlateau): a power of two, so scaling lr/bc1 is exact
+    const float step_size = sched[2 * si] * (lr_scale ? lr_scale[0] : 1.0f), bc2_sqrt = sched[2 * si + 1];
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
@@ -252,9 +253,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
         upd(p[i], g[i], m[i], v[i]);
 }
 
+static int adam_impl(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                     const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
+                     double weight_decay, float clamp, const float* lr_scale);
+
 extern "C" int gm_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
                        const float* sched, gm_slot sched_slot, double beta1, double beta2,
                        double eps, double weight_decay, float clamp) {
+    return adam_impl(stream, p, g, m, v, n, sched, sched_slot, beta1, beta2, eps, weight_decay, clamp,
+                     nullptr);
+}
+
+extern "C" int gm_adam_scaled(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                              const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                              double eps, double weight_decay, float clamp, const float* lr_scale) {
+    GM_CHECK_ARG(lr_scale);
+    return adam_impl(stream, p, g, m, v, n, sched, sched_slot, beta1, beta2, eps, weight_decay, clamp,
+                     lr_scale);
+}
+
+static int adam_impl(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                     const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
+                     double weight_decay, float clamp, const float* lr_scale) {
     GM_CHECK_ARG(p && g && m && v && sched && n > 0);
     GM_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                    reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
@@ -265,7 +285,7 @@ extern "C" int gm_adam(void* stream, float* p, const float* g, float* m, float* 
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        sched, sched_slot, omb1, (float)beta2, omb2, (float)eps, (float)weight_decay,
-                       clamp);
+                       clamp, lr_scale);
     GM_LAUNCH_RET();
 }
 

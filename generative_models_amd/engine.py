@@ -113,7 +113,7 @@ class GANEngine:
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
     (ns, mm, w, ls, ra, f, fisher, wgp)."""
 
-    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info")
+    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info", "be")
 
     def __init__(self, variant, model, data, B, device, method=None, use_graph=True,
                  world_size=1, rank=0, process_group=None):
@@ -139,7 +139,7 @@ class GANEngine:
         self.Z = self.G1.W.shape[1]
         self.H = self.G1.W.shape[0]
         self.Hd_dim = self.D1.W.shape[0]
-        assert self.D2.W.shape[0] == 1, "score-based critics only"
+        assert self.D2.W.shape[0] == 1 or variant == "be", "score-based critics (BEGAN: autoencoder)"
         self.use_graph = use_graph
         self.force_segments = False    # tests: exercise the DP launch structure on one rank
         import os
@@ -243,7 +243,9 @@ class GANEngine:
         tail = [lambda st, it: self._issue_G_post(st, it)]
         if self.variant == "info":
             tail.append(lambda st, it: self._issue_Q(st, it))
-        if self.use_graph and not self._tick_in_head():
+        if self.variant == "be":
+            tail.append(lambda st, it: self._issue_end(st, it))       # K / schedulers / tick
+        elif self.use_graph and not self._tick_in_head():
             tail.append(lambda st, it: ops.tick(self.ctr, 1, stream=st))
         seg(tail, None)
         return segs
@@ -653,7 +655,7 @@ class GANEngine:
             else:
                 self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
                 self.graph_k = None
-                if self.graph_iters > 1 and self._tick_in_head():
+                if self.graph_iters > 1:      # the counter advances inside every iteration
                     k = self.graph_iters          # the device counter advances inside each iteration
                     self.graph_k = ops.Graph().capture(
                         lambda st: [self._issue_iteration(st, 0) for _ in range(k)])
@@ -919,3 +921,86 @@ class VAEEngine:
             self.vrecon = torch.zeros(n, device=self.device)
             self.vkl = torch.zeros(n, device=self.device)
             self.graphs = {k: g for k, g in self.graphs.items() if k[1]}   # drop eval graphs
+
+
+class BEGANEngine(GANEngine):
+    """be_gan.py:109-258 as a hipGraph: autoencoder critic (784->400->784), per-row L1 losses, the
+    proportional controller K and both ReduceLROnPlateau schedulers kept in device memory and
+    advanced by a one-thread kernel at the end of every iteration (which also carries the tick) --
+    the reference's four `.item()` syncs per step disappear."""
+
+    def __init__(self, model, data, B, device, use_graph=True, world_size=1, rank=0,
+                 process_group=None):
+        super().__init__("be", model, data, B, device, use_graph=use_graph, world_size=world_size,
+                         rank=rank, process_group=process_group)
+        Bl, I = self.Bl, self.I
+        z = lambda *s, **k: torch.zeros(*s, device=device, **k)
+        self.Yd, self.dY, self.rows = z(2 * Bl, I), z(2 * Bl, I), z(2 * Bl)
+        self.st, self.dst, self.ist = z(8), z(8, dtype=torch.float64), z(2, dtype=torch.int64)
+
+    # fusions that do not apply here
+    def _tick_in_head(self):
+        return False
+
+    def _adam_in_epilogue(self, net):
+        return False                      # Adam needs the device-side lr scale: separate launch
+
+    def configure(self, n_iters, G_lr, D_lr, D_steps, GAMMA=0.5, LAMBDA=1e-3, K=0.0, patience=0,
+                  **kw):
+        if self.world > 1:
+            raise GMError("BEGAN's K controller needs global DX/DG means; data-parallel BEGAN is "
+                          "not wired yet")
+        super().configure(n_iters, G_lr, D_lr, D_steps)
+        self.gamma, self.lam, self.patience = float(GAMMA), float(LAMBDA), int(patience)
+        self.st.zero_()
+        self.st[0] = float(K)
+        self.st[4] = 1.0
+        self.st[5] = 1.0
+        self.dst.zero_()
+        self.dst[0] = float("inf")                 # ReduceLROnPlateau.best (mode='min')
+        self.dst[1], self.dst[2], self.dst[3], self.dst[4] = D_lr, G_lr, D_lr, G_lr
+        self.ist.zero_()
+
+    def _D_rest(self, st, it, j):
+        from . import ops_fused as of
+        Bl, d = self.Bl, self.D_steps
+        D1, D2 = self.D1, self.D2
+        X2, Hd, Yd, dY, dHd = self.X2, self.Hd, self.Yd, self.dY, self.dHd
+        ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)            # encoder
+        ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=2 * Bl, stream=st)              # decoder
+        of.l1_rows(Yd, X2, 2 * Bl, Bl, self.st, dY, self.rows, stream=st)          # K = st[0]
+        of.began_dloss(self.rows, Bl, self.st, self.lossD, self._slot(it, d, j, 0, 1), stream=st)
+        ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
+        ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
+        ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
+
+    def _issue_D_post(self, st, it, j):
+        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
+                 self._slot(it, self.D_steps, j, 0, 1), lr_scale=self.st[4:5], stream=st)
+
+    def _G_critic(self, st, it):
+        from . import ops_fused as of
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        Hd, Yd, dY, dHd, Xg = self.Hd, self.Yd, self.dY, self.dHd, self.Xg2
+        ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
+        ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=Bl, stream=st)
+        of.l1_rows(Yd, Xg, Bl, Bl, None, dY, self.rows, stream=st)
+        of.sum_finalize(self.rows, Bl, self.lossG, scale=self.inv_b,
+                        out_slot=self._slot(it, 1, self.g_off, 0, 1), stream=st)
+        ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
+        # G(z) enters |D(G(z)) - G(z)| twice: through D and directly (-sign/B = -dY)
+        ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, add=dY, add_scale=-1.0,
+                          stream=st)
+
+    def _issue_G_post(self, st, it):
+        ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
+                 self._G_sched_slot(it), lr_scale=self.st[5:6], stream=st)
+
+    def _issue_end(self, st, it):
+        from . import ops_fused as of
+        of.began_update(self.st, self.dst, self.ist, self.gamma, self.lam, self.patience,
+                        self.ctr if self.use_graph else None, stream=st)
+
+    def K_value(self):
+        return float(self.st[0].item())

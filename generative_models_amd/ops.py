@@ -42,10 +42,17 @@ def linear_fwd(x, W, b, y, act, M=None, x_slot=NO_SLOT, stream=None):
     return y
 
 
-def linear_bwd_dx(dA, W, dX, below=None, epi="id", M=None, stream=None):
-    """dX[M,K] = dA[M,N] @ W[N,K] (* act'(below))."""
+def linear_bwd_dx(dA, W, dX, below=None, epi="id", M=None, add=None, add_scale=1.0, stream=None):
+    """dX[M,K] = (dA[M,N] @ W[N,K] + add_scale*add) (* act'(below))."""
     N, K = W.shape
     M = dA.shape[0] if M is None else M
+    if add is not None:
+        _lib.call("gm_linear_bwd_dx_add", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+                  W.data_ptr(), _chk(dX, "dX").data_ptr(), _ld(dX),
+                  below.data_ptr() if below is not None else None,
+                  _ld(below) if below is not None else 0, M, K, N,
+                  ACT[epi] if not isinstance(epi, int) else epi, add.data_ptr(), _ld(add), add_scale)
+        return dX
     _lib.call("gm_linear_bwd_dx", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
               W.data_ptr(), _chk(dX, "dX").data_ptr(), _ld(dX),
               below.data_ptr() if below is not None else None,
@@ -102,8 +109,14 @@ def gan_loss(variant, gen_mode, sx, sg, B, out_act, loss_out, dax, dag, hyper=()
 
 
 def adam(p, g, m, v, sched, sched_slot=NO_SLOT, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-         clamp=0.0, stream=None):
-    """Flat Adam step, torch _single_tensor_adam order."""
+         clamp=0.0, lr_scale=None, stream=None):
+    """Flat Adam step, torch _single_tensor_adam order.  lr_scale: device float
+    multiplying the learning rate (BEGAN's plateau schedulers)."""
+    if lr_scale is not None:
+        _lib.call("gm_adam_scaled", stream or stream_ptr(), p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                  v.data_ptr(), p.numel(), sched.data_ptr(), sched_slot, betas[0], betas[1], eps,
+                  weight_decay, clamp, lr_scale.data_ptr())
+        return
     _lib.call("gm_adam", stream or stream_ptr(), p.data_ptr(), g.data_ptr(), m.data_ptr(),
               v.data_ptr(), p.numel(), sched.data_ptr(), sched_slot, betas[0], betas[1], eps,
               weight_decay, clamp)

@@ -651,6 +651,24 @@ class BEGANModel(nn.Module):
 
 class BEGANTrainerBase(GANTrainer):
     variant = "be"
+    _gm_stock_class = True
+
+    def _get_engine(self):
+        from .engine import BEGANEngine
+        it = self.train_iter
+        key = (id(it.dataset), it.batch_size)
+        if self._engine is None or self._engine_key != key:
+            if not torch.cuda.is_available():
+                raise GMError("no MI355X visible: the fused step engine has no CPU fallback")
+            from . import dp
+            world, rank, group = dp.current()
+            dev = next(self.model.parameters()).device
+            imgs = it.dataset.tensors[0]
+            data = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
+            self._engine = BEGANEngine(self.model, data, it.batch_size, dev, use_graph=self.use_graph,
+                                       world_size=world, rank=rank, process_group=group)
+            self._engine_key = key
+        return self._engine
 
     def train_D(self, images, K):
         """be_gan.py:212-238."""
@@ -669,6 +687,20 @@ class BEGANTrainerBase(GANTrainer):
     def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=1, GAMMA=0.50, LAMBDA=1e-3, K=0.00,
               quiet=False):
         """be_gan.py:109-210."""
+        if self._stock():
+            eng = self._get_engine()
+            eng.use_graph = self.use_graph
+            epoch_steps = int(np.ceil(len(self.train_iter) / D_steps))
+            eng.configure(num_epochs * epoch_steps, G_lr, D_lr, D_steps, GAMMA=GAMMA, LAMBDA=LAMBDA,
+                          K=K, patience=5 * len(self.train_iter))
+            for epoch in range(1, num_epochs + 1):
+                self.model.train()
+                it0 = (epoch - 1) * epoch_steps
+                eng.run(epoch_steps, it_start=it0)
+                G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)
+                self.K = eng.K_value()
+                self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+            return
         from torch.optim.lr_scheduler import ReduceLROnPlateau
         m = self.model
         G_opt, D_opt = FlatAdam(m.G.parameters(), G_lr), FlatAdam(m.D.parameters(), D_lr)

@@ -178,6 +178,28 @@ int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, const float* dS
                       const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
                       double weight_decay, float clamp, int64_t* tick);
 
+/* ---- K16: BEGAN (be_gan.py:189-195, 212-258).  l1_rows: per-row L1 reconstruction error and its
+ * gradient (coefficient 1/B for the first B rows, -K/B for the rest when K_dev is given);
+ * began_dloss: DX, DG, D_loss = DX - K*DG from the row sums; began_update: convergence measure,
+ * proportional control of K, the two ReduceLROnPlateau steps and the graph tick -- all on device
+ * state (layout documented in csrc/gm_fused.hip), so the algorithm's per-step .item() syncs vanish. */
+int gm_l1_rows(void* stream, const float* Y, int64_t ldy, const float* X, int64_t ldx, int R, int I,
+               int B, const float* K_dev, float* dY, int64_t lddy, float* rowsum);
+int gm_began_dloss(void* stream, const float* rows, int B, float* state, float* loss_out,
+                   gm_slot loss_slot);
+int gm_began_update(void* stream, float* state, double* dstate, int64_t* istate, float gamma,
+                    float lambda, int64_t patience, int64_t* tick);
+/* gm_adam with a device-resident learning-rate scale (a power of two: exact). */
+int gm_adam_scaled(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                   const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
+                   double weight_decay, float clamp, const float* lr_scale);
+/* gm_linear_bwd_dx with an additive term before the activation gradient:
+ * dX = (dA*W + add_scale*add) * act'(below)   (BEGAN's generator sees G(z) both through D and
+ * directly in |D(G(z)) - G(z)|, be_gan.py:256). */
+int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
+                         int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
+                         int epi, const float* add, int64_t ldadd, float add_scale);
+
 /* ---- K15: InfoGAN mutual-information loss (train_Q, info_gan.py:269-304): cross-entropy of the
  * categorical code + mean-squared error of the continuous code, and d loss / d q.  noise rows are
  * [z | one-hot c1 | c2] as built by compute_noise (info_gan.py:306-325). */

@@ -120,6 +120,10 @@ def test_engine_vs_oracle(variant, kw, cfg):
         err = (psd[k].cpu() - osd[k]).abs().max().item()
         assert err <= ptol, (k, err)
     assert p_tr.num_epochs == kw["num_epochs"]
+    if variant != "dra":          # everything but DRAGAN runs on the fused hipGraph engine
+        assert p_tr._engine is not None and p_tr._stock(), "fast path was not taken"
+    if variant == "be":
+        assert abs(p_tr.K - o_tr.K) <= 1e-6
     if variant == "info":
         lclose(p_tr.MIlosses, o_tr.MIlosses, "info MIlosses")
 
