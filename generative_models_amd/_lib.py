@@ -79,6 +79,13 @@ _SIGNATURES = {
                                ctypes.c_double, ctypes.c_double, c_float, _P]),
     "gm_linear_bwd_dx_add": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                      c_int, c_int, _P, c_int64, c_float]),
+    "gm_std_all": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "gm_dragan_xhat": (c_int, [_P, _P, c_int64, _P, Slot, _P, Slot, _P, c_float, _P, c_int64, c_int,
+                               c_int]),
+    "gm_dragan_rows": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, _P, c_float, c_float, c_float,
+                               c_int, c_int]),
+    "gm_dragan_head_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int,
+                                   c_int]),
     "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,
                                _P, c_int64, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
         float lx, lg, dx, dg;
         sample_terms(p.variant, D, is_x ? s : 0.5f, is_x ? 0.5f : s, p.inv_b, p.hyper, lx, lg, dx, dg);
         float l = is_x ? lx : lg;
-        if (is_x && p.pen && p.variant == GM_LOSS_W) l += p.hyper[0] * p.pen[r];
+        if (is_x && p.pen) l += p.hyper[7] * p.pen[r];     // gradient penalty rows (WGAN-GP, DRAGAN)
         p.S[r] = s;
         p.dS[r] = act_grad(is_x ? dx : dg, s, p.out_act);
         p.rowloss[r] = l;
@@ -610,5 +610,167 @@ extern "C" int gm_began_update(void* stream, float* state, double* dstate, int64
     GM_CHECK_ARG(state && dstate && istate);
     hipLaunchKernelGGL(began_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, dstate,
                        istate, gamma, lambda, patience, tick);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// K13 DRAGAN (dra_gan.py:198-223; second backward hand-derived in SURVEY.md A.3).
+// Critic D = sigma(a2), a2 = h.w2 + b2, h = relu(a1), a1 = x_hat W1^T + b1.
+//   std   : unbiased std of ALL B*I elements of the real batch (images.data.std(), :204)
+//   x_hat : delta*x + (1-delta)*(x + C*std*U)                     (:203-205, a fresh leaf)
+//   rows  : g_b = s'_b v_b with v_b = (m1_b . w2) W1 (GEMM), n_b = ||g_b||, pen_b = (n_b-K)^2,
+//           gamma_b = lambda*inv_b*2(n_b-K) g_b/n_b,  dv_b = s'_b gamma_b,
+//           ds'_b = gamma_b . v_b,  da2_b = ds'_b * s'_b (1-2 s_b)
+//   head  : gw2 += colsum(m1 . T) + da2^T h ; gb2 += sum da2 ; da1 = (da2 w2) . m1   (T = dv W1^T)
+// ------------------------------------------------------------------------------------------
+// out[0] = unbiased std over n = R*I elements (two fp64 sums; one workgroup)
+__global__ __launch_bounds__(1024) void std_all_kernel(const float* __restrict__ X, int64_t ldx, int R,
+                                                      int I, float* __restrict__ out) {
+    __shared__ double sh[2][16];
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t n = (int64_t)R * I;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)X[(i / I) * ldx + (i % I)];
+        s1 += v; s2 += v * v;
+    }
+    s1 = gm_wave_sum_d(s1); s2 = gm_wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < 16; ++q) { a += sh[0][q]; b += sh[1][q]; }
+        const double mean = a / (double)n;
+        const double var = (b - (double)n * mean * mean) / (double)(n - 1);
+        out[0] = (float)sqrt(var > 0.0 ? var : 0.0);
+    }
+}
+
+extern "C" int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out) {
+    GM_CHECK_ARG(X && out && R > 0 && I > 0 && (int64_t)R * I > 1);
+    hipLaunchKernelGGL(std_all_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, X, ldx, R, I, out);
+    GM_LAUNCH_RET();
+}
+
+__global__ __launch_bounds__(256) void dragan_xhat_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ delta,
+                                                         gm_slot delta_slot,
+                                                         const float* __restrict__ U, gm_slot u_slot,
+                                                         const float* __restrict__ stdv, float C,
+                                                         float* __restrict__ out, int64_t ldo, int B,
+                                                         int I) {
+    const float* dl = delta + gm_slot_offset(delta_slot);
+    const float* u = U + gm_slot_offset(u_slot);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float d = dl[b], om = 1.f - d, cs = C * stdv[0];
+    for (int i = lane; i < I; i += 64) {
+        const float xv = x[(int64_t)b * ldx + i];
+        out[(int64_t)b * ldo + i] = d * xv + om * (xv + cs * u[(int64_t)b * I + i]);
+    }
+}
+
+extern "C" int gm_dragan_xhat(void* stream, const float* x, int64_t ldx, const float* delta,
+                              gm_slot delta_slot, const float* U, gm_slot u_slot, const float* std_dev,
+                              float C, float* out, int64_t ldo, int B, int I) {
+    GM_CHECK_ARG(x && delta && U && std_dev && out && B > 0 && I > 0);
+    hipLaunchKernelGGL(dragan_xhat_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       delta, delta_slot, U, u_slot, std_dev, C, out, ldo, B, I);
+    GM_LAUNCH_RET();
+}
+
+__global__ __launch_bounds__(256) void dragan_rows_kernel(const float* __restrict__ s,
+                                                         const float* __restrict__ V, int64_t ldv,
+                                                         float* __restrict__ dv, int64_t lddv,
+                                                         float* __restrict__ da2,
+                                                         float* __restrict__ pen, float lambda,
+                                                         float inv_b, float Kn, int B, int I) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float sb = s[b], sp = (1.f - sb) * sb;             // s' = sigma'(a2)
+    const float* v = V + (int64_t)b * ldv;
+    float ss = 0.f;
+    for (int i = lane; i < I; i += 64) { const float g = sp * v[i]; ss += g * g; }
+    ss = gm_wave_sum(ss);
+    const float n = sqrtf(ss);                                // ||g_b||
+    const float dn = n - Kn;
+    const float coef = (n > 0.f) ? (lambda * (inv_b * (2.f * dn))) / n : 0.f;   // gamma = coef * g
+    // ds' = sum_j gamma_j v_j = coef * s' * ||v||^2 = coef * ||g||^2 / s'
+    float dot = 0.f;
+    float* o = dv + (int64_t)b * lddv;
+    for (int i = lane; i < I; i += 64) {
+        const float g = sp * v[i];
+        const float gam = coef * g;
+        dot += gam * v[i];
+        o[i] = sp * gam;                                      // dv = s' * gamma
+    }
+    dot = gm_wave_sum(dot);
+    if (lane == 0) {
+        pen[b] = dn * dn;
+        da2[b] = dot * (sp * (1.f - 2.f * sb));               // ds' * d s'/d a2
+    }
+}
+
+extern "C" int gm_dragan_rows(void* stream, const float* s, const float* V, int64_t ldv, float* dv,
+                              int64_t lddv, float* da2, float* pen, float lambda, float inv_b,
+                              float K_norm, int B, int I) {
+    GM_CHECK_ARG(s && V && dv && da2 && pen && B > 0 && I > 0);
+    hipLaunchKernelGGL(dragan_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, V,
+                       ldv, dv, lddv, da2, pen, lambda, inv_b, K_norm, B, I);
+    GM_LAUNCH_RET();
+}
+
+__global__ __launch_bounds__(1024) void dragan_head_bwd_kernel(const float* __restrict__ H, int64_t ldh,
+                                                              const float* __restrict__ T, int64_t ldt,
+                                                              const float* __restrict__ da2,
+                                                              const float* __restrict__ w2,
+                                                              float* __restrict__ gw2,
+                                                              float* __restrict__ gb2,
+                                                              float* __restrict__ dA1, int64_t ldd,
+                                                              int B, int Hd) {
+    __shared__ float sh[HB_RG][HB_COLS + 1];
+    __shared__ double shd[16];
+    const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
+    const int c = blockIdx.x * HB_COLS + cl;
+    float acc = 0.f;
+    if (c < Hd) {
+        const float w = w2[c];
+        for (int r = rg; r < B; r += HB_RG) {
+            const float h = H[(int64_t)r * ldh + c];
+            const float d = da2[r];
+            const bool on = h > 0.f;
+            acc += (on ? T[(int64_t)r * ldt + c] : 0.f) + d * h;
+            dA1[(int64_t)r * ldd + c] = on ? d * w : 0.f;
+        }
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < Hd) {
+        float v = 0.f;
+        for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
+        gw2[c] += v;
+    }
+    if (blockIdx.x == 0) {
+        double sd = 0.0;
+        for (int r = threadIdx.x; r < B; r += 1024) sd += (double)da2[r];
+        sd = gm_wave_sum_d(sd);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = sd;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < 16; ++q) tot += shd[q];
+            gb2[0] += (float)tot;
+        }
+    }
+}
+
+extern "C" int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, const float* T,
+                                  int64_t ldt, const float* da2, const float* w2, float* gw2,
+                                  float* gb2, float* dA1, int64_t ldd, int B, int Hd) {
+    GM_CHECK_ARG(H && T && da2 && w2 && gw2 && gb2 && dA1 && B > 0 && Hd > 0);
+    hipLaunchKernelGGL(dragan_head_bwd_kernel, dim3((Hd + HB_COLS - 1) / HB_COLS), dim3(1024), 0,
+                       (hipStream_t)stream, H, ldh, T, ldt, da2, w2, gw2, gb2, dA1, ldd, B, Hd);
     GM_LAUNCH_RET();
 }

@@ -113,7 +113,7 @@ class GANEngine:
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
     (ns, mm, w, ls, ra, f, fisher, wgp)."""
 
-    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info", "be")
+    SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info", "be", "dra")
 
     def __init__(self, variant, model, data, B, device, method=None, use_graph=True,
                  world_size=1, rank=0, process_group=None):
@@ -121,7 +121,7 @@ class GANEngine:
         self.variant, self.model, self.device = variant, model, device
         self.method = method
         self.loss_key = ("f_" + method) if variant == "f" else \
-            {"wgp": "w", "info": "ns"}.get(variant, variant)
+            {"wgp": "w", "info": "ns", "dra": "ns"}.get(variant, variant)
         self.out_act = "relu" if variant == "wgp" else "sigmoid"
         self.B = B                         # GLOBAL batch (reference semantics)
         self.world, self.rank, self.pg = world_size, rank, process_group
@@ -168,10 +168,12 @@ class GANEngine:
         self.dHg = z(Bl, H)
         self.rowloss = z(2 * Bl)
         self.aux = z(8)                    # Fisher lambda + moments
-        if variant == "wgp":
+        if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
             self.U, self.Gr, self.Gam, self.T = z(Bl, Hd), z(Bl, I), z(Bl, I), z(Bl, Hd)
             self.pen = z(Bl)
+        if variant == "dra":
+            self.da2, self.dA1, self.stdv = z(Bl), z(Bl, Hd), z(1)
         if variant == "info":
             # InfoGAN (info_gan.py:78-148): auxiliary net Q and a third optimizer over G u Q that
             # keeps its OWN Adam moments for G's parameters
@@ -205,7 +207,7 @@ class GANEngine:
         if not (self.fuse_adam and self._single()) or self.dag:
             return False
         if net == "D":
-            return self.fuse_head and self.variant not in ("ra", "fisher", "wgp")
+            return self.fuse_head and self.variant not in ("ra", "fisher", "wgp", "dra")
         return True
 
     def _slot(self, it, mul, add, ring, stride, post=False):
@@ -303,7 +305,10 @@ class GANEngine:
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
             self._issue_gp_forward(st, it, j)
-            aux, hyper = self.pen, (self.gp_lambda,)
+            aux, hyper = self.pen, (0.0,) * 7 + (self.gp_lambda,)
+        if self.variant == "dra":
+            self._issue_dra_forward(st, it, j)
+            aux, hyper = self.pen, tuple(self.hyper) + (0.0,) * (7 - len(self.hyper)) + (self.gp_lambda,)
         if self.fuse_head and self.variant not in ("ra", "fisher"):
             from . import ops_fused as of
             of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
@@ -325,6 +330,8 @@ class GANEngine:
             ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp":
             self._issue_gp_backward(st)
+        if self.variant == "dra":
+            self._issue_dra_backward(st)
 
     def _issue_D_pre(self, st, it, j):
         self._D_gather(st, it, j)
@@ -499,6 +506,32 @@ class GANEngine:
         ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                # g = u W1
         ops_gp.gp_norm(self.Gr, self.Gam, self.pen, self.gp_lambda, self.inv_b, stream=st)
 
+    # -- DRAGAN penalty: dra_gan.py:198-223; sigmoid critic => second-order terms --
+    def _issue_dra_forward(self, st, it, j):
+        from . import ops_fused as of
+        Bl, d, R = self.Bl, self.D_steps, self.R
+        D1, D2 = self.D1, self.D2
+        x = self.X2[:Bl]
+        of.std_all(x, Bl, self.stdv, stream=st)                                   # images.data.std()
+        of.dragan_xhat(x, self.delta_ring.view(-1), self._slot(it, d, j, R * d, self.B),
+                       self.U_ring.view(-1), self._slot(it, d, j, R * d, self.B * self.I),
+                       self.stdv, self.Xh, Bl, stream=st)
+        ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
+        ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "sigmoid", M=Bl, stream=st)
+        of.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)                          # m1 . w2 (sigma > 0)
+        ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                   # v = (m1.w2) W1
+        of.dragan_rows(self.Sh, self.Gr, self.Gam, self.da2, self.pen, self.gp_lambda, self.inv_b,
+                       Bl, stream=st)                                               # Gam = dv
+
+    def _issue_dra_backward(self, st):
+        from . import ops_fused as of
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        ops.linear_bwd_dw(self.U, self.Gam, D1.gW, None, M=Bl, accumulate=True, stream=st)
+        ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)          # T = dv W1^T
+        of.dragan_head_bwd(self.Hh, self.T, self.da2, D2.W, D2.gW, D2.gb, self.dA1, Bl, stream=st)
+        ops.linear_bwd_dw(self.dA1, self.Xh, D1.gW, D1.gb, M=Bl, accumulate=True, stream=st)
+
     def _issue_gp_backward(self, st):
         from . import ops_fused as ops_gp
         Bl = self.Bl
@@ -538,11 +571,16 @@ class GANEngine:
                 s["eps"] = pin(R * d, B)
             if self.variant == "info":
                 s["zQ"] = pin(R, B, Z)
+            if self.variant == "dra":
+                s["delta"], s["U"] = pin(R * d, B), pin(R * d, B, self.I)
             self.stage.append(s)
         if self.variant == "wgp":
             self.eps_ring = torch.zeros(R * d, B, device=dev)
         if self.variant == "info":
             self.zQ_ring = torch.zeros(R, B, Z, device=dev)
+        if self.variant == "dra":
+            self.delta_ring = torch.zeros(R * d, B, device=dev)
+            self.U_ring = torch.zeros(R * d, B, self.I, device=dev)
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -566,6 +604,9 @@ class GANEngine:
         s["zD"][k].normal_()                         # torch.randn(B, Z)   ns_gan.py:183,220
         if self.variant == "wgp":
             s["eps"][k].uniform_()                   # torch.rand(B, 1)    w_gp_gan.py:197
+        if self.variant == "dra":
+            s["delta"][k].uniform_()                 # torch.rand(B, 1)    dra_gan.py:200
+            s["U"][k].uniform_()                     # torch.rand(B, 784)  dra_gan.py:205
 
     def _draw_G(self, s, k):
         if self.variant == "info":
@@ -596,6 +637,9 @@ class GANEngine:
             self.eps_ring[r * d:(r + n_it) * d].copy_(s["eps"][:n_it * d], non_blocking=True)
         if self.variant == "info":
             self.zQ_ring[r:r + n_it].copy_(s["zQ"][:n_it], non_blocking=True)
+        if self.variant == "dra":
+            self.delta_ring[r * d:(r + n_it) * d].copy_(s["delta"][:n_it * d], non_blocking=True)
+            self.U_ring[r * d:(r + n_it) * d].copy_(s["U"][:n_it * d], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         s["event"] = ev
@@ -624,7 +668,8 @@ class GANEngine:
             self.lossMI = torch.zeros(max(1, n_iters), device=dev)
         self.aux.zero_()
         self.ctr.zero_()
-        R = max(1, min(CHUNK, n_iters))
+        # DRAGAN prefetches a B x 784 uniform tensor per critic step: keep its ring small
+        R = max(1, min(16 if self.variant == "dra" else CHUNK, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
                self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen())
         self.D_steps = D_steps
@@ -668,6 +713,9 @@ class GANEngine:
 
     def run(self, n_iters, it_start=0):
         """Run iterations [it_start, it_start+n_iters) (chunked prefetch + graph replays)."""
+        if self.world > 1 and self.variant == "dra":
+            raise GMError("DRAGAN perturbs with the std of the GLOBAL batch; its data-parallel form "
+                          "needs a pre-all-reduce of (sum x, sum x^2) (SURVEY.md 8e): not wired yet")
         if self.world > 1 and self.variant == "info":
             raise GMError("InfoGAN's three-optimizer step is not wired for data parallelism yet")
         if self.world > 1 and self.variant in ("ra", "fisher"):

@@ -108,3 +108,24 @@ def began_dloss(rows, B, state, loss_out, loss_slot, stream=None):
 def began_update(state, dstate, istate, gamma, lam, patience, tick, stream=None):
     _lib.call("gm_began_update", stream or stream_ptr(), state.data_ptr(), dstate.data_ptr(),
               istate.data_ptr(), gamma, lam, patience, tick.data_ptr() if tick is not None else None)
+
+
+def std_all(X, R, out, stream=None):
+    _lib.call("gm_std_all", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out.data_ptr())
+
+
+def dragan_xhat(x, delta, delta_slot, U, u_slot, std_dev, out, B, C=1.0, stream=None):
+    _lib.call("gm_dragan_xhat", stream or stream_ptr(), x.data_ptr(), _ld(x), delta.data_ptr(),
+              delta_slot, U.data_ptr(), u_slot, std_dev.data_ptr(), C, out.data_ptr(), _ld(out), B,
+              out.shape[1])
+
+
+def dragan_rows(s, V, dv, da2, pen, lam, inv_b, B, K=1.0, stream=None):
+    _lib.call("gm_dragan_rows", stream or stream_ptr(), s.data_ptr(), V.data_ptr(), _ld(V),
+              dv.data_ptr(), _ld(dv), da2.data_ptr(), pen.data_ptr(), lam, inv_b, K, B, V.shape[1])
+
+
+def dragan_head_bwd(H, T, da2, w2, gw2, gb2, dA1, B, stream=None):
+    _lib.call("gm_dragan_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), T.data_ptr(), _ld(T),
+              da2.data_ptr(), w2.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), dA1.data_ptr(), _ld(dA1),
+              B, H.shape[1])

@@ -98,7 +98,7 @@ int gm_linear_bwd_dw_adam(void* stream, const float* dA, int64_t lda, const floa
 /* ---- K4: adversarial loss + its gradient w.r.t. the critic's PRE-activation output.
  * sx,sg: [B] post-activation scores D(x), D(G(z)) (sx NULL in generator mode).
  * out_act: activation that produced the scores (sigmoid, or relu for WGAN-GP).
- * hyper: host array of up to 8 floats (LS: a,b,c ; Fisher: rho).
+ * hyper: host array of up to 8 floats (LS: a,b,c ; Fisher: rho ; [7]: weight of the penalty rows).
  * inv_b: fp32 1/B used for every mean and its gradient (1/B_global under data parallelism).
  * loss_out[slot]: scalar loss.  dax/dag: [B] gradients (dax NULL in generator mode).
  * aux_io: device state/extra terms (Fisher: lambda, moments; WGAN-GP: penalty rows) or NULL.
@@ -199,6 +199,21 @@ int gm_adam_scaled(void* stream, float* p, const float* g, float* m, float* v, i
 int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
                          int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
                          int epi, const float* add, int64_t ldadd, float add_scale);
+
+/* ---- K13: DRAGAN penalty (dra_gan.py:198-223; derivation in SURVEY.md A.3).  std_all: unbiased std
+ * of the whole real batch; xhat: delta*x + (1-delta)*(x + C*std*U); rows: per-row norm of the input
+ * gradient s'*v (v = (m1.w2) W1 from gm_gp_u + gm_linear_bwd_dx), penalty rows, dv and da2 of the
+ * second backward; head_bwd: the w2/b2 accumulations and da1.  Penalty rows are added to the loss by
+ * gm_head_fwd_loss / gm_gan_loss with weight hyper[7]. */
+int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out);
+int gm_dragan_xhat(void* stream, const float* x, int64_t ldx, const float* delta, gm_slot delta_slot,
+                   const float* U, gm_slot u_slot, const float* std_dev, float C, float* out,
+                   int64_t ldo, int B, int I);
+int gm_dragan_rows(void* stream, const float* s, const float* V, int64_t ldv, float* dv, int64_t lddv,
+                   float* da2, float* pen, float lambda, float inv_b, float K_norm, int B, int I);
+int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, const float* T, int64_t ldt,
+                       const float* da2, const float* w2, float* gw2, float* gb2, float* dA1,
+                       int64_t ldd, int B, int Hd);
 
 /* ---- K15: InfoGAN mutual-information loss (train_Q, info_gan.py:269-304): cross-entropy of the
  * categorical code + mean-squared error of the continuous code, and d loss / d q.  noise rows are
