@@ -278,3 +278,79 @@ def test_graph_replay_with_tick():
     assert ctr.item() == 6
     close(y, yy, 1e-5, "graph y")
     close(acc, ref, 1e-5, "graph acc")
+
+
+def test_began_update_matches_python_controller_and_plateau_scheduler():
+    """gm_began_update vs be_gan.py:189-195 executed with torch's own ReduceLROnPlateau (small
+    patience so that learning-rate halvings actually happen)."""
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(0)
+    gamma, lam, patience, lrD, lrG = 0.5, 1e-3, 3, 1e-4, 2e-4
+    pD, pG = torch.zeros(1, requires_grad=True), torch.zeros(1, requires_grad=True)
+    oD, oG = torch.optim.Adam([pD], lr=lrD), torch.optim.Adam([pG], lr=lrG)
+    sD = ReduceLROnPlateau(oD, factor=0.50, threshold=0.01, patience=patience)
+    sG = ReduceLROnPlateau(oG, factor=0.50, threshold=0.01, patience=patience)
+    st = torch.zeros(8, device=DEV)
+    st[4] = 1.0; st[5] = 1.0
+    dst = torch.zeros(8, dtype=torch.float64, device=DEV)
+    dst[0] = float("inf"); dst[1] = lrD; dst[2] = lrG; dst[3] = lrD; dst[4] = lrG
+    ist = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    K = 0.0
+    for step in range(40):
+        DX = torch.tensor(30.0 - 0.4 * min(step, 8) + 0.01 * (step % 3))      # plateaus after 8 steps
+        DG = torch.tensor(12.0 + 0.3 * step)
+        convergence = (DX + torch.abs(gamma * DX - DG)).item()
+        K_update = (K + lam * (gamma * DX - DG)).item()
+        K = min(max(0, K_update), 1)
+        sD.step(convergence); sG.step(convergence)
+        st[1] = DX.item(); st[2] = DG.item()
+        of.began_update(st, dst, ist, gamma, lam, patience, ctr)
+        got = st.cpu()
+        assert abs(got[0].item() - K) <= 1e-7, (step, got[0].item(), K)
+        assert abs(got[3].item() - convergence) <= 1e-5
+        assert abs(got[4].item() * lrD - oD.param_groups[0]["lr"]) <= 1e-12, step
+        assert abs(got[5].item() * lrG - oG.param_groups[0]["lr"]) <= 1e-12, step
+    assert oD.param_groups[0]["lr"] < lrD, "the test must exercise at least one halving"
+    assert ctr.item() == 40
+
+
+def test_info_q_loss_vs_torch():
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(2)
+    B, zd, nd, nc = 48, 8, 10, 10
+    q = torch.randn(B, nd + nc, requires_grad=True)
+    noise = torch.zeros(B, zd + nd + nc)
+    noise[:, :zd] = torch.randn(B, zd)
+    cat = torch.randint(0, nd, (B,))
+    noise[torch.arange(B), zd + cat] = 1
+    noise[:, zd + nd:] = torch.randn(B, nc)
+    loss = F.cross_entropy(q[:, :nd], torch.max(noise[:, zd:zd + nd], 1)[1]) + \
+        F.mse_loss(q[:, nd:], noise[:, zd + nd:])
+    loss.backward()
+    dq = torch.empty(B, nd + nc, device=DEV)
+    out = torch.zeros(2, device=DEV)
+    of.info_q_loss(q.detach().to(DEV), noise.to(DEV), ops.NO_SLOT, B, zd, nd, nc, dq, out,
+                   ops.slot(0, 0, 1, 0, 1))
+    close(out[1], loss.detach(), 2e-6, "MI loss", atol=1e-6)
+    close(dq, q.grad, 1e-5, "d MI / dq")
+
+
+def test_l1_rows_and_dx_add():
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(4)
+    B, I, H = 40, 64, 48
+    Y, X = torch.randn(2 * B, I), torch.randn(2 * B, I)
+    Kv = torch.tensor([0.37], device=DEV)
+    dY, rows = torch.empty(2 * B, I, device=DEV), torch.empty(2 * B, device=DEV)
+    of.l1_rows(Y.to(DEV), X.to(DEV), 2 * B, B, Kv, dY, rows)
+    close(rows, (Y - X).abs().sum(1), 1e-6, "row sums")
+    coef = torch.cat([torch.full((B, 1), 1.0 / B), torch.full((B, 1), -0.37 / B)])
+    close(dY, torch.sign(Y - X) * coef, 1e-6, "L1 grad")
+    dA, W = torch.randn(B, H), torch.randn(H, I) / 7
+    below, add = torch.rand(B, I), torch.randn(B, I)
+    out = torch.empty(B, I, device=DEV)
+    ops.linear_bwd_dx(dA.to(DEV), W.to(DEV), out, below=below.to(DEV), epi="sigmoid",
+                      add=add.to(DEV), add_scale=-1.0)
+    close(out, (dA @ W - add) * below * (1 - below), 1e-5, "dx with addend")
