@@ -37,7 +37,12 @@ def run(name, module, model_cls, trainer_cls, batch, train_kw, epochs=6):
     mod = importlib.import_module(module)
     ld = loaders(batch)
     torch.manual_seed(1234)
-    model = getattr(mod, model_cls)(784, 400, 20) if module != "vae" else getattr(mod, model_cls)()
+    if module == "vae":
+        model = getattr(mod, model_cls)()
+    elif module == "info_gan":
+        model = getattr(mod, model_cls)(784, 400, 20, 10, 10)
+    else:
+        model = getattr(mod, model_cls)(784, 400, 20)
     tr = getattr(mod, trainer_cls)(model, *ld)
     with contextlib.redirect_stdout(io.StringIO()):
         tr.train(1, **train_kw)                      # warm-up epoch (graph capture, clocks)
@@ -46,7 +51,7 @@ def run(name, module, model_cls, trainer_cls, batch, train_kw, epochs=6):
         tr.train(epochs, **train_kw)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    d_steps = train_kw.get("D_steps", 1)
+    d_steps = train_kw.get("D_steps", 5 if module == "w_gan" else 1)
     if module == "vae":
         images = epochs * N_TRAIN
         steps = epochs * len(ld[0])
@@ -68,6 +73,10 @@ def main():
         ("WGAN-GP bs=256 D_steps=1", "w_gp_gan", "WGPGAN", "WGPGANTrainer", 256, {"D_steps": 1}),
         ("WGAN-GP bs=256 D_steps=5", "w_gp_gan", "WGPGAN", "WGPGANTrainer", 256, {"D_steps": 5}),
         ("VAE bs=512 (train epoch + 10k-image validation pass)", "vae", "VAE", "VAETrainer", 512, {}),
+        ("DRAGAN bs=256 D_steps=1", "dra_gan", "DRAGAN", "DRAGANTrainer", 256, {"D_steps": 1}),
+        ("BEGAN bs=256", "be_gan", "BEGAN", "BEGANTrainer", 256, {}),
+        ("InfoGAN bs=256", "info_gan", "InfoGAN", "InfoGANTrainer", 256, {}),
+        ("WGAN bs=256 D_steps=5", "w_gan", "WGAN", "WGANTrainer", 256, {}),
     ]
     for c in cfgs:
         if args.only and args.only not in c[0]:
