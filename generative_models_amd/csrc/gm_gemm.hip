@@ -147,6 +147,57 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
     return v;
 }
 
+// Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
+template <int MODE, int WAVES>
+__device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
+                                                 int n0) {
+#pragma unroll
+    for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
+    const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+
+    const int m = m0 + row, n = n0 + col;
+    if (m >= p.M || n >= p.N) continue;
+    if (MODE == MODE_FWD) {
+        if (p.bias) v += p.bias[n];
+        if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
+        p.C[(int64_t)m * p.ldc + n] = v;
+    } else if (MODE == MODE_DX) {
+        if (p.add) v += p.add_scale * p.add[(int64_t)m * p.ldadd + n];
+        if (p.epi == GM_ACT_RELU) {
+            v = (p.aux[(int64_t)m * p.ldaux + n] > 0.f) ? v : 0.f;
+        } else if (p.epi == GM_ACT_SIGMOID) {
+            const float y = p.aux[(int64_t)m * p.ldaux + n];
+            v = v * (y * (1.f - y));
+        }
+        float* cp = p.C + (int64_t)m * p.ldc + n;
+        *cp = p.accumulate ? (*cp + v) : v;
+    } else {
+        const bool is_b = (n == p.n_real);
+        float* cp = is_b ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
+        if (p.accumulate) v += *cp;
+        *cp = v;
+        if (p.adam.enabled) {
+            // optimizer fused into the gradient epilogue: every gradient element is produced by
+            // exactly one thread, so Adam can run here and the separate launch disappears
+            const int64_t si = gm_slot_index(p.adam.sched_slot);
+            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
+            const int64_t o = is_b ? (int64_t)m : ((int64_t)m * p.ldc + n);
+            float* pp = (is_b ? p.adam.pb : p.adam.pW) + o;
+            float* mm = (is_b ? p.adam.mb : p.adam.mW) + o;
+            float* vv = (is_b ? p.adam.vb : p.adam.vW) + o;
+            float P = *pp, M = *mm, V = *vv;
+            adam_update(P, v, M, V, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
+                        p.adam.eps, p.adam.wd, p.adam.clamp);
+            *pp = P; *mm = M; *vv = V;
+        }
+    }
+    }
+}
+
 template <int MODE, bool VEC, int WAVES, int G, bool XV>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
@@ -253,51 +304,105 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
         red[(w * 32 + row) * 32 + r] = acc[i];
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
-    const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
-    float v = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+    reduce_and_store<MODE, WAVES>(p, red, t, m0, n0);
+}
 
-    const int m = m0 + row, n = n0 + col;
-    if (m >= p.M || n >= p.N) continue;
-    if (MODE == MODE_FWD) {
-        if (p.bias) v += p.bias[n];
-        if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
-        p.C[(int64_t)m * p.ldc + n] = v;
-    } else if (MODE == MODE_DX) {
-        if (p.add) v += p.add_scale * p.add[(int64_t)m * p.ldadd + n];
-        if (p.epi == GM_ACT_RELU) {
-            v = (p.aux[(int64_t)m * p.ldaux + n] > 0.f) ? v : 0.f;
-        } else if (p.epi == GM_ACT_SIGMOID) {
-            const float y = p.aux[(int64_t)m * p.ldaux + n];
-            v = v * (y * (1.f - y));
+// ------------------------------------------------------------------------------------------
+// Variant on v_mfma_f32_16x16x4_f32 (experiment, GM_MFMA16=1): same decomposition, but a wave's
+// operand fragments are 16 rows x 16 k per instruction -- lane (i = lane&15, g = lane>>4) loads the
+// 4 consecutive k = 16c+4g..+3 of row i, so ONE load instruction touches 16 cache lines with 64
+// useful bytes each (the 32x32x2 form touches 32 lines with 32 bytes each): half the L1 tag
+// lookups per byte.  The wave keeps four independent 16x16 accumulators (2x2 sub-tiles of the
+// 32x32 tile), so the 40-cycle dependent latency of the 16x16x4 MFMA is always covered.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_t ld, int x0, int X,
+                                             int c, int K, int lane) {
+    const int e = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
+    const int k = min(16 * c + 4 * g + e, K - 1);
+    const int x = min(x0 + 4 * q, X - 4);
+    return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
+}
+
+template <int MODE, bool VEC, int WAVES, int G, bool XV>
+__global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
+    __shared__ float red[WAVES * 32 * 32];
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+
+    const float* A = p.A + gm_slot_offset(p.a_slot);
+    const float* B = p.B + gm_slot_offset(p.b_slot);
+    const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;
+    const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
+    const int nchunks = (p.K + 15) >> 4;
+
+    auto load_a = [&](int c, int mi) -> float4 {
+        const int kb = 16 * c + 4 * g4, x0 = m0 + 16 * mi;
+        if (MODE == MODE_DW) {
+            if (XV) return raw_xc4_16(A, p.lda, x0, p.M, c, p.K, lane);
+            return raw_xc(A, p.lda, x0 + i16, p.M, kb, p.K);
         }
-        float* cp = p.C + (int64_t)m * p.ldc + n;
-        *cp = p.accumulate ? (*cp + v) : v;
-    } else {
-        const bool is_b = (n == p.n_real);
-        float* cp = is_b ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
-        if (p.accumulate) v += *cp;
-        *cp = v;
-        if (p.adam.enabled) {
-            // optimizer fused into the gradient epilogue: every gradient element is produced by
-            // exactly one thread, so Adam can run here and the separate launch disappears
-            const int64_t si = gm_slot_index(p.adam.sched_slot);
-            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
-            const int64_t o = is_b ? (int64_t)m : ((int64_t)m * p.ldc + n);
-            float* pp = (is_b ? p.adam.pb : p.adam.pW) + o;
-            float* mm = (is_b ? p.adam.mb : p.adam.mW) + o;
-            float* vv = (is_b ? p.adam.vb : p.adam.vW) + o;
-            float P = *pp, M = *mm, V = *vv;
-            adam_update(P, v, M, V, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
-                        p.adam.eps, p.adam.wd, p.adam.clamp);
-            *pp = P; *mm = M; *vv = V;
+        return raw_kc<VEC>(A, p.lda, x0 + i16, p.M, kb, p.K);
+    };
+    auto load_b = [&](int c, int ni) -> float4 {
+        const int kb = 16 * c + 4 * g4, x0 = n0 + 16 * ni;
+        if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
+        if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
+        return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
+    };
+    auto fix_a = [&](float4 v, int c, int mi) -> float4 {
+        const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + i16;
+        if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
+        return fix_kc(v, x, p.M, kb, p.K);
+    };
+    auto fix_b = [&](float4 v, int c, int ni) -> float4 {
+        const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
+        if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
+        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
+    };
+
+    f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    const int nq = (nchunks - w + WAVES - 1) / WAVES;        // chunks w, w+WAVES, ... of this wave
+    for (int q0 = 0; q0 < nq; q0 += G) {
+        float4 a0[G], a1[G], b0[G], b1[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int cc = w + min(q0 + i, nq - 1) * WAVES;
+            a0[i] = load_a(cc, 0); a1[i] = load_a(cc, 1);
+            b0[i] = load_b(cc, 0); b1[i] = load_b(cc, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = q0 + i;
+            if (q < nq) {                                    // wave-uniform
+                const int cq = w + q * WAVES;
+                const float4 fa0 = fix_a(a0[i], cq, 0), fa1 = fix_a(a1[i], cq, 1);
+                const float4 fb0 = fix_b(b0[i], cq, 0), fb1 = fix_b(b1[i], cq, 1);
+#define GM_MM4(AA, BB, CC)                                                          \
+    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.x, BB.x, CC, 0, 0, 0);             \
+    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.y, BB.y, CC, 0, 0, 0);             \
+    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.z, BB.z, CC, 0, 0, 0);             \
+    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.w, BB.w, CC, 0, 0, 0);
+                GM_MM4(fa0, fb0, acc00) GM_MM4(fa0, fb1, acc01)
+                GM_MM4(fa1, fb0, acc10) GM_MM4(fa1, fb1, acc11)
+#undef GM_MM4
+            }
         }
     }
+    // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) {
+        const int row = g4 * 4 + rgi;
+        red[(w * 32 + row) * 32 + i16] = acc00[rgi];
+        red[(w * 32 + row) * 32 + 16 + i16] = acc01[rgi];
+        red[(w * 32 + 16 + row) * 32 + i16] = acc10[rgi];
+        red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc11[rgi];
     }
+    __syncthreads();
+    reduce_and_store<MODE, WAVES>(p, red, t, m0, n0);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -355,6 +460,28 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
     static int xv_on = -1;
     if (xv_on < 0) { const char* e = getenv("GM_XVEC"); xv_on = e ? atoi(e) : 1; }
     const bool xv = xvec && xv_on && MODE != MODE_FWD;
+    static int mfma16 = -1;
+    if (mfma16 < 0) { const char* e = getenv("GM_MFMA16"); mfma16 = e ? atoi(e) : 0; }
+    if (mfma16 && p.xr == 0 && p.cpw == 0) {
+        // 16-deep chunks: batch depth from {1, 2, 4}
+        const int pw16 = ((p.K + 15) / 16 + nw - 1) / nw;
+        int g16 = 4, bc = 1 << 30;
+        for (int cand : {1, 2, 4}) {
+            const int batches = (pw16 + cand - 1) / cand;
+            const int cost = batches * cand + 1 * (batches - 1);
+            if (cost <= bc) { bc = cost; g16 = cand; }
+        }
+#define GM_L16(V, W, GG, X) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
+#define GM_L16_G(V, W, X) do { if (g16 == 1) GM_L16(V, W, 1, X); else if (g16 == 2) GM_L16(V, W, 2, X); else GM_L16(V, W, 4, X); } while (0)
+#define GM_L16_W(V, X) do { if (use8) GM_L16_G(V, 8, X); else GM_L16_G(V, 16, X); } while (0)
+        if (MODE == MODE_FWD) { if (vec) GM_L16_W(true, false); else GM_L16_W(false, false); }
+        else if (xv)          { if (vec) GM_L16_W(true, true); else GM_L16_W(false, true); }
+        else                  { if (vec) GM_L16_W(true, false); else GM_L16_W(false, false); }
+#undef GM_L16_W
+#undef GM_L16_G
+#undef GM_L16
+        GM_LAUNCH_RET();
+    }
 #define GM_LAUNCH(V, W, GG, X) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
 #define GM_LAUNCH_G(V, W, X) do { if (g == 2) GM_LAUNCH(V, W, 2, X); else if (g == 4) GM_LAUNCH(V, W, 4, X); else GM_LAUNCH(V, W, 7, X); } while (0)
 #define GM_LAUNCH_W(V, X) do { if (use8) GM_LAUNCH_G(V, 8, X); else GM_LAUNCH_G(V, 16, X); } while (0)
