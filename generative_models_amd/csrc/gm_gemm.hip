@@ -308,7 +308,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Variant on v_mfma_f32_16x16x4_f32 (experiment, GM_MFMA16=1): same decomposition, but a wave's
+// Variant on v_mfma_f32_16x16x4_f32 (default; GM_MFMA16=0 selects the 32x32x2 kernel above): same
+// decomposition, but a wave's
 // operand fragments are 16 rows x 16 k per instruction -- lane (i = lane&15, g = lane>>4) loads the
 // 4 consecutive k = 16c+4g..+3 of row i, so ONE load instruction touches 16 cache lines with 64
 // useful bytes each (the 32x32x2 form touches 32 lines with 32 bytes each): half the L1 tag
@@ -461,7 +462,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
     if (xv_on < 0) { const char* e = getenv("GM_XVEC"); xv_on = e ? atoi(e) : 1; }
     const bool xv = xvec && xv_on && MODE != MODE_FWD;
     static int mfma16 = -1;
-    if (mfma16 < 0) { const char* e = getenv("GM_MFMA16"); mfma16 = e ? atoi(e) : 0; }
+    if (mfma16 < 0) { const char* e = getenv("GM_MFMA16"); mfma16 = e ? atoi(e) : 1; }
     if (mfma16 && p.xr == 0 && p.cpw == 0) {
         // 16-deep chunks: batch depth from {1, 2, 4}
         const int pw16 = ((p.K + 15) / 16 + nw - 1) / nw;
