@@ -429,11 +429,12 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
         const int nchunks = (p.K + 7) / 8;
         p.cpw = blocked ? (nchunks + MAXW - 1) / MAXW : 0;
     }
-    // More tiles than CUs: 8-wave workgroups (107 VGPRs -> 4 waves/SIMD -> TWO workgroups per CU)
-    // run all tiles in one round instead of two; otherwise 16 waves halve the MFMA chain.
+    // GM_WAVES8=1: 8-wave workgroups (two per CU) when there are more tiles than CUs, =2: always.
+    // Measured with the 16x16x4 kernel: 16 waves everywhere is fastest (0.1059 vs 0.1086 / 0.1123 ms
+    // per iteration), so the default is 0; the 32x32x2 kernel preferred =1.
     static int w8 = -1;
-    if (w8 < 0) { const char* e = getenv("GM_WAVES8"); w8 = e ? atoi(e) : 1; }
-    const bool use8 = w8 && (tm * tn > 256) && p.cpw == 0;
+    if (w8 < 0) { const char* e = getenv("GM_WAVES8"); w8 = e ? atoi(e) : 0; }
+    const bool use8 = (w8 == 2 || (w8 && (tm * tn > 256))) && p.cpw == 0;   // GM_WAVES8=2: always
     if (xcd_mode() && tm * tn >= 16) {
         // pick the XCD grid xr x xc (xr*xc == 8) minimising per-XCD operand rows tm/xr + tn/xc
         int best = 1 << 30, bxr = 8;
