@@ -53,27 +53,27 @@ def gemm_shapes(B, fused_head=True, batch_gen=True):
 
 
 def gemm_variant(kind, M, K, N):
-    """Name of the gemm_kernel instantiation csrc/gm_gemm.hip launches for this layer shape
-    (mirrors launch<MODE>(): 8 waves when the grid has more than 256 tiles, batch depth G from the
-    chunks per wave, 16-byte paths by alignment) -- the name rocprofv3 reports."""
+    """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
+    default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, batch
+    depth from the 16-deep chunks per wave, 16-byte paths by alignment) -- the name rocprofv3
+    reports."""
     if kind == "fwd":
-        mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
+        mode, Kr, vec, xv = 0, K, K % 4 == 0, False
     elif kind == "dx":
-        mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
+        mode, Kr, vec, xv = 1, N, N % 4 == 0, K % 4 == 0
     else:
-        mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
+        mode, Kr, vec = 2, M, False
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
-    tiles = -(-Mg // 32) * -(-Ng // 32)
-    nw = 8 if tiles > 256 else 16
-    per_wave = -(--(-Kr // 8) // nw)
-    g, best = 7, 1 << 30
-    for cand in (2, 4, 7):
+    nw = 16
+    per_wave = -(--(-Kr // 16) // nw)
+    g, best = 4, 1 << 30
+    for cand in (1, 2, 4):
         batches = -(-per_wave // cand)
-        cost = batches * cand + 2 * (batches - 1)
+        cost = batches * cand + (batches - 1)
         if cost <= best:
             best, g = cost, cand
     b = lambda v: "true" if v else "false"
-    return "gemm_kernel<%d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv))
+    return "gemm16_kernel<%d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv))
 
 
 def clock_probe():
