@@ -359,6 +359,9 @@ def test_full_size_engine_vs_oracle(variant, kw):
     if variant == "info":
         lclose(tr.MIlosses, o.MIlosses, "info full-size MIlosses")
     assert torch.equal(o_rng, torch.get_rng_state())
-    ptol = 1.5e-4 if variant == "be" else 2e-5
+    # Parameters: weights whose gradient is O(eps_adam = 1e-8) (hidden units that fire for a handful
+    # of rows) turn fp32 summation-order noise into a fraction of an Adam step (lr = 1e-4..2e-4),
+    # so the bound is one step for the maximum and 1e-6 for the mean deviation.
     for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
-        assert (a.cpu() - b).abs().max().item() <= ptol, k
+        d = (a.cpu() - b).abs()
+        assert d.max().item() <= 2e-4 and d.mean().item() <= 1e-6, (k, d.max().item(), d.mean().item())
