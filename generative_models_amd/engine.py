@@ -615,8 +615,11 @@ class GANEngine:
             return
         s["zG"][k].normal_()                         # ns_gan.py:208
 
-    def _prefetch(self, it0, n_it, which):
-        s = self.stage[which]
+    def _fill(self, s, n_it):
+        """HOST: replay the reference's draw order for n_it iterations into pinned staging `s`.
+        Runs on the prefetch thread while the main thread enqueues the previous chunk's graphs
+        (torch releases the GIL inside the RNG kernels; the draws stay strictly in order because
+        there is a single worker and chunks are submitted in order)."""
         if s["event"] is not None:
             s["event"].synchronize()                 # staging buffer free again?
         if "idx_np" not in s:
@@ -626,6 +629,11 @@ class GANEngine:
             for j in range(d):
                 self._draw_D(s, i * d + j)
             self._draw_G(s, i)
+        return s
+
+    def _upload(self, s, it0, n_it):
+        """One H2D copy per ring, stream-ordered behind the graphs that still read the old slots."""
+        d = self.D_steps
         r = it0 % self.R                 # ring slot of the chunk's first iteration (n_it <= R - r)
         self.idx_ring[r * d:(r + n_it) * d].copy_(s["idx"][:n_it * d], non_blocking=True)
         if self.z_joint:
@@ -724,11 +732,20 @@ class GANEngine:
                           "not implemented: run them on one GPU")
         self._ensure_graph()
         R = self.R
-        it, end, which = it_start, it_start + n_iters, 0
+        chunks, it, end = [], it_start, it_start + n_iters
         while it < end:
             n = min(R - (it % R), end - it)
-            self._prefetch(it, n, which)
-            which ^= 1
+            chunks.append((it, n))
+            it += n
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gm-rng-prefetch")
+        fut = self._pool.submit(self._fill, self.stage[0], chunks[0][1]) if chunks else None
+        for ci, (it, n) in enumerate(chunks):
+            s = fut.result()                          # re-raises anything the worker hit
+            self._upload(s, it, n)
+            if ci + 1 < len(chunks):                  # draw the next chunk while this one runs
+                fut = self._pool.submit(self._fill, self.stage[(ci + 1) & 1], chunks[ci + 1][1])
             if self.use_graph and self.world == 1 and not self.force_segments:
                 left = n
                 gk = getattr(self, "graph_k", None)
@@ -747,7 +764,6 @@ class GANEngine:
                 st = ops.stream_ptr()
                 for k in range(n):
                     self._issue_iteration(st, it + k)
-            it += n
 
     def g_init_steps(self, n):
         """MMGAN pre-training (mm_gan.py:121-136): process_batch draws + G step, eager."""
