@@ -109,6 +109,20 @@ def draw_sampler_indices(n, B, out):
     return seed
 
 
+_POOL = None
+
+
+def _prefetch_pool():
+    """One process-wide worker thread for the host RNG replay (its first HIP call pays a one-time
+    per-thread runtime initialisation, so engines share it; a single worker also keeps the global
+    generator's draw order strictly sequential)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gm-rng-prefetch")
+    return _POOL
+
+
 class GANEngine:
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
     (ns, mm, w, ls, ra, f, fisher, wgp)."""
@@ -737,15 +751,13 @@ class GANEngine:
             n = min(R - (it % R), end - it)
             chunks.append((it, n))
             it += n
-        if getattr(self, "_pool", None) is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gm-rng-prefetch")
-        fut = self._pool.submit(self._fill, self.stage[0], chunks[0][1]) if chunks else None
+        pool = _prefetch_pool()
+        fut = pool.submit(self._fill, self.stage[0], chunks[0][1]) if chunks else None
         for ci, (it, n) in enumerate(chunks):
             s = fut.result()                          # re-raises anything the worker hit
             self._upload(s, it, n)
             if ci + 1 < len(chunks):                  # draw the next chunk while this one runs
-                fut = self._pool.submit(self._fill, self.stage[(ci + 1) & 1], chunks[ci + 1][1])
+                fut = pool.submit(self._fill, self.stage[(ci + 1) & 1], chunks[ci + 1][1])
             if self.use_graph and self.world == 1 and not self.force_segments:
                 left = n
                 gk = getattr(self, "graph_k", None)
