@@ -326,13 +326,16 @@ __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_
     return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
 }
 
-template <int MODE, bool VEC, int WAVES, int G, bool XV>
+// MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
+// (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
+// rounds of one workgroup per CU): one round, 6 fragment loads per 32 MFMAs instead of 4 per 16.
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = blockIdx.y * (16 * MI), n0 = blockIdx.x * (16 * NI);
 
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
@@ -365,45 +368,65 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
         return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
     };
 
-    f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     const int nq = (nchunks - w + WAVES - 1) / WAVES;        // chunks w, w+WAVES, ... of this wave
     for (int q0 = 0; q0 < nq; q0 += G) {
-        float4 a0[G], a1[G], b0[G], b1[G];
+        float4 ra[G][MI], rb[G][NI];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int cc = w + min(q0 + i, nq - 1) * WAVES;
-            a0[i] = load_a(cc, 0); a1[i] = load_a(cc, 1);
-            b0[i] = load_b(cc, 0); b1[i] = load_b(cc, 1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[i][mi] = load_a(cc, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[i][ni] = load_b(cc, ni);
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int q = q0 + i;
             if (q < nq) {                                    // wave-uniform
                 const int cq = w + q * WAVES;
-                const float4 fa0 = fix_a(a0[i], cq, 0), fa1 = fix_a(a1[i], cq, 1);
-                const float4 fb0 = fix_b(b0[i], cq, 0), fb1 = fix_b(b1[i], cq, 1);
-#define GM_MM4(AA, BB, CC)                                                          \
-    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.x, BB.x, CC, 0, 0, 0);             \
-    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.y, BB.y, CC, 0, 0, 0);             \
-    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.z, BB.z, CC, 0, 0, 0);             \
-    CC = __builtin_amdgcn_mfma_f32_16x16x4f32(AA.w, BB.w, CC, 0, 0, 0);
-                GM_MM4(fa0, fb0, acc00) GM_MM4(fa0, fb1, acc01)
-                GM_MM4(fa1, fb0, acc10) GM_MM4(fa1, fb1, acc11)
-#undef GM_MM4
+                float4 fa[MI], fb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[i][mi], cq, mi);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[ni] = fix_b(rb[i][ni], cq, ni);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        f32x4 c4 = acc[mi][ni];
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].x, fb[ni].x, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].y, fb[ni].y, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].z, fb[ni].z, c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].w, fb[ni].w, c4, 0, 0, 0);
+                        acc[mi][ni] = c4;
+                    }
             }
         }
     }
-    // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
+    // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
 #pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) {
-        const int row = g4 * 4 + rgi;
-        red[(w * 32 + row) * 32 + i16] = acc00[rgi];
-        red[(w * 32 + row) * 32 + 16 + i16] = acc01[rgi];
-        red[(w * 32 + 16 + row) * 32 + i16] = acc10[rgi];
-        red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc11[rgi];
-    }
-    __syncthreads();
-    reduce_and_store<MODE, WAVES>(p, red, t, m0, n0);
+    for (int bm = 0; bm < MI / 2; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < NI / 2; ++bn) {
+            if (bm + bn > 0) __syncthreads();                // previous block fully consumed
+#pragma unroll
+            for (int rgi = 0; rgi < 4; ++rgi) {
+                const int row = g4 * 4 + rgi;
+                red[(w * 32 + row) * 32 + i16] = acc[2 * bm][2 * bn][rgi];
+                red[(w * 32 + row) * 32 + 16 + i16] = acc[2 * bm][2 * bn + 1][rgi];
+                red[(w * 32 + 16 + row) * 32 + i16] = acc[2 * bm + 1][2 * bn][rgi];
+                red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[2 * bm + 1][2 * bn + 1][rgi];
+            }
+            __syncthreads();
+            reduce_and_store<MODE, WAVES>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
+        }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -473,7 +496,17 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
             const int cost = batches * cand + 1 * (batches - 1);
             if (cost <= bc) { bc = cost; g16 = cand; }
         }
-#define GM_L16(V, W, GG, X) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
+        // more 32x32 tiles than CUs: widen the tile along the longer grid axis (one round)
+        static int wide_on = -1;
+        if (wide_on < 0) { const char* e = getenv("GM_WIDE_TILES"); wide_on = e ? atoi(e) : 1; }
+        int wide = 0;                                         // 0: 32x32, 1: 32x64, 2: 64x32
+        if (wide_on && !use8 && tm * tn > 256) wide = (tn >= tm) ? 1 : 2;
+        if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
+        if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
+#define GM_L16(V, W, GG, X) do {                                                                   \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
+        else hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 2>), grid, dim3(W * 64), 0, s, p); } while (0)
 #define GM_L16_G(V, W, X) do { if (g16 == 1) GM_L16(V, W, 1, X); else if (g16 == 2) GM_L16(V, W, 2, X); else GM_L16(V, W, 4, X); } while (0)
 #define GM_L16_W(V, X) do { if (use8) GM_L16_G(V, 8, X); else GM_L16_G(V, 16, X); } while (0)
         if (MODE == MODE_FWD) { if (vec) GM_L16_W(true, false); else GM_L16_W(false, false); }
