@@ -500,7 +500,9 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
         static int wide_on = -1;
         if (wide_on < 0) { const char* e = getenv("GM_WIDE_TILES"); wide_on = e ? atoi(e) : 1; }
         int wide = 0;                                         // 0: 32x32, 1: 32x64, 2: 64x32
-        if (wide_on && !use8 && tm * tn > 256) wide = (tn >= tm) ? 1 : 2;
+        // measured (profiles/r01_experiments.md): pays only when a wave still has >= 2 chunks of
+        // reduction work per tile (dW over 2B = 512 rows: 11.65 -> 10.37 us), loses otherwise
+        if (wide_on && !use8 && tm * tn > 256 && (p.K + 15) / 16 >= 32) wide = (tn >= tm) ? 1 : 2;
         if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
 #define GM_L16(V, W, GG, X) do {                                                                   \
