@@ -39,7 +39,7 @@ def synthetic_dataset():
     return ds
 
 
-def gemm_shapes(B, fused_head=True, batch_gen=True):
+def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True):
     """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
     critic-head kernels (default) the N=1 layer is not a GEMM launch any more; with the batched
     generator forward (default at D_steps=1) G(zD) and G(zG) are one 2B-row launch pair."""
@@ -47,7 +47,9 @@ def gemm_shapes(B, fused_head=True, batch_gen=True):
     g_head = [] if fused_head else [("fwd", B, HID, 1), ("dx", B, HID, 1)]
     gen = [("fwd", 2 * B, Z, HID), ("fwd", 2 * B, HID, IMG)] if batch_gen else \
         [("fwd", B, Z, HID), ("fwd", B, HID, IMG)] * 2
-    return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [("dw", 2 * B, IMG, HID)] +
+    # "dwh": the first critic layer's weight gradient carrying the head's backward workgroups
+    dw1 = "dwh" if (fused_head and group_head) else "dw"
+    return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [(dw1, 2 * B, IMG, HID)] +
             [("fwd", B, IMG, HID)] + g_head +
             [("dx", B, IMG, HID), ("dx", B, HID, IMG), ("dw", B, HID, IMG), ("dw", B, Z, HID)])
 
@@ -55,25 +57,35 @@ def gemm_shapes(B, fused_head=True, batch_gen=True):
 def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, batch
-    depth from the 16-deep chunks per wave, 16-byte paths by alignment) -- the name rocprofv3
-    reports."""
+    depth from the 16-deep chunks per wave, 16-byte paths by alignment, tile shape from the tile
+    count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
     if kind == "fwd":
-        mode, Kr, vec, xv = 0, K, K % 4 == 0, False
+        mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind == "dx":
-        mode, Kr, vec, xv = 1, N, N % 4 == 0, K % 4 == 0
+        mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
     else:
-        mode, Kr, vec = 2, M, False
+        mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
     nw = 16
-    per_wave = -(--(-Kr // 16) // nw)
+    chunks = -(-Kr // 16)
+    per_wave = -(-chunks // nw)
     g, best = 4, 1 << 30
     for cand in (1, 2, 4):
         batches = -(-per_wave // cand)
         cost = batches * cand + (batches - 1)
         if cost <= best:
             best, g = cost, cand
+    tm, tn = -(-Mg // 32), -(-Ng // 32)
+    mi, ni = 2, 2
+    if tm * tn > 256 and chunks >= 32:                 # wide tiles: one round of workgroups
+        mi, ni = (2, 4) if tn >= tm else (4, 2)
+        g = min(g, 2)
+    elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
+        mi, ni = 1, 2
     b = lambda v: "true" if v else "false"
-    return "gemm16_kernel<%d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv))
+    if kind == "dwh":
+        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d>" % (g, b(xv), mi, ni)
+    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d>" % (mode, b(vec), nw, g, b(xv), mi, ni)
 
 
 def clock_probe():
@@ -88,7 +100,15 @@ def clock_probe():
     return cyc / max(wall, 1) * 100.0, cyc / 4000.0
 
 
-def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True):
+def _holder(N, K, dev):
+    """Stand-in for engine._Linear: parameter / gradient / Adam-moment views of one layer."""
+    from types import SimpleNamespace
+    z = lambda *s: torch.zeros(*s, device=dev)
+    return SimpleNamespace(W=torch.randn(N, K, device=dev) / K ** 0.5, b=z(N), gW=z(N, K), gb=z(N),
+                           mW=z(N * K), vW=z(N * K), mb=z(N), vb=z(N))
+
+
+def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -96,7 +116,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True):
     dev = "cuda"
     out = {}
     st = ops.stream_ptr()
-    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen):
+    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -109,8 +129,20 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True):
             fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st)
         elif kind == "dx":
             fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
-        else:
-            fn = lambda: ops.linear_bwd_dw(dA, x, dW, db, stream=st)
+        elif kind == "dwh":
+            L1, L2 = _holder(N, K, dev), _holder(1, N, dev)
+            Hh = torch.relu(torch.randn(M, N, device=dev))
+            dS, rl, lo = torch.randn(M, device=dev) / M, torch.rand(M, device=dev), torch.zeros(1, device=dev)
+            sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+            head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
+                        inv_b=2.0 / M, B=M // 2, adam=ad)
+            fn = lambda: ops.linear_bwd_dw_adam_head(dA, x, L1, ad, head, stream=st)
+        else:                                   # as in the step: Adam in the gradient epilogue
+            L1 = _holder(N, K, dev)
+            sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+            fn = lambda: ops.linear_bwd_dw_adam(dA, x, L1, ad, stream=st)
         fn()
         torch.cuda.synchronize()
         # capture `reps` back-to-back launches into one hipGraph so that the host-side launch
@@ -246,7 +278,8 @@ def main():
     img_s = K * B_global / dt
 
     if rank == 0:
-        kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen())
+        kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
+                                   group_head=eng.group_head and eng._adam_in_epilogue("D"))
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         log('isolated kernel timing done')

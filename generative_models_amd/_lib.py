@@ -29,6 +29,18 @@ def slot(ctr=0, mul=0, add=0, ring=0, stride=0):
 
 NO_SLOT = Slot(None, 0, 0, 0, 0)
 
+
+class HeadBwdArgs(ctypes.Structure):
+    """gm_head_bwd_args (include/gm_hip.h): gm_head_bwd_fused's arguments as one block."""
+    _fields_ = [("H", c_void_p), ("ldh", c_int64), ("dS", c_void_p), ("w2", c_void_p),
+                ("b2", c_void_p), ("rowloss", c_void_p), ("dH", c_void_p), ("lddh", c_int64),
+                ("gw2", c_void_p), ("gb2", c_void_p), ("loss_out", c_void_p), ("loss_slot", Slot),
+                ("inv_b", c_float), ("gen_mode", c_int), ("B", c_int), ("Hd", c_int),
+                ("with_adam", c_int), ("mW", c_void_p), ("vW", c_void_p), ("mb", c_void_p),
+                ("vb", c_void_p), ("sched", c_void_p), ("sched_slot", Slot),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p)]
+
 _P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
 
 _SIGNATURES = {
@@ -60,12 +72,19 @@ _SIGNATURES = {
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
+    "gm_linear_bwd_dw_adam_head": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
+                                           c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
+                                           POINTER(HeadBwdArgs)]),
     "gm_head_bwd_fused": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot,
                                   c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, Slot,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, c_float, _P]),
     "gm_head_fwd_loss": (c_int, [_P, c_int, c_int, _P, c_int64, _P, _P, c_int, c_int, c_int,
-                                 POINTER(c_float), c_int, c_float, _P, _P, _P, _P]),
+                                 POINTER(c_float), c_int, c_float, _P, _P, _P, _P, _P, c_int64]),
+    "gm_head_fwd_loss_final": (c_int, [_P, c_int, c_int, _P, c_int64, _P, _P, c_int, c_int, c_int,
+                                       POINTER(c_float), c_int, c_float, _P, _P, _P, _P, _P, c_int64,
+                                       _P, Slot, _P, _P]),
     "gm_head_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot, c_float,
                             c_int, c_int, c_int]),
     "gm_clock_probe": (c_int, [_P, c_int, _P, _P]),

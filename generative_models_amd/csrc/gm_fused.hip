@@ -7,6 +7,7 @@
 // All are HBM/L2-bound elementwise or row/column reductions: coalesced float4 rows, wave64
 // shuffle reductions, LDS only to combine the 4 waves of a workgroup.
 #include "gm_common.h"
+#include "gm_head.h"
 
 // ------------------------------------------------------------------------------------------
 // K9  x_hat = eps*x + (1-eps)*G(z)            (w_gp_gan.py:197-201)
@@ -263,12 +264,13 @@ struct HeadP {
     float inv_b;
     const float* pen;                             // WGAN-GP penalty rows (x rows) or null
     float* S; float* dS; float* rowloss;
+    float* dH; int64_t lddh;                      // optional: dH[r,:] = dS_r * w2 * [h > 0] right here
+    // optional finalisation by the last workgroup to finish (generator mode: nothing else is left
+    // for head_bwd to do): loss = inv_b * sum_r l_r in a fixed order, then the per-graph tick
+    float* loss_out; gm_slot loss_slot; unsigned int* done; int64_t* tick;
 };
 
-__global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= p.R) return;
+__device__ __forceinline__ void head_row(const HeadP& p, int r, int lane) {
     const float* h = p.H + (int64_t)r * p.ldh;
     float acc = 0.f;
     for (int i = lane; i < p.Hd; i += 64) acc = fmaf(h[i], p.w2[i], acc);
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
     float s = a2;
     if (p.out_act == GM_ACT_SIGMOID) s = gm_sigmoid(a2);
     else if (p.out_act == GM_ACT_RELU) s = fmaxf(a2, 0.f);
+    float ds = 0.f;
     if (lane == 0) {
         const bool D = !p.gen_mode;
         const bool is_x = D && r < p.B;
@@ -284,16 +287,93 @@ __global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
         sample_terms(p.variant, D, is_x ? s : 0.5f, is_x ? 0.5f : s, p.inv_b, p.hyper, lx, lg, dx, dg);
         float l = is_x ? lx : lg;
         if (is_x && p.pen) l += p.hyper[7] * p.pen[r];     // gradient penalty rows (WGAN-GP, DRAGAN)
+        ds = act_grad(is_x ? dx : dg, s, p.out_act);
         p.S[r] = s;
-        p.dS[r] = act_grad(is_x ? dx : dg, s, p.out_act);
+        p.dS[r] = ds;
         p.rowloss[r] = l;
     }
+    if (p.dH) {
+        // this wave still has its row of h hot in L1: write the hidden-layer gradient now, so the
+        // backward head kernel only reads h once more for the column sums and writes nothing wide
+        ds = __shfl(ds, 0, 64);
+        float* o = p.dH + (int64_t)r * p.lddh;
+        for (int i = lane; i < p.Hd; i += 64) o[i] = (h[i] > 0.f) ? ds * p.w2[i] : 0.f;
+    }
 }
+
+// "Last workgroup done" reduction: every workgroup publishes its rows (agent-scope fence), bumps a
+// device counter, and the one that observes gridDim-1 sums ALL row terms in a fixed order -- the
+// result does not depend on which workgroup happens to be last.  It re-arms the counter for the
+// next launch and advances the iteration counter (single writer; later kernels of the same
+// iteration address their slots with add - mul).
+__device__ void head_finalize(const HeadP& p) {
+    __shared__ int is_last;
+    __shared__ double part[4];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_ACQ_REL,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double sl = 0.0;
+    for (int r = threadIdx.x; r < p.R; r += 256)
+        sl += (double)__hip_atomic_load(p.rowloss + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sl = gm_wave_sum_d(sl);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = ((part[0] + part[1]) + part[2]) + part[3];
+        p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot * (double)p.inv_b);
+        __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.tick) *p.tick += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r < p.R) head_row(p, r, lane);
+    if (p.loss_out) head_finalize(p);           // kernel-argument uniform: every thread takes it
+}
+
+static int head_fwd_impl(void* stream, int variant, int gen_mode, const float* H, int64_t ldh,
+                         const float* w2, const float* b2, int out_act, int B, int Hd,
+                         const float* hyper, int n_hyper, float inv_b, const float* pen, float* S,
+                         float* dS, float* rowloss, float* dH, int64_t lddh, float* loss_out,
+                         gm_slot loss_slot, unsigned int* done, int64_t* tick);
 
 extern "C" int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const float* H,
                                 int64_t ldh, const float* w2, const float* b2, int out_act, int B,
                                 int Hd, const float* hyper, int n_hyper, float inv_b,
-                                const float* pen, float* S, float* dS, float* rowloss) {
+                                const float* pen, float* S, float* dS, float* rowloss, float* dH,
+                                int64_t lddh) {
+    gm_slot z; z.ctr = nullptr; z.mul = 0; z.add = 0; z.ring = 0; z.stride = 0;
+    return head_fwd_impl(stream, variant, gen_mode, H, ldh, w2, b2, out_act, B, Hd, hyper, n_hyper,
+                         inv_b, pen, S, dS, rowloss, dH, lddh, nullptr, z, nullptr, nullptr);
+}
+
+// head_fwd_loss that also finalises the loss scalar (and optionally ticks the iteration counter)
+// from its last workgroup: generator mode needs no head_bwd launch at all then.
+extern "C" int gm_head_fwd_loss_final(void* stream, int variant, int gen_mode, const float* H,
+                                      int64_t ldh, const float* w2, const float* b2, int out_act,
+                                      int B, int Hd, const float* hyper, int n_hyper, float inv_b,
+                                      const float* pen, float* S, float* dS, float* rowloss,
+                                      float* dH, int64_t lddh, float* loss_out, gm_slot loss_slot,
+                                      unsigned int* done_ctr, int64_t* tick) {
+    GM_CHECK_ARG(loss_out && done_ctr);
+    return head_fwd_impl(stream, variant, gen_mode, H, ldh, w2, b2, out_act, B, Hd, hyper, n_hyper,
+                         inv_b, pen, S, dS, rowloss, dH, lddh, loss_out, loss_slot, done_ctr, tick);
+}
+
+static int head_fwd_impl(void* stream, int variant, int gen_mode, const float* H, int64_t ldh,
+                         const float* w2, const float* b2, int out_act, int B, int Hd,
+                         const float* hyper, int n_hyper, float inv_b, const float* pen, float* S,
+                         float* dS, float* rowloss, float* dH, int64_t lddh, float* loss_out,
+                         gm_slot loss_slot, unsigned int* done, int64_t* tick) {
     GM_CHECK_ARG(H && w2 && b2 && S && dS && rowloss && B > 0 && Hd > 0 && n_hyper >= 0 && n_hyper <= 8);
     GM_CHECK_ARG(variant != GM_LOSS_RA || gen_mode);
     GM_CHECK_ARG(variant != GM_LOSS_FISHER || gen_mode);
@@ -301,109 +381,33 @@ extern "C" int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const f
     p.H = H; p.ldh = ldh; p.w2 = w2; p.b2 = b2; p.variant = variant; p.gen_mode = gen_mode;
     p.out_act = out_act; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd; p.inv_b = inv_b;
     for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
-    p.pen = pen; p.S = S; p.dS = dS; p.rowloss = rowloss;
+    p.pen = pen; p.S = S; p.dS = dS; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
+    p.loss_out = loss_out; p.loss_slot = loss_slot; p.done = done; p.tick = tick;
     hipLaunchKernelGGL(head_fwd_loss_kernel, dim3((p.R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }
 
-struct HeadBwdP {
-    const float* H; int64_t ldh;
-    const float* dS; const float* w2; const float* rowloss;
-    float* dH; int64_t lddh;
-    float* gw2; float* gb2;                 // null in generator mode (D grads are not needed)
-    float* loss_out; gm_slot loss_slot;
-    float inv_b;
-    int R, B, Hd, gen_mode;
-    gm_adam_epi adam;                       // optional: Adam on (w2, b2) right here (pW=w2, pb=b2)
-    int64_t* tick;                          // optional: *tick += 1 after the loss slot is written
-};
+// HeadBwdP, head_bwd_body and head_bwd_kernel live in gm_head.h: the weight-gradient GEMM can
+// co-schedule the head workgroups in its own launch (gm_linear_bwd_dw_adam_head, gm_gemm.hip).
 
-// 16 columns x 64 row-groups per 1024-thread workgroup: 25 workgroups for Hd=400, 8 rows per thread
-// at R=512 -- enough parallelism that the 800 KB read + 800 KB write is not a serial row walk.
-constexpr int HB_COLS = 16, HB_RG = 64;
-
-__global__ __launch_bounds__(1024) void head_bwd_kernel(HeadBwdP p) {
-    __shared__ float sh[HB_RG][HB_COLS + 1];
-    __shared__ double shd[16];
-    const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
-    const int c = blockIdx.x * HB_COLS + cl;
-    float acc = 0.f;
-    if (c < p.Hd) {
-        const float w = p.w2[c];
-        for (int r = rg; r < p.R; r += HB_RG) {
-            const float h = p.H[(int64_t)r * p.ldh + c];
-            const float d = p.dS[r];
-            p.dH[(int64_t)r * p.lddh + c] = (h > 0.f) ? d * w : 0.f;
-            acc = fmaf(d, h, acc);
-        }
-    }
-    if (p.gw2) {
-        sh[rg][cl] = acc;
-        __syncthreads();
-        if (rg == 0 && c < p.Hd) {
-            float v = 0.f;
-            for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
-            p.gw2[c] = v;
-            if (p.adam.enabled) {          // every thread of this block read w2[c] before the barrier
-                const int64_t si = gm_slot_index(p.adam.sched_slot);
-                float P = p.adam.pW[c], M = p.adam.mW[c], V = p.adam.vW[c];
-                adam_update(P, v, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1], p.adam.omb1,
-                            p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
-                p.adam.pW[c] = P; p.adam.mW[c] = M; p.adam.vW[c] = V;
-            }
-        }
-    }
-    if (blockIdx.x == 0) {
-        // scalars: loss = inv_b * sum l_r ; gb2 = fl(sum over x rows) + fl(sum over g rows)
-        double sl = 0.0, sx = 0.0, sg = 0.0;
-        for (int r = threadIdx.x; r < p.R; r += 1024) {
-            sl += (double)p.rowloss[r];
-            const double d = (double)p.dS[r];
-            if (!p.gen_mode && r < p.B) sx += d; else sg += d;
-        }
-        double v[3] = {sl, sx, sg};
-        float outv[3];
-        for (int k = 0; k < 3; ++k) {
-            double a = gm_wave_sum_d(v[k]);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = a;
-            __syncthreads();
-            double tot = 0.0;
-            for (int q = 0; q < 16; ++q) tot += shd[q];
-            outv[k] = (k == 0) ? (float)(tot * (double)p.inv_b) : (float)tot;
-        }
-        if (threadIdx.x == 0) {
-            p.loss_out[gm_slot_index(p.loss_slot)] = outv[0];
-            if (p.gb2) {
-                const float gb = outv[1] + outv[2];
-                p.gb2[0] = gb;
-                if (p.adam.enabled) {
-                    const int64_t si = gm_slot_index(p.adam.sched_slot);
-                    float P = p.adam.pb[0], M = p.adam.mb[0], V = p.adam.vb[0];
-                    adam_update(P, gb, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1],
-                                p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd,
-                                p.adam.clamp);
-                    p.adam.pb[0] = P; p.adam.mb[0] = M; p.adam.vb[0] = V;
-                }
-            }
-            // the per-graph tick folded into this single-writer point: kernels later in the same
-            // iteration address their slots with add - mul (engine), the next iteration sees ctr+1
-            if (p.tick) *p.tick += 1;
-        }
-    }
+static int head_bwd_launch(void* stream, const gm_head_bwd_args& a) {
+    HeadBwdP p{};
+    const int rc = gm_head_from_args(a, &p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(p)), dim3(1024), 0,
+                       (hipStream_t)stream, p);
+    GM_LAUNCH_RET();
 }
-
-static int head_bwd_impl(void* stream, const float* H, int64_t ldh, const float* dS,
-                         const float* w2, const float* rowloss, float* dH, int64_t lddh, float* gw2,
-                         float* gb2, float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode,
-                         int B, int Hd, const gm_adam_epi* adam, int64_t* tick);
 
 extern "C" int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS,
                            const float* w2, const float* rowloss, float* dH, int64_t lddh,
                            float* gw2, float* gb2, float* loss_out, gm_slot loss_slot, float inv_b,
                            int gen_mode, int B, int Hd) {
-    return head_bwd_impl(stream, H, ldh, dS, w2, rowloss, dH, lddh, gw2, gb2, loss_out, loss_slot,
-                         inv_b, gen_mode, B, Hd, nullptr, nullptr);
+    gm_head_bwd_args a{};
+    a.H = H; a.ldh = ldh; a.dS = dS; a.w2 = const_cast<float*>(w2); a.rowloss = rowloss; a.dH = dH;
+    a.lddh = lddh; a.gw2 = gw2; a.gb2 = gb2; a.loss_out = loss_out; a.loss_slot = loss_slot;
+    a.inv_b = inv_b; a.gen_mode = gen_mode; a.B = B; a.Hd = Hd;
+    return head_bwd_launch(stream, a);
 }
 
 // head_bwd with the optimizer step for (w2, b2) and/or the per-graph tick folded in.
@@ -414,32 +418,14 @@ extern "C" int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, cons
                                  int with_adam, float* mW, float* vW, float* mb, float* vb,
                                  const float* sched, gm_slot sched_slot, double beta1, double beta2,
                                  double eps, double weight_decay, float clamp, int64_t* tick) {
-    gm_adam_epi a{};
-    if (with_adam) {
-        GM_CHECK_ARG(gw2 && gb2 && b2 && mW && vW && mb && vb && sched && !gen_mode);
-        a.pW = w2; a.mW = mW; a.vW = vW; a.pb = b2; a.mb = mb; a.vb = vb; a.sched = sched;
-        a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
-        a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay;
-        a.clamp = clamp; a.enabled = 1;
-    }
-    return head_bwd_impl(stream, H, ldh, dS, w2, rowloss, dH, lddh, gw2, gb2, loss_out, loss_slot,
-                         inv_b, gen_mode, B, Hd, with_adam ? &a : nullptr, tick);
-}
-
-static int head_bwd_impl(void* stream, const float* H, int64_t ldh, const float* dS,
-                         const float* w2, const float* rowloss, float* dH, int64_t lddh, float* gw2,
-                         float* gb2, float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode,
-                         int B, int Hd, const gm_adam_epi* adam, int64_t* tick) {
-    GM_CHECK_ARG(H && dS && w2 && rowloss && dH && loss_out && B > 0 && Hd > 0);
-    HeadBwdP p{};
-    if (adam) p.adam = *adam;
-    p.tick = tick;
-    p.H = H; p.ldh = ldh; p.dS = dS; p.w2 = w2; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
-    p.gw2 = gw2; p.gb2 = gb2; p.loss_out = loss_out; p.loss_slot = loss_slot; p.inv_b = inv_b;
-    p.gen_mode = gen_mode; p.B = B; p.R = gen_mode ? B : 2 * B; p.Hd = Hd;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((Hd + HB_COLS - 1) / HB_COLS), dim3(1024), 0,
-                       (hipStream_t)stream, p);
-    GM_LAUNCH_RET();
+    gm_head_bwd_args a{};
+    a.H = H; a.ldh = ldh; a.dS = dS; a.w2 = w2; a.b2 = b2; a.rowloss = rowloss; a.dH = dH;
+    a.lddh = lddh; a.gw2 = gw2; a.gb2 = gb2; a.loss_out = loss_out; a.loss_slot = loss_slot;
+    a.inv_b = inv_b; a.gen_mode = gen_mode; a.B = B; a.Hd = Hd; a.with_adam = with_adam;
+    a.mW = mW; a.vW = vW; a.mb = mb; a.vb = vb; a.sched = sched; a.sched_slot = sched_slot;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.clamp = clamp;
+    a.tick = tick;
+    return head_bwd_launch(stream, a);
 }
 
 // ------------------------------------------------------------------------------------------

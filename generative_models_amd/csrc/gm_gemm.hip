@@ -33,6 +33,7 @@
 //   * optional optimizer-in-epilogue: the thread that produces a gradient element also applies
 //     Adam to the parameter (single-GPU fast path), removing the separate Adam launches.
 #include "gm_common.h"
+#include "gm_head.h"
 
 #include <cstdlib>
 
@@ -148,12 +149,13 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
 }
 
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, int ROWS = 32>
 __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
                                                  int n0) {
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
     const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
+    if (ROWS < 32 && row >= ROWS) continue;                  // 16-row tiles: half the threads idle
     float v = 0.f;
 #pragma unroll
     for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
@@ -330,12 +332,11 @@ __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_
 // (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
 // rounds of one workgroup per CU): one round, 6 fragment loads per 32 MFMAs instead of 4 per 16.
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
-__global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
-    __shared__ float red[WAVES * 32 * 32];
+__device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by) {
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
-    const int m0 = blockIdx.y * (16 * MI), n0 = blockIdx.x * (16 * NI);
+    const int m0 = by * (16 * MI), n0 = bx * (16 * NI);
 
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
@@ -411,8 +412,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     }
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
+    static_assert(NI % 2 == 0 && (MI == 1 || MI % 2 == 0), "tile shapes: 16xN or 32-multiples");
 #pragma unroll
-    for (int bm = 0; bm < MI / 2; ++bm)
+    for (int bm = 0; bm < (MI + 1) / 2; ++bm)
 #pragma unroll
         for (int bn = 0; bn < NI / 2; ++bn) {
             if (bm + bn > 0) __syncthreads();                // previous block fully consumed
@@ -421,12 +423,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
                 const int row = g4 * 4 + rgi;
                 red[(w * 32 + row) * 32 + i16] = acc[2 * bm][2 * bn][rgi];
                 red[(w * 32 + row) * 32 + 16 + i16] = acc[2 * bm][2 * bn + 1][rgi];
-                red[(w * 32 + 16 + row) * 32 + i16] = acc[2 * bm + 1][2 * bn][rgi];
-                red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[2 * bm + 1][2 * bn + 1][rgi];
+                if constexpr (MI > 1) {
+                    red[(w * 32 + 16 + row) * 32 + i16] = acc[2 * bm + 1][2 * bn][rgi];
+                    red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[2 * bm + 1][2 * bn + 1][rgi];
+                }
             }
             __syncthreads();
-            reduce_and_store<MODE, WAVES>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
+            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
         }
+}
+
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
+__global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
+    __shared__ float red[WAVES * 32 * 32];
+    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y);
+}
+
+// The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
+// rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
+// two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
+// boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
+template <bool VEC, int G, bool XV, int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
+                                                              int hblocks) {
+    __shared__ float red[16 * 32 * 32];
+    if ((int)blockIdx.y < hrows) {                           // workgroup-uniform
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (bid < hblocks) head_bwd_body(hp, bid);
+        return;
+    }
+    gemm16_body<MODE_DW, VEC, 16, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y - hrows);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -441,7 +467,8 @@ int xcd_mode() {
 }
 
 template <int MODE>
-int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
+int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false,
+           const HeadBwdP* head = nullptr) {
     GemmP p = p_in;
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
@@ -503,11 +530,38 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
         // measured (profiles/r01_experiments.md): pays only when a wave still has >= 2 chunks of
         // reduction work per tile (dW over 2B = 512 rows: 11.65 -> 10.37 us), loses otherwise
         if (wide_on && !use8 && tm * tn > 256 && (p.K + 15) / 16 >= 32) wide = (tn >= tm) ? 1 : 2;
+        // fewer than half as many 32x32 tiles as CUs: 16-row tiles double the workgroups and halve
+        // each one's A-fragment loads and MFMA chain (the critic pass over B = 256 rows: 104 tiles)
+        static int narrow_on = -1;
+        if (narrow_on < 0) { const char* e = getenv("GM_NARROW_TILES"); narrow_on = e ? atoi(e) : 1; }
+        if (narrow_on && !use8 && !wide && tm * tn <= 128 && p.M > 16) wide = 3;   // 3: 16x32
         if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
+        if (wide == 3) grid = dim3(tn, (p.M + 15) / 16);
+        if constexpr (MODE == MODE_DW) {
+            if (head && !use8) {
+                const int hblocks = gm_head_bwd_blocks(*head);
+                const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
+                const dim3 hgrid(grid.x, grid.y + hrows);
+#define GM_LH(V, GG, X) do {                                                                       \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, (GG > 2 ? 2 : GG), X, 2, 4>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, (GG > 2 ? 2 : GG), X, 4, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
+#define GM_LH_G(V, X) do { if (g16 == 1) GM_LH(V, 1, X); else if (g16 == 2) GM_LH(V, 2, X); else GM_LH(V, 4, X); } while (0)
+                if (xv) GM_LH_G(false, true); else GM_LH_G(false, false);   // VEC is a k-contiguous notion
+#undef GM_LH_G
+#undef GM_LH
+                GM_LAUNCH_RET();
+            }
+        }
+        if (head) {      // this configuration cannot carry the head workgroups: separate launch
+            hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
+        }
 #define GM_L16(V, W, GG, X) do {                                                                   \
         if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 3) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 1, 2>), grid, dim3(W * 64), 0, s, p); \
         else hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 2>), grid, dim3(W * 64), 0, s, p); } while (0)
 #define GM_L16_G(V, W, X) do { if (g16 == 1) GM_L16(V, W, 1, X); else if (g16 == 2) GM_L16(V, W, 2, X); else GM_L16(V, W, 4, X); } while (0)
 #define GM_L16_W(V, X) do { if (use8) GM_L16_G(V, 8, X); else GM_L16_G(V, 16, X); } while (0)
@@ -519,6 +573,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false) {
 #undef GM_L16
         GM_LAUNCH_RET();
     }
+    if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
 #define GM_LAUNCH(V, W, GG, X) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
 #define GM_LAUNCH_G(V, W, X) do { if (g == 2) GM_LAUNCH(V, W, 2, X); else if (g == 4) GM_LAUNCH(V, W, 4, X); else GM_LAUNCH(V, W, 7, X); } while (0)
 #define GM_LAUNCH_W(V, X) do { if (use8) GM_LAUNCH_G(V, 8, X); else GM_LAUNCH_G(V, 16, X); } while (0)
@@ -585,7 +640,7 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam);
+                   const gm_adam_epi* adam, const HeadBwdP* head = nullptr);
 
 extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X,
                                 int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K,
@@ -608,9 +663,30 @@ extern "C" int gm_linear_bwd_dw_adam(void* stream, const float* dA, int64_t lda,
     return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, &a);
 }
 
+extern "C" int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda,
+                                          const float* X, int64_t ldx, gm_slot x_slot, float* dW,
+                                          float* db, int M, int K, int N, float* pW, float* mW,
+                                          float* vW, float* pb, float* mb, float* vb,
+                                          const float* sched, gm_slot sched_slot, double beta1,
+                                          double beta2, double eps, double weight_decay, float clamp,
+                                          const gm_head_bwd_args* head) {
+    GM_CHECK_ARG(db && pW && mW && vW && pb && mb && vb && sched && head);
+    // the head may update (w2, b2) and writes gw2/gb2/loss: none of it may alias the GEMM's operands
+    GM_CHECK_ARG(head->w2 != pW && head->gw2 != dW);
+    HeadBwdP hp{};
+    const int rc = gm_head_from_args(*head, &hp);
+    if (rc) return rc;
+    gm_adam_epi a{};
+    a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
+    a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+    a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
+    a.enabled = 1;
+    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, &a, &hp);
+}
+
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam) {
+                   const gm_adam_epi* adam, const HeadBwdP* head) {
     GM_CHECK_ARG(dA && X && dW && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GemmP p{};
     if (adam) p.adam = *adam;
@@ -622,5 +698,5 @@ static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, i
     // the tile edges on 4-element boundaries (the virtual ones-column sits at x == K, K % 4 == 0)
     const bool xvec = aligned16(dA) && aligned16(X) && (lda % 4 == 0) && (ldx % 4 == 0) &&
                       (N % 4 == 0) && (K % 4 == 0) && (x_slot.stride % 4 == 0) && N >= 4 && K >= 4;
-    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec);
+    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, head);
 }

@@ -161,6 +161,8 @@ class GANEngine:
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
+        self.head_final = os.environ.get("GM_HEAD_FINAL", "1") != "0"
+        self.group_head = os.environ.get("GM_GROUP_HEAD", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))   # iterations / graph
         self._standalone_G = False
@@ -181,6 +183,7 @@ class GANEngine:
         self.dXg = z(Bl, I)
         self.dHg = z(Bl, H)
         self.rowloss = z(2 * Bl)
+        self.done_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.aux = z(8)                    # Fisher lambda + moments
         if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
@@ -315,6 +318,7 @@ class GANEngine:
         D1, D2 = self.D1, self.D2
         X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
         loss_slot = self._slot(it, d, j, 0, 1)
+        grouped = False
         ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
@@ -326,10 +330,19 @@ class GANEngine:
         if self.fuse_head and self.variant not in ("ra", "fisher"):
             from . import ops_fused as of
             of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
-                             self.inv_b, aux, S2, dS, self.rowloss, stream=st)
+                             self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
             adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, D2.gW, D2.gb, self.lossD, loss_slot,
-                        self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
+            if adam is not None and self.group_head:
+                # head backward + first-layer weight gradient (+ both Adam steps): ONE launch
+                ops.linear_bwd_dw_adam_head(
+                    dHd, X2, D1, adam,
+                    dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
+                         loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam),
+                    M=2 * Bl, stream=st)
+                grouped = True
+            else:
+                of.head_bwd(Hd, dS, D2.W, self.rowloss, None, D2.gW, D2.gb, self.lossD, loss_slot,
+                            self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
             ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
@@ -337,7 +350,9 @@ class GANEngine:
                          aux=aux, db=D2.gb, stream=st)
             ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
             ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        if self._adam_in_epilogue("D"):
+        if grouped:
+            pass
+        elif self._adam_in_epilogue("D"):
             ops.linear_bwd_dw_adam(dHd, X2, D1, self._adam_args("D", self._slot(it, d, j, 0, 1)),
                                    M=2 * Bl, stream=st)
         else:
@@ -423,11 +438,18 @@ class GANEngine:
         ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
         if self.fuse_head:
             from . import ops_fused as of
-            of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
-                             self.inv_b, None, S2, dS, self.rowloss, stream=st)
-            of.head_bwd(Hd, dS, D2.W, self.rowloss, dHd, None, None, self.lossG, loss_slot,
-                        self.inv_b, True, Bl, tick=self.ctr if self._tick_in_head() else None,
-                        stream=st)
+            tick = self.ctr if self._tick_in_head() else None
+            if self.head_final:
+                # the last workgroup of the head kernel writes the loss scalar and ticks
+                of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
+                                 self.inv_b, None, S2, dS, self.rowloss, dH=dHd,
+                                 final=dict(loss_out=self.lossG, loss_slot=loss_slot,
+                                            done=self.done_ctr, tick=tick), stream=st)
+            else:
+                of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
+                                 self.inv_b, None, S2, dS, self.rowloss, dH=dHd, stream=st)
+                of.head_bwd(Hd, dS, D2.W, self.rowloss, None, None, None, self.lossG, loss_slot,
+                            self.inv_b, True, Bl, tick=tick, stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
             ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,

@@ -1,4 +1,6 @@
 """Tensor-level wrappers for the variant-specific fused kernels (csrc/gm_fused.hip)."""
+import torch
+
 from . import _lib
 from ._lib import NO_SLOT
 from .ops import _ld, stream_ptr
@@ -51,15 +53,25 @@ def sum_finalize(partial, n, out, scale=1.0, out_slot=NO_SLOT, stream=None):
 
 
 def head_fwd_loss(variant, gen_mode, H, w2, b2, out_act, B, hyper, inv_b, pen, S, dS, rowloss,
-                  stream=None):
-    """Fused critic head forward + per-row loss + d loss/d pre-activation (separable variants)."""
+                  dH=None, final=None, stream=None):
+    """Fused critic head forward + per-row loss + d loss/d pre-activation (separable variants).
+    dH: also write the hidden-layer gradient.  final = dict(loss_out, loss_slot, done, tick=None):
+    the last workgroup also writes the loss scalar (and ticks) -- no head_bwd needed for scalars."""
     import ctypes
     from ._lib import ACT, LOSS
     h = (ctypes.c_float * 8)(*([float(x) for x in hyper] + [0.0] * (8 - len(hyper))))
-    _lib.call("gm_head_fwd_loss", stream or stream_ptr(), LOSS[variant], 1 if gen_mode else 0,
-              H.data_ptr(), _ld(H), w2.data_ptr(), b2.data_ptr(), ACT[out_act], B, H.shape[1], h,
-              len(hyper), inv_b, pen.data_ptr() if pen is not None else None, S.data_ptr(),
-              dS.data_ptr(), rowloss.data_ptr())
+    args = [stream or stream_ptr(), LOSS[variant], 1 if gen_mode else 0,
+            H.data_ptr(), _ld(H), w2.data_ptr(), b2.data_ptr(), ACT[out_act], B, H.shape[1], h,
+            len(hyper), inv_b, pen.data_ptr() if pen is not None else None, S.data_ptr(),
+            dS.data_ptr(), rowloss.data_ptr(), dH.data_ptr() if dH is not None else None,
+            _ld(dH) if dH is not None else 0]
+    if final is None:
+        _lib.call("gm_head_fwd_loss", *args)
+        return
+    done, tick = final["done"], final.get("tick")
+    assert done.dtype == torch.int32 and done.numel() >= 1
+    _lib.call("gm_head_fwd_loss_final", *args, final["loss_out"].data_ptr(), final["loss_slot"],
+              done.data_ptr(), tick.data_ptr() if tick is not None else None)
 
 
 def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_mode, B, lin=None,
@@ -68,15 +80,16 @@ def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_m
     adam (dict(sched, sched_slot, clamp)) + lin (engine._Linear of the head): also apply Adam to
     (w2, b2) here.  tick: device int64 counter to advance once the loss slot is written."""
     g = lambda t: t.data_ptr() if t is not None else None
+    ldd = _ld(dH) if dH is not None else 0      # dH=None: head_fwd_loss already wrote it
     if adam is None and tick is None:
         _lib.call("gm_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
-                  w2.data_ptr(), rowloss.data_ptr(), dH.data_ptr(), _ld(dH), g(gw2), g(gb2),
+                  w2.data_ptr(), rowloss.data_ptr(), g(dH), ldd, g(gw2), g(gb2),
                   loss_out.data_ptr(), loss_slot, inv_b, 1 if gen_mode else 0, B, H.shape[1])
         return
     with_adam = adam is not None
     _lib.call("gm_head_bwd_fused", stream or stream_ptr(), H.data_ptr(), _ld(H), dS.data_ptr(),
               w2.data_ptr(), lin.b.data_ptr() if with_adam else None, rowloss.data_ptr(),
-              dH.data_ptr(), _ld(dH), g(gw2), g(gb2), loss_out.data_ptr(), loss_slot, inv_b,
+              g(dH), ldd, g(gw2), g(gb2), loss_out.data_ptr(), loss_slot, inv_b,
               1 if gen_mode else 0, B, H.shape[1], 1 if with_adam else 0,
               lin.mW.data_ptr() if with_adam else None, lin.vW.data_ptr() if with_adam else None,
               lin.mb.data_ptr() if with_adam else None, lin.vb.data_ptr() if with_adam else None,

@@ -159,12 +159,22 @@ int gm_sum_finalize(void* stream, const float* partial, int n, float scale, floa
  * (`self.discriminate`, ns_gan.py:59), the loss lines of train_D / train_G (appendix A.2) and, in
  * the backward, the N=1 dW + K=1 dX launches.  H: hidden activations [R,Hd] (critic mode R=2B,
  * rows 0..B-1 real then B generated; generator mode R=B).  head_fwd_loss writes scores S[R],
- * dS[R] = d loss / d pre-activation and per-row loss terms; head_bwd writes
- * dH = dS (x) w2 masked by H>0, gw2 = dS^T H, gb2 (fp64 half-sums) and the loss scalar. */
+ * dS[R] = d loss / d pre-activation, per-row loss terms and -- when dH is given -- dH = dS (x) w2
+ * masked by H>0 while the row is hot; head_bwd writes gw2 = dS^T H, gb2 (fp64 half-sums), the loss
+ * scalar, and dH when head_fwd_loss did not (its dH may be NULL; all-NULL outputs = scalars only). */
 int gm_head_fwd_loss(void* stream, int variant, int gen_mode, const float* H, int64_t ldh,
                      const float* w2, const float* b2, int out_act, int B, int Hd,
                      const float* hyper, int n_hyper, float inv_b, const float* pen, float* S,
-                     float* dS, float* rowloss);
+                     float* dS, float* rowloss, float* dH_or_null, int64_t lddh);
+/* Same, and the LAST workgroup to finish also writes loss_out[slot] = inv_b * sum(rowloss) (fixed
+ * order, fp64) and, when tick != NULL, advances the iteration counter: the generator step needs no
+ * head_bwd launch.  done_ctr: one zero-initialised device word, re-armed by the kernel. */
+int gm_head_fwd_loss_final(void* stream, int variant, int gen_mode, const float* H, int64_t ldh,
+                           const float* w2, const float* b2, int out_act, int B, int Hd,
+                           const float* hyper, int n_hyper, float inv_b, const float* pen, float* S,
+                           float* dS, float* rowloss, float* dH_or_null, int64_t lddh,
+                           float* loss_out, gm_slot loss_slot, unsigned int* done_ctr,
+                           int64_t* tick_or_null);
 int gm_head_bwd(void* stream, const float* H, int64_t ldh, const float* dS, const float* w2,
                 const float* rowloss, float* dH, int64_t lddh, float* gw2, float* gb2,
                 float* loss_out, gm_slot loss_slot, float inv_b, int gen_mode, int B, int Hd);
@@ -193,6 +203,28 @@ int gm_began_update(void* stream, float* state, double* dstate, int64_t* istate,
 int gm_adam_scaled(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
                    const float* sched, gm_slot sched_slot, double beta1, double beta2, double eps,
                    double weight_decay, float clamp, const float* lr_scale);
+/* The critic head's backward and the first layer's weight gradient are independent once
+ * gm_head_fwd_loss has written dH: this entry point runs gm_linear_bwd_dw_adam AND gm_head_bwd_fused
+ * as ONE launch (the head workgroups ride in the GEMM's grid; 25 + 169 workgroups for the 784-400-1
+ * critic at B = 256 -- one round of the 256 CUs).  `head` mirrors gm_head_bwd_fused's arguments. */
+typedef struct gm_head_bwd_args {
+    const float* H; int64_t ldh;
+    const float* dS; float* w2; float* b2; const float* rowloss;
+    float* dH; int64_t lddh;              /* NULL when gm_head_fwd_loss wrote it */
+    float* gw2; float* gb2;
+    float* loss_out; gm_slot loss_slot;
+    float inv_b; int gen_mode, B, Hd;
+    int with_adam; float* mW; float* vW; float* mb; float* vb;
+    const float* sched; gm_slot sched_slot;
+    double beta1, beta2, eps, weight_decay; float clamp;
+    int64_t* tick;
+} gm_head_bwd_args;
+int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const float* X,
+                               int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
+                               float* pW, float* mW, float* vW, float* pb, float* mb, float* vb,
+                               const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                               double eps, double weight_decay, float clamp,
+                               const gm_head_bwd_args* head);
 /* gm_linear_bwd_dx with an additive term before the activation gradient:
  * dX = (dA*W + add_scale*add) * act'(below)   (BEGAN's generator sees G(z) both through D and
  * directly in |D(G(z)) - G(z)|, be_gan.py:256). */

@@ -354,3 +354,120 @@ def test_l1_rows_and_dx_add():
     ops.linear_bwd_dx(dA.to(DEV), W.to(DEV), out, below=below.to(DEV), epi="sigmoid",
                       add=add.to(DEV), add_scale=-1.0)
     close(out, (dA @ W - add) * below * (1 - below), 1e-5, "dx with addend")
+
+
+@pytest.mark.parametrize("variant,out_act", [("ns", "sigmoid"), ("w", "id"), ("ls", "id")])
+@pytest.mark.parametrize("gen_mode", [False, True])
+@pytest.mark.parametrize("B,Hd", [(256, 400), (24, 37)])
+def test_fused_head_pair(variant, out_act, gen_mode, B, Hd):
+    """head_fwd_loss (+ dH written while the row is hot) and head_bwd (gw2, gb2, loss) against autograd
+    on the same tail: s = act(h.w2 + b2) -> loss (oracle formulas, ns_gan.py:191-214)."""
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(B + Hd)
+    R = B if gen_mode else 2 * B
+    H = torch.relu(torch.randn(R, Hd)).requires_grad_(True)
+    w2 = (torch.randn(1, Hd) / Hd ** 0.5).requires_grad_(True)
+    b2 = torch.randn(1).requires_grad_(True)
+    hyper = [0.0, 1.0, 1.0]
+    s = act_cpu(H @ w2.t() + b2, out_act)[:, 0]
+    eps = 1e-8
+    if variant == "ns":
+        loss = -torch.mean(torch.log(s + eps)) if gen_mode else \
+            -torch.mean(torch.log(s[:B] + eps)) - torch.mean(torch.log(1 - s[B:] + eps))
+    elif variant == "w":
+        loss = -torch.mean(s) if gen_mode else -(torch.mean(s[:B]) - torch.mean(s[B:]))
+    else:
+        loss = 0.5 * torch.mean((s - 1.0) ** 2) if gen_mode else \
+            0.5 * torch.mean((s[:B] - 1.0) ** 2) + 0.5 * torch.mean((s[B:] - 0.0) ** 2)
+    loss.backward()
+    dH_ref = H.grad * (H.detach() > 0)      # ReluBackward of the hidden layer folded in
+    Hd_, w2d, b2d = H.detach().to(DEV), w2.detach().to(DEV).clone(), b2.detach().to(DEV).clone()
+    S = torch.empty(R, device=DEV); dS = torch.empty(R, device=DEV); rl = torch.empty(R, device=DEV)
+    dH = torch.full((R, Hd), 7.0, device=DEV)
+    gw2 = torch.empty(1, Hd, device=DEV); gb2 = torch.empty(1, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    of.head_fwd_loss(variant, gen_mode, Hd_, w2d, b2d, out_act, B, hyper, 1.0 / B, None, S, dS, rl,
+                     dH=dH)
+    of.head_bwd(Hd_, dS, w2d, rl, None, None if gen_mode else gw2, None if gen_mode else gb2, out,
+                ops.NO_SLOT, 1.0 / B, gen_mode, B)
+    close(S, s, 1e-5, "scores")
+    close(out[0], loss, 1e-5, "loss", atol=1e-6)
+    close(dH, dH_ref, 1e-5, "dH")
+    if not gen_mode:
+        close(gw2, w2.grad, 1e-5, "gw2")
+        close(gb2, b2.grad, 1e-5, "gb2", atol=1e-9)
+    # the unfused split (dH from head_bwd) must agree bit for bit
+    dH2 = torch.empty_like(dH)
+    of.head_fwd_loss(variant, gen_mode, Hd_, w2d, b2d, out_act, B, hyper, 1.0 / B, None, S, dS, rl)
+    of.head_bwd(Hd_, dS, w2d, rl, dH2, None, None, out, ops.NO_SLOT, 1.0 / B, gen_mode, B)
+    assert torch.equal(dH, dH2)
+
+
+@pytest.mark.parametrize("B,Hd", [(256, 400), (1024, 400), (24, 37), (3, 5)])
+def test_head_fwd_loss_final(B, Hd):
+    """The last-workgroup finalisation (loss scalar + tick, no head_bwd launch) equals head_bwd's
+    scalar path, re-arms its counter, and is repeatable launch after launch."""
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(B)
+    H = torch.relu(torch.randn(B, Hd)).to(DEV)
+    w2 = (torch.randn(1, Hd) / Hd ** 0.5).to(DEV); b2 = torch.randn(1).to(DEV)
+    S = torch.empty(B, device=DEV); dS = torch.empty(B, device=DEV); rl = torch.empty(B, device=DEV)
+    dH = torch.empty(B, Hd, device=DEV)
+    ref = torch.zeros(1, device=DEV)
+    of.head_fwd_loss("ns", True, H, w2, b2, "sigmoid", B, [], 1.0 / B, None, S, dS, rl, dH=dH)
+    of.head_bwd(H, dS, w2, rl, None, None, None, ref, ops.NO_SLOT, 1.0 / B, True, B)
+    dH_ref = dH.clone()
+    out = torch.zeros(4, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for k in range(4):                      # slot k of the loss ring, counter-addressed
+        dH.zero_()
+        of.head_fwd_loss("ns", True, H, w2, b2, "sigmoid", B, [], 1.0 / B, None, S, dS, rl, dH=dH,
+                         final=dict(loss_out=out, loss_slot=ops.slot(ctr.data_ptr(), 1, 0, 4, 1),
+                                    done=done, tick=ctr))
+    torch.cuda.synchronize()
+    assert ctr.item() == 4 and done.item() == 0
+    assert torch.equal(dH, dH_ref)
+    close(out, ref.expand(4), 1e-6, "final loss")
+    s_cpu = torch.sigmoid(H.cpu() @ w2.cpu().t() + b2.cpu())[:, 0]
+    close(out[0], -torch.mean(torch.log(s_cpu + 1e-8)), 1e-5, "loss vs torch")
+
+
+@pytest.mark.parametrize("B,I,Hd", [(256, 784, 400), (24, 36, 20), (512, 784, 400)])
+def test_dw_adam_with_head_in_one_launch(B, I, Hd):
+    """gm_linear_bwd_dw_adam_head == gm_head_bwd_fused followed by gm_linear_bwd_dw_adam, bit for
+    bit (the head workgroups only ride in the GEMM's grid; the arithmetic is the same code)."""
+    import torch.nn as nn
+    from generative_models_amd import ops_fused as of
+    from generative_models_amd.engine import FlatParams, _Linear
+
+    def run(grouped):
+        torch.manual_seed(7)
+        net = nn.Sequential(nn.Linear(I, Hd), nn.Linear(Hd, 1))
+        fp = FlatParams(net.parameters(), DEV)
+        fp.m.normal_().mul_(1e-3); fp.v.uniform_(0.0, 1e-4)
+        L1, L2 = _Linear(fp, net[0]), _Linear(fp, net[1])
+        X2 = torch.rand(2 * B, I).to(DEV)
+        H = torch.relu(torch.randn(2 * B, Hd)).to(DEV)
+        S = torch.empty(2 * B, device=DEV); dS = torch.empty_like(S); rl = torch.empty_like(S)
+        dH = torch.empty(2 * B, Hd, device=DEV)
+        loss = torch.zeros(1, device=DEV)
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(DEV)
+        adam = dict(sched=sched, sched_slot=ops.slot(0, 0, 2, 0, 1), clamp=0.0)
+        of.head_fwd_loss("ns", False, H, L2.W, L2.b, "sigmoid", B, [], 1.0 / B, None, S, dS, rl, dH=dH)
+        if grouped:
+            ops.linear_bwd_dw_adam_head(dH, X2, L1, adam,
+                                        dict(H=H, dS=dS, lin=L2, rowloss=rl, loss_out=loss,
+                                             loss_slot=ops.NO_SLOT, inv_b=1.0 / B, B=B, adam=adam),
+                                        M=2 * B)
+        else:
+            of.head_bwd(H, dS, L2.W, rl, None, L2.gW, L2.gb, loss, ops.NO_SLOT, 1.0 / B, False, B,
+                        lin=L2, adam=adam)
+            ops.linear_bwd_dw_adam(dH, X2, L1, adam, M=2 * B)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (fp.flat, fp.grad, fp.m, fp.v, loss)]
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq", "loss")):
+        assert torch.equal(x, y), name
+    assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
