@@ -39,7 +39,7 @@ def synthetic_dataset():
     return ds
 
 
-def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True):
+def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather=True, pair_dw=True):
     """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
     critic-head kernels (default) the N=1 layer is not a GEMM launch any more; with the batched
     generator forward (default at D_steps=1) G(zD) and G(zG) are one 2B-row launch pair."""
@@ -49,9 +49,12 @@ def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True):
         [("fwd", B, Z, HID), ("fwd", B, HID, IMG)] * 2
     # "dwh": the first critic layer's weight gradient carrying the head's backward workgroups
     dw1 = "dwh" if (fused_head and group_head) else "dw"
+    if ride_gather:                      # "fwdg": the batch gather rides in this launch's grid
+        gen[0] = ("fwdg",) + gen[0][1:]
+    # "dwp": both generator weight gradients as one launch (second GEMM: dW1, [HID, Z])
+    g_dw = [("dwp", B, HID, IMG)] if pair_dw else [("dw", B, HID, IMG), ("dw", B, Z, HID)]
     return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [(dw1, 2 * B, IMG, HID)] +
-            [("fwd", B, IMG, HID)] + g_head +
-            [("dx", B, IMG, HID), ("dx", B, HID, IMG), ("dw", B, HID, IMG), ("dw", B, Z, HID)])
+            [("fwd", B, IMG, HID)] + g_head + [("dx", B, IMG, HID), ("dx", B, HID, IMG)] + g_dw)
 
 
 def gemm_variant(kind, M, K, N):
@@ -59,7 +62,7 @@ def gemm_variant(kind, M, K, N):
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, batch
     depth from the 16-deep chunks per wave, 16-byte paths by alignment, tile shape from the tile
     count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
-    if kind == "fwd":
+    if kind in ("fwd", "fwdg"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind == "dx":
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
@@ -85,6 +88,12 @@ def gemm_variant(kind, M, K, N):
     b = lambda v: "true" if v else "false"
     if kind == "dwh":
         return "gemm16_dw_head_kernel<false, %d, %s, %d, %d>" % (g, b(xv), mi, ni)
+    if kind == "fwdg":
+        assert vec and (mi, ni) in ((2, 2), (1, 2))
+        return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
+    if kind == "dwp":
+        assert xv and (mi, ni) != (1, 2)
+        return "gemm16_dw_pair_kernel<%d, true, %d, %d>" % (g, mi, ni)
     return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d>" % (mode, b(vec), nw, g, b(xv), mi, ni)
 
 
@@ -108,7 +117,8 @@ def _holder(N, K, dev):
                            mW=z(N * K), vW=z(N * K), mb=z(N), vb=z(N))
 
 
-def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True):
+def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True,
+                          ride_gather=True, pair_dw=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -116,7 +126,8 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
     dev = "cuda"
     out = {}
     st = ops.stream_ptr()
-    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head):
+    data = idx = xr = None
+    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather, pair_dw):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -125,8 +136,23 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
         dW = torch.empty(N, K, device=dev)
         db = torch.empty(N, device=dev)
         b = torch.zeros(N, device=dev)
+        flop = 2.0 * M * K * N
         if kind == "fwd":
             fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st)
+        elif kind == "fwdg":
+            if data is None:
+                data = (torch.rand(N_TRAIN, IMG, device=dev) > 0.5).float()
+                idx = torch.randint(0, N_TRAIN, (B,), device=dev)
+                xr = torch.empty(B, IMG, device=dev)
+            fn = lambda: ops.linear_fwd_gather(x, W, b, y, "relu", data, idx, xr, stream=st)
+        elif kind == "dwp":
+            L2, L1 = _holder(N, K, dev), _holder(K, Z, dev)
+            dH2, zz = torch.randn(M, K, device=dev), torch.randn(M, Z, device=dev)
+            sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+            fn = lambda: ops.linear_bwd_dw_adam_pair(dict(dA=dA, X=x, lin=L2, adam=ad),
+                                                     dict(dA=dH2, X=zz, lin=L1, adam=ad), stream=st)
+            flop += 2.0 * M * Z * K
         elif kind == "dx":
             fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
         elif kind == "dwh":
@@ -161,10 +187,10 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
         e1.record(st)
         e1.sync()
         us = e0.elapsed_ms(e1) * 1e3 / reps
-        log('  %-3s M=%4d K=%4d N=%4d : %7.2f us  %6.2f TFLOP/s' % (kind, M, K, N, us, 2.0*M*K*N/us/1e6))
+        log('  %-4s M=%4d K=%4d N=%4d : %7.2f us  %6.2f TFLOP/s' % (kind, M, K, N, us, flop / us / 1e6))
         name = gemm_variant(kind, M, K, N)
         t, f, n = out.get(name, (0.0, 0.0, 0))
-        out[name] = (t + us, f + 2.0 * M * K * N, n + 1)
+        out[name] = (t + us, f + flop, n + 1)
     return out
 
 
@@ -279,7 +305,9 @@ def main():
 
     if rank == 0:
         kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
-                                   group_head=eng.group_head and eng._adam_in_epilogue("D"))
+                                   group_head=eng.group_head and eng._adam_in_epilogue("D"),
+                                   ride_gather=eng._gather_rides(),
+                                   pair_dw=eng.pair_dw and eng._adam_in_epilogue("G"))
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         log('isolated kernel timing done')

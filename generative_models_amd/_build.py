@@ -19,7 +19,7 @@ def needs_build():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "gm_common.h"), os.path.join(CSRC, "gm_head.h"),
+    deps = sources() + [os.path.join(CSRC, "gm_common.h"), os.path.join(CSRC, "gm_head.h"), os.path.join(CSRC, "gm_gather.h"),
                         os.path.join(os.path.dirname(HERE), "include", "gm_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 

@@ -41,6 +41,18 @@ class HeadBwdArgs(ctypes.Structure):
                 ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p)]
 
+
+
+class DwAdamArgs(ctypes.Structure):
+    """gm_dw_adam_args (include/gm_hip.h): gm_linear_bwd_dw_adam's arguments as one block."""
+    _fields_ = [("dA", c_void_p), ("lda", c_int64), ("X", c_void_p), ("ldx", c_int64),
+                ("x_slot", Slot), ("dW", c_void_p), ("db", c_void_p), ("M", c_int), ("K", c_int),
+                ("N", c_int), ("pW", c_void_p), ("mW", c_void_p), ("vW", c_void_p),
+                ("pb", c_void_p), ("mb", c_void_p), ("vb", c_void_p), ("sched", c_void_p),
+                ("sched_slot", Slot), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("clamp", c_float)]
+
+
 _P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
 
 _SIGNATURES = {
@@ -72,6 +84,9 @@ _SIGNATURES = {
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
+    "gm_linear_fwd_gather": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
+                                     c_int, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
+    "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),
     "gm_linear_bwd_dw_adam_head": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
                                            c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,

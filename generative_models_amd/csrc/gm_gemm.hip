@@ -34,6 +34,7 @@
 //     Adam to the parameter (single-GPU fast path), removing the separate Adam launches.
 #include "gm_common.h"
 #include "gm_head.h"
+#include "gm_gather.h"
 
 #include <cstdlib>
 
@@ -466,9 +467,44 @@ int xcd_mode() {
     return mode;
 }
 
+// The forward GEMM with the batch gather's workgroups riding in the same grid (rows [0, grows) of
+// the grid; 16 image rows per workgroup): the gather only needs the index ring and the resident
+// dataset, so it costs no launch of its own when the generator's first layer carries it.
+template <bool VEC, int G, int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, GatherP gp, int grows,
+                                                                 int gblocks) {
+    __shared__ float red[16 * 32 * 32];
+    if ((int)blockIdx.y < grows) {                           // workgroup-uniform
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (bid < gblocks) gather_body(gp, bid);
+        return;
+    }
+    gemm16_body<MODE_FWD, VEC, 16, G, false, MI, NI>(p, red, blockIdx.x, blockIdx.y - grows);
+}
+
+// Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
+// ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
+// generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
+template <int G, bool XV, int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
+                                                              int tnb) {
+    __shared__ float red[16 * 32 * 32];
+    const int id = blockIdx.x;
+    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pa, red, id % tna, id / tna);
+    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pb, red, (id - na) % tnb, (id - na) / tnb);
+}
+
+// Work that rides in (or pairs with) a GEMM launch.
+struct Rider {
+    const HeadBwdP* head = nullptr;      // MODE_DW: critic-head backward workgroups
+    const GatherP* gather = nullptr;     // MODE_FWD: batch-gather workgroups
+    const GemmP* pair = nullptr;         // MODE_DW: a second weight-gradient GEMM
+    bool pair_xvec = false;
+};
+
 template <int MODE>
-int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false,
-           const HeadBwdP* head = nullptr) {
+int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const Rider& rider = Rider()) {
+    const HeadBwdP* head = rider.head;
     GemmP p = p_in;
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
@@ -558,6 +594,46 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false,
         if (head) {      // this configuration cannot carry the head workgroups: separate launch
             hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
         }
+        if constexpr (MODE == MODE_FWD) {
+            if (rider.gather) {
+                const GatherP& gp = *rider.gather;
+                if (vec && !use8 && (wide == 0 || wide == 3)) {
+                    const int gblocks = gm_gather_blocks(gp, 16);
+                    const int grows = (gblocks + (int)grid.x - 1) / (int)grid.x;
+                    const dim3 ggrid(grid.x, grid.y + grows);
+#define GM_LG(GG) do {                                                                             \
+        if (wide == 3) hipLaunchKernelGGL((gemm16_fwd_gather_kernel<true, GG, 1, 2>), ggrid, dim3(1024), 0, s, p, gp, grows, gblocks); \
+        else hipLaunchKernelGGL((gemm16_fwd_gather_kernel<true, GG, 2, 2>), ggrid, dim3(1024), 0, s, p, gp, grows, gblocks); } while (0)
+                    if (g16 == 1) GM_LG(1); else if (g16 == 2) GM_LG(2); else GM_LG(4);
+#undef GM_LG
+                    GM_LAUNCH_RET();
+                }
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(gp, 4)), dim3(256), 0, s, gp);
+            }
+        }
+        if constexpr (MODE == MODE_DW) {
+            if (rider.pair) {
+                const GemmP& pb = *rider.pair;
+                if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
+                    const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
+                    const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
+                    const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
+                    const dim3 pgrid(na + tnb * tmb);
+#define GM_LP(GG) do {                                                                             \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<(GG > 2 ? 2 : GG), true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<(GG > 2 ? 2 : GG), true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); } while (0)
+                    if (g16 == 1) GM_LP(1); else if (g16 == 2) GM_LP(2); else GM_LP(4);
+#undef GM_LP
+                    GM_LAUNCH_RET();
+                }
+                // not pairable in this configuration: the second GEMM gets its own launch afterwards
+                Rider none;
+                const int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
+                if (rc) return rc;
+                return launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
+            }
+        }
 #define GM_L16(V, W, GG, X) do {                                                                   \
         if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
@@ -574,6 +650,14 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false,
         GM_LAUNCH_RET();
     }
     if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
+    if (rider.gather)
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(*rider.gather, 4)), dim3(256), 0, s, *rider.gather);
+    if (rider.pair) {
+        Rider none;
+        const int rc = launch<MODE>(s, p_in, vec, xvec, none);
+        if (rc) return rc;
+        return launch<MODE>(s, *rider.pair, false, rider.pair_xvec, none);
+    }
 #define GM_LAUNCH(V, W, GG, X) hipLaunchKernelGGL((gemm_kernel<MODE, V, W, GG, X>), grid, dim3(W * 64), 0, s, p)
 #define GM_LAUNCH_G(V, W, X) do { if (g == 2) GM_LAUNCH(V, W, 2, X); else if (g == 4) GM_LAUNCH(V, W, 4, X); else GM_LAUNCH(V, W, 7, X); } while (0)
 #define GM_LAUNCH_W(V, X) do { if (use8) GM_LAUNCH_G(V, 8, X); else GM_LAUNCH_G(V, 16, X); } while (0)
@@ -602,6 +686,29 @@ extern "C" int gm_linear_fwd(void* stream, const float* X, int64_t ldx, gm_slot 
     const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
                      (x_slot.stride % 4 == 0);
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);
+}
+
+extern "C" int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                    const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                    int K, int N, int act, const float* data, int64_t n_rows,
+                                    const int64_t* idx, gm_slot idx_slot, float* out,
+                                    int64_t ld_out, int B, int row_elems) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
+    GatherP g{};
+    const int rc = gm_gather_fill(data, n_rows, idx, idx_slot, out, ld_out, B, row_elems, &g);
+    if (rc) return rc;
+    // the gathered rows must not be an operand or the output of this GEMM
+    GM_CHECK_ARG(out != Y && out != X);
+    GemmP p{};
+    p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
+    p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = act;
+    p.a_slot = x_slot; p.b_slot = no_slot();
+    const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
+                     (x_slot.stride % 4 == 0);
+    Rider r;
+    r.gather = &g;
+    return launch<MODE_FWD>((hipStream_t)stream, p, vec, false, r);
 }
 
 static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
@@ -641,6 +748,9 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
                    const gm_adam_epi* adam, const HeadBwdP* head = nullptr);
+static int dw_fill(const float* dA, int64_t lda, const float* X, int64_t ldx, gm_slot x_slot,
+                   float* dW, float* db, int M, int K, int N, int accumulate,
+                   const gm_adam_epi* adam, GemmP* out, bool* xvec);
 
 extern "C" int gm_linear_bwd_dw(void* stream, const float* dA, int64_t lda, const float* X,
                                 int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K,
@@ -684,9 +794,50 @@ extern "C" int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t
     return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, &a, &hp);
 }
 
+static int dw_adam_fill(const gm_dw_adam_args& a, GemmP* p, bool* xvec) {
+    GM_CHECK_ARG(a.db && a.pW && a.mW && a.vW && a.pb && a.mb && a.vb && a.sched);
+    gm_adam_epi e{};
+    e.pW = a.pW; e.mW = a.mW; e.vW = a.vW; e.pb = a.pb; e.mb = a.mb; e.vb = a.vb; e.sched = a.sched;
+    e.sched_slot = a.sched_slot; e.omb1 = (float)(1.0 - a.beta1); e.b2 = (float)a.beta2;
+    e.omb2 = (float)(1.0 - a.beta2); e.eps = (float)a.eps; e.wd = (float)a.weight_decay;
+    e.clamp = a.clamp; e.enabled = 1;
+    return dw_fill(a.dA, a.lda, a.X, a.ldx, a.x_slot, a.dW, a.db, a.M, a.K, a.N, 0, &e, p, xvec);
+}
+
+extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* first,
+                                          const gm_dw_adam_args* second) {
+    GM_CHECK_ARG(first && second);
+    // neither may consume what the other produces or updates
+    GM_CHECK_ARG(first->dW != second->dW && first->pW != second->pW);
+    GM_CHECK_ARG((const float*)first->pW != second->dA && (const float*)first->pW != second->X);
+    GM_CHECK_ARG((const float*)second->pW != first->dA && (const float*)second->pW != first->X);
+    GemmP pa{}, pb{};
+    bool xa = false, xb = false;
+    int rc = dw_adam_fill(*first, &pa, &xa);
+    if (rc) return rc;
+    rc = dw_adam_fill(*second, &pb, &xb);
+    if (rc) return rc;
+    Rider r;
+    r.pair = &pb;
+    r.pair_xvec = xb;
+    return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
+}
+
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
                    const gm_adam_epi* adam, const HeadBwdP* head) {
+    GemmP p{};
+    bool xvec = false;
+    const int rc = dw_fill(dA, lda, X, ldx, x_slot, dW, db, M, K, N, accumulate, adam, &p, &xvec);
+    if (rc) return rc;
+    Rider r;
+    r.head = head;
+    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, r);
+}
+
+static int dw_fill(const float* dA, int64_t lda, const float* X, int64_t ldx, gm_slot x_slot,
+                   float* dW, float* db, int M, int K, int N, int accumulate,
+                   const gm_adam_epi* adam, GemmP* out, bool* xvec_out) {
     GM_CHECK_ARG(dA && X && dW && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GemmP p{};
     if (adam) p.adam = *adam;
@@ -698,5 +849,7 @@ static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, i
     // the tile edges on 4-element boundaries (the virtual ones-column sits at x == K, K % 4 == 0)
     const bool xvec = aligned16(dA) && aligned16(X) && (lda % 4 == 0) && (ldx % 4 == 0) &&
                       (N % 4 == 0) && (K % 4 == 0) && (x_slot.stride % 4 == 0) && N >= 4 && K >= 4;
-    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, head);
+    *out = p;
+    *xvec_out = xvec;
+    return 0;
 }

@@ -1,6 +1,7 @@
 // gm_ops.hip -- non-GEMM kernels of the GAN/VAE step: batch gather, adversarial losses with their
 // score gradients, flat Adam (+WGAN clamp), the per-graph tick, and HIP-graph / event helpers.
 #include "gm_common.h"
+#include "gm_gather.h"
 
 #include <string>
 
@@ -28,38 +29,15 @@ extern "C" int gm_tick(void* stream, int64_t* ctr, int64_t inc) {
 // K1 gather: out[b,:] = data[idx[b],:]   (process_batch, ns_gan.py:222-226)
 // One 3136-byte image row per wave: 196 float4 -> lanes issue coalesced 16-B loads.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ data,
-                                                         int64_t n_rows,
-                                                         const int64_t* __restrict__ idx,
-                                                         gm_slot idx_slot, float* __restrict__ out,
-                                                         int64_t ld_out, int B, int row_elems,
-                                                         int vec) {
-    const int64_t* ix = idx + gm_slot_offset(idx_slot);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    int64_t r = ix[b];
-    if (r < 0 || r >= n_rows) r = 0;     // never fault on a corrupt index; parity tests catch it
-    const float* src = data + r * (int64_t)row_elems;
-    float* dst = out + (int64_t)b * ld_out;
-    if (vec) {
-        const int n4 = row_elems >> 2;
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int i = lane; i < n4; i += 64) d4[i] = s4[i];
-    } else {
-        for (int i = lane; i < row_elems; i += 64) dst[i] = src[i];
-    }
-}
-
+// The body lives in gm_gather.h: the generator's first forward GEMM can carry the gather workgroups
+// in its own grid (gm_linear_fwd_gather, gm_gemm.hip).
 extern "C" int gm_gather_rows(void* stream, const float* data, int64_t n_rows, const int64_t* idx,
                               gm_slot idx_slot, float* out, int64_t ld_out, int B, int row_elems) {
-    GM_CHECK_ARG(data && idx && out && B > 0 && row_elems > 0 && ld_out >= row_elems);
-    const int vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) &&
-                    ((reinterpret_cast<uintptr_t>(data) & 15) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       data, n_rows, idx, idx_slot, out, ld_out, B, row_elems, vec);
+    GatherP g{};
+    const int rc = gm_gather_fill(data, n_rows, idx, idx_slot, out, ld_out, B, row_elems, &g);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(g, 4)), dim3(256), 0,
+                       (hipStream_t)stream, g);
     GM_LAUNCH_RET();
 }
 

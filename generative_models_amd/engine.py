@@ -163,6 +163,8 @@ class GANEngine:
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
         self.head_final = os.environ.get("GM_HEAD_FINAL", "1") != "0"
         self.group_head = os.environ.get("GM_GROUP_HEAD", "1") != "0"
+        self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
+        self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))   # iterations / graph
         self._standalone_G = False
@@ -292,11 +294,20 @@ class GANEngine:
         self._issue_G_post(st, it)
 
     # ---- pieces of one critic step (composed sequentially, or as parallel graph branches) -----
-    def _D_gather(self, st, it, j):
+    def _gather_rides(self):
+        """The batch gather rides in the grid of the generator's first forward launch."""
+        return self.ride_gather and not self.dag
+
+    def _gather_args(self, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
         r0 = self.rank * Bl                       # this rank's rows of the global batch
-        ops.gather_rows(self.data, self.idx_ring.view(-1)[r0:], self.X2, B=Bl,
-                        idx_slot=self._slot(it, d, j, R * d, self.B), stream=st)
+        return dict(data=self.data, idx=self.idx_ring.view(-1)[r0:], out=self.X2, B=Bl,
+                    idx_slot=self._slot(it, d, j, R * d, self.B))
+
+    def _D_gather(self, st, it, j):
+        if self._gather_rides():
+            return                                  # done by _D_gen's first launch
+        ops.gather_rows(stream=st, **self._gather_args(it, j))
 
     def _batch_gen(self):
         """Both generator forwards of an iteration (critic step's G(zD), generator step's G(zG))
@@ -310,7 +321,11 @@ class GANEngine:
         zD_slot = self._slot(it, d, j, R * d, self.zD_stride)
         zbase = self.zD_base[self.rank * Bl * self.Z:].view(-1, self.Z)
         rows = 2 * Bl if (self._batch_gen() and not self._standalone_G) else Bl
-        ops.linear_fwd(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot, stream=st)
+        if self._gather_rides():
+            ops.linear_fwd_gather(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot,
+                                  stream=st, **self._gather_args(it, j))
+        else:
+            ops.linear_fwd(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot, stream=st)
         ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
 
     def _D_rest(self, st, it, j):
@@ -491,6 +506,16 @@ class GANEngine:
         self._G_gen(st, it)
         self._G_critic(st, it)
         self._G_dh(st, it)                          # reads G2.W before _G_dw2 may update it
+        if self.pair_dw and self._adam_in_epilogue("G"):
+            # both weight gradients of the generator (+ their Adam steps): ONE launch
+            adam = self._adam_args("G", self._G_sched_slot(it))
+            zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+            zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
+            ops.linear_bwd_dw_adam_pair(
+                dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
+                dict(dA=self.dHg, X=zbase, lin=self.G1, adam=adam, M=self.Bl, x_slot=zG_slot),
+                stream=st)
+            return
         self._G_dw2(st, it)
         self._G_dw1(st, it)
 

@@ -84,6 +84,46 @@ def linear_bwd_dw_adam(dA, X, lin, adam, M=None, x_slot=NO_SLOT, betas=(0.9, 0.9
               betas[0], betas[1], eps, weight_decay, adam.get("clamp", 0.0))
 
 
+def linear_fwd_gather(x, W, b, y, act, data, idx, out, M=None, B=None, x_slot=NO_SLOT,
+                      idx_slot=NO_SLOT, stream=None):
+    """linear_fwd(x, W, b, y, act) and gather_rows(data, idx, out) as ONE launch (the gather
+    workgroups ride in the GEMM's grid; `out` must not be an operand of this GEMM)."""
+    N, K = W.shape
+    M = x.shape[0] if M is None else M
+    n_rows, row = data.shape
+    B = out.shape[0] if B is None else B
+    _lib.call("gm_linear_fwd_gather", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
+              x_slot, _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
+              _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act], _chk(data, "data").data_ptr(),
+              n_rows, idx.data_ptr(), idx_slot, out.data_ptr(), _ld(out), B, row)
+    return y
+
+
+def _dw_adam_args(dA, X, lin, adam, M, x_slot, betas, eps, weight_decay):
+    from ._lib import DwAdamArgs
+    N, K = lin.gW.shape
+    a = DwAdamArgs()
+    a.dA, a.lda, a.X, a.ldx, a.x_slot = _chk(dA, "dA").data_ptr(), _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot
+    a.dW, a.db, a.M, a.K, a.N = lin.gW.data_ptr(), lin.gb.data_ptr(), (dA.shape[0] if M is None else M), K, N
+    a.pW, a.mW, a.vW = lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr()
+    a.pb, a.mb, a.vb = lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr()
+    a.sched, a.sched_slot = adam["sched"].data_ptr(), adam["sched_slot"]
+    a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, weight_decay
+    a.clamp = adam.get("clamp", 0.0)
+    return a
+
+
+def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                            stream=None):
+    """Two linear_bwd_dw_adam calls over the same batch rows as ONE launch.  first / second:
+    dict(dA, X, lin, adam, M=None, x_slot=NO_SLOT)."""
+    import ctypes
+    mk = lambda d: _dw_adam_args(d["dA"], d["X"], d["lin"], d["adam"], d.get("M"),
+                                 d.get("x_slot", NO_SLOT), betas, eps, weight_decay)
+    a, b = mk(first), mk(second)
+    _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
+
+
 def linear_bwd_dw_adam_head(dA, X, lin, adam, head, M=None, x_slot=NO_SLOT, betas=(0.9, 0.999),
                             eps=1e-8, weight_decay=0.0, stream=None):
     """linear_bwd_dw_adam and the critic head's backward (ops_fused.head_bwd with Adam on the head

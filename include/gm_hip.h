@@ -225,6 +225,25 @@ int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const
                                const float* sched, gm_slot sched_slot, double beta1, double beta2,
                                double eps, double weight_decay, float clamp,
                                const gm_head_bwd_args* head);
+/* gm_linear_fwd and gm_gather_rows as ONE launch: the gather workgroups ride in the GEMM's grid.  The
+ * gather only reads the index ring and the resident dataset, so any forward launch that does not
+ * touch `out` can carry it (the engine uses the generator's first layer, ns_gan.py:44 + :222-226). */
+int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                         const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                         const float* data, int64_t n_rows, const int64_t* idx, gm_slot idx_slot,
+                         float* out, int64_t ld_out, int B, int row_elems);
+/* Two gm_linear_bwd_dw_adam calls over the same batch rows as ONE launch (the generator step's two
+ * weight gradients are independent once d loss / d hidden is known).  Falls back to two launches
+ * when the pair cannot share a tile configuration. */
+typedef struct gm_dw_adam_args {
+    const float* dA; int64_t lda; const float* X; int64_t ldx; gm_slot x_slot;
+    float* dW; float* db; int M, K, N;
+    float* pW; float* mW; float* vW; float* pb; float* mb; float* vb;
+    const float* sched; gm_slot sched_slot;
+    double beta1, beta2, eps, weight_decay; float clamp;
+} gm_dw_adam_args;
+int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* first,
+                               const gm_dw_adam_args* second);
 /* gm_linear_bwd_dx with an additive term before the activation gradient:
  * dX = (dA*W + add_scale*add) * act'(below)   (BEGAN's generator sees G(z) both through D and
  * directly in |D(G(z)) - G(z)|, be_gan.py:256). */

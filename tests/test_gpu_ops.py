@@ -471,3 +471,56 @@ def test_dw_adam_with_head_in_one_launch(B, I, Hd):
     for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq", "loss")):
         assert torch.equal(x, y), name
     assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
+
+
+@pytest.mark.parametrize("M,K,N,B,I", [(512, 20, 400, 256, 784), (256, 20, 400, 256, 784),
+                                       (33, 13, 31, 7, 10), (64, 20, 400, 100, 36)])
+def test_linear_fwd_with_gather_riding(M, K, N, B, I):
+    """gm_linear_fwd_gather == gm_linear_fwd + gm_gather_rows, bit for bit (aligned shapes ride
+    in the GEMM's grid, the ragged case takes the two-launch fallback inside the library)."""
+    torch.manual_seed(M + B)
+    x, W, b = torch.randn(M, K).to(DEV), (torch.randn(N, K) / K ** 0.5).to(DEV), torch.randn(N).to(DEV)
+    data = torch.rand(1000, I).to(DEV)
+    ring = torch.randint(0, 1000, (3, B)).to(DEV)
+    ctr = torch.full((1,), 2, dtype=torch.int64, device=DEV)
+    slot = ops.slot(ctr.data_ptr(), 1, 0, 3, B)
+    y1, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    o1, o2 = torch.zeros(B, I, device=DEV), torch.zeros(B, I, device=DEV)
+    ops.linear_fwd_gather(x, W, b, y1, "relu", data, ring.view(-1), o1, idx_slot=slot)
+    ops.linear_fwd(x, W, b, y2, "relu")
+    ops.gather_rows(data, ring.view(-1), o2, idx_slot=slot)
+    assert torch.equal(y1, y2) and torch.equal(o1, o2)
+    assert torch.equal(o1.cpu(), data.cpu()[ring[2].cpu()])
+
+
+@pytest.mark.parametrize("B,H,I,Z", [(256, 400, 784, 20), (1024, 400, 784, 20), (24, 20, 36, 8),
+                                     (32, 31, 33, 5)])
+def test_dw_adam_pair_in_one_launch(B, H, I, Z):
+    """gm_linear_bwd_dw_adam_pair == two gm_linear_bwd_dw_adam launches, bit for bit (incl. the
+    wide-tile configuration at B = 1024 and the unaligned two-launch fallback)."""
+    import torch.nn as nn
+    from generative_models_amd.engine import FlatParams, _Linear
+
+    def run(paired):
+        torch.manual_seed(11)
+        net = nn.Sequential(nn.Linear(Z, H), nn.Linear(H, I))
+        fp = FlatParams(net.parameters(), DEV)
+        fp.m.normal_().mul_(1e-3); fp.v.uniform_(0.0, 1e-4)
+        L1, L2 = _Linear(fp, net[0]), _Linear(fp, net[1])
+        dX, Hg = torch.randn(B, I).to(DEV), torch.relu(torch.randn(B, H)).to(DEV)
+        dH, z = torch.randn(B, H).to(DEV), torch.randn(B, Z).to(DEV)
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(DEV)
+        adam = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+        if paired:
+            ops.linear_bwd_dw_adam_pair(dict(dA=dX, X=Hg, lin=L2, adam=adam),
+                                        dict(dA=dH, X=z, lin=L1, adam=adam))
+        else:
+            ops.linear_bwd_dw_adam(dX, Hg, L2, adam)
+            ops.linear_bwd_dw_adam(dH, z, L1, adam)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (fp.flat, fp.grad, fp.m, fp.v)]
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(x, y), name
+    assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
