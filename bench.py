@@ -39,7 +39,8 @@ def synthetic_dataset():
     return ds
 
 
-def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather=True, pair_dw=True):
+def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather=True, pair_dw=True,
+                ride_head_dx=True):
     """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
     critic-head kernels (default) the N=1 layer is not a GEMM launch any more; with the batched
     generator forward (default at D_steps=1) G(zD) and G(zG) are one 2B-row launch pair."""
@@ -54,7 +55,9 @@ def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather
     # "dwp": both generator weight gradients as one launch (second GEMM: dW1, [HID, Z])
     g_dw = [("dwp", B, HID, IMG)] if pair_dw else [("dw", B, HID, IMG), ("dw", B, Z, HID)]
     return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [(dw1, 2 * B, IMG, HID)] +
-            [("fwd", B, IMG, HID)] + g_head + [("dx", B, IMG, HID), ("dx", B, HID, IMG)] + g_dw)
+            [("fwd", B, IMG, HID)] + g_head +
+            # "dxh": the generator-mode head's scalar workgroup (loss + tick) rides in this launch
+            [("dxh" if (fused_head and ride_head_dx) else "dx", B, IMG, HID), ("dx", B, HID, IMG)] + g_dw)
 
 
 def gemm_variant(kind, M, K, N):
@@ -64,7 +67,7 @@ def gemm_variant(kind, M, K, N):
     count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
     if kind in ("fwd", "fwdg"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
-    elif kind == "dx":
+    elif kind in ("dx", "dxh"):
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
     else:
         mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
@@ -88,6 +91,9 @@ def gemm_variant(kind, M, K, N):
     b = lambda v: "true" if v else "false"
     if kind == "dwh":
         return "gemm16_dw_head_kernel<false, %d, %s, %d, %d>" % (g, b(xv), mi, ni)
+    if kind == "dxh":
+        assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
+        return "gemm16_dx_head_kernel<%d, %d, %d>" % (g, mi, ni)
     if kind == "fwdg":
         assert vec and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
@@ -118,7 +124,7 @@ def _holder(N, K, dev):
 
 
 def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True,
-                          ride_gather=True, pair_dw=True):
+                          ride_gather=True, pair_dw=True, ride_head_dx=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -127,7 +133,8 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
     out = {}
     st = ops.stream_ptr()
     data = idx = xr = None
-    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather, pair_dw):
+    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather, pair_dw,
+                                     ride_head_dx):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -145,6 +152,13 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
                 idx = torch.randint(0, N_TRAIN, (B,), device=dev)
                 xr = torch.empty(B, IMG, device=dev)
             fn = lambda: ops.linear_fwd_gather(x, W, b, y, "relu", data, idx, xr, stream=st)
+        elif kind == "dxh":
+            L2 = _holder(1, N, dev)
+            Hh = torch.relu(torch.randn(M, N, device=dev))
+            dS, rl, lo = torch.randn(M, device=dev) / M, torch.rand(M, device=dev), torch.zeros(1, device=dev)
+            head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
+                        inv_b=1.0 / M, B=M, gen_mode=True)
+            fn = lambda: ops.linear_bwd_dx_head(dA, W, dX, head, below=x, epi="relu", stream=st)
         elif kind == "dwp":
             L2, L1 = _holder(N, K, dev), _holder(K, Z, dev)
             dH2, zz = torch.randn(M, K, device=dev), torch.randn(M, Z, device=dev)
@@ -307,7 +321,8 @@ def main():
         kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
                                    group_head=eng.group_head and eng._adam_in_epilogue("D"),
                                    ride_gather=eng._gather_rides(),
-                                   pair_dw=eng.pair_dw and eng._adam_in_epilogue("G"))
+                                   pair_dw=eng.pair_dw and eng._adam_in_epilogue("G"),
+                                   ride_head_dx=eng.ride_head_dx and not eng.head_final)
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         log('isolated kernel timing done')

@@ -69,6 +69,7 @@ struct GemmP {
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
+    int adam_prefetch;        // load (p, m, v) + schedule scalars at kernel start (GM_ADAM_PREFETCH)
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
     float add_scale;
@@ -150,9 +151,15 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
 }
 
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
+// Adam state of the one output element a thread owns, loaded at kernel start so that the epilogue
+// does not pay the ctr -> schedule -> (p, m, v) chain of dependent round trips after the reduction.
+struct AdamPre { float P, M, V; };
+
 template <int MODE, int WAVES, int ROWS = 32>
 __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
-                                                 int n0) {
+                                                 int n0, bool has_pre = false,
+                                                 AdamPre pre = AdamPre{0.f, 0.f, 0.f},
+                                                 float pre_step = 0.f, float pre_bc2 = 0.f) {
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
     const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
@@ -186,13 +193,18 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
         if (p.adam.enabled) {
             // optimizer fused into the gradient epilogue: every gradient element is produced by
             // exactly one thread, so Adam can run here and the separate launch disappears
-            const int64_t si = gm_slot_index(p.adam.sched_slot);
-            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
             const int64_t o = is_b ? (int64_t)m : ((int64_t)m * p.ldc + n);
             float* pp = (is_b ? p.adam.pb : p.adam.pW) + o;
             float* mm = (is_b ? p.adam.mb : p.adam.mW) + o;
             float* vv = (is_b ? p.adam.vb : p.adam.vW) + o;
-            float P = *pp, M = *mm, V = *vv;
+            float step_size, bc2_sqrt, P, M, V;
+            if (has_pre) {
+                step_size = pre_step; bc2_sqrt = pre_bc2; P = pre.P; M = pre.M; V = pre.V;
+            } else {
+                const int64_t si = gm_slot_index(p.adam.sched_slot);
+                step_size = p.adam.sched[2 * si]; bc2_sqrt = p.adam.sched[2 * si + 1];
+                P = *pp; M = *mm; V = *vv;
+            }
             adam_update(P, v, M, V, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
                         p.adam.eps, p.adam.wd, p.adam.clamp);
             *pp = P; *mm = M; *vv = V;
@@ -370,6 +382,34 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
     };
 
+    // Adam in the epilogue: fetch the schedule scalars and this thread's (p, m, v) now
+    constexpr int NBLK = ((MI + 1) / 2) * (NI / 2);
+    AdamPre pre[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) pre[i] = AdamPre{0.f, 0.f, 0.f};
+    float pre_step = 0.f, pre_bc2 = 0.f;
+    const bool use_pre = (MODE == MODE_DW) && WAVES == 16 && p.adam.enabled && p.adam_prefetch;
+    if (MODE == MODE_DW && use_pre) {
+        const int64_t si = gm_slot_index(p.adam.sched_slot);
+        pre_step = p.adam.sched[2 * si]; pre_bc2 = p.adam.sched[2 * si + 1];
+#pragma unroll
+        for (int bm = 0; bm < (MI + 1) / 2; ++bm)
+#pragma unroll
+            for (int bn = 0; bn < NI / 2; ++bn) {
+                const int row = t >> 5;
+                const int m = m0 + 32 * bm + row, n = n0 + 32 * bn + (t & 31);
+                // branch-free: out-of-tile threads read a clamped (valid) element and never use it
+                const int mc = min(m, p.M - 1), nc = min(n, p.N - 1);
+                const bool is_b = (nc == p.n_real);
+                const int64_t o = is_b ? (int64_t)mc : ((int64_t)mc * p.ldc + nc);
+                AdamPre v;
+                v.P = (is_b ? p.adam.pb : p.adam.pW)[o];
+                v.M = (is_b ? p.adam.mb : p.adam.mW)[o];
+                v.V = (is_b ? p.adam.vb : p.adam.vW)[o];
+                pre[bm * (NI / 2) + bn] = v;
+            }
+    }
+
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -430,7 +470,9 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 }
             }
             __syncthreads();
-            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
+            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn,
+                                                              use_pre, pre[bm * (NI / 2) + bn],
+                                                              pre_step, pre_bc2);
         }
 }
 
@@ -444,16 +486,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <bool VEC, int G, bool XV, int MI, int NI>
-__global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
-                                                              int hblocks) {
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI>
+__device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
+                                                 int hblocks) {
     __shared__ float red[16 * 32 * 32];
     if ((int)blockIdx.y < hrows) {                           // workgroup-uniform
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (bid < hblocks) head_bwd_body(hp, bid);
         return;
     }
-    gemm16_body<MODE_DW, VEC, 16, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y - hrows);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y - hrows);
+}
+
+template <bool VEC, int G, bool XV, int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
+                                                              int hblocks) {
+    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI>(p, hp, hrows, hblocks);
+}
+
+// The generator step's dX GEMM carrying the one scalar workgroup of the head (loss + tick): the
+// generator-mode head_bwd has nothing else to do once head_fwd_loss wrote dH.
+template <int G, int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_dx_head_kernel(GemmP p, HeadBwdP hp, int hrows,
+                                                              int hblocks) {
+    gemm16_with_head<MODE_DX, true, G, true, MI, NI>(p, hp, hrows, hblocks);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -506,6 +562,11 @@ template <int MODE>
 int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const Rider& rider = Rider()) {
     const HeadBwdP* head = rider.head;
     GemmP p = p_in;
+    {
+        static int pf = -1;
+        if (pf < 0) { const char* e = getenv("GM_ADAM_PREFETCH"); pf = e ? atoi(e) : 1; }
+        p.adam_prefetch = pf;
+    }
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
@@ -591,6 +652,19 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 GM_LAUNCH_RET();
             }
         }
+        if constexpr (MODE == MODE_DX) {
+            if (head && vec && xv && !use8 && (wide == 0 || wide == 3)) {
+                const int hblocks = gm_head_bwd_blocks(*head);
+                const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
+                const dim3 hgrid(grid.x, grid.y + hrows);
+#define GM_LXH(GG) do {                                                                            \
+        if (wide == 3) hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
+                if (g16 == 1) GM_LXH(1); else if (g16 == 2) GM_LXH(2); else GM_LXH(4);
+#undef GM_LXH
+                GM_LAUNCH_RET();
+            }
+        }
         if (head) {      // this configuration cannot carry the head workgroups: separate launch
             hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
         }
@@ -613,7 +687,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
-                const GemmP& pb = *rider.pair;
+                GemmP pb = *rider.pair;
+                pb.adam_prefetch = p.adam_prefetch;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
@@ -713,7 +788,20 @@ extern "C" int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, g
 
 static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
                    const float* below, int64_t ld_below, int M, int K, int N, int epi,
-                   const float* add, int64_t ldadd, float add_scale);
+                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head = nullptr);
+
+extern "C" int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W,
+                                     float* dX, int64_t ldx, const float* below, int64_t ld_below,
+                                     int M, int K, int N, int epi, const gm_head_bwd_args* head) {
+    GM_CHECK_ARG(head);
+    // the head workgroups only read dS / rowloss / H: none of them may be this GEMM's output
+    GM_CHECK_ARG((const float*)dX != head->H && (const float*)dX != head->dS &&
+                 (const float*)dX != head->rowloss && dX != head->dH);
+    HeadBwdP hp{};
+    const int rc = gm_head_from_args(*head, &hp);
+    if (rc) return rc;
+    return dx_impl(stream, dA, lda, W, dX, ldx, below, ld_below, M, K, N, epi, nullptr, 0, 0.f, &hp);
+}
 
 extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, const float* W,
                                 float* dX, int64_t ldx, const float* below, int64_t ld_below,
@@ -731,7 +819,7 @@ extern "C" int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, 
 
 static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
                    const float* below, int64_t ld_below, int M, int K, int N, int epi,
-                   const float* add, int64_t ldadd, float add_scale) {
+                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head) {
     GM_CHECK_ARG(dA && W && dX && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GM_CHECK_ARG(epi == GM_ACT_ID || (below && ld_below >= K));
     GemmP p{};
@@ -742,7 +830,9 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
     p.a_slot = no_slot(); p.b_slot = no_slot();
     const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0);
     const bool xvec = aligned16(W) && (K % 4 == 0);
-    return launch<MODE_DX>((hipStream_t)stream, p, vec, xvec);
+    Rider r;
+    r.head = head;
+    return launch<MODE_DX>((hipStream_t)stream, p, vec, xvec, r);
 }
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,

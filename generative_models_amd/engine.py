@@ -161,7 +161,9 @@ class GANEngine:
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
-        self.head_final = os.environ.get("GM_HEAD_FINAL", "1") != "0"
+        # measured slower (agent-scope fences in every workgroup; profiles/r01_experiments.md)
+        self.head_final = os.environ.get("GM_HEAD_FINAL", "0") != "0"
+        self.ride_head_dx = os.environ.get("GM_RIDE_HEAD_DX", "1") != "0"
         self.group_head = os.environ.get("GM_GROUP_HEAD", "1") != "0"
         self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
@@ -463,6 +465,14 @@ class GANEngine:
             else:
                 of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
                                  self.inv_b, None, S2, dS, self.rowloss, dH=dHd, stream=st)
+                if self.ride_head_dx and not self.dag:
+                    # the head's one scalar workgroup (loss + tick) rides in the dX launch
+                    ops.linear_bwd_dx_head(
+                        dHd, D1.W, self.dXg,
+                        dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossG,
+                             loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
+                        below=Xg, epi="sigmoid", M=Bl, stream=st)
+                    return
                 of.head_bwd(Hd, dS, D2.W, self.rowloss, None, None, None, self.lossG, loss_slot,
                             self.inv_b, True, Bl, tick=tick, stream=st)
         else:

@@ -124,28 +124,54 @@ def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_
     _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
 
 
+def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
+    """gm_head_bwd_args from dict(H, dS, lin (head _Linear), rowloss, loss_out, loss_slot, inv_b, B,
+    gen_mode=False, adam=None (dict(sched, sched_slot, clamp)), tick=None, grads=True)."""
+    from ._lib import HeadBwdArgs
+    hl, ha, H = head["lin"], head.get("adam"), head["H"]
+    gen = bool(head.get("gen_mode", False))
+    a = HeadBwdArgs()
+    a.H, a.ldh, a.dS = H.data_ptr(), _ld(H), head["dS"].data_ptr()
+    a.w2, a.b2, a.rowloss = hl.W.data_ptr(), hl.b.data_ptr(), head["rowloss"].data_ptr()
+    a.dH, a.lddh = None, 0                      # written by head_fwd_loss
+    if not gen:
+        a.gw2, a.gb2 = hl.gW.data_ptr(), hl.gb.data_ptr()
+    a.loss_out, a.loss_slot = head["loss_out"].data_ptr(), head["loss_slot"]
+    a.inv_b, a.gen_mode, a.B, a.Hd = head["inv_b"], 1 if gen else 0, head["B"], H.shape[1]
+    a.with_adam = 1 if ha is not None else 0
+    if ha is not None:
+        a.mW, a.vW, a.mb, a.vb = hl.mW.data_ptr(), hl.vW.data_ptr(), hl.mb.data_ptr(), hl.vb.data_ptr()
+        a.sched, a.sched_slot = ha["sched"].data_ptr(), ha["sched_slot"]
+        a.clamp = ha.get("clamp", 0.0)
+    a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, 0.0
+    tick = head.get("tick")
+    a.tick = tick.data_ptr() if tick is not None else None
+    return a
+
+
+def linear_bwd_dx_head(dA, W, dX, head, below=None, epi="id", M=None, stream=None):
+    """linear_bwd_dx with the head's backward workgroups riding in the launch (generator step: the
+    scalar workgroup that writes the loss and ticks).  head: see _head_args."""
+    import ctypes
+    N, K = W.shape
+    M = dA.shape[0] if M is None else M
+    a = _head_args(head)
+    _lib.call("gm_linear_bwd_dx_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+              _chk(W, "W").data_ptr(), _chk(dX, "dX").data_ptr(), _ld(dX),
+              below.data_ptr() if below is not None else None, _ld(below) if below is not None else 0,
+              M, K, N, ACT[epi] if not isinstance(epi, int) else epi, ctypes.byref(a))
+    return dX
+
+
 def linear_bwd_dw_adam_head(dA, X, lin, adam, head, M=None, x_slot=NO_SLOT, betas=(0.9, 0.999),
                             eps=1e-8, weight_decay=0.0, stream=None):
     """linear_bwd_dw_adam and the critic head's backward (ops_fused.head_bwd with Adam on the head
     layer) as ONE launch.  head: dict(H, dS, lin (head _Linear), rowloss, loss_out, loss_slot,
     inv_b, B, adam (dict(sched, sched_slot, clamp))); dH must already be written by head_fwd_loss."""
     import ctypes
-    from ._lib import HeadBwdArgs
     N, K = lin.gW.shape
     M = dA.shape[0] if M is None else M
-    hl, ha, H = head["lin"], head["adam"], head["H"]
-    a = HeadBwdArgs()
-    a.H, a.ldh, a.dS = H.data_ptr(), _ld(H), head["dS"].data_ptr()
-    a.w2, a.b2, a.rowloss = hl.W.data_ptr(), hl.b.data_ptr(), head["rowloss"].data_ptr()
-    a.dH, a.lddh = None, 0
-    a.gw2, a.gb2 = hl.gW.data_ptr(), hl.gb.data_ptr()
-    a.loss_out, a.loss_slot = head["loss_out"].data_ptr(), head["loss_slot"]
-    a.inv_b, a.gen_mode, a.B, a.Hd = head["inv_b"], 0, head["B"], H.shape[1]
-    a.with_adam = 1
-    a.mW, a.vW, a.mb, a.vb = hl.mW.data_ptr(), hl.vW.data_ptr(), hl.mb.data_ptr(), hl.vb.data_ptr()
-    a.sched, a.sched_slot = ha["sched"].data_ptr(), ha["sched_slot"]
-    a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, 0.0
-    a.clamp, a.tick = ha.get("clamp", 0.0), None
+    a = _head_args(head, betas, eps)
     _lib.call("gm_linear_bwd_dw_adam_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
               _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
               lin.gb.data_ptr(), M, K, N, lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(),

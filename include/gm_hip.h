@@ -225,6 +225,11 @@ int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const
                                const float* sched, gm_slot sched_slot, double beta1, double beta2,
                                double eps, double weight_decay, float clamp,
                                const gm_head_bwd_args* head);
+/* gm_linear_bwd_dx carrying the head's backward workgroups (generator step: the single scalar
+ * workgroup that writes the loss and ticks the iteration counter). */
+int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
+                          int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
+                          int epi, const gm_head_bwd_args* head);
 /* gm_linear_fwd and gm_gather_rows as ONE launch: the gather workgroups ride in the GEMM's grid.  The
  * gather only reads the index ring and the resident dataset, so any forward launch that does not
  * touch `out` can carry it (the engine uses the generator's first layer, ns_gan.py:44 + :222-226). */

@@ -524,3 +524,31 @@ def test_dw_adam_pair_in_one_launch(B, H, I, Z):
     for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq")):
         assert torch.equal(x, y), name
     assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
+
+
+@pytest.mark.parametrize("B,I,Hd", [(256, 784, 400), (24, 36, 20), (33, 30, 17)])
+def test_dx_with_scalar_head_riding(B, I, Hd):
+    """gm_linear_bwd_dx_head == gm_head_bwd (generator mode: loss scalar + tick) followed by
+    gm_linear_bwd_dx, bit for bit; the counter advances exactly once per launch."""
+    from types import SimpleNamespace
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(B)
+    H = torch.relu(torch.randn(B, Hd)).to(DEV)
+    W1 = (torch.randn(Hd, I) / I ** 0.5).to(DEV)
+    Xg = torch.rand(B, I).to(DEV)
+    L2 = SimpleNamespace(W=(torch.randn(1, Hd) / Hd ** 0.5).to(DEV), b=torch.randn(1).to(DEV))
+    S = torch.empty(B, device=DEV); dS = torch.empty(B, device=DEV); rl = torch.empty(B, device=DEV)
+    dH = torch.empty(B, Hd, device=DEV)
+    of.head_fwd_loss("ns", True, H, L2.W, L2.b, "sigmoid", B, [], 1.0 / B, None, S, dS, rl, dH=dH)
+    ref_loss = torch.zeros(3, device=DEV); dX_ref = torch.empty(B, I, device=DEV)
+    of.head_bwd(H, dS, L2.W, rl, None, None, None, ref_loss, ops.slot(0, 0, 1, 0, 1), 1.0 / B, True, B)
+    ops.linear_bwd_dx(dH, W1, dX_ref, below=Xg, epi="sigmoid")
+    ctr = torch.ones(1, dtype=torch.int64, device=DEV)
+    loss = torch.zeros(3, device=DEV); dX = torch.empty(B, I, device=DEV)
+    ops.linear_bwd_dx_head(dH, W1, dX,
+                           dict(H=H, dS=dS, lin=L2, rowloss=rl, loss_out=loss,
+                                loss_slot=ops.slot(ctr.data_ptr(), 1, 0, 3, 1), inv_b=1.0 / B, B=B,
+                                gen_mode=True, tick=ctr), below=Xg, epi="sigmoid")
+    torch.cuda.synchronize()
+    assert ctr.item() == 2
+    assert torch.equal(dX, dX_ref) and torch.equal(loss, ref_loss) and loss[1].item() != 0.0
