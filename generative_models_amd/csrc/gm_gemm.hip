@@ -69,7 +69,6 @@ struct GemmP {
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
-    int adam_prefetch;        // load (p, m, v) + schedule scalars at kernel start (GM_ADAM_PREFETCH)
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
     float add_scale;
@@ -151,15 +150,9 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
 }
 
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
-// Adam state of the one output element a thread owns, loaded at kernel start so that the epilogue
-// does not pay the ctr -> schedule -> (p, m, v) chain of dependent round trips after the reduction.
-struct AdamPre { float P, M, V; };
-
 template <int MODE, int WAVES, int ROWS = 32>
 __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
-                                                 int n0, bool has_pre = false,
-                                                 AdamPre pre = AdamPre{0.f, 0.f, 0.f},
-                                                 float pre_step = 0.f, float pre_bc2 = 0.f) {
+                                                 int n0) {
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
     const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
@@ -197,14 +190,12 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
             float* pp = (is_b ? p.adam.pb : p.adam.pW) + o;
             float* mm = (is_b ? p.adam.mb : p.adam.mW) + o;
             float* vv = (is_b ? p.adam.vb : p.adam.vW) + o;
-            float step_size, bc2_sqrt, P, M, V;
-            if (has_pre) {
-                step_size = pre_step; bc2_sqrt = pre_bc2; P = pre.P; M = pre.M; V = pre.V;
-            } else {
-                const int64_t si = gm_slot_index(p.adam.sched_slot);
-                step_size = p.adam.sched[2 * si]; bc2_sqrt = p.adam.sched[2 * si + 1];
-                P = *pp; M = *mm; V = *vv;
-            }
+            // (prefetching p/m/v or the schedule scalars at kernel start was measured SLOWER: vmcnt
+            // and lgkmcnt retire in order, so the early requests hold back the operand loads --
+            // profiles/r01_experiments.md)
+            const int64_t si = gm_slot_index(p.adam.sched_slot);
+            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
+            float P = *pp, M = *mm, V = *vv;
             adam_update(P, v, M, V, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
                         p.adam.eps, p.adam.wd, p.adam.clamp);
             *pp = P; *mm = M; *vv = V;
@@ -382,34 +373,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
     };
 
-    // Adam in the epilogue: fetch the schedule scalars and this thread's (p, m, v) now
-    constexpr int NBLK = ((MI + 1) / 2) * (NI / 2);
-    AdamPre pre[NBLK];
-#pragma unroll
-    for (int i = 0; i < NBLK; ++i) pre[i] = AdamPre{0.f, 0.f, 0.f};
-    float pre_step = 0.f, pre_bc2 = 0.f;
-    const bool use_pre = (MODE == MODE_DW) && WAVES == 16 && p.adam.enabled && p.adam_prefetch;
-    if (MODE == MODE_DW && use_pre) {
-        const int64_t si = gm_slot_index(p.adam.sched_slot);
-        pre_step = p.adam.sched[2 * si]; pre_bc2 = p.adam.sched[2 * si + 1];
-#pragma unroll
-        for (int bm = 0; bm < (MI + 1) / 2; ++bm)
-#pragma unroll
-            for (int bn = 0; bn < NI / 2; ++bn) {
-                const int row = t >> 5;
-                const int m = m0 + 32 * bm + row, n = n0 + 32 * bn + (t & 31);
-                // branch-free: out-of-tile threads read a clamped (valid) element and never use it
-                const int mc = min(m, p.M - 1), nc = min(n, p.N - 1);
-                const bool is_b = (nc == p.n_real);
-                const int64_t o = is_b ? (int64_t)mc : ((int64_t)mc * p.ldc + nc);
-                AdamPre v;
-                v.P = (is_b ? p.adam.pb : p.adam.pW)[o];
-                v.M = (is_b ? p.adam.mb : p.adam.mW)[o];
-                v.V = (is_b ? p.adam.vb : p.adam.vW)[o];
-                pre[bm * (NI / 2) + bn] = v;
-            }
-    }
-
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -470,9 +433,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 }
             }
             __syncthreads();
-            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn,
-                                                              use_pre, pre[bm * (NI / 2) + bn],
-                                                              pre_step, pre_bc2);
+            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
         }
 }
 
@@ -562,11 +523,6 @@ template <int MODE>
 int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const Rider& rider = Rider()) {
     const HeadBwdP* head = rider.head;
     GemmP p = p_in;
-    {
-        static int pf = -1;
-        if (pf < 0) { const char* e = getenv("GM_ADAM_PREFETCH"); pf = e ? atoi(e) : 1; }
-        p.adam_prefetch = pf;
-    }
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
@@ -687,8 +643,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
-                GemmP pb = *rider.pair;
-                pb.adam_prefetch = p.adam_prefetch;
+                const GemmP& pb = *rider.pair;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
