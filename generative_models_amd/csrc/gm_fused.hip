@@ -270,10 +270,32 @@ struct HeadP {
     float* loss_out; gm_slot loss_slot; unsigned int* done; int64_t* tick;
 };
 
+// One wave per row.  VEC4 (Hd % 4 == 0, 16-byte aligned rows; Hd <= 512): each lane keeps its one or
+// two float4 of h and w2 in registers -- one round of 16-byte loads for the dot product, and the dH
+// row is written from those registers without touching h again.
+template <bool VEC4>
 __device__ __forceinline__ void head_row(const HeadP& p, int r, int lane) {
     const float* h = p.H + (int64_t)r * p.ldh;
     float acc = 0.f;
-    for (int i = lane; i < p.Hd; i += 64) acc = fmaf(h[i], p.w2[i], acc);
+    float4 hv[2], wv[2];
+    if (VEC4) {
+        const int n4 = p.Hd >> 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = min(lane + 64 * j, n4 - 1);                   // clamped: branch-free loads
+            hv[j] = reinterpret_cast<const float4*>(h)[i4];
+            wv[j] = reinterpret_cast<const float4*>(p.w2)[i4];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (lane + 64 * j < n4) {
+                acc = fmaf(hv[j].x, wv[j].x, acc); acc = fmaf(hv[j].y, wv[j].y, acc);
+                acc = fmaf(hv[j].z, wv[j].z, acc); acc = fmaf(hv[j].w, wv[j].w, acc);
+            }
+        }
+    } else {
+        for (int i = lane; i < p.Hd; i += 64) acc = fmaf(h[i], p.w2[i], acc);
+    }
     acc = gm_wave_sum(acc);
     float a2 = acc + p.b2[0];
     float s = a2;
@@ -297,7 +319,21 @@ __device__ __forceinline__ void head_row(const HeadP& p, int r, int lane) {
         // backward head kernel only reads h once more for the column sums and writes nothing wide
         ds = __shfl(ds, 0, 64);
         float* o = p.dH + (int64_t)r * p.lddh;
-        for (int i = lane; i < p.Hd; i += 64) o[i] = (h[i] > 0.f) ? ds * p.w2[i] : 0.f;
+        if (VEC4) {
+            const int n4 = p.Hd >> 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i4 = lane + 64 * j;
+                if (i4 < n4) {
+                    float4 d;
+                    d.x = (hv[j].x > 0.f) ? ds * wv[j].x : 0.f; d.y = (hv[j].y > 0.f) ? ds * wv[j].y : 0.f;
+                    d.z = (hv[j].z > 0.f) ? ds * wv[j].z : 0.f; d.w = (hv[j].w > 0.f) ? ds * wv[j].w : 0.f;
+                    reinterpret_cast<float4*>(o)[i4] = d;
+                }
+            }
+        } else {
+            for (int i = lane; i < p.Hd; i += 64) o[i] = (h[i] > 0.f) ? ds * p.w2[i] : 0.f;
+        }
     }
 }
 
@@ -333,10 +369,13 @@ __device__ void head_finalize(const HeadP& p) {
     }
 }
 
+// Launched with one wave per workgroup (R workgroups spread over all CUs: the kernel is a chain of
+// dependent latencies, not bandwidth) -- or with 4 waves when the last-workgroup finalisation is on.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void head_fwd_loss_kernel(HeadP p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    if (r < p.R) head_row(p, r, lane);
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r < p.R) head_row<VEC4>(p, r, lane);
     if (p.loss_out) head_finalize(p);           // kernel-argument uniform: every thread takes it
 }
 
@@ -383,7 +422,13 @@ static int head_fwd_impl(void* stream, int variant, int gen_mode, const float* H
     for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
     p.pen = pen; p.S = S; p.dS = dS; p.rowloss = rowloss; p.dH = dH; p.lddh = lddh;
     p.loss_out = loss_out; p.loss_slot = loss_slot; p.done = done; p.tick = tick;
-    hipLaunchKernelGGL(head_fwd_loss_kernel, dim3((p.R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    const bool vec4 = (Hd % 4 == 0) && Hd <= 512 && (ldh % 4 == 0) && (!dH || lddh % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(H) | reinterpret_cast<uintptr_t>(w2) |
+                        reinterpret_cast<uintptr_t>(dH)) & 15) == 0;
+    const int wpb = loss_out ? 4 : 1;                      // the finalisation sums with 256 threads
+    const dim3 grid((p.R + wpb - 1) / wpb), block(64 * wpb);
+    if (vec4) hipLaunchKernelGGL(head_fwd_loss_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(head_fwd_loss_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }
 

@@ -3,10 +3,9 @@
 # rocprofv3 kernel-trace stats of the bench command, and the two PMC passes (each in its own run).
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/final_pytest.log
+timeout 600 python -m pytest tests -m gpu -q > gpurun_out/final_pytest.log 2>&1; grep -E "passed|failed|error" gpurun_out/final_pytest.log | tail -3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee gpurun_out/final_smoke.log
 GM_BENCH_VERBOSE=1 timeout 400 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$?"; cat gpurun_out/bench_final.json
-for gi in 16 32; do echo "== GM_GRAPH_ITERS=$gi"; GM_GRAPH_ITERS=$gi timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; done
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o ns -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_final.log; echo "prof rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
