@@ -124,7 +124,7 @@ def _holder(N, K, dev):
 
 
 def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True,
-                          ride_gather=True, pair_dw=True, ride_head_dx=True):
+                          ride_gather=True, pair_dw=True, ride_head_dx=True, fused_adam=True):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -163,7 +163,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             L2, L1 = _holder(N, K, dev), _holder(K, Z, dev)
             dH2, zz = torch.randn(M, K, device=dev), torch.randn(M, Z, device=dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
-            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
             fn = lambda: ops.linear_bwd_dw_adam_pair(dict(dA=dA, X=x, lin=L2, adam=ad),
                                                      dict(dA=dH2, X=zz, lin=L1, adam=ad), stream=st)
             flop += 2.0 * M * Z * K
@@ -174,7 +174,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             Hh = torch.relu(torch.randn(M, N, device=dev))
             dS, rl, lo = torch.randn(M, device=dev) / M, torch.rand(M, device=dev), torch.zeros(1, device=dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
-            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
             head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
                         inv_b=2.0 / M, B=M // 2, adam=ad)
             fn = lambda: ops.linear_bwd_dw_adam_head(dA, x, L1, ad, head, stream=st)
@@ -182,7 +182,8 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             L1 = _holder(N, K, dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
             ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
-            fn = lambda: ops.linear_bwd_dw_adam(dA, x, L1, ad, stream=st)
+            fn = (lambda: ops.linear_bwd_dw_adam(dA, x, L1, ad, stream=st)) if fused_adam else \
+                (lambda: ops.linear_bwd_dw(dA, x, L1.gW, L1.gb, stream=st))
         fn()
         torch.cuda.synchronize()
         # capture `reps` back-to-back launches into one hipGraph so that the host-side launch
@@ -271,6 +272,14 @@ def main():
                      "%d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     pg = None
+    # diagnostic: GM_FORCE_DP=1 runs the data-parallel launch structure (segment graphs + RCCL
+    # all-reduces of the gradient buckets) on ONE rank, to price its host/launch overhead
+    force_dp = world == 1 and os.environ.get("GM_FORCE_DP") == "1"
+    if force_dp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -291,6 +300,7 @@ def main():
     eng = gm_engine.GANEngine("ns", trainer.model, data, B_global, dev,
                               use_graph=not args.no_graph,
                               world_size=world, rank=rank)
+    eng.force_segments = force_dp
     W, K = args.warmup, args.steps
     log('engine built')
     eng.configure(W + K, 2e-4, 2e-4, 1)
@@ -319,9 +329,9 @@ def main():
 
     if rank == 0:
         kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
-                                   group_head=eng.group_head and eng._adam_in_epilogue("D"),
+                                   group_head=eng.group_head,
                                    ride_gather=eng._gather_rides(),
-                                   pair_dw=eng.pair_dw and eng._adam_in_epilogue("G"),
+                                   pair_dw=eng.pair_dw, fused_adam=eng._adam_in_epilogue("G"),
                                    ride_head_dx=eng.ride_head_dx and not eng.head_final)
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
@@ -350,7 +360,7 @@ def main():
                                    "784-400-20 MLPs, N=50000 synthetic Bernoulli images, parity-mode "
                                    "RNG protocol, Adam 2e-4, D_steps=1",
                        "global_batch": B_global,
-                       "launch": ("hipGraph/iteration" if world == 1 else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
+                       "launch": ("hipGraph/iteration" if (world == 1 and not force_dp) else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world},
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
@@ -363,6 +373,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
+    if force_dp:
+        torch.distributed.destroy_process_group()
     if world > 1:
         torch.distributed.barrier()          # rank 0 may still be in its reporting section
         torch.distributed.destroy_process_group()

@@ -587,7 +587,9 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         // each one's A-fragment loads and MFMA chain (the critic pass over B = 256 rows: 104 tiles)
         static int narrow_on = -1;
         if (narrow_on < 0) { const char* e = getenv("GM_NARROW_TILES"); narrow_on = e ? atoi(e) : 1; }
-        if (narrow_on && !use8 && !wide && tm * tn <= 128 && p.M > 16) wide = 3;   // 3: 16x32
+        static int narrow_max = -1;
+        if (narrow_max < 0) { const char* e = getenv("GM_NARROW_MAX_TILES"); narrow_max = e ? atoi(e) : 128; }
+        if (narrow_on && !use8 && !wide && tm * tn <= narrow_max && p.M > 16) wide = 3;   // 3: 16x32
         if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
         if (wide == 3) grid = dim3(tn, (p.M + 15) / 16);
@@ -825,22 +827,29 @@ extern "C" int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t
                                           const float* sched, gm_slot sched_slot, double beta1,
                                           double beta2, double eps, double weight_decay, float clamp,
                                           const gm_head_bwd_args* head) {
-    GM_CHECK_ARG(db && pW && mW && vW && pb && mb && vb && sched && head);
+    GM_CHECK_ARG(head);
+    // sched == NULL: plain gradients (data-parallel runs all-reduce before the optimizer step)
+    GM_CHECK_ARG(!sched || (db && pW && mW && vW && pb && mb && vb));
     // the head may update (w2, b2) and writes gw2/gb2/loss: none of it may alias the GEMM's operands
-    GM_CHECK_ARG(head->w2 != pW && head->gw2 != dW);
+    GM_CHECK_ARG((const float*)head->w2 != pW || !pW);
+    GM_CHECK_ARG(head->gw2 != dW);
     HeadBwdP hp{};
     const int rc = gm_head_from_args(*head, &hp);
     if (rc) return rc;
     gm_adam_epi a{};
-    a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
-    a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
-    a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
-    a.enabled = 1;
-    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, &a, &hp);
+    if (sched) {
+        a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
+        a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+        a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
+        a.enabled = 1;
+    }
+    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp);
 }
 
 static int dw_adam_fill(const gm_dw_adam_args& a, GemmP* p, bool* xvec) {
-    GM_CHECK_ARG(a.db && a.pW && a.mW && a.vW && a.pb && a.mb && a.vb && a.sched);
+    if (!a.sched)            // plain gradient (no optimizer step in the epilogue)
+        return dw_fill(a.dA, a.lda, a.X, a.ldx, a.x_slot, a.dW, a.db, a.M, a.K, a.N, 0, nullptr, p, xvec);
+    GM_CHECK_ARG(a.db && a.pW && a.mW && a.vW && a.pb && a.mb && a.vb);
     gm_adam_epi e{};
     e.pW = a.pW; e.mW = a.mW; e.vW = a.vW; e.pb = a.pb; e.mb = a.mb; e.vb = a.vb; e.sched = a.sched;
     e.sched_slot = a.sched_slot; e.omb1 = (float)(1.0 - a.beta1); e.b2 = (float)a.beta2;
@@ -853,9 +862,10 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
                                           const gm_dw_adam_args* second) {
     GM_CHECK_ARG(first && second);
     // neither may consume what the other produces or updates
-    GM_CHECK_ARG(first->dW != second->dW && first->pW != second->pW);
-    GM_CHECK_ARG((const float*)first->pW != second->dA && (const float*)first->pW != second->X);
-    GM_CHECK_ARG((const float*)second->pW != first->dA && (const float*)second->pW != first->X);
+    GM_CHECK_ARG(first->dW != second->dW && (first->pW != second->pW || !first->pW));
+    GM_CHECK_ARG(!first->pW || ((const float*)first->pW != second->dA && (const float*)first->pW != second->X));
+    GM_CHECK_ARG(!second->pW || ((const float*)second->pW != first->dA && (const float*)second->pW != first->X));
+    GM_CHECK_ARG(first->dW != second->dA && first->dW != second->X && second->dW != first->dA && second->dW != first->X);
     GemmP pa{}, pb{};
     bool xa = false, xb = false;
     int rc = dw_adam_fill(*first, &pa, &xa);

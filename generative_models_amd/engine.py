@@ -349,8 +349,9 @@ class GANEngine:
             of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
                              self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
             adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            if adam is not None and self.group_head:
-                # head backward + first-layer weight gradient (+ both Adam steps): ONE launch
+            if self.group_head and not self.dag:
+                # head backward + first-layer weight gradient (+ both Adam steps when they are
+                # fused: one GPU, nothing accumulates into these gradients later): ONE launch
                 ops.linear_bwd_dw_adam_head(
                     dHd, X2, D1, adam,
                     dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
@@ -516,9 +517,9 @@ class GANEngine:
         self._G_gen(st, it)
         self._G_critic(st, it)
         self._G_dh(st, it)                          # reads G2.W before _G_dw2 may update it
-        if self.pair_dw and self._adam_in_epilogue("G"):
-            # both weight gradients of the generator (+ their Adam steps): ONE launch
-            adam = self._adam_args("G", self._G_sched_slot(it))
+        if self.pair_dw and not self.dag:
+            # both weight gradients of the generator (+ their Adam steps on one GPU): ONE launch
+            adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
             zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
             zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
             ops.linear_bwd_dw_adam_pair(

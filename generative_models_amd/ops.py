@@ -105,11 +105,12 @@ def _dw_adam_args(dA, X, lin, adam, M, x_slot, betas, eps, weight_decay):
     a = DwAdamArgs()
     a.dA, a.lda, a.X, a.ldx, a.x_slot = _chk(dA, "dA").data_ptr(), _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot
     a.dW, a.db, a.M, a.K, a.N = lin.gW.data_ptr(), lin.gb.data_ptr(), (dA.shape[0] if M is None else M), K, N
-    a.pW, a.mW, a.vW = lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr()
-    a.pb, a.mb, a.vb = lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr()
-    a.sched, a.sched_slot = adam["sched"].data_ptr(), adam["sched_slot"]
+    if adam is not None:                        # None: plain gradients, no optimizer step
+        a.pW, a.mW, a.vW = lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr()
+        a.pb, a.mb, a.vb = lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr()
+        a.sched, a.sched_slot = adam["sched"].data_ptr(), adam["sched_slot"]
+        a.clamp = adam.get("clamp", 0.0)
     a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, weight_decay
-    a.clamp = adam.get("clamp", 0.0)
     return a
 
 
@@ -118,7 +119,7 @@ def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_
     """Two linear_bwd_dw_adam calls over the same batch rows as ONE launch.  first / second:
     dict(dA, X, lin, adam, M=None, x_slot=NO_SLOT)."""
     import ctypes
-    mk = lambda d: _dw_adam_args(d["dA"], d["X"], d["lin"], d["adam"], d.get("M"),
+    mk = lambda d: _dw_adam_args(d["dA"], d["X"], d["lin"], d.get("adam"), d.get("M"),
                                  d.get("x_slot", NO_SLOT), betas, eps, weight_decay)
     a, b = mk(first), mk(second)
     _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
@@ -172,6 +173,12 @@ def linear_bwd_dw_adam_head(dA, X, lin, adam, head, M=None, x_slot=NO_SLOT, beta
     N, K = lin.gW.shape
     M = dA.shape[0] if M is None else M
     a = _head_args(head, betas, eps)
+    if adam is None:                            # plain gradients (the head's dict has adam=None too)
+        _lib.call("gm_linear_bwd_dw_adam_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
+                  _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
+                  lin.gb.data_ptr(), M, K, N, None, None, None, None, None, None, None, NO_SLOT,
+                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a))
+        return
     _lib.call("gm_linear_bwd_dw_adam_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
               _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
               lin.gb.data_ptr(), M, K, N, lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(),

@@ -206,7 +206,9 @@ int gm_adam_scaled(void* stream, float* p, const float* g, float* m, float* v, i
 /* The critic head's backward and the first layer's weight gradient are independent once
  * gm_head_fwd_loss has written dH: this entry point runs gm_linear_bwd_dw_adam AND gm_head_bwd_fused
  * as ONE launch (the head workgroups ride in the GEMM's grid; 25 + 169 workgroups for the 784-400-1
- * critic at B = 256 -- one round of the 256 CUs).  `head` mirrors gm_head_bwd_fused's arguments. */
+ * critic at B = 256 -- one round of the 256 CUs).  `head` mirrors gm_head_bwd_fused's arguments.
+ * sched == NULL (and head->with_adam == 0): plain gradients, no optimizer step (data-parallel runs
+ * all-reduce the gradients first). */
 typedef struct gm_head_bwd_args {
     const float* H; int64_t ldh;
     const float* dS; float* w2; float* b2; const float* rowloss;
@@ -239,7 +241,8 @@ int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, gm_slot x_sl
                          float* out, int64_t ld_out, int B, int row_elems);
 /* Two gm_linear_bwd_dw_adam calls over the same batch rows as ONE launch (the generator step's two
  * weight gradients are independent once d loss / d hidden is known).  Falls back to two launches
- * when the pair cannot share a tile configuration. */
+ * when the pair cannot share a tile configuration.  sched == NULL in an argument block: plain
+ * gradient for that GEMM (no optimizer step). */
 typedef struct gm_dw_adam_args {
     const float* dA; int64_t lda; const float* X; int64_t ldx; gm_slot x_slot;
     float* dW; float* db; int M, K, N;
