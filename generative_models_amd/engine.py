@@ -908,6 +908,7 @@ class VAEEngine:
         self._bufB = None
         import os
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
+        self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))
 
     def _alloc(self, B):
@@ -957,16 +958,24 @@ class VAEEngine:
                 dw = lambda dA, X, lin: ops.linear_bwd_dw_adam(dA, X, lin, adam, M=b,
                                                                weight_decay=self.wd, stream=st)
             else:
+                adam = None
                 dw = lambda dA, X, lin: ops.linear_bwd_dw(dA, X, lin.gW, lin.gb, M=b, stream=st)
+            if self.pair_dw:
+                # weight gradients of two layers as ONE launch once both their inputs exist (the dX
+                # GEMMs that still read those weights are issued first)
+                dw2 = lambda a1, a2: ops.linear_bwd_dw_adam_pair(
+                    dict(dA=a1[0], X=a1[1], lin=a1[2], adam=adam, M=b),
+                    dict(dA=a2[0], X=a2[1], lin=a2[2], adam=adam, M=b),
+                    weight_decay=self.wd if adam is not None else 0.0, stream=st)
+            else:
+                dw2 = lambda a1, a2: (dw(*a1), dw(*a2))
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            dw(self.dA, self.Hdec, D2)
             ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
-            dw(self.dHdec, self.Zs, D1)
+            dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
             of.vae_reparam_bwd(self.ml, self.eps_ring.view(-1), self.dZ, self.dml, b, Z,
                                eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            dw(self.dml, self.He, ML)
-            dw(self.dHe, self.X, E1)
+            dw2((self.dml, self.He, ML), (self.dHe, self.X, E1))
             if not self.fuse_adam:
                 ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
                          weight_decay=self.wd, stream=st)
