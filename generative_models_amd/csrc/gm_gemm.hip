@@ -448,114 +448,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y);
 }
 
-// ------------------------------------------------------------------------------------------
-// Large problems (more than two rounds of 32x32 tiles, i.e. batch >= 1024 on these layers): a 64x64
-// tile per workgroup, the 16 waves arranged as 4 quadrants (32x32 each) x 4 reduction groups.  Same
-// register-streamed fragments, same chunk arithmetic (group kg owns chunks kg, kg+4, ...), but 4x
-// fewer workgroups, 4 partial tiles instead of 16 through the same 64 KB of LDS (one pass), and the
-// two waves of a quadrant row / column that share a reduction group hit the same operand lines.
-// ------------------------------------------------------------------------------------------
-template <int MODE, bool VEC, int G, bool XV>
-__global__ __launch_bounds__(1024) void gemm16q_kernel(GemmP p) {
-    __shared__ float red[4 * 64 * 64];
-    const int t = threadIdx.x;
-    const int lane = t & 63, w = t >> 6;
-    const int i16 = lane & 15, g4 = lane >> 4;
-    const int kg = w & 3, qm = w >> 3, qn = (w >> 2) & 1;
-    const int m0 = blockIdx.y * 64 + 32 * qm, n0 = blockIdx.x * 64 + 32 * qn;
-
-    const float* A = p.A + gm_slot_offset(p.a_slot);
-    const float* B = p.B + gm_slot_offset(p.b_slot);
-    const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;
-    const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
-    const int nchunks = (p.K + 15) >> 4;
-
-    auto load_a = [&](int c, int mi) -> float4 {
-        const int kb = 16 * c + 4 * g4, x0 = m0 + 16 * mi;
-        if (MODE == MODE_DW) {
-            if (XV) return raw_xc4_16(A, p.lda, x0, p.M, c, p.K, lane);
-            return raw_xc(A, p.lda, x0 + i16, p.M, kb, p.K);
-        }
-        return raw_kc<VEC>(A, p.lda, x0 + i16, p.M, kb, p.K);
-    };
-    auto load_b = [&](int c, int ni) -> float4 {
-        const int kb = 16 * c + 4 * g4, x0 = n0 + 16 * ni;
-        if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
-        if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
-        return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
-    };
-    auto fix_a = [&](float4 v, int c, int mi) -> float4 {
-        const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + i16;
-        if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
-        return fix_kc(v, x, p.M, kb, p.K);
-    };
-    auto fix_b = [&](float4 v, int c, int ni) -> float4 {
-        const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
-        if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
-    };
-
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nq = (nchunks - kg + 3) / 4;                   // chunks kg, kg+4, ... of this group
-    for (int q0 = 0; q0 < nq; q0 += G) {
-        float4 ra[G][2], rb[G][2];
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int cc = kg + min(q0 + i, nq - 1) * 4;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) ra[i][mi] = load_a(cc, mi);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) rb[i][ni] = load_b(cc, ni);
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int q = q0 + i;
-            if (q < nq) {                                    // wave-uniform
-                const int cq = kg + q * 4;
-                float4 fa[2], fb[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) fa[mi] = fix_a(ra[i][mi], cq, mi);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) fb[ni] = fix_b(rb[i][ni], cq, ni);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        f32x4 c4 = acc[mi][ni];
-                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].x, fb[ni].x, c4, 0, 0, 0);
-                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].y, fb[ni].y, c4, 0, 0, 0);
-                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].z, fb[ni].z, c4, 0, 0, 0);
-                        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].w, fb[ni].w, c4, 0, 0, 0);
-                        acc[mi][ni] = c4;
-                    }
-            }
-        }
-    }
-    // partial tiles: red[kg][64 rows][64 cols]; C layout col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) {
-        const int row = 32 * qm + g4 * 4 + rgi, col = 32 * qn + i16;
-        red[(kg * 64 + row) * 64 + col] = acc[0][0][rgi];
-        red[(kg * 64 + row) * 64 + col + 16] = acc[0][1][rgi];
-        red[(kg * 64 + row + 16) * 64 + col] = acc[1][0][rgi];
-        red[(kg * 64 + row + 16) * 64 + col + 16] = acc[1][1][rgi];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = t + 1024 * e, row = idx >> 6, col = idx & 63;
-        const float v = ((red[row * 64 + col] + red[(64 + row) * 64 + col]) +
-                         red[(128 + row) * 64 + col]) + red[(192 + row) * 64 + col];
-        const int m = blockIdx.y * 64 + row, n = blockIdx.x * 64 + col;
-        if (m < p.M && n < p.N) store_element<MODE>(p, v, m, n);
-    }
-}
-
 // The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
@@ -688,32 +580,6 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             const int batches = (pw16 + cand - 1) / cand;
             const int cost = batches * cand + 1 * (batches - 1);
             if (cost <= bc) { bc = cost; g16 = cand; }
-        }
-        // more than two rounds of 32x32 tiles: 64x64 tiles, 4 quadrants x 4 reduction groups
-        static int quad_min = -1;
-        if (quad_min < 0) { const char* e = getenv("GM_QUAD_MIN_TILES"); quad_min = e ? atoi(e) : 512; }
-        if (!use8 && !rider.pair && tm * tn > quad_min) {
-            // riders keep their own launch here (a 64x64 grid has no spare workgroups to hide them)
-            if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
-            if (rider.gather)
-                hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(*rider.gather, 4)), dim3(256), 0, s, *rider.gather);
-            const dim3 qgrid((p.N + 63) / 64, (p.M + 63) / 64);
-            const int pwq = ((p.K + 15) / 16 + 3) / 4;
-            int gq = 4, bq = 1 << 30;
-            for (int cand : {1, 2, 4}) {
-                const int batches = (pwq + cand - 1) / cand;
-                const int cost = batches * cand + 1 * (batches - 1);
-                if (cost <= bq) { bq = cost; gq = cand; }
-            }
-#define GM_LQ(V, GG, X) hipLaunchKernelGGL((gemm16q_kernel<MODE, V, GG, X>), qgrid, dim3(1024), 0, s, p)
-#define GM_LQ_G(V, X) do { if (gq == 1) GM_LQ(V, 1, X); else if (gq == 2) GM_LQ(V, 2, X); else GM_LQ(V, 4, X); } while (0)
-            if (MODE == MODE_FWD) { if (vec) GM_LQ_G(true, false); else GM_LQ_G(false, false); }
-            else if (MODE == MODE_DW) { if (xv) GM_LQ_G(false, true); else GM_LQ_G(false, false); }
-            else if (xv)          { if (vec) GM_LQ_G(true, true); else GM_LQ_G(false, true); }
-            else                  { if (vec) GM_LQ_G(true, false); else GM_LQ_G(false, false); }
-#undef GM_LQ_G
-#undef GM_LQ
-            GM_LAUNCH_RET();
         }
         // more 32x32 tiles than CUs: widen the tile along the longer grid axis (one round)
         static int wide_on = -1;

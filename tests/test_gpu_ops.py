@@ -30,7 +30,7 @@ SHAPES = [  # (M, K, N)  -- layer shapes of the path + ragged edges
     (256, 784, 400), (512, 784, 400), (256, 400, 784), (256, 20, 400), (256, 400, 1),
     (64, 784, 400), (1024, 784, 400), (336, 784, 400), (256, 400, 40), (256, 40, 400),
     (7, 13, 5), (33, 65, 31), (1, 784, 400), (256, 400, 20), (100, 64, 48),
-    # > 512 tiles of 32x32: the 64x64 quadrant kernel (fwd / dx at batch >= 1024, dw of wide layers)
+    # > 512 tiles of 32x32: several rounds of workgroups (batch >= 1024, wide layers)
     (2048, 784, 400), (1100, 130, 500), (1025, 77, 519), (64, 1000, 900), (1024, 400, 784),
 ]
 

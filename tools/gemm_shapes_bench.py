@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Isolated timing of GEMM launch shapes (hipGraph of back-to-back launches, HIP events on the launch
+stream): python tools/gemm_shapes_bench.py fwd:2048:784:400 dx:1024:784:400 ...   (kind:M:K:N in
+layer terms).  Kernel-selection knobs (GM_QUAD_MIN_TILES, GM_WIDE_TILES, ...) are read once per
+process, so A/B runs are separate invocations."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from generative_models_amd import ops  # noqa: E402
+
+
+def time_shape(kind, M, K, N, reps=50):
+    dev = "cuda"
+    x = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    dA = torch.randn(M, N, device=dev)
+    y, dX = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
+    dW, db, b = torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.zeros(N, device=dev)
+    st = [ops.stream_ptr()]
+    if kind == "fwd":
+        fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st[0])
+    elif kind == "dx":
+        fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st[0])
+    else:
+        fn = lambda: ops.linear_bwd_dw(dA, x, dW, db, stream=st[0])
+    fn()
+    torch.cuda.synchronize()
+
+    def body(gst):
+        st[0] = gst
+        for _ in range(reps):
+            fn()
+    g = ops.Graph().capture(body)
+    s = ops.stream_ptr()
+    for _ in range(3):
+        g.launch()
+    e0, e1 = ops.Event(), ops.Event()
+    e0.record(s)
+    g.launch()
+    e1.record(s)
+    e1.sync()
+    us = e0.elapsed_ms(e1) * 1e3 / reps
+    return us, 2.0 * M * K * N / us / 1e6
+
+
+if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        kind, M, K, N = a.split(":")
+        us, tf = time_shape(kind, int(M), int(K), int(N))
+        print("%-3s M=%5s K=%4s N=%4s : %8.2f us  %6.2f TFLOP/s" % (kind, M, K, N, us, tf), flush=True)
