@@ -62,9 +62,8 @@ def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather
 
 def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
-    default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, batch
-    depth from the 16-deep chunks per wave, 16-byte paths by alignment, tile shape from the tile
-    count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
+    default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
+    load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
     if kind in ("fwd", "fwdg"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind in ("dx", "dxh"):
@@ -74,18 +73,11 @@ def gemm_variant(kind, M, K, N):
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
     nw = 16
     chunks = -(-Kr // 16)
-    per_wave = -(-chunks // nw)
-    g, best = 4, 1 << 30
-    for cand in (1, 2, 4):
-        batches = -(-per_wave // cand)
-        cost = batches * cand + (batches - 1)
-        if cost <= best:
-            best, g = cost, cand
+    g = 2 if os.environ.get("GM_ROLL", "0") not in ("", "0") else 1     # chunk schedule (1 = default)
     tm, tn = -(-Mg // 32), -(-Ng // 32)
     mi, ni = 2, 2
     if tm * tn > 256 and chunks >= 32:                 # wide tiles: one round of workgroups
         mi, ni = (2, 4) if tn >= tm else (4, 2)
-        g = min(g, 2)
     elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
         mi, ni = 1, 2
     b = lambda v: "true" if v else "false"
