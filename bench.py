@@ -73,7 +73,7 @@ def gemm_variant(kind, M, K, N):
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
     nw = 16
     chunks = -(-Kr // 16)
-    g = 2 if os.environ.get("GM_ROLL", "0") not in ("", "0") else 1     # chunk schedule (1 = default)
+    g = 1                                  # per-chunk load/consume schedule
     tm, tn = -(-Mg // 32), -(-Ng // 32)
     mi, ni = 2, 2
     if tm * tn > 256 and chunks >= 32:                 # wide tiles: one round of workgroups

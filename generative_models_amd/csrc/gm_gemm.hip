@@ -388,8 +388,9 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // G = 1: load a chunk's fragments, consume them, next chunk.  The four waves of a SIMD drift
     // apart and overlap each other's loads and MFMAs; batching G chunks of loads ahead of their
     // MFMAs (the 32x32x2 kernel's scheme) keeps the waves in lockstep -- load phase, then MFMA phase
-    // -- and measured slower here (fwd 512x784x400: G=4 8.8 us, G=2 7.7, G=1 7.4-7.6).
-    // G = 2: rolling prefetch, the next chunk's loads are issued before this chunk's MFMAs.
+    // -- and measured slower here (fwd 512x784x400: G=4 8.8 us, G=2 7.7, G=1 7.4-7.6); a rolling
+    // prefetch of the next chunk was slower still (iteration 71.7 -> 76.3 us).  G stays a template
+    // parameter (= 1) so that kernel names keep their shape across rounds.
     auto consume = [&](const float4 (&ra)[MI], const float4 (&rb)[NI], int q) {
         const int cq = w + q * WAVES;
         float4 fa[MI], fb[NI];
@@ -409,35 +410,15 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 acc[mi][ni] = c4;
             }
     };
-    if constexpr (G == 1) {
-        for (int q = 0; q < nq; ++q) {
-            float4 ra[MI], rb[NI];
-            const int cc = w + q * WAVES;
+    static_assert(G == 1, "the 16x16x4 kernel runs the per-chunk schedule only");
+    for (int q = 0; q < nq; ++q) {
+        float4 ra[MI], rb[NI];
+        const int cc = w + q * WAVES;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
-            consume(ra, rb, q);
-        }
-    } else {
-        float4 ca[MI], cb[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ca[mi] = load_a(w, mi);          // clamped inside the loaders
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) cb[ni] = load_b(w, ni);
-        for (int q = 0; q < nq; ++q) {
-            float4 na[MI], nb[NI];
-            const int cn = w + min(q + 1, nq - 1) * WAVES;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) na[mi] = load_a(cn, mi);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) nb[ni] = load_b(cn, ni);
-            consume(ca, cb, q);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ca[mi] = na[mi];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) cb[ni] = nb[ni];
-        }
+        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+        consume(ra, rb, q);
     }
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
@@ -593,11 +574,6 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     static int mfma16 = -1;
     if (mfma16 < 0) { const char* e = getenv("GM_MFMA16"); mfma16 = e ? atoi(e) : 1; }
     if (mfma16 && p.xr == 0 && p.cpw == 0) {
-        // chunk schedule of the 16x16x4 kernel: 1 = load/consume per chunk (default), 2 = rolling
-        // prefetch of the next chunk (GM_ROLL=1)
-        static int roll = -1;
-        if (roll < 0) { const char* e = getenv("GM_ROLL"); roll = e ? atoi(e) : 0; }
-        const int g16 = roll ? 2 : 1;
         // more 32x32 tiles than CUs: widen the tile along the longer grid axis (one round)
         static int wide_on = -1;
         if (wide_on < 0) { const char* e = getenv("GM_WIDE_TILES"); wide_on = e ? atoi(e) : 1; }
@@ -621,11 +597,11 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
 #define GM_LH(V, GG, X) do {                                                                       \
-        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, (GG > 2 ? 2 : GG), X, 2, 4>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, (GG > 2 ? 2 : GG), X, 4, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
-#define GM_LH_G(V, X) do { if (g16 == 1) GM_LH(V, 1, X); else if (g16 == 2) GM_LH(V, 2, X); else GM_LH(V, 2, X); } while (0)
+#define GM_LH_G(V, X) GM_LH(V, 1, X)
                 if (xv) GM_LH_G(false, true); else GM_LH_G(false, false);   // VEC is a k-contiguous notion
 #undef GM_LH_G
 #undef GM_LH
@@ -640,7 +616,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
 #define GM_LXH(GG) do {                                                                            \
         if (wide == 3) hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
-                if (g16 == 1) GM_LXH(1); else if (g16 == 2) GM_LXH(2); else GM_LXH(2);
+                GM_LXH(1);
 #undef GM_LXH
                 GM_LAUNCH_RET();
             }
@@ -658,7 +634,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
 #define GM_LG(GG) do {                                                                             \
         if (wide == 3) hipLaunchKernelGGL((gemm16_fwd_gather_kernel<true, GG, 1, 2>), ggrid, dim3(1024), 0, s, p, gp, grows, gblocks); \
         else hipLaunchKernelGGL((gemm16_fwd_gather_kernel<true, GG, 2, 2>), ggrid, dim3(1024), 0, s, p, gp, grows, gblocks); } while (0)
-                    if (g16 == 1) GM_LG(1); else if (g16 == 2) GM_LG(2); else GM_LG(2);
+                    GM_LG(1);
 #undef GM_LG
                     GM_LAUNCH_RET();
                 }
@@ -674,10 +650,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                     const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                     const dim3 pgrid(na + tnb * tmb);
 #define GM_LP(GG) do {                                                                             \
-        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<(GG > 2 ? 2 : GG), true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
-        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<(GG > 2 ? 2 : GG), true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); } while (0)
-                    if (g16 == 1) GM_LP(1); else if (g16 == 2) GM_LP(2); else GM_LP(2);
+                    GM_LP(1);
 #undef GM_LP
                     GM_LAUNCH_RET();
                 }
@@ -689,11 +665,11 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             }
         }
 #define GM_L16(V, W, GG, X) do {                                                                   \
-        if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
-        else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, (GG > 2 ? 2 : GG), X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 3) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 1, 2>), grid, dim3(W * 64), 0, s, p); \
         else hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 2>), grid, dim3(W * 64), 0, s, p); } while (0)
-#define GM_L16_G(V, W, X) do { if (g16 == 1) GM_L16(V, W, 1, X); else if (g16 == 2) GM_L16(V, W, 2, X); else GM_L16(V, W, 2, X); } while (0)
+#define GM_L16_G(V, W, X) GM_L16(V, W, 1, X)
 #define GM_L16_W(V, X) do { if (use8) GM_L16_G(V, 8, X); else GM_L16_G(V, 16, X); } while (0)
         if (MODE == MODE_FWD) { if (vec) GM_L16_W(true, false); else GM_L16_W(false, false); }
         else if (xv)          { if (vec) GM_L16_W(true, true); else GM_L16_W(false, true); }
