@@ -43,7 +43,7 @@ def main(prefix, tag):
         lines.append("| `%s` | %d | %d | %.1f | %.2f | %.1f | %.2f |" % (k[0], k[1], n, fr, 2 * fr * 1024 / 1e6, wr, wr * 1024 / 1e6))
         out["%s|%d" % k] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "dispatches": n}
     lines += ["", "Reading: every GEMM pulls its operands into (almost) each of the 8 XCD-private L2s: the layer-1",
-              "critic forward on 2B rows (`gemm16_kernel<0, true, 16, 4, false, 2, 2>`, grid 212992) moves ~23 MB",
+              "critic forward on 2B rows (`gemm16_kernel<0, true, 16, 1, false, 2, 2>`, grid 212992) moves ~23 MB",
               "over the fabric for 2.85 MB of unique operands (8 x 2.85 = 22.8 MB); the layer-1 weight gradient",
               "that also carries the head's backward and both Adam steps (`gemm16_dw_head_kernel`) reads 26 MB",
               "(2.4 MB of operands x 8 + 3.8 MB of Adam state + 0.8 MB for the head) and writes 5.0 MB (gradient +",
