@@ -18,7 +18,7 @@ from generative_models_amd import _lib, engine, ops, trainers  # noqa: E402
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.load()
     declared = _lib.declared_symbols()
-    assert len(declared) >= 29
+    assert len(declared) >= 52
     for name in declared:
         assert hasattr(lib, name), name
         assert name in _lib._SIGNATURES, "declared in gm_hip.h but not bound: " + name
@@ -139,3 +139,43 @@ def test_flat_params_pack_and_alias():
     assert torch.equal(lin_a.weight.data, w0)
     fp.flat[0] = 42.0
     assert lin_a.weight.data[0, 0].item() == 42.0 and fp.still_bound()
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The argument blocks passed by pointer (gm_slot, gm_head_bwd_args, gm_dw_adam_args) must have
+    the same size and field offsets in ctypes as in include/gm_hip.h compiled by the host C
+    compiler (the header is plain C)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None:
+        pytest.skip("no host C compiler")
+    root = os.path.dirname(HERE)
+    structs = {"gm_slot": _lib.Slot, "gm_head_bwd_args": _lib.HeadBwdArgs,
+               "gm_dw_adam_args": _lib.DwAdamArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gm_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, field, val = line.split()
+        ct = structs[cname]
+        if field == "size":
+            assert ctypes_sizeof(ct) == int(val), (cname, ctypes_sizeof(ct), val)
+        else:
+            assert getattr(ct, field).offset == int(val), (cname, field)
+        seen += 1
+    assert seen == sum(len(ct._fields_) + 1 for ct in structs.values())
+
+
+def ctypes_sizeof(ct):
+    import ctypes
+    return ctypes.sizeof(ct)
