@@ -903,6 +903,11 @@ class VAEEngine:
             mW, vW = fp.m[o_w:o_w + 2 * Z * H], fp.v[o_w:o_w + 2 * Z * H]
             mb, vb = fp.m[o_b:o_b + 2 * Z], fp.v[o_b:o_b + 2 * Z]
         self.ML = _Packed
+        self._common_init(device)
+
+    has_eps = True              # the VAE draws eps per batch (vae.py:104); the plain AE does not
+
+    def _common_init(self, device):
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
         self.graphs = {}
         self._bufB = None
@@ -1033,10 +1038,12 @@ class VAEEngine:
                 b = min(B, n - lo)
                 sizes.append(b)
                 s["idx"][k, :b].copy_(perm[lo:lo + b])
-                s["eps"][k].view(-1)[:b * Z].normal_()        # torch.randn(mu.shape), vae.py:104
+                if self.has_eps:
+                    s["eps"][k].view(-1)[:b * Z].normal_()    # torch.randn(mu.shape), vae.py:104
             r = t % R
             self.idx_ring[r:r + cnt].copy_(s["idx"][:cnt], non_blocking=True)
-            self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
+            if self.has_eps:
+                self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             s["event"] = ev
@@ -1064,6 +1071,58 @@ class VAEEngine:
             self.vrecon = torch.zeros(n, device=self.device)
             self.vkl = torch.zeros(n, device=self.device)
             self.graphs = {k: g for k, g in self.graphs.items() if k[1]}   # drop eval graphs
+
+
+class AEEngine(VAEEngine):
+    """ae.py:104-164 on the VAE engine's machinery: encoder layer (relu),
+    decoder layer (sigmoid), squared-error loss; no sampling, so no eps ring and no KL term."""
+
+    has_eps = False
+
+    def __init__(self, model, device, use_graph=True):
+        self.model, self.device, self.use_graph = model, device, use_graph
+        enc, dec = model.encoder, model.decoder
+        self.fp = FlatParams([enc.linear.weight, enc.linear.bias, dec.linear.weight,
+                              dec.linear.bias], device)
+        self.E1, self.D2 = _Linear(self.fp, enc.linear), _Linear(self.fp, dec.linear)
+        self.H, self.I = enc.linear.weight.shape
+        self.Z = 1                                   # dummy width of the (unused) eps ring
+        self._common_init(device)
+
+    def _alloc(self, B):
+        if self._bufB == B:
+            return
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.X, self.He, self.Xr, self.dA = z(B, self.I), z(B, self.H), z(B, self.I), z(B, self.I)
+        self.dHe, self.part = z(B, self.H), z(B)
+        self._bufB = B
+        self.graphs = {}
+
+    def _issue(self, st, t, b, train):
+        """One batch of size b: ae.py:147-160 (+ backward and Adam when train)."""
+        from . import ops_fused as of
+        E1, D2 = self.E1, self.D2
+        idx_slot = self._slot(t, 1, 0, self.R, self.B)
+        loss_slot = self._slot(t, 1, 0, 0, 1)
+        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
+        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        ops.linear_fwd(self.He, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
+        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
+        of.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
+                        stream=st)
+        if train:
+            sched_slot = self._slot(t, 1, 0, 0, 1)
+            adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
+            # dH reads the decoder weights before the paired dW launch updates them
+            ops.linear_bwd_dx(self.dA, D2.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
+            ops.linear_bwd_dw_adam_pair(dict(dA=self.dA, X=self.He, lin=D2, adam=adam, M=b),
+                                        dict(dA=self.dHe, X=self.X, lin=E1, adam=adam, M=b),
+                                        weight_decay=self.wd if adam is not None else 0.0, stream=st)
+            if adam is None:
+                ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
+                         weight_decay=self.wd, stream=st)
+        if self.use_graph:
+            ops.tick(self.ctr, 1, stream=st)
 
 
 class BEGANEngine(GANEngine):

@@ -454,6 +454,7 @@ def _epoch_order(loader):
 class VAETrainer:
     """vae.py:109-223."""
     _gm_stock_class = True
+    _hook_names = ("compute_batch", "kl_divergence", "evaluate")
 
     def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
         self.model = to_cuda(model)
@@ -497,7 +498,7 @@ class VAETrainer:
 
     def _stock(self):
         cls = type(self)
-        for name in ("compute_batch", "kl_divergence", "evaluate"):
+        for name in self._hook_names:
             if name in self.__dict__:
                 return False
             for base in cls.__mro__:
@@ -580,6 +581,126 @@ class VAETrainer:
 
     def load_model(self, loadpath):
         self.model.load_state_dict(torch.load(loadpath))
+
+
+# ============================================================================================
+# Autoencoder (ae.py:29-205) -- exported by src/ae.py as Encoder / Decoder /
+# Autoencoder / AutoencoderTrainer.  Runs on the VAE engine's machinery (engine.AEEngine).
+# ============================================================================================
+class AEEncoder(nn.Module):
+    """ae.py:29-39."""
+
+    def __init__(self, image_size, hidden_dim):
+        super().__init__()
+        self.linear = nn.Linear(image_size, hidden_dim)
+
+    def forward(self, x):
+        return _lin(self.linear, x, "relu")
+
+
+class AEDecoder(nn.Module):
+    """ae.py:42-52."""
+
+    def __init__(self, hidden_dim, image_size):
+        super().__init__()
+        self.linear = nn.Linear(hidden_dim, image_size)
+
+    def forward(self, encoder_output):
+        return _lin(self.linear, encoder_output, "sigmoid")
+
+
+class Autoencoder(nn.Module):
+    """ae.py:55-67."""
+
+    def __init__(self, image_size=784, hidden_dim=32):
+        super().__init__()
+        self.image_size, self.hidden_dim = image_size, hidden_dim
+        self.encoder = AEEncoder(image_size=image_size, hidden_dim=hidden_dim)
+        self.decoder = AEDecoder(hidden_dim=hidden_dim, image_size=image_size)
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+
+class AutoencoderTrainer(VAETrainer):
+    """ae.py:69-205: same loop as the VAE trainer with one loss list (`recon_loss`)."""
+    _gm_stock_class = True
+    _hook_names = ("compute_batch", "evaluate")
+
+    def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
+        self.model = to_cuda(model)
+        self.name = model.__class__.__name__
+        self.train_iter, self.val_iter, self.test_iter = train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))          # ae.py:80 (consumes RNG)
+        self.viz = viz
+        self.recon_loss = []
+        self.num_epochs = 0
+        self._engine = None
+        self.use_graph = True
+
+    def compute_batch(self, batch):
+        """ae.py:147-160 (general path: autograd over the fused linear kernels)."""
+        images, _ = batch
+        images = to_cuda(images.view(images.shape[0], -1))
+        return torch.sum((images - self.model(images)) ** 2)
+
+    def evaluate(self, iterator):
+        """ae.py:162-164."""
+        return np.mean([self.compute_batch(batch).item() for batch in iterator])
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5, quiet=False):
+        """ae.py:87-145."""
+        from copy import deepcopy
+        if self._stock():
+            if not torch.cuda.is_available():
+                raise GMError("no MI355X visible: the fused step engine has no CPU fallback")
+            from .engine import AEEngine
+            dev = next(self.model.parameters()).device
+            if self._engine is None:
+                self._engine = AEEngine(self.model, dev, use_graph=self.use_graph)
+            eng = self._engine
+            eng.use_graph = self.use_graph
+            steps = len(self.train_iter)
+            eng.configure(self.train_iter.batch_size, num_epochs * steps, lr, weight_decay)
+            tdata, vdata = self._device_data(self.train_iter), self._device_data(self.val_iter)
+            nval = len(self.val_iter)
+            eng.alloc_val(nval)
+            for epoch in range(1, num_epochs + 1):
+                self.model.train()
+                t0 = (epoch - 1) * steps
+                eng.run_pass(tdata, _epoch_order(self.train_iter), True, t0)
+                self.model.eval()
+                eng.run_pass(vdata, _epoch_order(self.val_iter), False, 0)
+                recon = [float(x) for x in eng.recon[t0:t0 + steps].cpu().numpy()]   # one sync
+                val_loss = np.mean([float(x) for x in eng.vrecon[:nval].cpu().numpy()])
+                self._end_epoch_ae(epoch, num_epochs, recon, val_loss, deepcopy, quiet)
+            return
+        # GENERAL path (compute_batch / evaluate overridden)
+        opt = FlatAdam([p for p in self.model.parameters() if p.requires_grad], lr,
+                       weight_decay=weight_decay)
+        for epoch in range(1, num_epochs + 1):
+            self.model.train()
+            recon = []
+            for batch in self.train_iter:
+                opt.zero_grad()
+                loss = self.compute_batch(batch)
+                loss.backward()
+                opt.step()
+                recon.append(loss.item())
+            self.model.eval()
+            val_loss = self.evaluate(self.val_iter)
+            self._end_epoch_ae(epoch, num_epochs, recon, val_loss, deepcopy, quiet)
+
+    def _end_epoch_ae(self, epoch, num_epochs, recon, val_loss, deepcopy, quiet):
+        self.recon_loss.extend(recon)
+        if val_loss < self.best_val_loss:
+            self.best_model = deepcopy(self.model)
+            self.best_val_loss = val_loss
+        if not quiet:
+            print("Epoch[%d/%d], Train Loss: %.4f, Val Loss: %.4f"
+                  % (epoch, num_epochs, np.mean(recon), val_loss))
+        self.num_epochs += 1
 
 
 # ============================================================================================

@@ -152,5 +152,32 @@ def main():
                                        rng=rng_digest(), torch=torch.__version__))
 
 
+def gen_ae():
+    """ae.py fixtures: small dims with full parameters (2 epochs, ragged last
+    batch of the validation pass) and 784-32 at B = 512 with a ragged last training batch."""
+    mod = ref_harness.load("ae")
+    for name, cfg, hidden, batch, n_train, epochs, full in (
+            ("ae_small", SMALL, 8, SMALL["batch"], 150, 2, False),
+            ("ae_full_b512", FULL, 32, 512, 512 * 6 + 336, 1, True)):
+        loaders = ref_harness.synthetic_loaders(batch, n_train=n_train, n_val=cfg["n_val"],
+                                                n_test=cfg["n_test"],
+                                                image_shape=cfg["image_shape"])
+        torch.manual_seed(1234)
+        model = mod.Autoencoder(image_size=cfg["image_size"], hidden_dim=hidden)
+        tr = mod.AutoencoderTrainer(model, *loaders, viz=False)
+        with ref_harness.quiet():
+            tr.train(num_epochs=epochs)
+        arrays = {"recon_loss": np.array(tr.recon_loss), "best_val_loss": np.array(tr.best_val_loss)}
+        for k, v in model.state_dict().items():
+            arrays[("digest:" if full else "param:") + k] = digest(v) if full else v.numpy()
+        save(name, arrays, dict(variant="ae", cfg=cfg, hidden=hidden, batch=batch, n_train=n_train,
+                                train_kw=dict(num_epochs=epochs), rng=rng_digest(),
+                                torch=torch.__version__))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["ae"]:
+        gen_ae()                 # only the ae.py fixtures (the others are unchanged)
+    else:
+        main()
+        gen_ae()

@@ -109,6 +109,35 @@ class VAEModel(nn.Module):
         return self.decoder(z), mu, log_var
 
 
+class AEModel(nn.Module):
+    """ae.py:29-67.  Keys encoder.linear, decoder.linear."""
+
+    class Enc(nn.Module):
+        def __init__(self, image_size, hidden_dim):
+            super().__init__()
+            self.linear = nn.Linear(image_size, hidden_dim)
+
+        def forward(self, x):
+            return F.relu(self.linear(x))                 # ae.py:39
+
+    class Dec(nn.Module):
+        def __init__(self, hidden_dim, image_size):
+            super().__init__()
+            self.linear = nn.Linear(hidden_dim, image_size)
+
+        def forward(self, h):
+            return torch.sigmoid(self.linear(h))          # ae.py:52
+
+    def __init__(self, image_size=784, hidden_dim=32):
+        super().__init__()
+        self.image_size, self.hidden_dim = image_size, hidden_dim
+        self.encoder = AEModel.Enc(image_size, hidden_dim)
+        self.decoder = AEModel.Dec(hidden_dim, image_size)
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))              # ae.py:66
+
+
 # --------------------------------------------------------------------------------------------
 # Per-variant defaults: (G_lr, D_lr, D_steps) of each train() signature (SURVEY.md section 8b).
 # --------------------------------------------------------------------------------------------
@@ -126,6 +155,7 @@ REFERENCE_NAMES = {
     "f": ("f_gan", "fGAN", "fGANTrainer"), "fisher": ("fisher_gan", "FisherGAN",
                                                       "FisherGANTrainer"),
     "info": ("info_gan", "InfoGAN", "InfoGANTrainer"), "vae": ("vae", "VAE", "VAETrainer"),
+    "ae": ("ae", "Autoencoder", "AutoencoderTrainer"),
 }
 
 
@@ -424,6 +454,47 @@ class VAEPort:
             self.num_epochs += 1
 
 
+class AEPort:
+    """ae.py:69-168 (train loop, compute_batch, evaluate)."""
+
+    def __init__(self, model, train_iter, val_iter, test_iter):
+        self.model, self.train_iter, self.val_iter, self.test_iter = \
+            model, train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))       # ae.py:80 (2 RNG draws)
+        self.recon_loss, self.val_losses = [], []
+        self.num_epochs = 0
+
+    def compute_batch(self, batch):
+        images, _ = batch
+        images = images.view(images.shape[0], -1)
+        return torch.sum((images - self.model(images)) ** 2)                     # ae.py:158
+
+    def evaluate(self, iterator):
+        return np.mean([self.compute_batch(batch).item() for batch in iterator])  # ae.py:164
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5):
+        opt = optim.Adam(params=[p for p in self.model.parameters() if p.requires_grad], lr=lr,
+                         weight_decay=weight_decay)                              # ae.py:98-101
+        for _epoch in range(1, num_epochs + 1):
+            self.model.train()
+            e_loss = []
+            for batch in self.train_iter:
+                opt.zero_grad()
+                loss = self.compute_batch(batch)
+                loss.backward()
+                opt.step()
+                e_loss.append(loss.item())
+            self.recon_loss.extend(e_loss)
+            self.model.eval()
+            val = self.evaluate(self.val_iter)
+            self.val_losses.append(val)
+            if val < self.best_val_loss:
+                self.best_model = copy.deepcopy(self.model)
+                self.best_val_loss = val
+            self.num_epochs += 1
+
+
 # --------------------------------------------------------------------------------------------
 # Synthetic data (same recipe as oracle/ref_harness.synthetic_loaders; BASELINE.md section 2).
 # --------------------------------------------------------------------------------------------
@@ -447,4 +518,6 @@ def build(variant, image_size=784, hidden_dim=400, z_dim=20, seed=1234, **kw):
         torch.manual_seed(seed)
     if variant == "vae":
         return VAEModel(image_size, hidden_dim, z_dim)
+    if variant == "ae":
+        return AEModel(image_size, hidden_dim)
     return GANModel(variant, image_size, hidden_dim, z_dim, **kw)

@@ -22,7 +22,7 @@ def load(name):
 
 
 SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
-               if not os.path.basename(p).startswith("vae"))
+               if not os.path.basename(p).startswith(("vae", "ae_")))
 FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256"]
 
 
@@ -40,7 +40,7 @@ def run_port_gan(meta, batch, max_steps=None):
 
 def test_fixture_inventory():
     assert len(SMALL) == 16, SMALL          # 10 variants + 6 f-divergences
-    for n in FULL + ["vae_small", "vae_full_b512"]:
+    for n in FULL + ["vae_small", "vae_full_b512", "ae_small", "ae_full_b512"]:
         assert os.path.isfile(os.path.join(GOLDEN, n + ".npz")), n
 
 
@@ -84,3 +84,20 @@ def test_vae(name):
     np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
     np.testing.assert_allclose(np.array(tr.kl_loss), z["kl_loss"], rtol=RTOL)
     np.testing.assert_allclose(tr.best_val_loss, float(z["best_val_loss"]), rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", ["ae_small", "ae_full_b512"])
+def test_ae(name):
+    """ae.py: the port against fixtures from the unmodified reference."""
+    z, meta = load(name)
+    cfg = meta["cfg"]
+    loaders = port.synthetic_loaders(meta["batch"], n_train=meta["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    model = port.build("ae", cfg["image_size"], meta["hidden"])
+    tr = port.AEPort(model, *loaders)
+    tr.train(**meta["train_kw"])
+    np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
+    np.testing.assert_allclose(tr.best_val_loss, float(z["best_val_loss"]), rtol=RTOL)
+    for k, v in model.state_dict().items():
+        if "param:" + k in z:
+            np.testing.assert_allclose(v.numpy(), z["param:" + k], rtol=RTOL, atol=ATOL)

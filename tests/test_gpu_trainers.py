@@ -285,6 +285,88 @@ def test_vae_engine_vs_reference_golden(name):
     assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
 
 
+# ---------------------------------------------------------------------------------------------
+# Autoencoder (ae.py) on the VAE engine's machinery
+# ---------------------------------------------------------------------------------------------
+def run_ae_product(cfg, hidden, batch, n_train, epochs, use_graph=True):
+    import ae
+    loaders = port.synthetic_loaders(batch, n_train=n_train, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    model = ae.Autoencoder(image_size=cfg["image_size"], hidden_dim=hidden)
+    tr = ae.AutoencoderTrainer(model, *loaders, viz=False)
+    tr.use_graph = use_graph
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=epochs)
+    torch.cuda.synchronize()
+    return tr, model, torch.get_rng_state()
+
+
+@pytest.mark.parametrize("cfg,n_train,use_graph", [(SMALL, 160, True), (RAGGED, 200, True),
+                                                   (SMALL, 150, True), (SMALL, 150, False)],
+                         ids=["small", "ragged", "partial-batch", "eager"])
+def test_ae_engine_vs_oracle(cfg, n_train, use_graph):
+    hidden = cfg["z_dim"]
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=n_train, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build("ae", cfg["image_size"], hidden)
+    o = port.AEPort(o_model, *loaders)
+    o.train(2)
+    o_rng = torch.get_rng_state()
+    p, p_model, p_rng = run_ae_product(cfg, hidden, cfg["batch"], n_train, 2, use_graph)
+    assert p._engine is not None                      # the fused engine ran, not the general path
+    lclose(np.array(p.recon_loss) / 100, np.array(o.recon_loss) / 100, "ae recon")   # sums ~1e3
+    assert abs(p.best_val_loss - o.best_val_loss) <= 1e-5 * max(1, abs(o.best_val_loss))
+    assert torch.equal(o_rng, p_rng)
+    for (k, a), (_, b) in zip(p_model.state_dict().items(), o_model.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5, k
+
+
+@pytest.mark.parametrize("name", ["ae_small", "ae_full_b512"])
+def test_ae_engine_vs_reference_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    p, p_model, _ = run_ae_product(cfg, meta["hidden"], meta["batch"], meta["n_train"],
+                                   meta["train_kw"]["num_epochs"])
+    ref, got = z["recon_loss"], np.array(p.recon_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
+    assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
+    for k, v in p_model.state_dict().items():
+        if "param:" + k in z:
+            assert np.abs(v.cpu().numpy() - z["param:" + k]).max() <= 5e-5, k
+
+
+def test_ae_general_path_when_hook_overridden():
+    """A user subclass overriding compute_batch runs the reference loop over the HIP autograd
+    Functions + flat HIP Adam and still matches the oracle."""
+    import ae
+    cfg = SMALL
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=96, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build("ae", cfg["image_size"], cfg["z_dim"])
+    o = port.AEPort(o_model, *loaders)
+    o.train(1)
+
+    class Mine(ae.AutoencoderTrainer):
+        def compute_batch(self, batch):
+            return super().compute_batch(batch)
+
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=96, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    model = ae.Autoencoder(image_size=cfg["image_size"], hidden_dim=cfg["z_dim"])
+    tr = Mine(model, *loaders, viz=False)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=1)
+    assert tr._engine is None
+    lclose(np.array(tr.recon_loss) / 100, np.array(o.recon_loss) / 100, "ae general recon")
+    for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5, k
+
+
 def test_dp_launch_structure_single_rank_rccl():
     """The data-parallel launch structure (one hipGraph per segment, RCCL all-reduce of the flat
     gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run

@@ -93,6 +93,12 @@ def test_dropin_surface_and_state_dict_keys():
         "D.encoder.weight", "D.encoder.bias", "D.decoder.weight", "D.decoder.bias"]
     assert "D.discriminator.weight" in info_gan.InfoGAN(784, 400, 20, 10, 10).state_dict()
     assert sum(p.numel() for p in vae.VAE().parameters()) == 652824
+    import ae
+    assert sum(p.numel() for p in ae.Autoencoder().parameters()) == 50992       # SURVEY A.1 PROBE
+    assert list(ae.Autoencoder().state_dict().keys()) == [
+        "encoder.linear.weight", "encoder.linear.bias", "decoder.linear.weight", "decoder.linear.bias"]
+    for name in ("Encoder", "Decoder", "Autoencoder", "AutoencoderTrainer", "get_data", "to_cuda"):
+        assert hasattr(ae, name), name
     for name in ("Generator", "Discriminator", "NSGAN", "NSGANTrainer", "to_cuda", "to_var", "get_data"):
         assert hasattr(ns_gan, name)
     assert hasattr(f_gan, "Divergence") and hasattr(info_gan, "Q")

@@ -79,6 +79,31 @@ def test_gan_port_bit_exact(variant, kw):
 
 
 @needs_ref
+def test_ae_port_bit_exact():
+    """ae.py: same protocol as the VAE pin, one loss list."""
+    mod = ref_harness.load("ae")
+    tr_i, va_i, te_i = _loaders(B)
+    torch.manual_seed(1234)
+    ref_model = mod.Autoencoder(image_size=IMG, hidden_dim=Z)
+    ref_tr = mod.AutoencoderTrainer(ref_model, tr_i, va_i, te_i, viz=False)
+    with ref_harness.quiet():
+        ref_tr.train(num_epochs=2)
+    ref_state = torch.get_rng_state()
+
+    tr_i, va_i, te_i = _loaders(B)
+    my_model = port.build("ae", IMG, Z)
+    my_tr = port.AEPort(my_model, tr_i, va_i, te_i)
+    my_tr.train(num_epochs=2)
+    np.testing.assert_array_equal(np.array(ref_tr.recon_loss), np.array(my_tr.recon_loss))
+    assert ref_tr.best_val_loss == my_tr.best_val_loss
+    ref_sd, my_sd = ref_model.state_dict(), my_model.state_dict()
+    assert list(ref_sd.keys()) == list(my_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], my_sd[k]), k
+    assert torch.equal(ref_state, torch.get_rng_state())
+
+
+@needs_ref
 def test_vae_port_bit_exact():
     mod = ref_harness.load("vae")
     tr_i, va_i, te_i = _loaders(B)
