@@ -726,9 +726,12 @@ class GANEngine:
 
     # -- public: run `n_iters` iterations starting a fresh train() ----------------------------
     def configure(self, n_iters, G_lr, D_lr, D_steps, clip=0.0, hyper=(), g_init=0,
-                  gp_lambda=10.0):
+                  gp_lambda=10.0, resume=None):
         """Called once per train(): fresh Adam state (optimizers are locals of the reference's
-        train()), schedules, loss buffers, rings, graph."""
+        train()), schedules, loss buffers, rings, graph.
+        resume: optimizer state of a checkpoint (optim_state()) -- the Adam moments are restored
+        and the bias-correction schedules continue from the saved step counts instead (an extension:
+        the reference saves weights only, ns_gan.py:283-290)."""
         dev = self.device
         self.D_steps, self.clip, self.hyper = D_steps, float(clip), tuple(hyper)
         self.g_off = g_init
@@ -737,8 +740,22 @@ class GANEngine:
         self.fG.rebind(); self.fD.rebind()
         self.fG.reset_state(); self.fD.reset_state()
         self.fG.grad.zero_(); self.fD.grad.zero_()
-        self.schedD = torch.from_numpy(ops.adam_schedule(D_lr, max(1, n_iters * D_steps))).to(dev)
-        self.schedG = torch.from_numpy(ops.adam_schedule(G_lr, n_iters + g_init)).to(dev)
+        self.step0 = {"G": 0, "D": 0}
+        if resume is not None:
+            if self.variant in ("info", "be", "fisher"):
+                raise GMError("checkpoint resume is not wired for %s (extra optimizer / controller "
+                              "state)" % self.variant)
+            for net, fp in (("G", self.fG), ("D", self.fD)):
+                st = resume[net]
+                if st["m"].numel() != fp.m.numel():
+                    raise GMError("checkpoint optimizer state does not match this model")
+                fp.m.copy_(st["m"]); fp.v.copy_(st["v"])
+                self.step0[net] = int(st["step"])
+        self.steps_planned = {"G": n_iters + g_init, "D": n_iters * D_steps}
+        self.schedD = torch.from_numpy(ops.adam_schedule(D_lr, max(1, n_iters * D_steps),
+                                                         start=self.step0["D"] + 1)).to(dev)
+        self.schedG = torch.from_numpy(ops.adam_schedule(G_lr, n_iters + g_init,
+                                                         start=self.step0["G"] + 1)).to(dev)
         self.lossD = torch.zeros(max(1, n_iters * D_steps), device=dev)
         self.lossG = torch.zeros(n_iters + g_init, device=dev)
         if self.variant == "info":
@@ -760,6 +777,13 @@ class GANEngine:
         # schedule / loss buffers are re-created per train(): pointers change => recapture
         self._graph_key = None
         self._key = key
+
+    def optim_state(self):
+        """Adam moments + step counts after the train() call that just finished (checkpointing)."""
+        torch.cuda.synchronize()
+        return {net: {"m": fp.m.detach().cpu().clone(), "v": fp.v.detach().cpu().clone(),
+                      "step": self.step0[net] + self.steps_planned[net]}
+                for net, fp in (("G", self.fG), ("D", self.fD))}
 
     def _ensure_graph(self):
         if not self.use_graph or self._graph_key == self._key:
@@ -987,14 +1011,22 @@ class VAEEngine:
         if self.use_graph:
             ops.tick(self.ctr, 1, stream=st)
 
-    def configure(self, B, n_train_steps, lr, weight_decay):
+    def configure(self, B, n_train_steps, lr, weight_decay, resume=None):
         dev = self.device
         self._alloc(B)
         self.B, self.wd = B, float(weight_decay)
         self.fp.rebind()
         self.fp.reset_state()
         self.fp.grad.zero_()
-        self.sched = torch.from_numpy(ops.adam_schedule(lr, max(1, n_train_steps))).to(dev)
+        self.step0 = 0
+        if resume is not None:                       # see GANEngine.configure
+            if resume["m"].numel() != self.fp.m.numel():
+                raise GMError("checkpoint optimizer state does not match this model")
+            self.fp.m.copy_(resume["m"]); self.fp.v.copy_(resume["v"])
+            self.step0 = int(resume["step"])
+        self.steps_planned = n_train_steps
+        self.sched = torch.from_numpy(ops.adam_schedule(lr, max(1, n_train_steps),
+                                                        start=self.step0 + 1)).to(dev)
         self.recon = torch.zeros(max(1, n_train_steps), device=dev)
         self.kl = torch.zeros(max(1, n_train_steps), device=dev)
         self.R = CHUNK
@@ -1005,6 +1037,11 @@ class VAEEngine:
                       for _ in range(2)]
         self.graphs = {}
         self.t_train = 0
+
+    def optim_state(self):
+        torch.cuda.synchronize()
+        return {"m": self.fp.m.detach().cpu().clone(), "v": self.fp.v.detach().cpu().clone(),
+                "step": self.step0 + self.steps_planned}
 
     def _graph(self, b, train, k=1):
         """hipGraph of k consecutive batches of size b (the device counter advances per batch)."""

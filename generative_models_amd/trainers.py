@@ -312,7 +312,7 @@ class GANTrainer:
         if self._stock():
             eng = self._get_engine()
             eng.configure(num_epochs * epoch_steps, G_lr, D_lr, D_steps, clip=clip, hyper=hyper,
-                          g_init=G_init)
+                          g_init=G_init, resume=self.__dict__.pop("_resume_optim", None))
             if G_init > 0:
                 eng.g_init_steps(G_init)
             for epoch in range(1, num_epochs + 1):
@@ -379,6 +379,17 @@ class GANTrainer:
     def save_model(self, savepath):
         torch.save(self.model.state_dict(), savepath)
 
+    # ---- full checkpoint / resume (the reference saves weights only) ----
+    def save_checkpoint(self, savepath):
+        """Weights (same state_dict keys as save_model, loadable by the reference), Adam moments and
+        step counts of the last train() call, the global CPU generator's state (= the cursor of the
+        sampling / noise protocol) and the loss history.  After load_checkpoint() the next train()
+        continues as if the run had never stopped."""
+        _save_checkpoint(self, savepath, ("Glosses", "Dlosses", "num_epochs"))
+
+    def load_checkpoint(self, loadpath):
+        _load_checkpoint(self, loadpath)
+
     def load_model(self, loadpath):
         state = torch.load(loadpath)
         self.model.load_state_dict(state)
@@ -391,6 +402,36 @@ def stock(cls):
     """Marks a trainer class shipped by this package (fast-path eligible when not overridden)."""
     cls._gm_stock_class = True
     return cls
+
+
+# ============================================================================================
+# Checkpoint / resume shared by all trainers (SURVEY.md 8f item 3)
+# ============================================================================================
+CHECKPOINT_VERSION = 1
+
+
+def _save_checkpoint(trainer, savepath, history):
+    eng = getattr(trainer, "_engine", None)
+    if eng is None or not hasattr(eng, "steps_planned"):
+        raise GMError("save_checkpoint needs a finished train() call on the fused engine")
+    torch.save({"version": CHECKPOINT_VERSION, "name": trainer.name,
+                "model": {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()},
+                "optim": eng.optim_state(), "rng": torch.get_rng_state(),
+                "history": {n: getattr(trainer, n) for n in history}}, savepath)
+
+
+def _load_checkpoint(trainer, loadpath):
+    if getattr(trainer, "variant", None) in ("be", "info", "fisher"):
+        raise GMError("checkpoint resume is not wired for this trainer (extra optimizer / "
+                      "controller state); use save_model / load_model")
+    ck = torch.load(loadpath, weights_only=False)
+    if ck.get("version") != CHECKPOINT_VERSION or ck.get("name") != trainer.name:
+        raise GMError("not a checkpoint of a %s trainer" % trainer.name)
+    trainer.model.load_state_dict(ck["model"])
+    for n, v in ck["history"].items():
+        setattr(trainer, n, list(v) if isinstance(v, list) else v)
+    trainer._resume_optim = ck["optim"]          # consumed by the next train()
+    torch.set_rng_state(ck["rng"])               # LAST: construction / loading drew nothing after
 
 
 # ============================================================================================
@@ -532,7 +573,8 @@ class VAETrainer:
             eng.use_graph = self.use_graph
             B = self.train_iter.batch_size
             steps = len(self.train_iter)
-            eng.configure(B, num_epochs * steps, lr, weight_decay)
+            eng.configure(B, num_epochs * steps, lr, weight_decay,
+                          resume=self.__dict__.pop("_resume_optim", None))
             tdata, vdata = self._device_data(self.train_iter), self._device_data(self.val_iter)
             nval = len(self.val_iter)
             eng.alloc_val(nval)
@@ -581,6 +623,15 @@ class VAETrainer:
 
     def load_model(self, loadpath):
         self.model.load_state_dict(torch.load(loadpath))
+
+    def save_checkpoint(self, savepath):
+        """See GANTrainer.save_checkpoint."""
+        hist = tuple(n for n in ("recon_loss", "kl_loss", "num_epochs", "best_val_loss")
+                     if hasattr(self, n))
+        _save_checkpoint(self, savepath, hist)
+
+    def load_checkpoint(self, loadpath):
+        _load_checkpoint(self, loadpath)
 
 
 # ============================================================================================
@@ -662,7 +713,8 @@ class AutoencoderTrainer(VAETrainer):
             eng = self._engine
             eng.use_graph = self.use_graph
             steps = len(self.train_iter)
-            eng.configure(self.train_iter.batch_size, num_epochs * steps, lr, weight_decay)
+            eng.configure(self.train_iter.batch_size, num_epochs * steps, lr, weight_decay,
+                          resume=self.__dict__.pop("_resume_optim", None))
             tdata, vdata = self._device_data(self.train_iter), self._device_data(self.val_iter)
             nval = len(self.val_iter)
             eng.alloc_val(nval)

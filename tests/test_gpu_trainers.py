@@ -367,6 +367,84 @@ def test_ae_general_path_when_hook_overridden():
         assert (a.cpu() - b).abs().max().item() <= 5e-5, k
 
 
+# ---------------------------------------------------------------------------------------------
+# Checkpoint / resume: train(1) + save + load into a FRESH trainer + train(1)
+# must equal one uninterrupted train(2) bit for bit -- weights, Adam moments and schedule position,
+# the RNG-protocol cursor and the loss history all travel in the checkpoint.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,kw", [("ns", {}), ("w", dict(D_steps=2)), ("wgp", dict(D_steps=1))],
+                         ids=["ns", "w", "wgp"])
+def test_gan_checkpoint_resume_is_bitwise_uninterrupted(variant, kw, tmp_path):
+    import contextlib, io
+    full, full_model, full_rng = run_product(variant, SMALL, 16, dict(num_epochs=2, **kw))
+    tr1, _ = build_product(variant, SMALL, 16)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr1.train(num_epochs=1, **kw)
+    path = str(tmp_path / "ck.pt")
+    tr1.save_checkpoint(path)
+    torch.manual_seed(999)                                 # a different init and RNG position
+    tr2, model2 = build_product(variant, SMALL, 16)
+    with torch.no_grad():
+        for p_ in model2.parameters():                     # nothing of the fresh init may survive
+            p_.add_(0.25)
+    torch.manual_seed(4242)
+    tr2.load_checkpoint(path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr2.train(num_epochs=1, **kw)
+    torch.cuda.synchronize()
+    assert tr2.num_epochs == 2
+    assert tr2.Glosses == full.Glosses and tr2.Dlosses == full.Dlosses
+    assert torch.equal(torch.get_rng_state(), full_rng)
+    for (k, a), (_, b) in zip(model2.state_dict().items(), full_model.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the reference's own weights-only checkpoint still loads
+    tr2.save_model(str(tmp_path / "w.pt"))
+    assert list(torch.load(str(tmp_path / "w.pt")).keys()) == list(full_model.state_dict().keys())
+
+
+@pytest.mark.parametrize("kind", ["vae", "ae"])
+def test_vae_ae_checkpoint_resume_is_bitwise_uninterrupted(kind, tmp_path):
+    import contextlib, io
+    cfg = SMALL
+
+    def build(seed):
+        loaders = port.synthetic_loaders(cfg["batch"], n_train=150, n_val=cfg["n_val"],
+                                         n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+        torch.manual_seed(seed)
+        if kind == "vae":
+            import vae
+            model = vae.VAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
+                            z_dim=cfg["z_dim"])
+            return vae.VAETrainer(model, *loaders, viz=False), model
+        import ae
+        model = ae.Autoencoder(image_size=cfg["image_size"], hidden_dim=cfg["z_dim"])
+        return ae.AutoencoderTrainer(model, *loaders, viz=False), model
+
+    def train(tr, n):
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(num_epochs=n)
+        torch.cuda.synchronize()
+
+    full, full_model = build(1234)
+    train(full, 2)
+    full_rng = torch.get_rng_state()
+    tr1, _ = build(1234)
+    train(tr1, 1)
+    path = str(tmp_path / "ck.pt")
+    tr1.save_checkpoint(path)
+    tr2, model2 = build(999)
+    torch.manual_seed(4242)
+    tr2.load_checkpoint(path)
+    train(tr2, 1)
+    assert tr2.num_epochs == 2 and tr2.recon_loss == full.recon_loss
+    if kind == "vae":
+        assert tr2.kl_loss == full.kl_loss
+    assert tr2.best_val_loss == full.best_val_loss
+    assert torch.equal(torch.get_rng_state(), full_rng)
+    for (k, a), (_, b) in zip(model2.state_dict().items(), full_model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_dp_launch_structure_single_rank_rccl():
     """The data-parallel launch structure (one hipGraph per segment, RCCL all-reduce of the flat
     gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run
