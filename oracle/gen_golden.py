@@ -175,9 +175,39 @@ def gen_ae():
                                 torch=torch.__version__))
 
 
+def gen_bir():
+    """bir_vae.py fixtures (second half): the oracle of the NEXT row, produced
+    ahead of the product.  numpy's global generator (reparameterisation noise) is seeded with 77
+    right before the model is built; small dims with full parameters, and 784-400-20 at B = 256."""
+    mod = ref_harness.load("bir_vae")
+    for name, cfg, batch, n_train, epochs, full in (
+            ("bir_small", SMALL, SMALL["batch"], 150, 2, False),
+            ("bir_full_b256", FULL, 256, 256 * 6 + 100, 1, True)):
+        loaders = ref_harness.synthetic_loaders(batch, n_train=n_train, n_val=cfg["n_val"],
+                                                n_test=cfg["n_test"],
+                                                image_shape=cfg["image_shape"])
+        torch.manual_seed(1234)
+        np.random.seed(77)
+        model = mod.BIRVAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
+                           z_dim=cfg["z_dim"])
+        tr = mod.BIRVAETrainer(model, *loaders, viz=False)
+        with ref_harness.quiet():
+            tr.train(num_epochs=epochs)
+        arrays = {"recon_loss": np.array(tr.recon_loss), "mmd_loss": np.array(tr.mmd_loss),
+                  "best_val_loss": np.array(tr.best_val_loss)}
+        for k, v in model.state_dict().items():
+            arrays[("digest:" if full else "param:") + k] = digest(v) if full else v.numpy()
+        save(name, arrays, dict(variant="bir", cfg=cfg, batch=batch, n_train=n_train, np_seed=77,
+                                train_kw=dict(num_epochs=epochs), rng=rng_digest(),
+                                torch=torch.__version__))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["ae"]:
         gen_ae()                 # only the ae.py fixtures (the others are unchanged)
+    elif sys.argv[1:] == ["bir"]:
+        gen_bir()
     else:
         main()
         gen_ae()
+        gen_bir()

@@ -138,6 +138,46 @@ class AEModel(nn.Module):
         return self.decoder(self.encoder(x))              # ae.py:66
 
 
+class BIRVAEModel(nn.Module):
+    """bir_vae.py:37-97 (second half; product side not built yet).  Keys
+    encoder.{linear,mu}, decoder.{linear,recon}.  One quirk is part of the contract: the
+    reparameterisation noise comes from NUMPY's global RNG with `scale = set_var` (a variance used
+    as a standard deviation, bir_vae.py:92-94)."""
+
+    class Enc(nn.Module):
+        def __init__(self, image_size, hidden_dim, z_dim):
+            super().__init__()
+            self.linear = nn.Linear(image_size, hidden_dim)
+            self.mu = nn.Linear(hidden_dim, z_dim)
+
+        def forward(self, x):
+            return self.mu(F.relu(self.linear(x)))        # bir_vae.py:47-50
+
+    class Dec(nn.Module):
+        def __init__(self, z_dim, hidden_dim, image_size):
+            super().__init__()
+            self.linear = nn.Linear(z_dim, hidden_dim)    # bir_vae.py:60
+            self.recon = nn.Linear(hidden_dim, image_size)
+
+        def forward(self, z):
+            return torch.sigmoid(self.recon(F.relu(self.linear(z))))   # bir_vae.py:63-66
+
+    def __init__(self, image_size=784, hidden_dim=400, z_dim=20, I=13.3):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim, self.I = image_size, hidden_dim, z_dim, I
+        self.encoder = BIRVAEModel.Enc(image_size, hidden_dim, z_dim)
+        self.decoder = BIRVAEModel.Dec(z_dim, hidden_dim, image_size)
+        self.shape = int(image_size ** 0.5)
+        self.set_var = 1 / (4 ** (I / z_dim))             # bir_vae.py:82
+
+    def forward(self, x):
+        mu = self.encoder(x)
+        eps = torch.from_numpy(np.random.normal(loc=0.0, scale=self.set_var,
+                                                size=mu.shape)).float()   # bir_vae.py:92-94
+        z = mu + eps
+        return self.decoder(z), z
+
+
 # --------------------------------------------------------------------------------------------
 # Per-variant defaults: (G_lr, D_lr, D_steps) of each train() signature (SURVEY.md section 8b).
 # --------------------------------------------------------------------------------------------
@@ -156,6 +196,7 @@ REFERENCE_NAMES = {
                                                       "FisherGANTrainer"),
     "info": ("info_gan", "InfoGAN", "InfoGANTrainer"), "vae": ("vae", "VAE", "VAETrainer"),
     "ae": ("ae", "Autoencoder", "AutoencoderTrainer"),
+    "bir": ("bir_vae", "BIRVAE", "BIRVAETrainer"),
 }
 
 
@@ -454,6 +495,68 @@ class VAEPort:
             self.num_epochs += 1
 
 
+class BIRVAEPort:
+    """bir_vae.py:99-232 (train loop, compute_batch, maximum_mean_discrepancy, compute_kernel,
+    evaluate).  Note: the reference never increments `num_epochs` here."""
+
+    def __init__(self, model, train_iter, val_iter, test_iter):
+        self.model, self.train_iter, self.val_iter, self.test_iter = \
+            model, train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))       # bir_vae.py:110 (2 RNG draws)
+        self.mmd_loss, self.recon_loss, self.val_losses = [], [], []
+        self.num_epochs = 0
+
+    @staticmethod
+    def compute_kernel(x, y):
+        """bir_vae.py:210-221: exp(-mean_d((x_i - y_j)^2) / dim)."""
+        x_size, y_size, dim = x.size(0), y.size(0), x.size(1)
+        tx = x.unsqueeze(1).expand(x_size, y_size, dim)
+        ty = y.unsqueeze(0).expand(x_size, y_size, dim)
+        return torch.exp(-torch.div(torch.mean(torch.pow(tx - ty, 2), dim=2), dim))
+
+    def maximum_mean_discrepancy(self, z):
+        x = torch.randn(z.shape)                              # bir_vae.py:203 (global CPU generator)
+        return (self.compute_kernel(x, x).sum() + self.compute_kernel(z, z).sum()
+                - 2 * self.compute_kernel(x, z).sum())        # bir_vae.py:207
+
+    def compute_batch(self, batch, LAMBDA=1000.):
+        images, _ = batch
+        images = images.view(images.shape[0], -1)
+        outputs, z = self.model(images)
+        mse = torch.sum((images - outputs) ** 2)              # bir_vae.py:194
+        return mse, LAMBDA * self.maximum_mean_discrepancy(z)  # bir_vae.py:197
+
+    def evaluate(self, iterator):
+        loss = []
+        for batch in iterator:
+            mse, mmd = self.compute_batch(batch)
+            loss.append((mse + mmd).item())
+        return np.mean(loss)
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5):
+        opt = optim.Adam(params=[p for p in self.model.parameters() if p.requires_grad], lr=lr,
+                         weight_decay=weight_decay)
+        for _epoch in range(1, num_epochs + 1):
+            self.model.train()
+            e_recon, e_mmd = [], []
+            for batch in self.train_iter:
+                opt.zero_grad()
+                mse, mmd = self.compute_batch(batch)
+                (mse + mmd).backward()
+                opt.step()
+                e_recon.append(mse.item())
+                e_mmd.append(mmd.item())
+            self.mmd_loss.extend(e_mmd)
+            self.recon_loss.extend(e_recon)
+            self.model.eval()
+            val = self.evaluate(self.val_iter)
+            self.val_losses.append(val)
+            if val < self.best_val_loss:
+                self.best_model = copy.deepcopy(self.model)
+                self.best_val_loss = val
+
+
 class AEPort:
     """ae.py:69-168 (train loop, compute_batch, evaluate)."""
 
@@ -520,4 +623,6 @@ def build(variant, image_size=784, hidden_dim=400, z_dim=20, seed=1234, **kw):
         return VAEModel(image_size, hidden_dim, z_dim)
     if variant == "ae":
         return AEModel(image_size, hidden_dim)
+    if variant == "bir":
+        return BIRVAEModel(image_size, hidden_dim, z_dim, **kw)
     return GANModel(variant, image_size, hidden_dim, z_dim, **kw)

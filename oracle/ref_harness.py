@@ -30,7 +30,7 @@ REFERENCE_ROOT = os.environ.get("GM_REFERENCE_ROOT", "/root/reference")
 REFERENCE_SRC = os.path.join(REFERENCE_ROOT, "src")
 
 MODULES = ("ns_gan", "mm_gan", "w_gan", "w_gp_gan", "ls_gan", "dra_gan", "be_gan", "ra_gan",
-           "f_gan", "fisher_gan", "info_gan", "vae", "ae")
+           "f_gan", "fisher_gan", "info_gan", "vae", "ae", "bir_vae")
 
 
 def available():

@@ -22,7 +22,7 @@ def load(name):
 
 
 SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
-               if not os.path.basename(p).startswith(("vae", "ae_")))
+               if not os.path.basename(p).startswith(("vae", "ae_", "bir_")))
 FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256"]
 
 
@@ -40,7 +40,8 @@ def run_port_gan(meta, batch, max_steps=None):
 
 def test_fixture_inventory():
     assert len(SMALL) == 16, SMALL          # 10 variants + 6 f-divergences
-    for n in FULL + ["vae_small", "vae_full_b512", "ae_small", "ae_full_b512"]:
+    for n in FULL + ["vae_small", "vae_full_b512", "ae_small", "ae_full_b512", "bir_small",
+                     "bir_full_b256"]:
         assert os.path.isfile(os.path.join(GOLDEN, n + ".npz")), n
 
 
@@ -97,6 +98,26 @@ def test_ae(name):
     tr = port.AEPort(model, *loaders)
     tr.train(**meta["train_kw"])
     np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
+    np.testing.assert_allclose(tr.best_val_loss, float(z["best_val_loss"]), rtol=RTOL)
+    for k, v in model.state_dict().items():
+        if "param:" + k in z:
+            np.testing.assert_allclose(v.numpy(), z["param:" + k], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["bir_small", "bir_full_b256"])
+def test_bir_vae(name):
+    """bir_vae.py (second half): the oracle of the next row against fixtures
+    from the unmodified reference (torch AND numpy global generators in play)."""
+    z, meta = load(name)
+    cfg = meta["cfg"]
+    loaders = port.synthetic_loaders(meta["batch"], n_train=meta["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    np.random.seed(meta["np_seed"])
+    model = port.build("bir", cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    tr = port.BIRVAEPort(model, *loaders)
+    tr.train(**meta["train_kw"])
+    np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(tr.mmd_loss), z["mmd_loss"], rtol=10 * RTOL, atol=1e-3)
     np.testing.assert_allclose(tr.best_val_loss, float(z["best_val_loss"]), rtol=RTOL)
     for k, v in model.state_dict().items():
         if "param:" + k in z:

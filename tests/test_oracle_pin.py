@@ -79,6 +79,36 @@ def test_gan_port_bit_exact(variant, kw):
 
 
 @needs_ref
+def test_bir_vae_port_bit_exact():
+    """bir_vae.py (second half): the oracle for the next row is pinned ahead of
+    the product.  Two generators are in play: torch's (sampling, MMD prior draws) and numpy's
+    (reparameterisation noise) -- both must end in the same state."""
+    mod = ref_harness.load("bir_vae")
+    tr_i, va_i, te_i = _loaders(B)
+    torch.manual_seed(1234); np.random.seed(77)
+    ref_model = mod.BIRVAE(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    ref_tr = mod.BIRVAETrainer(ref_model, tr_i, va_i, te_i, viz=False)
+    with ref_harness.quiet():
+        ref_tr.train(num_epochs=2)
+    ref_state, ref_np = torch.get_rng_state(), np.random.get_state()[1].copy()
+
+    tr_i, va_i, te_i = _loaders(B)
+    np.random.seed(77)
+    my_model = port.build("bir", IMG, HID, Z)
+    my_tr = port.BIRVAEPort(my_model, tr_i, va_i, te_i)
+    my_tr.train(num_epochs=2)
+    np.testing.assert_array_equal(np.array(ref_tr.recon_loss), np.array(my_tr.recon_loss))
+    np.testing.assert_array_equal(np.array(ref_tr.mmd_loss), np.array(my_tr.mmd_loss))
+    assert ref_tr.best_val_loss == my_tr.best_val_loss and ref_tr.num_epochs == my_tr.num_epochs == 0
+    ref_sd, my_sd = ref_model.state_dict(), my_model.state_dict()
+    assert list(ref_sd.keys()) == list(my_sd.keys())
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], my_sd[k]), k
+    assert torch.equal(ref_state, torch.get_rng_state())
+    np.testing.assert_array_equal(ref_np, np.random.get_state()[1])
+
+
+@needs_ref
 def test_ae_port_bit_exact():
     """ae.py: same protocol as the VAE pin, one loss list."""
     mod = ref_harness.load("ae")
