@@ -185,3 +185,32 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
 def ctypes_sizeof(ct):
     import ctypes
     return ctypes.sizeof(ct)
+
+
+def test_bench_kernel_names_match_the_committed_rocprof_summary():
+    """bench.py names the kernel instantiation of every GEMM launch shape of the step (it mirrors
+    the library's tile / schedule selection); those names must be the ones rocprofv3 recorded in
+    the committed round summary, and the bench line's dominant kernel must be one of them."""
+    import csv
+    import importlib.util
+    import json
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("gm_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = list(csv.DictReader(open(os.path.join(root, "profiles",
+                                                 "r01_nsgan_b256_final_kernel_stats.csv"))))
+    profiled = {r["kernel"] for r in rows}
+    names = {bench.gemm_variant(*shape) for shape in bench.gemm_shapes(256)}
+    assert len(names) >= 7
+    for n in names:
+        assert n in profiled, "bench names %r, rocprofv3 saw %s" % (n, sorted(profiled)[:12])
+    line = json.load(open(os.path.join(root, "profiles", "r01_bench_final.json")))
+    assert line["roofline"]["kernel"] in names
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"]
+    avg = {r["kernel"]: float(r["avg_us"]) for r in rows}
+    # the live HIP-event duration and the profiler's average of the same kernel agree
+    assert abs(avg[line["roofline"]["kernel"]] - line["roofline"]["avg_launch_us"]) <= 1.0
