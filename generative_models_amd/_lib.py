@@ -126,6 +126,7 @@ _SIGNATURES = {
                                _P, c_int64, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
+    "gm_mt19937_skip": (c_int, [_P, c_int64, ctypes.c_uint64]),
     "gm_graph_begin": (c_int, [_P]),
     "gm_graph_end": (c_int, [_P, POINTER(c_void_p)]),
     "gm_graph_launch": (c_int, [_P, _P]),

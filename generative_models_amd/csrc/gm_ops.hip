@@ -353,6 +353,71 @@ extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out)
 }
 
 // ------------------------------------------------------------------------------------------
+// HOST: advance a serialized torch CPU generator (mt19937) by n 32-bit outputs WITHOUT producing
+// them.  Data-parallel ranks replay the global draw protocol but only materialise their own rows of
+// each noise tensor; the other ranks' rows are skipped here (no tempering, no float math: one
+// twist per 624 outputs).  Layout = at::CPUGeneratorImplState (CPUGeneratorImpl.cpp): the legacy
+// POD {u64 seed; i32 left; i32 seeded; u64 next; u64 state[624]; 3 x f64; i32 valid} + {f32; bool}.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct TorchCpuGenState {
+    uint64_t the_initial_seed;
+    int32_t left;
+    int32_t seeded;
+    uint64_t next;
+    uint64_t state[624];
+    double normal_x, normal_y, normal_rho;
+    int32_t normal_is_valid;
+    float next_float_normal_sample;
+    bool is_next_float_normal_sample_valid;
+};
+
+inline uint32_t mt_tw(uint64_t u, uint64_t v) {
+    const uint32_t y = ((uint32_t)u & 0x80000000u) | ((uint32_t)v & 0x7fffffffu);
+    return (y >> 1) ^ (((uint32_t)v & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// at::mt19937::next_state(): the three-segment form (no modulo).  Dependence distances are 397 and
+// 227 elements and s[k+1] is read before it is written, so any SIMD width is safe; an AVX2 clone
+// is picked at run time (0.33 vs 0.55 us per twist).
+#define GM_MT_NEXT_STATE_BODY                                                                      \
+    _Pragma("clang loop vectorize(assume_safety)")                                                 \
+    for (int k = 0; k < 624 - 397; ++k) s[k] = (uint32_t)s[k + 397] ^ mt_tw(s[k], s[k + 1]);       \
+    _Pragma("clang loop vectorize(assume_safety)")                                                 \
+    for (int k = 624 - 397; k < 623; ++k) s[k] = (uint32_t)s[k + 397 - 624] ^ mt_tw(s[k], s[k + 1]); \
+    s[623] = (uint32_t)s[396] ^ mt_tw(s[623], s[0]);
+__attribute__((target("avx2"))) void mt_next_state_avx2(uint64_t* s) { GM_MT_NEXT_STATE_BODY }
+inline void mt_next_state_base(uint64_t* s) { GM_MT_NEXT_STATE_BODY }
+#undef GM_MT_NEXT_STATE_BODY
+inline void mt_next_state(uint64_t* s) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) mt_next_state_avx2(s); else mt_next_state_base(s);
+}
+}  // namespace
+
+extern "C" int gm_mt19937_skip(void* torch_cpu_rng_state, int64_t state_bytes, uint64_t n) {
+    GM_CHECK_ARG(torch_cpu_rng_state && state_bytes == (int64_t)sizeof(TorchCpuGenState));
+    TorchCpuGenState* g = reinterpret_cast<TorchCpuGenState*>(torch_cpu_rng_state);
+    GM_CHECK_ARG(g->seeded == 1 && g->left >= 1 && g->left <= 624 && g->next <= 624);
+    // at::mt19937::operator(): if (--left == 0) next_state();  y = state[next++];
+    while (n > 0) {
+        const uint64_t avail = (uint64_t)(g->left - 1);       // outputs before the next twist
+        if (avail == 0) {
+            mt_next_state(g->state);
+            g->left = 624;
+            g->next = 1;                                      // this call's output was state[0]
+            n -= 1;
+            continue;
+        }
+        const uint64_t take = avail < n ? avail : n;
+        g->left -= (int32_t)take;
+        g->next += take;
+        n -= take;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // HIP graph + event helpers
 // ------------------------------------------------------------------------------------------
 #define GM_HIP(call)                                              \

@@ -109,6 +109,37 @@ def draw_sampler_indices(n, B, out):
     return seed
 
 
+def _rng_skip(n):
+    """Advance torch's global CPU generator by n 32-bit outputs without producing them."""
+    if n <= 0:
+        return
+    from . import _lib
+    st = torch.get_rng_state()
+    _lib.call("gm_mt19937_skip", st.data_ptr(), st.numel(), n)
+    torch.set_rng_state(st)
+
+
+def draw_rows(dst, r0, r1, kind="normal"):
+    """Fill rows [r0, r1) of the contiguous fp32 tensor dst[B, W] exactly as `dst.normal_()` /
+    `dst.uniform_()` would, leave the other rows untouched, and leave the global CPU generator
+    where the full draw would have left it.  A data-parallel rank only needs its own rows of each
+    noise tensor; the other ranks' share of the stream is skipped (gm_mt19937_skip) instead of
+    generated.  Relies on ATen's CPU kernels for contiguous fp32 tensors of >= 16 elements
+    (DistributionTemplates.h normal_fill / uniform via a serial loop): one 32-bit output per
+    element, element i depending only on outputs of its own 16-element group -- so a 16-aligned
+    row range is self-contained.  Anything else falls back to the full draw."""
+    B, W = dst.shape
+    e0, e1, total = r0 * W, r1 * W, B * W
+    aligned = (e0 % 16 == 0 and e1 % 16 == 0 and total % 16 == 0 and e1 - e0 >= 16
+               and dst.is_contiguous() and dst.dtype == torch.float32)
+    if not aligned or (r0 == 0 and r1 == B):
+        getattr(dst, kind + "_")()
+        return
+    _rng_skip(e0)
+    getattr(dst.view(-1)[e0:e1], kind + "_")()
+    _rng_skip(total - e1)
+
+
 _POOL = None
 
 
@@ -673,9 +704,9 @@ class GANEngine:
         if self.variant == "info":
             self._draw_info_noise(s["zD"][k])
             return
-        s["zD"][k].normal_()                         # torch.randn(B, Z)   ns_gan.py:183,220
+        self._noise(s["zD"][k], "normal")            # torch.randn(B, Z)   ns_gan.py:183,220
         if self.variant == "wgp":
-            s["eps"][k].uniform_()                   # torch.rand(B, 1)    w_gp_gan.py:197
+            self._noise(s["eps"][k].view(-1, 1), "uniform")   # torch.rand(B, 1)  w_gp_gan.py:197
         if self.variant == "dra":
             s["delta"][k].uniform_()                 # torch.rand(B, 1)    dra_gan.py:200
             s["U"][k].uniform_()                     # torch.rand(B, 784)  dra_gan.py:205
@@ -685,7 +716,17 @@ class GANEngine:
             self._draw_info_noise(s["zG"][k])        # train_G: info_gan.py:258-260
             self._draw_info_noise(s["zQ"][k])        # train_Q: info_gan.py:283-284
             return
-        s["zG"][k].normal_()                         # ns_gan.py:208
+        self._noise(s["zG"][k], "normal")            # ns_gan.py:208
+
+    def _noise(self, dst, kind):
+        """One noise tensor of the GLOBAL batch.  A single process draws it whole; a data-parallel
+        rank materialises only its own rows and skips the rest of the stream (draw_rows): the
+        per-iteration host cost stays ~constant instead of growing with the number of ranks."""
+        if self.world == 1:
+            getattr(dst, kind + "_")()
+        else:
+            r0 = self.rank * self.Bl
+            draw_rows(dst, r0, r0 + self.Bl, kind)
 
     def _fill(self, s, n_it):
         """HOST: replay the reference's draw order for n_it iterations into pinned staging `s`.

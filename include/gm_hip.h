@@ -291,6 +291,11 @@ int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t
  * forward Fisher-Yates `z = random() % (n-i); swap(r[i], r[i+z])` as in ATen randperm_cpu.
  * Bit-exact sampling indices without materialising the 50 000-entry permutation. */
 int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out_host);
+/* HOST: advance a serialized torch CPU generator state (torch.get_rng_state(), 5056 bytes,
+ * mt19937) by n 32-bit outputs without producing them.  Data-parallel ranks replay the reference's
+ * global draw protocol (ns_gan.py:183,208,220) but materialise only their own rows of each noise
+ * tensor; the draws belonging to other ranks' rows are skipped with this call. */
+int gm_mt19937_skip(void* torch_cpu_rng_state, int64_t state_bytes, uint64_t n);
 
 /* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ------------------ */
 int gm_graph_begin(void* stream);

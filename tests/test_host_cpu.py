@@ -214,3 +214,68 @@ def test_bench_kernel_names_match_the_committed_rocprof_summary():
     avg = {r["kernel"]: float(r["avg_us"]) for r in rows}
     # the live HIP-event duration and the profiler's average of the same kernel agree
     assert abs(avg[line["roofline"]["kernel"]] - line["roofline"]["avg_launch_us"]) <= 1.0
+
+
+@pytest.mark.parametrize("kind", ["normal", "uniform"])
+@pytest.mark.parametrize("B,W,r0,r1", [(2048, 20, 256, 512), (2048, 20, 0, 256), (512, 20, 384, 512),
+                                       (256, 784, 64, 128), (2048, 1, 256, 512), (48, 8, 16, 32),
+                                       (24, 10, 8, 16), (7, 3, 2, 4)])
+def test_draw_rows_is_a_bit_exact_slice_of_the_full_draw(kind, B, W, r0, r1):
+    """Data-parallel ranks materialise only their own rows of each noise tensor: the rows must be
+    bit-identical to the same rows of the full draw and the global generator must end where the
+    full draw would have left it (unaligned shapes fall back to the full draw)."""
+    torch.manual_seed(11); torch.empty(5).random_()
+    full = getattr(torch.empty(B, W), kind + "_")()
+    ref_state = torch.get_rng_state().clone()
+    torch.manual_seed(11); torch.empty(5).random_()
+    part = torch.full((B, W), -7.0)
+    engine.draw_rows(part, r0, r1, kind)
+    assert torch.equal(part[r0:r1], full[r0:r1])
+    assert torch.equal(ref_state, torch.get_rng_state())
+    nxt = torch.randn(33)
+    torch.set_rng_state(ref_state)
+    assert torch.equal(nxt, torch.randn(33))
+
+
+def test_mt19937_skip_equals_discarding_outputs():
+    for n in (1, 623, 624, 625, 5120, 123457):
+        torch.manual_seed(7); torch.empty(3).random_()
+        torch.empty(n, dtype=torch.int32).random_()            # one 32-bit output per element
+        ref = torch.get_rng_state().clone()
+        torch.manual_seed(7); torch.empty(3).random_()
+        engine._rng_skip(n)
+        assert torch.equal(ref, torch.get_rng_state()), n
+
+
+@pytest.mark.parametrize("variant", ["ns", "wgp"])
+def test_dp_ranks_replay_the_global_draw_protocol(variant):
+    """_draw_D / _draw_G on rank r of a 4-rank job: own rows bit-identical to the single-process
+    draws, identical sampling indices, identical generator position afterwards."""
+    from types import SimpleNamespace
+    B, Z, N, R = 64, 20, 5000, 3
+
+    def stage():
+        s = dict(idx=torch.zeros(R, B, dtype=torch.int64), zD=torch.full((R, B, Z), -9.0),
+                 zG=torch.full((R, B, Z), -9.0), eps=torch.full((R, B), -9.0))
+        s["idx_np"] = s["idx"].numpy()
+        return s
+
+    def replay(world, rank):
+        eng = SimpleNamespace(N=N, B=B, Bl=B // world, world=world, rank=rank, variant=variant)
+        eng._noise = lambda dst, kind: engine.GANEngine._noise(eng, dst, kind)
+        torch.manual_seed(99)
+        s = stage()
+        for k in range(R):
+            engine.GANEngine._draw_D(eng, s, k)
+            engine.GANEngine._draw_G(eng, s, k)
+        return s, torch.get_rng_state()
+
+    full, full_state = replay(1, 0)
+    for rank in range(4):
+        s, state = replay(4, rank)
+        r0, r1 = rank * 16, rank * 16 + 16
+        assert torch.equal(s["idx"], full["idx"])
+        for key in ("zD", "zG") + (("eps",) if variant == "wgp" else ()):
+            assert torch.equal(s[key][:, r0:r1], full[key][:, r0:r1]), (key, rank)
+            assert bool((s[key][:, :r0] == -9).all()) and bool((s[key][:, r1:] == -9).all())
+        assert torch.equal(state, full_state)
