@@ -119,6 +119,25 @@ def _rng_skip(n):
     torch.set_rng_state(st)
 
 
+_SKIP_OK = None
+
+
+def _skip_supported():
+    """gm_mt19937_skip understands this torch build's serialized CPU generator state (checked once,
+    on a copy: the global generator is not touched).  If not, data-parallel ranks simply draw the
+    full tensors -- slower on the host, same results."""
+    global _SKIP_OK
+    if _SKIP_OK is None:
+        from . import _lib
+        try:
+            st = torch.get_rng_state().clone()
+            _lib.call("gm_mt19937_skip", st.data_ptr(), st.numel(), 1)
+            _SKIP_OK = True
+        except Exception:                      # noqa: BLE001  (unknown layout: fall back for good)
+            _SKIP_OK = False
+    return _SKIP_OK
+
+
 def draw_rows(dst, r0, r1, kind="normal"):
     """Fill rows [r0, r1) of the contiguous fp32 tensor dst[B, W] exactly as `dst.normal_()` /
     `dst.uniform_()` would, leave the other rows untouched, and leave the global CPU generator
@@ -132,7 +151,7 @@ def draw_rows(dst, r0, r1, kind="normal"):
     e0, e1, total = r0 * W, r1 * W, B * W
     aligned = (e0 % 16 == 0 and e1 % 16 == 0 and total % 16 == 0 and e1 - e0 >= 16
                and dst.is_contiguous() and dst.dtype == torch.float32)
-    if not aligned or (r0 == 0 and r1 == B):
+    if not aligned or (r0 == 0 and r1 == B) or not _skip_supported():
         getattr(dst, kind + "_")()
         return
     _rng_skip(e0)
