@@ -102,3 +102,58 @@ def test_shard_range_and_errors():
     with pytest.raises(ValueError):
         dp.shard_range(100, 8, 0)
     assert dp.current() == (1, 0, None)
+
+
+def _replay_worker(rank, world, port_no, out_q):
+    """Each rank replays three iterations of the global draw protocol materialising only its own
+    noise rows (engine.GANEngine._draw_D/_draw_G on a stand-in engine), then the ranks all-gather
+    their rows: the assembled tensors must be the single-process draws, bit for bit."""
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_no)
+    os.environ["WORLD_SIZE"], os.environ["RANK"], os.environ["LOCAL_RANK"] = \
+        str(world), str(rank), str(rank)
+    torch.set_num_threads(1)
+    dp.init_from_env(backend="gloo")
+    Bg, Zg, R = 64, 20, 3                                    # 32 rows x 20 = 640 elements per rank
+
+    def replay(w, r):
+        eng = SimpleNamespace(N=N, B=Bg, Bl=Bg // w, world=w, rank=r, variant="ns")
+        eng._noise = lambda dst, kind: engine.GANEngine._noise(eng, dst, kind)
+        torch.manual_seed(2024)
+        s = dict(idx=torch.zeros(R, Bg, dtype=torch.int64), zD=torch.zeros(R, Bg, Zg),
+                 zG=torch.zeros(R, Bg, Zg))
+        s["idx_np"] = s["idx"].numpy()
+        for k in range(R):
+            engine.GANEngine._draw_D(eng, s, k)
+            engine.GANEngine._draw_G(eng, s, k)
+        return s, torch.get_rng_state()
+
+    mine, state = replay(world, rank)
+    lo, hi = dp.shard_range(Bg, world, rank)
+    ok = True
+    for key in ("zD", "zG"):
+        parts = [torch.zeros(R, Bg // world, Zg) for _ in range(world)]
+        dist.all_gather(parts, mine[key][:, lo:hi].contiguous())
+        mine[key + "_all"] = torch.cat(parts, dim=1)
+    full, full_state = replay(1, 0)                          # what ONE process would have drawn
+    ok = ok and torch.equal(mine["zD_all"], full["zD"]) and torch.equal(mine["zG_all"], full["zG"])
+    ok = ok and torch.equal(mine["idx"], full["idx"]) and torch.equal(state, full_state)
+    out_q.put((rank, bool(ok), bool(engine._skip_supported())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_assemble_the_single_process_noise_from_their_own_rows():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_no = _free_port()
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port_no, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)], res
