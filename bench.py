@@ -1,14 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the NSGAN D+G step (BASELINE.json metric), bs=256 per GPU, fp32.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: one rank per GPU; started under torch.distributed.run it uses the RANK/WORLD_SIZE it is
+    given, started from a bare shell it re-launches itself under torch.distributed.run)
 
 A "step" is one full reference iteration (ns_gan.py:122-156): process_batch -> train_D ->
 backward -> Adam(D) -> train_G -> backward -> Adam(G), in PARITY mode (reference RNG protocol,
 bit-exact sampling indices).  The dataset (synthetic 50 000 x 28x28 Bernoulli images, seed 3435)
 is resident in HBM before the timed region; the host-side RNG prefetch is inside it.
 Weak scaling: every rank runs bs=256 (global batch 256*N), gradients all-reduced over RCCL.
-Prints ONE JSON line on rank 0.
+The K-step timed region (barrier + synchronize on both sides, max over ranks) is repeated
+`--reps` times on fresh draws; `ms_per_step` / `value` are the MEDIAN repetition (all of them are
+listed in config.reps_ms_per_step).  The host draws of a timed step happen inside its timed region.
+At N=1 the same line carries `configs`: BASELINE.json configs 3/4/5 (WGAN-GP bs=256, VAE bs=512,
+NSGAN/LSGAN bs=1024) measured the same way, each with its dominant GEMM's roofline fraction and a
+bounded CPU-oracle baseline.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import contextlib
@@ -116,7 +123,7 @@ def _holder(N, K, dev):
 
 
 def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True,
-                          ride_gather=True, pair_dw=True, ride_head_dx=True, fused_adam=True):
+                          ride_gather=True, pair_dw=True, ride_head_dx=True, fused_adam=True, shapes=None):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -125,8 +132,8 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
     out = {}
     st = ops.stream_ptr()
     data = idx = xr = None
-    for kind, M, K, N in gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather, pair_dw,
-                                     ride_head_dx):
+    for kind, M, K, N in (shapes or gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather,
+                                                pair_dw, ride_head_dx)):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -209,41 +216,225 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline(seconds_target=12.0):
-    """Oracle port (CPU restatement of the reference trainer, oracle/port.py) timed as-written
-    (DataLoader reshuffle included) on this host's cores: NSGAN bs=256, same synthetic data.
-    Thread count: the fastest of {8,16,32} in a short probe (hundreds of OpenMP threads on
+def _probe_threads(fn_step, cands=(8, 16, 32)):
+    """Fastest OpenMP thread count for the CPU oracle in a short probe (hundreds of threads on
     256x400 GEMMs only add barrier time); the count used is reported as `cores`."""
-    from oracle import port
-    ds = synthetic_dataset()
-    loader = torch.utils.data.DataLoader(ds, batch_size=B_PER_GPU, shuffle=True)
-    model = port.build("ns", IMG, HID, Z)
-    tr = port.GANPort("ns", model, loader)
     ncpu = os.cpu_count() or 1
     best = None
-    for cand in [c for c in (8, 16, 32) if c <= ncpu] or [min(ncpu, 4)]:
+    for cand in [c for c in cands if c <= ncpu] or [min(ncpu, 4)]:
         torch.set_num_threads(cand)
-        tr.train(1, max_steps=3)                    # warm-up at this thread count
+        fn_step(3)
         t0 = time.perf_counter()
-        tr.train(1, max_steps=12)
-        ps = (time.perf_counter() - t0) / 12
+        fn_step(8)
+        ps = (time.perf_counter() - t0) / 8
         log("cpu probe %.1f ms/step on %d threads" % (ps * 1e3, cand))
         if best is None or ps < best[0]:
             best = (ps, cand)
-    per_step, cores = best
-    torch.set_num_threads(cores)
+    torch.set_num_threads(best[1])
+    return best
+
+
+def cpu_baseline_gan(variant="ns", B=B_PER_GPU, seconds_target=12.0, compute_only=False, cores=None):
+    """Oracle port (CPU restatement of the reference trainer, oracle/port.py, pinned bit-exact to
+    the unmodified reference) timed on this host's cores on the same synthetic data.
+    as-written: DataLoader reshuffle + collate per step included (the north-star "reference CPU
+    Trainer"); compute_only: process_batch returns one pre-fetched batch (separates
+    the data path from the math)."""
+    from oracle import port
+    ds = synthetic_dataset()
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True)
+    model = port.build(variant, IMG, HID, Z)
+    tr = port.GANPort(variant, model, loader)
+    kw = {"D_steps": 1} if variant == "wgp" else {}
+    if compute_only:
+        fixed = tr.process_batch()
+        tr.process_batch = lambda: fixed
+    step = lambda n: tr.train(1, max_steps=n, **kw)
+    if cores is None:
+        per_step, cores = _probe_threads(step)
+    else:
+        torch.set_num_threads(cores)
+        step(2)
+        t0 = time.perf_counter(); step(4); per_step = (time.perf_counter() - t0) / 4
     steps_per_epoch = int(np.ceil(len(loader)))
-    total, done, dt = int(max(10, min(2000, seconds_target / per_step))), 0, 0.0
+    total, done, dt = int(max(8, min(2000, seconds_target / per_step))), 0, 0.0
     while done < total:
         n = min(steps_per_epoch, total - done)
         t0 = time.perf_counter()
-        tr.train(1, max_steps=n)
+        step(n)
         dt += time.perf_counter() - t0
         done += n
-    return {"value": done * B_PER_GPU / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d NSGAN bs=256 D+G steps of oracle/port.py (torch %s CPU, %d threads), "
-                      "as-written incl. DataLoader reshuffle, %.1f s" % (done, torch.__version__,
-                                                                          cores, dt)}
+    return {"value": done * B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d %s bs=%d D+G steps of oracle/port.py (torch %s CPU, %d threads), %s, %.1f s"
+                      % (done, variant, B, torch.__version__, cores,
+                         "compute only (fixed pre-fetched batch)" if compute_only
+                         else "as-written incl. DataLoader reshuffle", dt)}
+
+
+def cpu_baseline_vae(B=512, seconds_target=5.0, cores=16):
+    from oracle import port
+    torch.set_num_threads(min(cores, os.cpu_count() or 1))
+    ds = synthetic_dataset()
+    mk = lambda: torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True)
+    tr = port.VAEPort(port.VAEModel(IMG, HID, Z), mk(), mk(), mk())
+    tr.train(1, max_steps=3, do_eval=False)
+    t0 = time.perf_counter(); tr.train(1, max_steps=4, do_eval=False); ps = (time.perf_counter() - t0) / 4
+    n = int(max(8, min(98, seconds_target / ps)))
+    t0 = time.perf_counter()
+    tr.train(1, max_steps=n, do_eval=False)
+    dt = time.perf_counter() - t0
+    return {"value": n * B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d VAE bs=%d training batches of oracle/port.py (as-written DataLoader "
+                      "iteration), %.1f s" % (n, B, dt)}
+
+
+# ------------------------------------------------------------------------------------------------
+def fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+
+def timed_reps(run_rep, reps, K, world, dev):
+    """run_rep(r) enqueues repetition r (K steps).  Returns seconds per repetition (max over
+    ranks), barrier + synchronize on both sides of each."""
+    out = []
+    for r in range(reps):
+        fence(world)
+        t0 = time.perf_counter()
+        run_rep(r)
+        fence(world)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = t.item()
+        out.append(dt)
+    return out
+
+
+def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=True, force_dp=False,
+              lrs=(2e-4, 2e-4), D_steps=1):
+    """W warm-up + reps x K timed iterations of the fused engine.  Returns (engine, [seconds])."""
+    import importlib
+    from generative_models_amd import engine as gm_engine
+    mod, cls = {"ns": ("ns_gan", "NSGAN"), "ls": ("ls_gan", "LSGAN"), "wgp": ("w_gp_gan", "WGPGAN")}[variant]
+    m = importlib.import_module(mod)
+    ds = synthetic_dataset()
+    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, shuffle=True)
+    torch.manual_seed(1234)
+    model = getattr(m, cls)(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    trainer = getattr(m, cls + "Trainer")(model, loader, None, None, viz=False)
+    data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
+    eng = gm_engine.GANEngine(variant, trainer.model, data, B_global, dev, use_graph=use_graph,
+                              world_size=world, rank=rank)
+    eng.force_segments = force_dp
+    eng.configure(W + reps * K, lrs[0], lrs[1], D_steps)
+    eng.run(W, it_start=0)
+    secs = timed_reps(lambda r: eng.run(K, it_start=W + r * K), reps, K, world, dev)
+    G, D = eng.losses(W, W + reps * K)
+    assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
+    return eng, secs
+
+
+def bench_vae(B, dev, with_eval, warm_epochs=1, epochs=3, n_val=10000):
+    """Full epochs of vae.py's train loop on the fused engine: 97 batches of 512 + the ragged 336
+    (50 000 mod 512); with_eval adds the reference's per-epoch validation pass (vae.py:174-175)."""
+    import vae
+    from generative_models_amd.engine import VAEEngine
+    from generative_models_amd.trainers import _epoch_order
+    ds = synthetic_dataset()
+    torch.manual_seed(3436)
+    vds = torch.utils.data.TensorDataset(torch.bernoulli(torch.full((n_val, 1, 28, 28), 0.1307)),
+                                         torch.zeros(n_val, dtype=torch.int64))
+    tl = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True)
+    vl = torch.utils.data.DataLoader(vds, batch_size=B, shuffle=True)
+    torch.manual_seed(1234)
+    tr = vae.VAETrainer(vae.VAE(IMG, HID, Z), tl, vl, vl)
+    eng = VAEEngine(tr.model, dev)
+    steps = len(tl)
+    eng.configure(B, (warm_epochs + epochs) * steps, 1e-3, 1e-5)
+    tdata = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()
+    vdata = vds.tensors[0].reshape(n_val, -1).to(dev).contiguous()
+    eng.alloc_val(len(vl))
+    t0 = None
+    for e in range(warm_epochs + epochs):
+        if e == warm_epochs:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        eng.run_pass(tdata, _epoch_order(tl), True, e * steps)
+        if with_eval:
+            eng.run_pass(vdata, _epoch_order(vl), False, 0)
+            eng.vrecon[:len(vl)].cpu()                # the reference reads the validation loss every epoch
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(eng.recon.cpu().numpy()).all()
+    return epochs * N_TRAIN / dt, dt / (epochs * steps) * 1e3, epochs * steps
+
+
+def dominant_gemm_roofline(M, K, N, reps=50):
+    """Isolated HIP-event timing of the forward GEMM [M,K]x[K,N] (the largest contraction of the
+    config) -> roofline entry."""
+    kt = time_kernels_isolated(0, reps=reps, shapes=[("fwd", M, K, N)])
+    (name, (us, flop, n)), = kt.items()
+    ach = flop / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": name, "shape": "fwd %dx%dx%d" % (M, K, N), "avg_launch_us": us,
+            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_MFMA_TFLOPS}
+
+
+def other_configs(dev, steps, warmup, reps, cpu=True):
+    """BASELINE.json configs 3/4/5 on one MI355X, >= 200 timed steps each."""
+    K, W = max(steps, 200), max(warmup, 20)
+    out = []
+
+    def gan(name, variant, B, lrs, flop_per_image, cpu_variant):
+        eng, secs = bench_gan(variant, B, W, K, reps, dev, lrs=lrs)
+        dt = float(np.median(secs))
+        e = {"workload": name, "img_s": K * B / dt, "ms_per_step": dt / K * 1e3, "steps": K,
+             "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
+             "step_mfma_frac": K * B / dt * flop_per_image / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+             "roofline": dominant_gemm_roofline(2 * B, IMG, HID)}
+        if cpu:
+            e["cpu_baseline"] = cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)
+        log("%s: %.0f img/s" % (name, e["img_s"]))
+        del eng
+        out.append(e)
+
+    gan("WGAN-GP MNIST bs=256 D_steps=1 (BASELINE.json configs[2]; w_gp_gan.py __main__)", "wgp", 256,
+        (1e-4, 1e-4), 8_836_000, "wgp")
+    gan("NSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ns", 1024,
+        (2e-4, 2e-4), FLOP_PER_IMAGE, "ns")
+    gan("LSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ls", 1024,
+        (1e-4, 1e-4), FLOP_PER_IMAGE, "ls")
+    for with_eval in (False, True):
+        img_s, ms, n = bench_vae(512, dev, with_eval)
+        e = {"workload": "VAE MNIST bs=512 full epochs incl. the ragged 336 batch, %s "
+                         "(BASELINE.json configs[3])" % ("train + per-epoch 10k-image validation pass"
+                                                         if with_eval else "train loop only"),
+             "img_s": img_s, "ms_per_step": ms, "steps": n,
+             "step_mfma_frac": img_s * 3_280_000 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+             "roofline": dominant_gemm_roofline(512, IMG, HID)}
+        if cpu and not with_eval:
+            e["cpu_baseline"] = cpu_baseline_vae(512)
+        log("%s: %.0f img/s" % (e["workload"], img_s))
+        out.append(e)
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: re-run under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -251,72 +442,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 3/4/5 section")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node "
-                     "%d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
-    pg = None
     # diagnostic: GM_FORCE_DP=1 runs the data-parallel launch structure (segment graphs + RCCL
     # all-reduces of the gradient buckets) on ONE rank, to price its host/launch overhead
     force_dp = world == 1 and os.environ.get("GM_FORCE_DP") == "1"
-    if force_dp:
+    ranks_seen = 1
+    if force_dp or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        ranks_seen = dist.get_world_size()
 
-    from generative_models_amd import engine as gm_engine, ops
-    import ns_gan
-
-    ds = synthetic_dataset()
-    B_global = B_PER_GPU * world
-    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, shuffle=True)
-    torch.manual_seed(1234)
-    model = ns_gan.NSGAN(image_size=IMG, hidden_dim=HID, z_dim=Z)
-    trainer = ns_gan.NSGANTrainer(model, loader, None, None, viz=False)
     dev = torch.device("cuda", local_rank)
-    data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
-    eng = gm_engine.GANEngine("ns", trainer.model, data, B_global, dev,
-                              use_graph=not args.no_graph,
-                              world_size=world, rank=rank)
-    eng.force_segments = force_dp
-    W, K = args.warmup, args.steps
-    log('engine built')
-    eng.configure(W + K, 2e-4, 2e-4, 1)
-    eng.run(W, it_start=0)
-    log('warmup issued')
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    eng.run(K, it_start=W)
-    fence()
-    dt = time.perf_counter() - t0
-    log('timed region done: %.3f s' % dt)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
-    G, D = eng.losses(W, W + K)
-    assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
+    W, K, reps = args.warmup, args.steps, max(1, args.reps)
+    B_global = B_PER_GPU * world
+    eng, secs = bench_gan("ns", B_global, W, K, reps, dev, world=world, rank=rank,
+                          use_graph=not args.no_graph, force_dp=force_dp)
+    dt = float(np.median(secs))
+    log('timed regions done: %s' % ["%.4f" % x for x in secs])
     img_s = K * B_global / dt
 
     if rank == 0:
@@ -327,21 +485,23 @@ def main():
                                    ride_head_dx=eng.ride_head_dx and not eng.head_final)
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
-        log('isolated kernel timing done')
         dom = max(kt, key=lambda k: kt[k][0])
         t_us, flop, n = kt[dom]
-        # HBM/fabric bytes per launch of that kernel from the committed PMC pass
-        # (profiles/r01_pmc_fetch_write.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; PMC counters
-        # cannot be read from inside this process, so the per-dispatch averages are loaded)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]
-            if rows:
-                nd = sum(v["dispatches"] for v in rows)
-                traffic = sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in rows) / nd
-        except Exception:
-            traffic = None
+        # HBM/fabric bytes per launch of that kernel from the COMMITTED PMC pass (profiles/: FETCH_SIZE
+        # x2 gfx950 correction + WRITE_SIZE per dispatch; PMC counters cannot be read from inside this
+        # process) -- the source file is named next to the number
+        traffic, traffic_src = None, None
+        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]
+                if rows:
+                    nd = sum(v["dispatches"] for v in rows)
+                    traffic = sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in rows) / nd
+                    traffic_src = "profiles/" + cand
+                    break
+            except Exception:
+                continue
         achieved = flop / (t_us * 1e-6) / 1e12
         line = {
             "metric": "images/sec (28x28 MNIST) per D+G step, NSGAN bs=256",
@@ -353,21 +513,29 @@ def main():
                                    "RNG protocol, Adam 2e-4, D_steps=1",
                        "global_batch": B_global,
                        "launch": ("hipGraph/iteration" if (world == 1 and not force_dp) else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
+                       "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
+                       "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
+                       "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw"},
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "shader_clock_mhz": round(mhz),
                          "launches_per_step": n, "avg_launch_us": t_us / n,
                          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+        del eng
+        if world == 1 and not force_dp:
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline_gan("ns", B_PER_GPU)
+                line["cpu_baseline_compute_only"] = cpu_baseline_gan(
+                    "ns", B_PER_GPU, seconds_target=5.0, compute_only=True, cores=line["cpu_baseline"]["cores"])
+            if not args.no_configs:
+                line["configs"] = other_configs(dev, min(K, 400), W, min(reps, 3), cpu=not args.no_cpu_baseline)
         print(json.dumps(line))
-    if force_dp:
-        torch.distributed.destroy_process_group()
-    if world > 1:
+    if force_dp or world > 1:
         torch.distributed.barrier()          # rank 0 may still be in its reporting section
         torch.distributed.destroy_process_group()
 

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgm_hip.so")
 SOURCES = ("gm_gemm.hip", "gm_ops.hip", "gm_fused.hip")
+HOST_SOURCES = ("gm_hostrng.cpp",)       # host-only C++ (RNG protocol replay): g++, linked in
 
 
 def sources():
@@ -19,7 +20,7 @@ def needs_build():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "gm_common.h"), os.path.join(CSRC, "gm_head.h"), os.path.join(CSRC, "gm_gather.h"),
+    deps = sources() + [os.path.join(CSRC, h) for h in HOST_SOURCES] + [os.path.join(CSRC, "gm_common.h"), os.path.join(CSRC, "gm_head.h"), os.path.join(CSRC, "gm_gather.h"),
                         os.path.join(os.path.dirname(HERE), "include", "gm_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
@@ -30,8 +31,28 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.isfile(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value"] + sources() + ["-o", LIB]
+    # compile every translation unit to an object (in parallel), then link: hipcc would otherwise
+    # treat the host object as HIP source
+    jobs = []
+    for src in sources():
+        obj = src.rsplit(".", 1)[0] + ".o"
+        jobs.append(([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+                      "-c", src, "-o", obj], obj))
+    for h in HOST_SOURCES:
+        # -ffp-contract=off: the float transformations must round exactly like ATen's
+        obj = os.path.join(CSRC, h.rsplit(".", 1)[0] + ".o")
+        jobs.append(([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                      "-pthread", "-c", os.path.join(CSRC, h), "-o", obj], obj))
+    procs = []
+    for cmd, _ in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd, cwd=CSRC))
+    for (cmd, _), pr in zip(jobs, procs):
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for _, o in jobs] + \
+        ["-lpthread", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -53,6 +53,15 @@ class DwAdamArgs(ctypes.Structure):
                 ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("clamp", c_float)]
 
 
+class DrawOp(ctypes.Structure):
+    """gm_draw_op (include/gm_hip.h): one draw of the per-iteration host RNG program."""
+    _fields_ = [("kind", c_int32), ("n", c_int32), ("a", c_int64), ("b", c_int32), ("c", c_int32),
+                ("dst", c_void_p), ("iter_stride", c_int64), ("e0", c_int64), ("e1", c_int64)]
+
+
+DRAW_SAMPLER, DRAW_NORMAL, DRAW_UNIFORM, DRAW_INFO = 0, 1, 2, 3
+GM_EUNSUPPORTED = -10002
+
 _P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
 
 _SIGNATURES = {
@@ -127,6 +136,9 @@ _SIGNATURES = {
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_mt19937_skip": (c_int, [_P, c_int64, ctypes.c_uint64]),
+    "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),
+    "gm_host_replay_threads": (c_int, [c_int]),
+    "gm_host_replay_flavour": (c_int, [c_int]),
     "gm_graph_begin": (c_int, [_P]),
     "gm_graph_end": (c_int, [_P, POINTER(c_void_p)]),
     "gm_graph_launch": (c_int, [_P, _P]),

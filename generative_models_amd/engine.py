@@ -173,6 +173,95 @@ def _prefetch_pool():
     return _POOL
 
 
+class HostReplay:
+    """The reference's draw protocol replayed by ONE C call per sub-chunk of iterations
+    (csrc/gm_hostrng.cpp: vectorized mt19937 + ATen's float uniform_/normal_/random_/randint
+    transformations restated) instead of one torch call per draw.  Before first use the
+    restatement is checked bit for bit against torch itself on a CLONE of the global generator
+    (values and final generator state, for every draw kind); if nothing matches on this host /
+    torch build, the engines keep drawing through torch (slower, same results)."""
+    _flavour = None          # None: not probed; False: unavailable; int: gm_host_replay_flavour
+
+    @classmethod
+    def available(cls):
+        if cls._flavour is None:
+            import os
+            cls._flavour = False if os.environ.get("GM_HOST_REPLAY", "1") == "0" else cls._selfcheck()
+            if cls._flavour is not False:
+                from . import _lib
+                _lib.call("gm_host_replay_flavour", cls._flavour)
+                _lib.call("gm_host_replay_threads", max(1, int(os.environ.get("GM_HOST_THREADS", "1"))))
+        return cls._flavour is not False
+
+    @staticmethod
+    def op(kind, n, dst, iter_stride, a=0, b=0, c=0, e0=0, e1=None):
+        from ._lib import DrawOp
+        return DrawOp(kind, n, a, b, c, dst.data_ptr(), iter_stride, e0, n if e1 is None else e1)
+
+    @staticmethod
+    def call(state, ops, n_iters):
+        """Advance the serialized generator `state` (uint8 tensor) through n_iters iterations of the
+        program.  Returns the C return code (0 ok, GM_EUNSUPPORTED: shape outside the restated paths)."""
+        from . import _lib
+        arr = (_lib.DrawOp * len(ops))(*ops)
+        return _lib.load().gm_host_replay(state.data_ptr(), state.numel(), arr, len(ops), n_iters)
+
+    @classmethod
+    def run(cls, ops, n_iters):
+        """Replay on torch's GLOBAL CPU generator."""
+        from . import _lib
+        st = torch.get_rng_state()
+        rc = cls.call(st, ops, n_iters)
+        if rc == _lib.GM_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "gm_host_replay")
+        torch.set_rng_state(st)
+        return True
+
+    @classmethod
+    def _selfcheck(cls):
+        from . import _lib
+        from ._lib import DRAW_INFO, DRAW_NORMAL, DRAW_SAMPLER, DRAW_UNIFORM
+        g = torch.Generator()
+        g.set_state(torch.get_rng_state())            # a clone: the global generator is not touched
+        g.manual_seed(0x5EED0DD)
+        torch.empty(7).normal_(generator=g)           # leave the twist boundary / cache mid-way
+        s0 = g.get_state()
+        N, B, zd, nd, nc = 1000, 24, 4, 10, 6
+        # torch's side, draw by draw, on the private generator
+        ref = {}
+        torch.empty((), dtype=torch.int64).random_(generator=g)
+        seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())
+        ref["idx"] = torch.randperm(N, generator=torch.Generator().manual_seed(seed))[:B]
+        ref["n1"] = torch.empty(5120 + 17).normal_(generator=g)
+        ref["u1"] = torch.empty(1003).uniform_(generator=g)
+        zz = torch.empty(B, zd).normal_(generator=g)
+        cat = torch.randint(0, nd, (B,), dtype=torch.long, generator=g)
+        cc = torch.empty(B, nc).normal_(generator=g)
+        info = torch.zeros(B, zd + nd + nc)
+        info[:, :zd] = zz
+        info[torch.arange(B), zd + cat] = 1
+        info[:, zd + nd:] = cc
+        ref["n2"] = torch.empty(64).normal_(generator=g)
+        s1 = g.get_state()
+        out = dict(idx=torch.empty(B, dtype=torch.int64), n1=torch.empty(5120 + 17),
+                   u1=torch.empty(1003), info=torch.empty(B, zd + nd + nc), n2=torch.empty(64))
+        ops = [cls.op(DRAW_SAMPLER, B, out["idx"], 0, a=N), cls.op(DRAW_NORMAL, 5137, out["n1"], 0),
+               cls.op(DRAW_UNIFORM, 1003, out["u1"], 0),
+               cls.op(DRAW_INFO, B, out["info"], 0, a=zd, b=nd, c=nc),
+               cls.op(DRAW_NORMAL, 64, out["n2"], 0)]
+        ref["info"] = info
+        for flavour in (1, 2, 0):
+            if _lib.load().gm_host_replay_flavour(flavour) != 0:
+                continue
+            st = s0.clone()
+            if cls.call(st, ops, 1) != 0:
+                continue
+            if torch.equal(st, s1) and all(torch.equal(out[k], ref[k]) for k in out):
+                return flavour
+        return False
+
+
 class GANEngine:
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
     (ns, mm, w, ls, ra, f, fisher, wgp)."""
@@ -663,9 +752,14 @@ class GANEngine:
         ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
+    NSTAGE = 3          # pinned staging buffers: the host may run this many sub-chunks ahead
+
     def _alloc_rings(self, R):
+        """Device rings of R iterations; pinned host staging of SUB iterations x NSTAGE (the host
+        replay fills one sub-chunk per C call while earlier ones are uploaded / consumed)."""
         d, B, Z, dev = self.D_steps, self.B, self.Z, self.device
         self.R = R
+        self.SUB = S = max(1, min(self.graph_iters, R))
         self.idx_ring = torch.zeros(R * d, B, dtype=torch.int64, device=dev)
         pin = lambda *s, **k: torch.zeros(*s, **k).pin_memory()
         self.stage = []
@@ -681,20 +775,22 @@ class GANEngine:
             self.zG_ring = torch.zeros(R, B, Z, device=dev)
             self.zD_base, self.zG_base = self.zD_ring.view(-1), self.zG_ring.view(-1)
             self.zD_stride = self.zG_stride = B * Z
-        for _ in range(2):
+        for _ in range(self.NSTAGE):
             if self.z_joint:
-                zz = pin(R, 2, B, Z)
-                s = dict(idx=pin(R * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1],
+                zz = pin(S, 2, B, Z)
+                s = dict(idx=pin(S * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1],
                          event=None)
             else:
-                s = dict(idx=pin(R * d, B, dtype=torch.int64), zD=pin(R * d, B, Z), zG=pin(R, B, Z),
+                s = dict(idx=pin(S * d, B, dtype=torch.int64), zD=pin(S * d, B, Z), zG=pin(S, B, Z),
                          event=None)
             if self.variant == "wgp":
-                s["eps"] = pin(R * d, B)
+                s["eps"] = pin(S * d, B)
             if self.variant == "info":
-                s["zQ"] = pin(R, B, Z)
+                s["zQ"] = pin(S, B, Z)
             if self.variant == "dra":
-                s["delta"], s["U"] = pin(R * d, B), pin(R * d, B, self.I)
+                s["delta"], s["U"] = pin(S * d, B), pin(S * d, B, self.I)
+            s["idx_np"] = s["idx"].numpy()
+            s["program"] = self._program(s)
             self.stage.append(s)
         if self.variant == "wgp":
             self.eps_ring = torch.zeros(R * d, B, device=dev)
@@ -703,6 +799,40 @@ class GANEngine:
         if self.variant == "dra":
             self.delta_ring = torch.zeros(R * d, B, device=dev)
             self.U_ring = torch.zeros(R * d, B, self.I, device=dev)
+        self._replay_ok = HostReplay.available()
+
+    def _program(self, s):
+        """The draws of ONE iteration in reference order as a gm_draw_op
+        list writing into staging `s`; HostReplay runs it for a whole sub-chunk in one C call."""
+        from ._lib import DRAW_INFO, DRAW_NORMAL, DRAW_SAMPLER, DRAW_UNIFORM
+        d, B, Z, I = self.D_steps, self.B, self.Z, self.I
+        op = HostReplay.op
+        # a data-parallel rank materialises only its own rows of the noise (16-aligned ranges of
+        # the normal_ stream are self-contained, see draw_rows); the stream advances in full
+        r0, r1 = self.rank * self.Bl, (self.rank + 1) * self.Bl
+        rows = lambda w: dict(e0=r0 * w, e1=r1 * w) if (
+            self.world > 1 and (r0 * w) % 16 == 0 and (r1 * w) % 16 == 0 and (B * w) % 16 == 0) else {}
+        urows = lambda w: dict(e0=r0 * w, e1=r1 * w) if self.world > 1 else {}
+        zs = (2 if self.z_joint else d) * B * Z * 4          # bytes between iterations of zD
+        gs = (2 if self.z_joint else 1) * B * Z * 4
+        prog = []
+        for j in range(d):
+            prog.append(op(DRAW_SAMPLER, B, s["idx"][j], d * B * 8, a=self.N))
+            if self.variant == "info":
+                prog.append(op(DRAW_INFO, B, s["zD"][j], zs, a=self.zd, b=self.nd, c=self.nc))
+                continue
+            prog.append(op(DRAW_NORMAL, B * Z, s["zD"][j], zs, **rows(Z)))    # ns_gan.py:183,220
+            if self.variant == "wgp":
+                prog.append(op(DRAW_UNIFORM, B, s["eps"][j], d * B * 4, **urows(1)))   # w_gp_gan.py:197
+            if self.variant == "dra":
+                prog.append(op(DRAW_UNIFORM, B, s["delta"][j], d * B * 4))             # dra_gan.py:200
+                prog.append(op(DRAW_UNIFORM, B * I, s["U"][j], d * B * I * 4))         # dra_gan.py:205
+        if self.variant == "info":
+            prog.append(op(DRAW_INFO, B, s["zG"][0], gs, a=self.zd, b=self.nd, c=self.nc))
+            prog.append(op(DRAW_INFO, B, s["zQ"][0], B * Z * 4, a=self.zd, b=self.nd, c=self.nc))
+        else:
+            prog.append(op(DRAW_NORMAL, B * Z, s["zG"][0], gs, **rows(Z)))    # ns_gan.py:208
+        return prog
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -749,13 +879,15 @@ class GANEngine:
 
     def _fill(self, s, n_it):
         """HOST: replay the reference's draw order for n_it iterations into pinned staging `s`.
-        Runs on the prefetch thread while the main thread enqueues the previous chunk's graphs
-        (torch releases the GIL inside the RNG kernels; the draws stay strictly in order because
-        there is a single worker and chunks are submitted in order)."""
+        Runs on the prefetch thread while the main thread uploads / launches earlier sub-chunks
+        (the C replay and torch's RNG kernels release the GIL; the draws stay strictly in order:
+        single worker, sub-chunks submitted in order)."""
         if s["event"] is not None:
             s["event"].synchronize()                 # staging buffer free again?
-        if "idx_np" not in s:
-            s["idx_np"] = s["idx"].numpy()
+        if self._replay_ok:
+            if HostReplay.run(s["program"], n_it):
+                return s
+            self._replay_ok = False                  # shape outside the restated paths: torch draws
         d = self.D_steps
         for i in range(n_it):
             for j in range(d):
@@ -825,6 +957,10 @@ class GANEngine:
             self.lossMI = torch.zeros(max(1, n_iters), device=dev)
         self.aux.zero_()
         self.ctr.zero_()
+        self._drain()
+        from collections import deque
+        self.n_planned = n_iters
+        self._pending, self._cursor, self._uploaded, self._next_it, self._stage_i = deque(), 0, 0, 0, 0
         # DRAGAN prefetches a B x 784 uniform tensor per critic step: keep its ring small
         R = max(1, min(16 if self.variant == "dra" else CHUNK, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
@@ -875,8 +1011,55 @@ class GANEngine:
                                for run, ar in self._segments()]
         self._graph_key = self._key
 
-    def run(self, n_iters, it_start=0):
-        """Run iterations [it_start, it_start+n_iters) (chunked prefetch + graph replays)."""
+    def _drain(self):
+        """Wait for host fills still in flight (configure / error paths)."""
+        pend = getattr(self, "_pending", None)
+        while pend:
+            _, _, fut = pend.popleft()
+            try:
+                fut.result()
+            except Exception:                         # noqa: BLE001  (a failed fill of a dead run)
+                pass
+
+    def _pump(self, limit):
+        """Keep up to NSTAGE sub-chunks of host draws in flight, never past `limit`."""
+        pool = _prefetch_pool()
+        while len(self._pending) < self.NSTAGE and self._cursor < limit:
+            it = self._cursor
+            n = min(self.SUB - it % self.SUB, self.R - it % self.R, limit - it)
+            s = self.stage[self._stage_i]
+            self._stage_i = (self._stage_i + 1) % self.NSTAGE
+            self._pending.append((it, n, pool.submit(self._fill, s, n)))
+            self._cursor += n
+
+    def _launch(self, it, k):
+        """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
+        if self.use_graph and self.world == 1 and not self.force_segments:
+            gk = getattr(self, "graph_k", None)
+            while gk is not None and k >= self.graph_iters:
+                gk.launch()
+                k -= self.graph_iters
+            for _ in range(k):
+                self.graph.launch()
+        elif self.use_graph:
+            for _ in range(k):
+                for g, ar in self.seg_graphs:
+                    g.launch()
+                    if ar is not None:
+                        self._allreduce(ar)
+        else:
+            st = ops.stream_ptr()
+            for i in range(k):
+                self._issue_iteration(st, it + i)
+
+    def run(self, n_iters, it_start=0, horizon=None):
+        """Run iterations [it_start, it_start+n_iters): host draws in sub-chunks of `SUB`
+        iterations on the prefetch thread, one H2D upload per sub-chunk, graph replays.  The GPU
+        starts after the FIRST sub-chunk is drawn, not after a whole ring.
+        horizon: the host may draw ahead up to this iteration (exclusive) while the caller does
+        something else after run() returns (train(): the epoch-end loss read-back); never past
+        what configure() planned.  Without it the host draws exactly what this call consumes, so a
+        caller that times run() times its draws too."""
         if self.world > 1 and self.variant == "dra":
             raise GMError("DRAGAN perturbs with the std of the GLOBAL batch; its data-parallel form "
                           "needs a pre-all-reduce of (sum x, sum x^2) (SURVEY.md 8e): not wired yet")
@@ -886,44 +1069,35 @@ class GANEngine:
             raise GMError("RaGAN / FisherGAN losses are not a mean of per-sample terms; their "
                           "data-parallel form needs a scalar pre-all-reduce (SURVEY.md 8e) and is "
                           "not implemented: run them on one GPU")
+        if it_start != self._next_it:
+            raise GMError("run(): iterations are consumed in order (next is %d, got %d)"
+                          % (self._next_it, it_start))
         self._ensure_graph()
-        R = self.R
-        chunks, it, end = [], it_start, it_start + n_iters
-        while it < end:
-            n = min(R - (it % R), end - it)
-            chunks.append((it, n))
-            it += n
-        pool = _prefetch_pool()
-        fut = pool.submit(self._fill, self.stage[0], chunks[0][1]) if chunks else None
-        for ci, (it, n) in enumerate(chunks):
-            s = fut.result()                          # re-raises anything the worker hit
-            self._upload(s, it, n)
-            if ci + 1 < len(chunks):                  # draw the next chunk while this one runs
-                fut = pool.submit(self._fill, self.stage[(ci + 1) & 1], chunks[ci + 1][1])
-            if self.use_graph and self.world == 1 and not self.force_segments:
-                left = n
-                gk = getattr(self, "graph_k", None)
-                while gk is not None and left >= self.graph_iters:
-                    gk.launch()
-                    left -= self.graph_iters
-                for _ in range(left):
-                    self.graph.launch()
-            elif self.use_graph:
-                for _ in range(n):
-                    for g, ar in self.seg_graphs:
-                        g.launch()
-                        if ar is not None:
-                            self._allreduce(ar)
-            else:
-                st = ops.stream_ptr()
-                for k in range(n):
-                    self._issue_iteration(st, it + k)
+        end = it_start + n_iters
+        if end > self.n_planned:
+            raise GMError("run(): configure() planned %d iterations" % self.n_planned)
+        limit = min(self.n_planned, max(end, horizon or 0))
+        it = it_start
+        try:
+            while it < end:
+                if it >= self._uploaded:
+                    self._pump(limit)
+                    c0, n, fut = self._pending.popleft()
+                    s = fut.result()                  # re-raises anything the worker hit
+                    self._upload(s, c0, n)
+                    self._uploaded = c0 + n
+                    self._pump(limit)                 # next draws overlap the launches below
+                k = min(end, self._uploaded) - it
+                self._launch(it, k)
+                it += k
+        except BaseException:
+            self._drain()
+            raise
+        self._next_it = end
 
     def g_init_steps(self, n):
         """MMGAN pre-training (mm_gan.py:121-136): process_batch draws + G step, eager."""
         s = self.stage[0]
-        if "idx_np" not in s:
-            s["idx_np"] = s["idx"].numpy()
         saved_graph, saved_off = self.use_graph, self.g_off
         self.use_graph = False
         self._standalone_G = True
@@ -1129,14 +1303,25 @@ class VAEEngine:
             which ^= 1
             if s["event"] is not None:
                 s["event"].synchronize()
-            sizes = []
-            for k in range(cnt):
-                lo = (done + k) * B
-                b = min(B, n - lo)
-                sizes.append(b)
-                s["idx"][k, :b].copy_(perm[lo:lo + b])
-                if self.has_eps:
-                    s["eps"][k].view(-1)[:b * Z].normal_()    # torch.randn(mu.shape), vae.py:104
+            sizes = [min(B, n - (done + k) * B) for k in range(cnt)]
+            lo = done * B
+            hi = min(n, lo + cnt * B)
+            s["idx"].view(-1)[:hi - lo].copy_(perm[lo:hi])    # rows of B indices, last one ragged
+            if self.has_eps:
+                # torch.randn(mu.shape) per batch (vae.py:104): the full batches of the chunk in
+                # one C call (HostReplay), a ragged last batch on its own
+                nfull = sum(1 for b in sizes if b == B)
+                from ._lib import DRAW_NORMAL
+                replay = HostReplay.available() and B * Z >= 16
+                if replay and nfull:
+                    replay = HostReplay.run([HostReplay.op(DRAW_NORMAL, B * Z, s["eps"], B * Z * 4)], nfull)
+                for k, b in enumerate(sizes):
+                    if replay and b == B:
+                        continue
+                    if replay and b * Z >= 16 and HostReplay.run(
+                            [HostReplay.op(DRAW_NORMAL, b * Z, s["eps"][k], 0)], 1):
+                        continue
+                    s["eps"][k].view(-1)[:b * Z].normal_()
             r = t % R
             self.idx_ring[r:r + cnt].copy_(s["idx"][:cnt], non_blocking=True)
             if self.has_eps:

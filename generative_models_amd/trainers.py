@@ -318,7 +318,7 @@ class GANTrainer:
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
-                eng.run(epoch_steps, it_start=it0)
+                eng.run(epoch_steps, it_start=it0, horizon=num_epochs * epoch_steps)
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)     # one sync per epoch
                 if self.variant == "info":
                     self.MIlosses.extend(eng.mi_losses(it0, it0 + epoch_steps))
@@ -869,7 +869,7 @@ class BEGANTrainerBase(GANTrainer):
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
-                eng.run(epoch_steps, it_start=it0)
+                eng.run(epoch_steps, it_start=it0, horizon=num_epochs * epoch_steps)
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)
                 self.K = eng.K_value()
                 self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)

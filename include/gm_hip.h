@@ -297,6 +297,37 @@ int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out_host);
  * tensor; the draws belonging to other ranks' rows are skipped with this call. */
 int gm_mt19937_skip(void* torch_cpu_rng_state, int64_t state_bytes, uint64_t n);
 
+/* ---- HOST: replay of the reference's global-CPU-generator protocol for a run of iterations in
+ * ONE call (csrc/gm_hostrng.cpp).  A program is the ordered list of draws of one iteration:
+ *   GM_DRAW_SAMPLER  process_batch (ns_gan.py:222-226): DataLoader base seed + RandomSampler seed
+ *                    (two int64 random_() draws), first n entries of randperm(a) -> int64 dst[n]
+ *   GM_DRAW_NORMAL   torch.randn(n) on contiguous fp32, n >= 16 (ns_gan.py:220, vae.py:104)
+ *   GM_DRAW_UNIFORM  torch.rand(n) fp32 (w_gp_gan.py:197, dra_gan.py:200,205)
+ *   GM_DRAW_INFO     info_gan.py:312-323: [randn(n,a) | one_hot(randint(0,b,(n,))) | randn(n,c)]
+ * executed n_iters times; iteration i writes to dst + i*iter_stride (host memory, e.g. pinned
+ * staging).  [e0,e1) limits what is materialised (a data-parallel rank's rows) while the stream
+ * advances as for the whole tensor.  Returns -10002 for shapes outside the restated ATen paths
+ * (the caller then draws through torch).  The serialized state (torch.get_rng_state()) is
+ * advanced in place. */
+typedef struct gm_draw_op {
+    int32_t kind;
+    int32_t n;
+    int64_t a;
+    int32_t b, c;
+    void* dst;
+    int64_t iter_stride;
+    int64_t e0, e1;
+} gm_draw_op;
+enum { GM_DRAW_SAMPLER = 0, GM_DRAW_NORMAL = 1, GM_DRAW_UNIFORM = 2, GM_DRAW_INFO = 3 };
+int gm_host_replay(void* torch_cpu_rng_state, int64_t state_bytes, const gm_draw_op* ops, int n_ops,
+                   int n_iters);
+/* HOST: which restatement of ATen's float normal_fill the replay uses: 0 = scalar libm
+ * (normal_fill_16<float>), 1 = avx_mathfun.h polynomials with the mul+add pairs contracted to FMAs,
+ * 2 = same without contraction.  Python picks the one that reproduces torch bit for bit. */
+int gm_host_replay_flavour(int flavour);
+/* HOST: size of the worker pool of gm_host_replay's Box-Muller stage (1 = caller only). */
+int gm_host_replay_threads(int n_threads);
+
 /* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ------------------ */
 int gm_graph_begin(void* stream);
 int gm_graph_end(void* stream, void** graph_exec_out);

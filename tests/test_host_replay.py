@@ -1,0 +1,183 @@
+"""CPU tests of the host RNG replay (csrc/gm_hostrng.cpp through engine.HostReplay): every draw
+kind and every variant's per-iteration draw program must reproduce torch's own draws BIT FOR BIT --
+values and the final state of the global CPU generator -- because the reference's observable RNG
+stream position is part of parity (ns_gan.py:183,208,220-226,
+w_gp_gan.py:197, dra_gan.py:200-205, info_gan.py:312-323, vae.py:104)."""
+import numpy as np
+import pytest
+import torch
+
+from generative_models_amd import _lib, engine
+from generative_models_amd._lib import DRAW_INFO, DRAW_NORMAL, DRAW_SAMPLER, DRAW_UNIFORM
+from generative_models_amd.engine import GANEngine, HostReplay
+
+pytestmark = pytest.mark.skipif(not HostReplay.available(),
+                                reason="host replay does not reproduce this torch build's CPU draws")
+
+
+def test_selfcheck_picks_a_flavour_and_leaves_the_generator_alone():
+    torch.manual_seed(77)
+    before = torch.get_rng_state().clone()
+    HostReplay._flavour = None
+    assert HostReplay.available()
+    assert HostReplay._flavour in (0, 1, 2)
+    assert torch.equal(before, torch.get_rng_state())
+
+
+@pytest.mark.parametrize("n", [16, 17, 31, 32, 100, 624, 625, 5120, 5121, 10240, 200704])
+def test_normal_and_uniform_match_torch(n):
+    torch.manual_seed(5)
+    torch.randn(3)                                   # odd position inside the mt19937 block
+    s0 = torch.get_rng_state()
+    ref_n, ref_u = torch.empty(n).normal_(), torch.empty(n).uniform_()
+    s1 = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    a, u = torch.empty(n), torch.empty(n)
+    assert HostReplay.run([HostReplay.op(DRAW_NORMAL, n, a, 0), HostReplay.op(DRAW_UNIFORM, n, u, 0)], 1)
+    assert torch.equal(a, ref_n) and torch.equal(u, ref_u)
+    assert torch.equal(torch.get_rng_state(), s1)
+
+
+def test_scalar_statement_equals_simd_statement():
+    """Flavours 3/4 are the lane-by-lane statement of the same arithmetic as 1/2."""
+    fl = HostReplay._flavour
+    if fl not in (1, 2):
+        pytest.skip("libm flavour in use")
+    torch.manual_seed(11)
+    s0 = torch.get_rng_state()
+    a, b = torch.empty(4096), torch.empty(4096)
+    HostReplay.run([HostReplay.op(DRAW_NORMAL, 4096, a, 0)], 1)
+    torch.set_rng_state(s0)
+    _lib.call("gm_host_replay_flavour", fl + 2)
+    try:
+        HostReplay.run([HostReplay.op(DRAW_NORMAL, 4096, b, 0)], 1)
+    finally:
+        _lib.call("gm_host_replay_flavour", fl)
+    assert torch.equal(a, b)
+
+
+def test_small_normal_is_refused_not_approximated():
+    """n < 16 takes ATen's scalar double path (cached second sample): not restated -> unsupported."""
+    torch.manual_seed(1)
+    s0 = torch.get_rng_state().clone()
+    out = torch.empty(8)
+    assert HostReplay.run([HostReplay.op(DRAW_NORMAL, 8, out, 0)], 1) is False
+    assert torch.equal(torch.get_rng_state(), s0)
+
+
+def test_sampler_matches_dataloader():
+    torch.manual_seed(7)
+    s0 = torch.get_rng_state()
+    ds = torch.utils.data.TensorDataset(torch.zeros(50000, 1), torch.arange(50000))
+    dl = torch.utils.data.DataLoader(ds, batch_size=256, shuffle=True)
+    ref = [next(iter(dl))[1].clone() for _ in range(4)]          # process_batch, ns_gan.py:222-226
+    s1 = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    idx = torch.empty(4, 256, dtype=torch.int64)
+    assert HostReplay.run([HostReplay.op(DRAW_SAMPLER, 256, idx, 256 * 8, a=50000)], 4)
+    assert all(torch.equal(idx[i], ref[i]) for i in range(4))
+    assert torch.equal(torch.get_rng_state(), s1)
+
+
+def test_partial_rows_match_full_draw():
+    """A data-parallel rank materialises only its rows; the stream advances as for the whole tensor."""
+    torch.manual_seed(11)
+    s0 = torch.get_rng_state()
+    ref_n, ref_u = torch.empty(2048, 20).normal_(), torch.empty(2048).uniform_()
+    s1 = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    d, u = torch.zeros(2048, 20), torch.zeros(2048)
+    assert HostReplay.run([HostReplay.op(DRAW_NORMAL, 2048 * 20, d, 0, e0=512 * 20, e1=768 * 20),
+                           HostReplay.op(DRAW_UNIFORM, 2048, u, 0, e0=512, e1=768)], 1)
+    assert torch.equal(d[512:768], ref_n[512:768]) and torch.equal(u[512:768], ref_u[512:768])
+    assert float(d[:512].abs().sum() + d[768:].abs().sum() + u[:512].sum() + u[768:].sum()) == 0.0
+    assert torch.equal(torch.get_rng_state(), s1)
+
+
+def _stub(variant, B, Z, N, d, world=1, rank=0, joint=False, I=24, info=None):
+    """A GANEngine shell with CPU staging: enough for _program / _fill (no device)."""
+    e = GANEngine.__new__(GANEngine)
+    e.variant, e.B, e.Z, e.N, e.I, e.D_steps = variant, B, Z, N, I, d
+    e.world, e.rank, e.Bl = world, rank, B // world
+    e.z_joint = joint
+    if info:
+        e.zd, e.nd, e.nc = info
+    S = 5
+    z = lambda *s, **k: torch.zeros(*s, **k)
+    stages = []
+    for _ in range(2):
+        if joint:
+            zz = z(S, 2, B, Z)
+            s = dict(idx=z(S * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1], event=None)
+        else:
+            s = dict(idx=z(S * d, B, dtype=torch.int64), zD=z(S * d, B, Z), zG=z(S, B, Z), event=None)
+        if variant == "wgp":
+            s["eps"] = z(S * d, B)
+        if variant == "info":
+            s["zQ"] = z(S, B, Z)
+        if variant == "dra":
+            s["delta"], s["U"] = z(S * d, B), z(S * d, B, I)
+        s["idx_np"] = s["idx"].numpy()
+        s["program"] = e._program(s)
+        stages.append(s)
+    return e, stages, S
+
+
+@pytest.mark.parametrize("variant,d,joint,world,rank", [
+    ("ns", 1, True, 1, 0), ("ns", 1, False, 1, 0), ("w", 5, False, 1, 0), ("wgp", 1, False, 1, 0),
+    ("wgp", 2, False, 1, 0), ("dra", 1, False, 1, 0), ("dra", 3, False, 1, 0),
+    ("info", 1, False, 1, 0), ("ns", 1, False, 4, 2), ("wgp", 1, False, 2, 1)])
+def test_variant_program_equals_torch_draw_order(variant, d, joint, world, rank):
+    """C replay of a sub-chunk == the per-draw torch path (_draw_D/_draw_G), staging and RNG state."""
+    info = (6, 10, 4) if variant == "info" else None
+    B, Z, N = 64, (20 if info else 12), 5000
+    e, (sa, sb), S = _stub(variant, B, Z, N, d, world, rank, joint, info=info)
+    torch.manual_seed(2024)
+    torch.rand(5)
+    s0 = torch.get_rng_state()
+    e._replay_ok = True
+    e._fill(sa, S)
+    assert e._replay_ok, "program fell outside the restated paths"
+    s_c = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    e._replay_ok = False
+    e._fill(sb, S)                                    # torch, draw by draw
+    assert torch.equal(torch.get_rng_state(), s_c)
+    r0, r1 = e.rank * e.Bl, (e.rank + 1) * e.Bl
+    for k in sa:
+        if k in ("event", "idx_np", "program", "z"):
+            continue
+        a, b = sa[k], sb[k]
+        if world > 1 and k != "idx":                  # only this rank's rows are materialised
+            a, b = a[:, r0:r1], b[:, r0:r1]
+        assert torch.equal(a, b), k
+
+
+def test_vae_eps_program_with_ragged_batch():
+    """vae.py:104: one randn(B, Z) per batch, the last batch of the epoch ragged."""
+    B, Z = 32, 20
+    torch.manual_seed(9)
+    s0 = torch.get_rng_state()
+    ref = [torch.randn(B, Z) for _ in range(3)] + [torch.randn(13, Z)]
+    s1 = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    eps = torch.zeros(4, B, Z)
+    assert HostReplay.run([HostReplay.op(DRAW_NORMAL, B * Z, eps, B * Z * 4)], 3)
+    assert HostReplay.run([HostReplay.op(DRAW_NORMAL, 13 * Z, eps[3], 0)], 1)
+    assert all(torch.equal(eps[i], ref[i]) for i in range(3))
+    assert torch.equal(eps[3].view(-1)[:13 * Z].view(13, Z), ref[3])
+    assert torch.equal(torch.get_rng_state(), s1)
+
+
+def test_replay_threads_do_not_change_results():
+    torch.manual_seed(21)
+    s0 = torch.get_rng_state()
+    a, b = torch.empty(8, 5120), torch.empty(8, 5120)
+    HostReplay.run([HostReplay.op(DRAW_NORMAL, 5120, a, 5120 * 4)], 8)
+    torch.set_rng_state(s0)
+    _lib.call("gm_host_replay_threads", 4)
+    try:
+        HostReplay.run([HostReplay.op(DRAW_NORMAL, 5120, b, 5120 * 4)], 8)
+    finally:
+        _lib.call("gm_host_replay_threads", 1)
+    assert torch.equal(a, b)
