@@ -332,7 +332,19 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     eng.force_segments = force_dp
     eng.configure(W + reps * K, lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
-    secs = timed_reps(lambda r: eng.run(K, it_start=W + r * K), reps, K, world, dev)
+    marks = []
+
+    def rep(r):
+        marks.append(time.perf_counter())
+        eng.run(K, it_start=W + r * K)
+        marks.append(time.perf_counter())
+    secs = timed_reps(rep, reps, K, world, dev)
+    if eng._trace:                                   # GM_TRACE_RUN=1: host timeline of each repetition
+        for r in range(reps):
+            t0, t1 = marks[2 * r], marks[2 * r + 1]
+            ev = [(k, a, round((t - t0) * 1e6)) for k, a, t in eng._trace if t0 <= t <= t1 + 1e-3]
+            print("[trace rep %d] run() returned at %d us, total %d us: %s"
+                  % (r, (t1 - t0) * 1e6, secs[r] * 1e6, ev), file=sys.stderr, flush=True)
     G, D = eng.losses(W, W + reps * K)
     assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
     return eng, secs

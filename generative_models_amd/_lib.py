@@ -59,6 +59,11 @@ class DrawOp(ctypes.Structure):
                 ("dst", c_void_p), ("iter_stride", c_int64), ("e0", c_int64), ("e1", c_int64)]
 
 
+class StageSeg(ctypes.Structure):
+    """gm_stage_seg (include/gm_hip.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("bytes_per_iter", c_int64)]
+
+
 DRAW_SAMPLER, DRAW_NORMAL, DRAW_UNIFORM, DRAW_INFO = 0, 1, 2, 3
 GM_EUNSUPPORTED = -10002
 
@@ -136,6 +141,8 @@ _SIGNATURES = {
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_mt19937_skip": (c_int, [_P, c_int64, ctypes.c_uint64]),
+    "gm_stage_in": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int]),
+    "gm_host_device_ptr": (c_int, [_P, POINTER(c_void_p)]),
     "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),
     "gm_host_replay_threads": (c_int, [c_int]),
     "gm_host_replay_flavour": (c_int, [c_int]),

@@ -26,6 +26,66 @@ extern "C" int gm_tick(void* stream, int64_t* ctr, int64_t inc) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage-in: the host replays the reference's RNG protocol (csrc/gm_hostrng.cpp) straight into PINNED
+// host rings that mirror the device rings slot for slot; the first kernel of every captured graph
+// pulls the slots of its own iterations over PCIe (each byte read exactly once, 16 B per lane) into
+// the device rings that all other kernels read.  This replaces hipMemcpyAsync uploads (three API calls
+// + DMA start-up per sub-chunk, 60-100 us at the head of a short run) by one ~2 us launch inside
+// the graph; the slot is resolved from the device counter like every other per-step address.
+// ------------------------------------------------------------------------------------------
+struct StageP {
+    gm_stage_seg seg[GM_STAGE_MAX_SEGS];
+    int n_segs;
+    gm_slot slot;
+    int n_iters;
+};
+
+__global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
+    const gm_stage_seg sg = p.seg[blockIdx.y];
+    const int64_t first = gm_slot_index(p.slot);
+    const int64_t bytes = sg.bytes_per_iter * (int64_t)p.n_iters;
+    const char* src = reinterpret_cast<const char*>(sg.src) + first * sg.bytes_per_iter;
+    char* dst = reinterpret_cast<char*>(sg.dst) + first * sg.bytes_per_iter;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (int64_t i = t; i < bytes / 16; i += stride) d4[i] = s4[i];
+    } else {                                          // odd test shapes: 4-byte granularity
+        const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+        for (int64_t i = t; i < bytes / 4; i += stride) d1[i] = s1[i];
+    }
+}
+
+extern "C" int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters) {
+    GM_CHECK_ARG(segs && n_segs > 0 && n_segs <= GM_STAGE_MAX_SEGS && n_iters > 0);
+    StageP p{};
+    int64_t most = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        GM_CHECK_ARG(segs[i].src && segs[i].dst && segs[i].bytes_per_iter > 0 && segs[i].bytes_per_iter % 4 == 0);
+        p.seg[i] = segs[i];
+        if (segs[i].bytes_per_iter > most) most = segs[i].bytes_per_iter;
+    }
+    p.n_segs = n_segs; p.slot = slot; p.n_iters = n_iters;
+    int64_t blocks = (most * n_iters / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    GM_LAUNCH_RET();
+}
+
+// Device-side address of pinned host memory (hipHostMalloc / torch pin_memory()).
+extern "C" int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out) {
+    GM_CHECK_ARG(host_ptr && dev_ptr_out);
+    hipError_t e = hipHostGetDevicePointer(dev_ptr_out, host_ptr, 0);
+    if (e != hipSuccess) { gm_set_error(hipGetErrorString(e)); return -(int)e; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // K1 gather: out[b,:] = data[idx[b],:]   (process_batch, ns_gan.py:222-226)
 // One 3136-byte image row per wave: 196 float4 -> lanes issue coalesced 16-B loads.
 // ------------------------------------------------------------------------------------------

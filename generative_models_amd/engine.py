@@ -752,58 +752,82 @@ class GANEngine:
         ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
-    NSTAGE = 3          # pinned staging buffers: the host may run this many sub-chunks ahead
+    AHEAD = 3           # sub-chunks of host draws that may be in flight ahead of the launches
 
     def _alloc_rings(self, R):
-        """Device rings of R iterations; pinned host staging of SUB iterations x NSTAGE (the host
-        replay fills one sub-chunk per C call while earlier ones are uploaded / consumed)."""
+        """Device rings of R iterations and PINNED host rings of the same layout.  The host replay
+        writes sub-chunks straight into the host rings; the first kernel of every graph
+        (gm_stage_in) pulls its own iterations' slots into the device rings."""
         d, B, Z, dev = self.D_steps, self.B, self.Z, self.device
         self.R = R
-        self.SUB = S = max(1, min(self.graph_iters, R))
-        self.idx_ring = torch.zeros(R * d, B, dtype=torch.int64, device=dev)
-        pin = lambda *s, **k: torch.zeros(*s, **k).pin_memory()
-        self.stage = []
+        self.SUB = max(1, min(self.graph_iters, R))
         self.z_joint = self._batch_gen()
+        shapes = {"idx": ((R * d, B), torch.int64)}
         if self.z_joint:          # one ring of [zD; zG] pairs: slot stride 2*B*Z
-            self.z_ring = torch.zeros(R, 2, B, Z, device=dev)
+            shapes["z"] = ((R, 2, B, Z), torch.float32)
+        else:
+            shapes["zD"] = ((R * d, B, Z), torch.float32)
+            shapes["zG"] = ((R, B, Z), torch.float32)
+        if self.variant == "wgp":
+            shapes["eps"] = ((R * d, B), torch.float32)
+        if self.variant == "info":
+            shapes["zQ"] = ((R, B, Z), torch.float32)
+        if self.variant == "dra":
+            shapes["delta"] = ((R * d, B), torch.float32)
+            shapes["U"] = ((R * d, B, self.I), torch.float32)
+        self.dring = {k: torch.zeros(*sh, dtype=dt, device=dev) for k, (sh, dt) in shapes.items()}
+        self.hring = {k: torch.zeros(*sh, dtype=dt).pin_memory() for k, (sh, dt) in shapes.items()}
+        self.idx_ring = self.dring["idx"]
+        if self.z_joint:
+            self.z_ring = self.dring["z"]
             self.zD_ring, self.zG_ring = self.z_ring[:, 0], self.z_ring[:, 1]
             flat = self.z_ring.view(-1)
             self.zD_base, self.zG_base = flat, flat[B * Z:]
             self.zD_stride = self.zG_stride = 2 * B * Z
         else:
-            self.zD_ring = torch.zeros(R * d, B, Z, device=dev)
-            self.zG_ring = torch.zeros(R, B, Z, device=dev)
+            self.zD_ring, self.zG_ring = self.dring["zD"], self.dring["zG"]
             self.zD_base, self.zG_base = self.zD_ring.view(-1), self.zG_ring.view(-1)
             self.zD_stride = self.zG_stride = B * Z
-        for _ in range(self.NSTAGE):
-            if self.z_joint:
-                zz = pin(S, 2, B, Z)
-                s = dict(idx=pin(S * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1],
-                         event=None)
-            else:
-                s = dict(idx=pin(S * d, B, dtype=torch.int64), zD=pin(S * d, B, Z), zG=pin(S, B, Z),
-                         event=None)
-            if self.variant == "wgp":
-                s["eps"] = pin(S * d, B)
-            if self.variant == "info":
-                s["zQ"] = pin(S, B, Z)
-            if self.variant == "dra":
-                s["delta"], s["U"] = pin(S * d, B), pin(S * d, B, self.I)
-            s["idx_np"] = s["idx"].numpy()
-            s["program"] = self._program(s)
-            self.stage.append(s)
-        if self.variant == "wgp":
-            self.eps_ring = torch.zeros(R * d, B, device=dev)
-        if self.variant == "info":
-            self.zQ_ring = torch.zeros(R, B, Z, device=dev)
-        if self.variant == "dra":
-            self.delta_ring = torch.zeros(R * d, B, device=dev)
-            self.U_ring = torch.zeros(R * d, B, self.I, device=dev)
+        self.eps_ring, self.zQ_ring = self.dring.get("eps"), self.dring.get("zQ")
+        self.delta_ring, self.U_ring = self.dring.get("delta"), self.dring.get("U")
+        # stage-in segments: (device-visible address of the host ring, device ring, bytes / iteration)
+        import ctypes
+        from . import _lib
+        segs = []
+        for k in shapes:
+            h, dv = self.hring[k], self.dring[k]
+            devp = ctypes.c_void_p()
+            _lib.call("gm_host_device_ptr", h.data_ptr(), ctypes.byref(devp))
+            segs.append(_lib.StageSeg(devp.value, dv.data_ptr(), h.numel() * h.element_size() // R))
+        self._segs = (_lib.StageSeg * len(segs))(*segs)
+        self._views = {}
+        for r in range(R):                            # every slot a sub-chunk can start at: built once
+            self._host_views(r)
         self._replay_ok = HostReplay.available()
+
+    def _host_views(self, r):
+        """Views of the host rings starting at ring slot r (what one sub-chunk's draws write), with
+        the gm_draw_op program of one iteration addressed at them.  Cached per slot."""
+        v = self._views.get(r)
+        if v is None:
+            d, h = self.D_steps, self.hring
+            v = dict(idx=h["idx"][r * d:])
+            if self.z_joint:
+                v["z"] = h["z"][r:]
+                v["zD"], v["zG"] = v["z"][:, 0], v["z"][:, 1]
+            else:
+                v["zD"], v["zG"] = h["zD"][r * d:], h["zG"][r:]
+            for k, per in (("eps", d), ("zQ", 1), ("delta", d), ("U", d)):
+                if k in h:
+                    v[k] = h[k][r * per:]
+            v["idx_np"] = v["idx"].numpy()
+            v["program"] = self._program(v)
+            self._views[r] = v
+        return v
 
     def _program(self, s):
         """The draws of ONE iteration in reference order as a gm_draw_op
-        list writing into staging `s`; HostReplay runs it for a whole sub-chunk in one C call."""
+        list writing into the ring views `s`; HostReplay runs it for a whole sub-chunk in one C call."""
         from ._lib import DRAW_INFO, DRAW_NORMAL, DRAW_SAMPLER, DRAW_UNIFORM
         d, B, Z, I = self.D_steps, self.B, self.Z, self.I
         op = HostReplay.op
@@ -833,6 +857,11 @@ class GANEngine:
         else:
             prog.append(op(DRAW_NORMAL, B * Z, s["zG"][0], gs, **rows(Z)))    # ns_gan.py:208
         return prog
+
+    def _issue_stage_in(self, st, it, k):
+        """First launch of a graph of k iterations: their ring slots, host ring -> device ring."""
+        from . import _lib
+        _lib.call("gm_stage_in", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k)
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -877,15 +906,41 @@ class GANEngine:
             r0 = self.rank * self.Bl
             draw_rows(dst, r0, r0 + self.Bl, kind)
 
-    def _fill(self, s, n_it):
-        """HOST: replay the reference's draw order for n_it iterations into pinned staging `s`.
-        Runs on the prefetch thread while the main thread uploads / launches earlier sub-chunks
-        (the C replay and torch's RNG kernels release the GIL; the draws stay strictly in order:
-        single worker, sub-chunks submitted in order)."""
-        if s["event"] is not None:
-            s["event"].synchronize()                 # staging buffer free again?
+    def _wait_slots_free(self, c0, n):
+        """The host ring slots of iterations [c0, c0+n) were last used by iterations c0-R ...: wait
+        until the graphs that staged those in have run (events recorded after every launch group)."""
+        need = c0 + n - self.R
+        if need <= 0:
+            return
+        import time
+        t_end = time.monotonic() + 60.0
+        while True:
+            ev = None
+            for it_end, e in list(self._launched):
+                if it_end >= need:
+                    ev = e
+                    break
+            if ev is not None:
+                ev.synchronize()
+                while self._launched and self._launched[0][0] < need:
+                    self._launched.popleft()
+                return
+            if time.monotonic() > t_end:              # cannot happen: iterations < c0 are launched
+                raise GMError("host ring: the launch of iteration %d never happened" % (need - 1))
+            time.sleep(20e-6)                         # the main thread is still launching them
+
+    def _fill(self, c0, n_it):
+        """HOST: replay the reference's draw order for iterations [c0, c0+n_it) into the pinned host
+        ring.  Runs on the prefetch thread while the main thread launches earlier sub-chunks (the C
+        replay and torch's RNG kernels release the GIL; the draws stay strictly in order: single
+        worker, sub-chunks submitted in order)."""
+        self._wait_slots_free(c0, n_it)
+        s = self._host_views(c0 % self.R)
         if self._replay_ok:
             if HostReplay.run(s["program"], n_it):
+                if self._trace is not None:
+                    import time
+                    self._trace.append(("filled", n_it, time.perf_counter()))
                 return s
             self._replay_ok = False                  # shape outside the restated paths: torch draws
         d = self.D_steps
@@ -894,27 +949,6 @@ class GANEngine:
                 self._draw_D(s, i * d + j)
             self._draw_G(s, i)
         return s
-
-    def _upload(self, s, it0, n_it):
-        """One H2D copy per ring, stream-ordered behind the graphs that still read the old slots."""
-        d = self.D_steps
-        r = it0 % self.R                 # ring slot of the chunk's first iteration (n_it <= R - r)
-        self.idx_ring[r * d:(r + n_it) * d].copy_(s["idx"][:n_it * d], non_blocking=True)
-        if self.z_joint:
-            self.z_ring[r:r + n_it].copy_(s["z"][:n_it], non_blocking=True)
-        else:
-            self.zD_ring[r * d:(r + n_it) * d].copy_(s["zD"][:n_it * d], non_blocking=True)
-            self.zG_ring[r:r + n_it].copy_(s["zG"][:n_it], non_blocking=True)
-        if self.variant == "wgp":
-            self.eps_ring[r * d:(r + n_it) * d].copy_(s["eps"][:n_it * d], non_blocking=True)
-        if self.variant == "info":
-            self.zQ_ring[r:r + n_it].copy_(s["zQ"][:n_it], non_blocking=True)
-        if self.variant == "dra":
-            self.delta_ring[r * d:(r + n_it) * d].copy_(s["delta"][:n_it * d], non_blocking=True)
-            self.U_ring[r * d:(r + n_it) * d].copy_(s["U"][:n_it * d], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        s["event"] = ev
 
     # -- public: run `n_iters` iterations starting a fresh train() ----------------------------
     def configure(self, n_iters, G_lr, D_lr, D_steps, clip=0.0, hyper=(), g_init=0,
@@ -960,7 +994,11 @@ class GANEngine:
         self._drain()
         from collections import deque
         self.n_planned = n_iters
-        self._pending, self._cursor, self._uploaded, self._next_it, self._stage_i = deque(), 0, 0, 0, 0
+        self._pending, self._cursor, self._uploaded, self._next_it = deque(), 0, 0, 0
+        self._launched, self._ramp = deque(), []
+        import os
+        self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
+        self._event_pool = []
         # DRAGAN prefetches a B x 784 uniform tensor per critic step: keep its ring small
         R = max(1, min(16 if self.variant == "dra" else CHUNK, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
@@ -996,19 +1034,34 @@ class GANEngine:
                         _lib.call("gm_stream_create", ctypes.byref(h))
                         self.side.append(h)
                 self.events = [ops.Event() for _ in range(4 + 2 * self.D_steps)]
-                self.graph = ops.Graph().capture(lambda st: self._issue_iteration_dag(st, 0))
+                self.graph = ops.Graph().capture(
+                    lambda st: (self._issue_stage_in(st, 0, 1), self._issue_iteration_dag(st, 0)))
+                self.graphs_by_size = [(1, self.graph)]
             else:
-                self.graph = ops.Graph().capture(lambda st: self._issue_iteration(st, 0))
-                self.graph_k = None
-                if self.graph_iters > 1:      # the counter advances inside every iteration
-                    k = self.graph_iters          # the device counter advances inside each iteration
-                    self.graph_k = ops.Graph().capture(
-                        lambda st: [self._issue_iteration(st, 0) for _ in range(k)])
+                # graphs of graph_iters, ..., 4, 2, 1 iterations (the device counter advances inside
+                # every iteration): any run length is a handful of launches
+                def body(k):
+                    def fn(st):
+                        self._issue_stage_in(st, 0, k)
+                        for _ in range(k):
+                            self._issue_iteration(st, 0)
+                    return fn
+                self.graph = ops.Graph().capture(body(1))
+                self.graphs_by_size = [(1, self.graph)]
+                k = 2
+                while k <= self.graph_iters:
+                    self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
+                    k *= 2
+                if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
+                    self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
+            segs = self._segments()
+            first = segs[0][0]
+            segs[0] = (lambda st, it: (self._issue_stage_in(st, it, 1), first(st, it)), segs[0][1])
             self.seg_graphs = [(ops.Graph().capture(lambda st, run=run: run(st, 0)), ar)
-                               for run, ar in self._segments()]
+                               for run, ar in segs]
         self._graph_key = self._key
 
     def _drain(self):
@@ -1021,26 +1074,39 @@ class GANEngine:
             except Exception:                         # noqa: BLE001  (a failed fill of a dead run)
                 pass
 
-    def _pump(self, limit):
-        """Keep up to NSTAGE sub-chunks of host draws in flight, never past `limit`."""
+    class _Done:
+        """A fill that ran on the calling thread (same interface as the pool's future)."""
+
+        def __init__(self, value):
+            self.value = value
+
+        def result(self):
+            return self.value
+
+    def _pump(self, limit, inline=False):
+        """Keep up to AHEAD sub-chunks of host draws in flight, never past `limit`.  The first
+        sub-chunks of a run that starts cold are short (`_ramp`: 1, then 3 iterations) so that the
+        GPU starts after one iteration's worth of draws; inline=True draws the next sub-chunk on
+        the calling thread (no hand-off latency at the start of a run)."""
         pool = _prefetch_pool()
-        while len(self._pending) < self.NSTAGE and self._cursor < limit:
+        while len(self._pending) < self.AHEAD and self._cursor < limit:
             it = self._cursor
-            n = min(self.SUB - it % self.SUB, self.R - it % self.R, limit - it)
-            s = self.stage[self._stage_i]
-            self._stage_i = (self._stage_i + 1) % self.NSTAGE
-            self._pending.append((it, n, pool.submit(self._fill, s, n)))
+            want = self._ramp.pop(0) if self._ramp else self.SUB
+            n = min(want, self.SUB, self.R - it % self.R, limit - it)
+            if inline:
+                self._pending.append((it, n, self._Done(self._fill(it, n))))
+                inline = False
+            else:
+                self._pending.append((it, n, pool.submit(self._fill, it, n)))
             self._cursor += n
 
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
         if self.use_graph and self.world == 1 and not self.force_segments:
-            gk = getattr(self, "graph_k", None)
-            while gk is not None and k >= self.graph_iters:
-                gk.launch()
-                k -= self.graph_iters
-            for _ in range(k):
-                self.graph.launch()
+            for size, g in self.graphs_by_size:           # largest first: 8, 4, 2, 1 iterations
+                while k >= size:
+                    g.launch()
+                    k -= size
         elif self.use_graph:
             for _ in range(k):
                 for g, ar in self.seg_graphs:
@@ -1049,6 +1115,7 @@ class GANEngine:
                         self._allreduce(ar)
         else:
             st = ops.stream_ptr()
+            self._issue_stage_in(st, it, k)
             for i in range(k):
                 self._issue_iteration(st, it + i)
 
@@ -1078,17 +1145,33 @@ class GANEngine:
             raise GMError("run(): configure() planned %d iterations" % self.n_planned)
         limit = min(self.n_planned, max(end, horizon or 0))
         it = it_start
+        cold = not self._pending and self._cursor == it_start     # nothing drawn ahead
+        if cold:
+            self._ramp = [1, 3]
+        trace = self._trace
+        if trace is not None:
+            import time
+            trace.append(("run", it_start, time.perf_counter()))
         try:
             while it < end:
                 if it >= self._uploaded:
-                    self._pump(limit)
+                    self._pump(limit, inline=cold)
+                    cold = False
                     c0, n, fut = self._pending.popleft()
-                    s = fut.result()                  # re-raises anything the worker hit
-                    self._upload(s, c0, n)
-                    self._uploaded = c0 + n
+                    fut.result()                      # re-raises anything the worker hit
+                    if trace is not None:
+                        trace.append(("got", c0, time.perf_counter()))
+                    self._uploaded = c0 + n           # drawn into the host ring
                     self._pump(limit)                 # next draws overlap the launches below
                 k = min(end, self._uploaded) - it
                 self._launch(it, k)
+                ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
+                ev.record()
+                self._launched.append((it + k, ev))
+                while len(self._launched) > 4 * self.R:          # recycle what nobody waits for
+                    self._event_pool.append(self._launched.popleft()[1])
+                if trace is not None:
+                    trace.append(("launched", it + k, time.perf_counter()))
                 it += k
         except BaseException:
             self._drain()
@@ -1097,7 +1180,7 @@ class GANEngine:
 
     def g_init_steps(self, n):
         """MMGAN pre-training (mm_gan.py:121-136): process_batch draws + G step, eager."""
-        s = self.stage[0]
+        s = self._host_views(0)
         saved_graph, saved_off = self.use_graph, self.g_off
         self.use_graph = False
         self._standalone_G = True
@@ -1108,7 +1191,7 @@ class GANEngine:
             self.zG_ring[0].copy_(s["zG"][0])
             self.g_off = k
             self._issue_G(st, 0)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()                 # the host slot is rewritten by the next pre-step
         self.use_graph, self.g_off = saved_graph, saved_off
         self._standalone_G = False
 

@@ -285,6 +285,22 @@ int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */
 int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t n, int act);
 
+/* ---- stage-in of the per-iteration inputs the reference moves host->device every step
+ * (`to_cuda` of the image batch indices and of the CPU-generated noise: ns_gan.py:220,225,
+ * utils.py:10-14).  The host writes them into PINNED rings that mirror the device rings; this kernel
+ * (first node of every captured graph) copies the slots [i, i+n_iters) of every segment, i resolved
+ * from `slot` (stride ignored), host ring -> device ring.  src: device-visible address of pinned
+ * host memory (gm_host_device_ptr). */
+#define GM_STAGE_MAX_SEGS 8
+typedef struct gm_stage_seg {
+    const void* src;
+    void* dst;
+    int64_t bytes_per_iter;
+} gm_stage_seg;
+int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters);
+/* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
+int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
+
 /* ---- HOST helper (no device work): first B entries of torch.randperm(n, generator=
  * Generator().manual_seed(seed)) in O(B): RandomSampler.__iter__ (torch/utils/data/sampler.py:160-185)
  * feeding process_batch (ns_gan.py:222-226).  mt19937 seeded with the low 32 bits of `seed`,

@@ -94,33 +94,31 @@ def test_partial_rows_match_full_draw():
     assert torch.equal(torch.get_rng_state(), s1)
 
 
-def _stub(variant, B, Z, N, d, world=1, rank=0, joint=False, I=24, info=None):
-    """A GANEngine shell with CPU staging: enough for _program / _fill (no device)."""
+def _stub(variant, B, Z, N, d, world=1, rank=0, joint=False, I=24, info=None, R=7):
+    """A GANEngine shell whose host rings are plain CPU tensors: enough for _host_views / _program /
+    _fill (no device)."""
+    from collections import deque
     e = GANEngine.__new__(GANEngine)
     e.variant, e.B, e.Z, e.N, e.I, e.D_steps = variant, B, Z, N, I, d
     e.world, e.rank, e.Bl = world, rank, B // world
-    e.z_joint = joint
+    e.z_joint, e.R = joint, R
+    e._trace, e._views, e._launched = None, {}, deque()
     if info:
         e.zd, e.nd, e.nc = info
-    S = 5
     z = lambda *s, **k: torch.zeros(*s, **k)
-    stages = []
-    for _ in range(2):
-        if joint:
-            zz = z(S, 2, B, Z)
-            s = dict(idx=z(S * d, B, dtype=torch.int64), z=zz, zD=zz[:, 0], zG=zz[:, 1], event=None)
-        else:
-            s = dict(idx=z(S * d, B, dtype=torch.int64), zD=z(S * d, B, Z), zG=z(S, B, Z), event=None)
-        if variant == "wgp":
-            s["eps"] = z(S * d, B)
-        if variant == "info":
-            s["zQ"] = z(S, B, Z)
-        if variant == "dra":
-            s["delta"], s["U"] = z(S * d, B), z(S * d, B, I)
-        s["idx_np"] = s["idx"].numpy()
-        s["program"] = e._program(s)
-        stages.append(s)
-    return e, stages, S
+    h = dict(idx=z(R * d, B, dtype=torch.int64))
+    if joint:
+        h["z"] = z(R, 2, B, Z)
+    else:
+        h["zD"], h["zG"] = z(R * d, B, Z), z(R, B, Z)
+    if variant == "wgp":
+        h["eps"] = z(R * d, B)
+    if variant == "info":
+        h["zQ"] = z(R, B, Z)
+    if variant == "dra":
+        h["delta"], h["U"] = z(R * d, B), z(R * d, B, I)
+    e.hring = h
+    return e
 
 
 @pytest.mark.parametrize("variant,d,joint,world,rank", [
@@ -128,28 +126,31 @@ def _stub(variant, B, Z, N, d, world=1, rank=0, joint=False, I=24, info=None):
     ("wgp", 2, False, 1, 0), ("dra", 1, False, 1, 0), ("dra", 3, False, 1, 0),
     ("info", 1, False, 1, 0), ("ns", 1, False, 4, 2), ("wgp", 1, False, 2, 1)])
 def test_variant_program_equals_torch_draw_order(variant, d, joint, world, rank):
-    """C replay of a sub-chunk == the per-draw torch path (_draw_D/_draw_G), staging and RNG state."""
+    """C replay of sub-chunks into the host ring == the per-draw torch path (_draw_D/_draw_G):
+    ring contents and RNG state, for a sub-chunk at slot 0 and one at a later slot."""
     info = (6, 10, 4) if variant == "info" else None
     B, Z, N = 64, (20 if info else 12), 5000
-    e, (sa, sb), S = _stub(variant, B, Z, N, d, world, rank, joint, info=info)
+    mk = lambda: _stub(variant, B, Z, N, d, world, rank, joint, info=info)
+    ea, eb = mk(), mk()
     torch.manual_seed(2024)
     torch.rand(5)
     s0 = torch.get_rng_state()
-    e._replay_ok = True
-    e._fill(sa, S)
-    assert e._replay_ok, "program fell outside the restated paths"
+    ea._replay_ok = True
+    ea._fill(0, 2)
+    ea._fill(2, 5)
+    assert ea._replay_ok, "program fell outside the restated paths"
     s_c = torch.get_rng_state()
     torch.set_rng_state(s0)
-    e._replay_ok = False
-    e._fill(sb, S)                                    # torch, draw by draw
+    eb._replay_ok = False
+    eb._fill(0, 2)                                    # torch, draw by draw
+    eb._fill(2, 5)
     assert torch.equal(torch.get_rng_state(), s_c)
-    r0, r1 = e.rank * e.Bl, (e.rank + 1) * e.Bl
-    for k in sa:
-        if k in ("event", "idx_np", "program", "z"):
-            continue
-        a, b = sa[k], sb[k]
+    r0, r1 = ea.rank * ea.Bl, (ea.rank + 1) * ea.Bl
+    for k in ea.hring:
+        a, b = ea.hring[k], eb.hring[k]
         if world > 1 and k != "idx":                  # only this rank's rows are materialised
-            a, b = a[:, r0:r1], b[:, r0:r1]
+            a, b = a[..., r0:r1, :] if a.dim() > 2 else a[:, r0:r1], \
+                b[..., r0:r1, :] if b.dim() > 2 else b[:, r0:r1]
         assert torch.equal(a, b), k
 
 
