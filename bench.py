@@ -36,6 +36,7 @@ FLOP_PER_IMAGE = 6_326_400        # 10 U GEMMs + small, algorith
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
+LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip try_launch_lds
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
 
 
@@ -75,6 +76,13 @@ def gemm_variant(kind, M, K, N):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind in ("dx", "dxh"):
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
+    if kind in ("fwd", "dx", "dxh", "fwdg") and Mg >= LDS_MIN_M and Kr >= 64 and Ng >= 32 and vec and (mode == 0 or xv):
+        # many-row launches: the LDS-staged macro-tile kernel (riders get their own launch)
+        cands = [(64, 64, "64, 64, 32, 64, 4, 1, 4"), (32, 64, "32, 64, 32, 32, 4, 1, 4")]
+        cost = lambda c: (-(-(-(-Mg // c[0]) * -(-Ng // c[1])) // 256)) * c[0] * c[1]
+        best = min(cands, key=lambda c: (cost(c), -c[0] * c[1]))
+        ns = -(-Kr // 32)
+        return "gemm_lds_kernel<%d, %s, %d>" % (mode, best[2], ns if Kr in (784, 400) else 0)
     else:
         mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4

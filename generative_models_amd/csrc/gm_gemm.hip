@@ -68,6 +68,7 @@ struct GemmP {
     // private L2 has to pull over the fabric shrink from "all of A and B" to 1/xr of A + 1/xc of B.
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
+    int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
@@ -206,6 +207,325 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
         const int m = m0 + row, n = n0 + col;
         if (m >= p.M || n >= p.N) continue;
         store_element<MODE>(p, v, m, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged macro-tile kernel for launches with many rows (batch >= ~512: the forward and dX GEMMs
+// of config 5, bs = 1024).  The split-reduction kernels below give every wave its own k-chunks and
+// therefore re-read each operand row once per 32x32 tile (8 FLOP per L2 byte) from whichever of the
+// 8 XCD L2s the tile landed on -- fine while latency bounds a B=256 launch, 5.8x the algorithmic
+// fabric traffic and the bound at B=1024.  Here a workgroup owns a BM x BN tile:
+//   * WM x WN waves tile it 32x32 each (one v_mfma_f32_32x32x2_f32 accumulator per wave), WK wave
+//     groups split each BK-deep stage between them (2 waves per SIMD hide each other's LDS latency;
+//     the WK partial tiles are summed in a fixed order through LDS at the end);
+//   * operands are staged through LDS, double-buffered, ONE barrier per stage: global 16-byte loads
+//     of stage s+1 are issued before the MFMAs of stage s and written to the other buffer after
+//     them (the K-tail zeroing select is applied at that write, never behind the load);
+//   * k-contiguous operands (X, dA; W in the forward) are stored [row][BK+4] and read back as ONE
+//     ds_read_b128 per lane = the 4 consecutive k the fragment trick needs (row stride = 4 mod 32
+//     words: conflict-free for the 16-lane b128 groups); x-contiguous operands (W in dX) are
+//     stored [k][BN+4] and read as 4 conflict-free ds_read_b32;
+//   * XCD-aware mapping: workgroup b runs on XCD b % 8 (observed placement, speed only), so XCD x
+//     gets the contiguous m-tiles [x*mpx, (x+1)*mpx): its private L2 holds 1/8 of A plus B instead
+//     of both in full.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 keep4(bool ok, float4 v) {      // componentwise: stays in registers
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// Instruction order of one pipeline stage: the stage OPENS with an MFMA (the matrix pipe restarts
+// right behind the barrier) and the stage's memory instructions -- fragment reads of the next
+// stage, global loads, LDS operand writes (last: they wait for data) -- are issued one per MFMA in
+// the shadow of the MFMAs.  Measured before this: all memory instructions ahead of the MFMAs left
+// the pipe idle 43 % of every stage (SQ_VALU_MFMA_BUSY_CYCLES 25.6k of 44.7k wave cycles).
+template <int NMFMA, int NDSR, int NVMEM, int NDSW>
+__device__ __forceinline__ void lds_stage_schedule() {
+    constexpr int NMEM = NDSR + NVMEM + NDSW;
+    int done = 0;
+#pragma unroll
+    for (int q = 0; q < NMFMA; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+        const int upto = (NMEM * (q + 1) + NMFMA - 1) / NMFMA;               // memory ops issued by now
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (done < upto) {
+                if (done < NDSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // DS read
+                else if (done < NDSR + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           // DS write
+                ++done;
+            }
+        }
+    }
+}
+
+// Workgroup tile BM x BN; every wave owns a WTM x WTN sub-tile (32 or 64 on a side = 1, 2 or 4
+// v_mfma_f32_32x32x2_f32 accumulators) and WK wave groups split each BK-deep stage between them.
+template <int MODE, int BM, int BN, int WTM, int WTN, int WK, int KU>
+struct LdsCfg {
+    static constexpr int WM = BM / WTM, WN = BN / WTN, NW = WM * WN * WK, NT = 64 * NW, BK = 8 * WK * KU;
+    static constexpr int TI = WTM / 32, TJ = WTN / 32;
+    static constexpr bool B_KC = (MODE == MODE_FWD);       // B(k,n) = W[n][k] (fwd) / W[k][n] (dx)
+    static constexpr int LDK = BK + 4, LDXB = BN + 4;
+    static constexpr int A_SZ = BM * LDK;
+    static constexpr int B_SZ = B_KC ? BN * LDK : BK * LDXB;
+    static constexpr int STAGE = A_SZ + B_SZ;
+    static constexpr int NBUF = 3;                          // LDS stage buffers (see the pipeline below)
+    static constexpr int RED = WK * BM * BN;
+    static constexpr int FLOATS = (NBUF * STAGE > RED) ? NBUF * STAGE : RED;
+};
+
+// Software pipeline of one workgroup (stage = BK reduction steps; one barrier per stage):
+//   during the MFMAs of stage s (fragments already in registers) every wave has, in flight,
+//     * the ds_read_b128 of stage s+1's fragments            (LDS buffer (s+1) % 3),
+//     * the ds_write_b128 of stage s+2's operand tile         (LDS buffer (s+2) % 3),
+//     * the global loads of stages s+3 .. s+2+PD              (PD register sets).
+//   Nothing but the barrier stands between two stages' MFMAs.
+// NS > 0: the reduction loop is fully unrolled for exactly NS stages (K = 784 / 400 with the shipped
+// tile depths): every s_waitcnt is a counted one, the global addresses of a stage are immediate
+// offsets from per-thread base pointers, and the K-tail clamp / zeroing exists only in the last
+// stage.  NS == 0 keeps a runtime loop (full vmcnt drain on the back-edge, clamps everywhere).
+template <int MODE, int BM, int BN, int WTM, int WTN, int WK, int KU, int PD, int NS>
+__global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_kernel(GemmP p) {
+    using C = LdsCfg<MODE, BM, BN, WTM, WTN, WK, KU>;
+    constexpr int NT = C::NT, BK = C::BK, LDK = C::LDK, LDXB = C::LDXB, TI = C::TI, TJ = C::TJ;
+    static_assert(PD >= 2, "two stages are stored before the first barrier");
+    __shared__ __attribute__((aligned(16))) float lds[C::FLOATS];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wk = w / (C::WM * C::WN), wmn = w % (C::WM * C::WN), wm = wmn / C::WN, wn = wmn % C::WN;
+    const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
+    const int tile_m = xcd * p.lds_mpx + l / p.tn, tile_n = l % p.tn;
+    if (tile_m >= p.lds_tm) return;                               // workgroup-uniform
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* A = p.A + gm_slot_offset(p.a_slot);
+    const float* B = p.B + gm_slot_offset(p.b_slot);
+
+    constexpr int KQ = BK / 4;                                    // 16-byte units per k-contiguous row
+    constexpr int XQ = BN / 4;                                    // 16-byte units per x-contiguous row
+    constexpr int UA = BM * KQ, CA = (UA + NT - 1) / NT;
+    constexpr int UB = C::B_KC ? BN * KQ : BK * XQ, CB = (UB + NT - 1) / NT;
+    // per-thread base address of each 16-byte unit of the stage tiles (row clamps applied once)
+    const float* baseA[CA];
+    const float* baseB[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int u = min(t + i * NT, UA - 1);
+        baseA[i] = A + (int64_t)min(m0 + u / KQ, p.M - 1) * p.lda + 4 * (u % KQ);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int u = min(t + i * NT, UB - 1);
+        if (C::B_KC) baseB[i] = B + (int64_t)min(n0 + u / KQ, p.N - 1) * p.ldb + 4 * (u % KQ);
+        else baseB[i] = B + min(n0 + 4 * (u % XQ), p.N - 4);      // + k * ldb per stage
+    }
+    // One 16-byte unit of stage q.  The lambdas RETURN the value (a lambda that writes a captured
+    // register array makes hipcc keep the array in scratch memory, with a vmcnt(0) behind every
+    // load -- measured: 1.4 us per stage).  Branch-free: `inside` (the whole stage lies below K) is
+    // a compile-time constant in the unrolled kernels, otherwise the k index is clamped.
+    auto load_a = [&](const float* base, int i, int q, bool inside) -> float4 {
+        if (inside) return *reinterpret_cast<const float4*>(base + q * BK);
+        const int kq4 = 4 * (min(t + i * NT, UA - 1) % KQ);
+        return *reinterpret_cast<const float4*>(base - kq4 + min(q * BK + kq4, p.K - 4));
+    };
+    auto load_b = [&](const float* base, int i, int q, bool inside) -> float4 {
+        const int u = min(t + i * NT, UB - 1);
+        if (C::B_KC) {
+            if (inside) return *reinterpret_cast<const float4*>(base + q * BK);
+            const int kq4 = 4 * (u % KQ);
+            return *reinterpret_cast<const float4*>(base - kq4 + min(q * BK + kq4, p.K - 4));
+        }
+        const int kk = q * BK + u / XQ;
+        return *reinterpret_cast<const float4*>(base + (int64_t)(inside ? kk : min(kk, p.K - 1)) * p.ldb);
+    };
+    // the K-tail zeroing select happens here, at the LDS write, never right behind the load
+    auto store_a = [&](int buf, int i, int q, bool inside, float4 v) {
+        const int u = t + i * NT, row = u / KQ, kq = u % KQ;
+        if (UA % NT != 0 && u >= UA) return;
+        *reinterpret_cast<float4*>(&lds[buf * C::STAGE + row * LDK + 4 * kq]) = inside ? v : keep4(q * BK + 4 * kq < p.K, v);
+    };
+    auto store_b = [&](int buf, int i, int q, bool inside, float4 v) {
+        const int u = t + i * NT;
+        if (UB % NT != 0 && u >= UB) return;
+        float* Bs = lds + buf * C::STAGE + C::A_SZ;
+        if (C::B_KC) {
+            const int row = u / KQ, kq = u % KQ;
+            *reinterpret_cast<float4*>(&Bs[row * LDK + 4 * kq]) = inside ? v : keep4(q * BK + 4 * kq < p.K, v);
+        } else {
+            const int kr = u / XQ, xq = u % XQ;
+            *reinterpret_cast<float4*>(&Bs[kr * LDXB + 4 * xq]) = inside ? v : keep4(q * BK + kr < p.K, v);
+        }
+    };
+    // MFMA fragments of one 8-deep k group: lane (r, h) holds k = kb + 4h + j, j = 0..3
+    auto frag_a = [&](int buf, int ku, int ti) -> float4 {
+        return *reinterpret_cast<const float4*>(
+            &lds[buf * C::STAGE + (wm * WTM + ti * 32 + r) * LDK + (wk * KU + ku) * 8 + 4 * h]);
+    };
+    auto frag_b = [&](int buf, int ku, int tj) -> float4 {
+        const float* Bs = lds + buf * C::STAGE + C::A_SZ;
+        const int kb = (wk * KU + ku) * 8, col = wn * WTN + tj * 32 + r;
+        if (C::B_KC) return *reinterpret_cast<const float4*>(&Bs[col * LDK + kb + 4 * h]);
+        const float* q = &Bs[(kb + 4 * h) * LDXB + col];
+        return make_float4(q[0], q[LDXB], q[2 * LDXB], q[3 * LDXB]);
+    };
+
+    constexpr int NDSR = KU * (TI + (C::B_KC ? TJ : 4 * TJ));     // LDS read instructions per stage
+    // a 32x32 wave tile alternates two accumulators MFMA by MFMA (consecutive MFMAs must not depend
+    // on each other); bigger wave tiles have 2 or 4 accumulators anyway
+    constexpr int NA = (TI * TJ == 1) ? 2 : 1;
+    float4 ra[PD][CA], rb[PD][CB];                               // global -> LDS staging registers
+    float4 fa[2][KU][TI], fb[2][KU][TJ];                         // fragments: this stage / next stage
+    f32x16 acc[NA][TI][TJ];
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[c][ti][tj][i] = 0.f;
+    // stage q lies wholly below K in the unrolled kernels iff q < NS - 1
+#define GM_LDS_INSIDE(q) (NS > 0 && (q) < NS - 1)
+#define GM_LDS_GLOAD(j, q)                                                         \
+    _Pragma("unroll") for (int i = 0; i < CA; ++i) ra[j][i] = load_a(baseA[i], i, (q), GM_LDS_INSIDE(q)); \
+    _Pragma("unroll") for (int i = 0; i < CB; ++i) rb[j][i] = load_b(baseB[i], i, (q), GM_LDS_INSIDE(q));
+#define GM_LDS_LSTORE(j, buf, q)                                                   \
+    _Pragma("unroll") for (int i = 0; i < CA; ++i) store_a((buf), i, (q), GM_LDS_INSIDE(q), ra[j][i]); \
+    _Pragma("unroll") for (int i = 0; i < CB; ++i) store_b((buf), i, (q), GM_LDS_INSIDE(q), rb[j][i]);
+#define GM_LDS_FRAGS(P, buf)                                                       \
+    _Pragma("unroll") for (int ku = 0; ku < KU; ++ku) {                            \
+        _Pragma("unroll") for (int ti = 0; ti < TI; ++ti) fa[P][ku][ti] = frag_a((buf), ku, ti); \
+        _Pragma("unroll") for (int tj = 0; tj < TJ; ++tj) fb[P][ku][tj] = frag_b((buf), ku, tj); \
+    }
+#define GM_LDS_MFMA1(P, ku, comp, cidx)                                            \
+    _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                              \
+        _Pragma("unroll") for (int tj = 0; tj < TJ; ++tj)                          \
+            acc[(NA == 2) ? (cidx) : 0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(   \
+                fa[P][ku][ti].comp, fb[P][ku][tj].comp, acc[(NA == 2) ? (cidx) : 0][ti][tj], 0, 0, 0);
+#define GM_LDS_MFMA(P)                                                             \
+    _Pragma("unroll") for (int ku = 0; ku < KU; ++ku) {                            \
+        GM_LDS_MFMA1(P, ku, x, 0) GM_LDS_MFMA1(P, ku, y, 1) GM_LDS_MFMA1(P, ku, z, 0) GM_LDS_MFMA1(P, ku, w, 1) \
+    }
+    // stage s: J = s % PD and P = s & 1 are compile-time after unrolling.  Loads and LDS writes are
+    // UNCONDITIONAL (past-the-end stages read clamped addresses and write zeros into an idle
+    // buffer): a guard would make hipcc drain vmcnt to 0 at its join.
+#define GM_LDS_STAGE(s_, J, P)                                                     \
+    {                                                                              \
+        GM_LDS_FRAGS((P) ^ 1, ((s_) + 1) % 3)                                      \
+        GM_LDS_LSTORE(((J) + 2) % PD, ((s_) + 2) % 3, (s_) + 2)                    \
+        GM_LDS_GLOAD(((J) + 2) % PD, (s_) + 2 + PD)                                \
+        GM_LDS_MFMA(P)                                                             \
+        lds_stage_schedule<4 * KU * TI * TJ, NDSR, CA + CB, CA + CB>();            \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        __syncthreads();                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+
+    const int S = (p.K + BK - 1) / BK;
+    GM_LDS_GLOAD(0, 0)
+    GM_LDS_GLOAD(1 % PD, 1)
+    GM_LDS_LSTORE(0, 0, 0)
+    GM_LDS_LSTORE(1 % PD, 1, 1)
+#pragma unroll
+    for (int q = 2; q < PD + 2; ++q) { GM_LDS_GLOAD(q % PD, q) }
+    __syncthreads();
+    GM_LDS_FRAGS(0, 0)
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) GM_LDS_STAGE(s, s % PD, s & 1)
+    } else {
+        constexpr int U = (PD % 2 == 0) ? PD : 2 * PD;           // lcm(2, PD)
+        for (int s0 = 0; s0 < S; s0 += U) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (s0 + j >= S) break;                           // workgroup-uniform
+                GM_LDS_STAGE(s0 + j, j % PD, j & 1)
+            }
+        }
+    }
+#undef GM_LDS_STAGE
+#undef GM_LDS_MFMA
+#undef GM_LDS_MFMA1
+#undef GM_LDS_FRAGS
+#undef GM_LDS_GLOAD
+#undef GM_LDS_LSTORE
+#undef GM_LDS_INSIDE
+    // partial tiles of the WK wave groups -> LDS (every stage buffer is idle after the last barrier)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[0][ti][tj][i];
+                if (NA == 2) v += acc[NA - 1][ti][tj][i];
+                lds[(wk * BM + wm * WTM + ti * 32 + row) * BN + wn * WTN + tj * 32 + r] = v;
+            }
+    __syncthreads();
+    for (int e = t; e < BM * BN; e += NT) {
+        const int row = e / BN, col = e % BN;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < WK; ++kk) v += lds[(kk * BM + row) * BN + col];
+        const int m = m0 + row, n = n0 + col;
+        if (m < p.M && n < p.N) store_element<MODE>(p, v, m, n);
+    }
+}
+
+// Tile shape of the LDS kernel for an M x N output: the fewest workgroup rounds on 256 CUs weighted
+// by tile area (time per round), the larger tile on ties.  1: 64x64, 2: 32x64.  Measured on MI355X
+// (profiles/r02_experiments.md): 128x64 tiles lose to two rounds of 64x64 on the 2048x784 output.
+inline int lds_pick_cfg(int M, int N) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("GM_LDS_CFG"); forced = e ? atoi(e) : 0; }
+    if (forced) return forced;
+    const int bm[2] = {64, 32}, bn[2] = {64, 64}, id[2] = {1, 2};
+    long best = -1; int pick = 0;
+    for (int i = 0; i < 2; ++i) {
+        const long tiles = (long)((M + bm[i] - 1) / bm[i]) * ((N + bn[i] - 1) / bn[i]);
+        const long cost = ((tiles + 255) / 256) * bm[i] * bn[i];
+        if (best < 0 || cost < best) { best = cost; pick = id[i]; }
+    }
+    return pick;
+}
+
+template <int MODE, int BM, int BN, int WTM, int WTN, int WK, int KU, int PD>
+int launch_lds_cfg(hipStream_t s, GemmP p) {
+    using C = LdsCfg<MODE, BM, BN, WTM, WTN, WK, KU>;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    p.lds_tm = tm; p.tn = tn; p.lds_mpx = (tm + 7) / 8;
+    const dim3 grid(8 * p.lds_mpx * tn), block(C::NT);
+    // fully unrolled instantiations for the reduction lengths of this model (784, 400: image and
+    // hidden widths); anything else takes the runtime loop
+    constexpr int NS784 = (784 + C::BK - 1) / C::BK, NS400 = (400 + C::BK - 1) / C::BK;
+    const int S = (p.K + C::BK - 1) / C::BK;
+    static int unroll_on = -1;
+    if (unroll_on < 0) { const char* e = getenv("GM_LDS_UNROLL"); unroll_on = e ? atoi(e) : 1; }
+    if (unroll_on && S == NS784) hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, NS784>), grid, block, 0, s, p);
+    else if (unroll_on && S == NS400) hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, NS400>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, 0>), grid, block, 0, s, p);
+    GM_LAUNCH_RET();
+}
+
+// Returns -1 when the launch is not for this kernel (caller continues with the split-reduction
+// kernels), else the launch's return code.
+template <int MODE>
+int try_launch_lds(hipStream_t s, const GemmP& p, bool vec, bool xv) {
+    if constexpr (MODE == MODE_DW) {
+        return -1;
+    } else {
+        static int min_m = -1;
+        if (min_m < 0) { const char* e = getenv("GM_LDS_MIN_M"); min_m = e ? atoi(e) : 1024; }
+        if (p.M < min_m || p.K < 64 || !vec || (MODE == MODE_DX && !xv) || p.N < 32) return -1;
+        switch (lds_pick_cfg(p.M, p.N)) {
+            // 64x64 tile: 2 x 1 waves of 32x64 (two accumulators each) x 4 reduction groups, BK = 32
+            case 1: return launch_lds_cfg<MODE, 64, 64, 32, 64, 4, 1, 4>(s, p);
+            // 32x64 tile: 1 x 2 waves of 32x32 x 4 reduction groups, BK = 32
+            case 2: return launch_lds_cfg<MODE, 32, 64, 32, 32, 4, 1, 4>(s, p);
+            default: return -1;
+        }
     }
 }
 
@@ -557,6 +877,26 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             p.xr = bxr; p.xc = 8 / bxr; p.tm = tm; p.tn = tn;
             const int per = ((tm + p.xr - 1) / p.xr) * ((tn + p.xc - 1) / p.xc);
             grid = dim3(8 * per, 1);
+        }
+    }
+    {
+        // many-row launches: LDS-staged macro tiles.  Riders get their own launch first (a head /
+        // gather workgroup set is microseconds next to a >= 1024-row GEMM).
+        static int xvq = -1;
+        if (xvq < 0) { const char* e = getenv("GM_XVEC"); xvq = e ? atoi(e) : 1; }
+        const bool xv_l = xvec && xvq && MODE != MODE_FWD;
+        if (!rider.pair && p.xr == 0 && p.cpw == 0) {
+            static int min_m = -1;
+            if (min_m < 0) { const char* e = getenv("GM_LDS_MIN_M"); min_m = e ? atoi(e) : 1024; }
+            const bool fits = MODE != MODE_DW && p.M >= min_m && p.K >= 64 && p.N >= 32 && vec &&
+                              (MODE != MODE_DX || xv_l);
+            if (fits) {
+                if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
+                if (rider.gather)
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(*rider.gather, 4)), dim3(256), 0, s, *rider.gather);
+                const int rc = try_launch_lds<MODE>(s, p, vec, xv_l);
+                if (rc != -1) return rc;
+            }
         }
     }
     const int nw = use8 ? 8 : 16;
