@@ -76,6 +76,9 @@ def gemm_variant(kind, M, K, N):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind in ("dx", "dxh"):
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
+    else:
+        mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
+        xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
     if kind in ("fwd", "dx", "dxh", "fwdg") and Mg >= LDS_MIN_M and Kr >= 64 and Ng >= 32 and vec and (mode == 0 or xv):
         # many-row launches: the LDS-staged macro-tile kernel (riders get their own launch)
         cands = [(64, 64, "64, 64, 32, 64, 4, 1, 4"), (32, 64, "32, 64, 32, 32, 4, 1, 4")]
@@ -83,9 +86,6 @@ def gemm_variant(kind, M, K, N):
         best = min(cands, key=lambda c: (cost(c), -c[0] * c[1]))
         ns = -(-Kr // 32)
         return "gemm_lds_kernel<%d, %s, %d>" % (mode, best[2], ns if Kr in (784, 400) else 0)
-    else:
-        mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
-        xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
     nw = 16
     chunks = -(-Kr // 16)
     g = 1                                  # per-chunk load/consume schedule
