@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
         sample_terms(p.variant, D, x, g, ib, p.hyper, lx, lg, dx, dg);
         // WGAN-GP: + lambda * mean((||grad|| - 1)^2), per-row terms in aux
         // (w_gp_gan.py:215-218; rows produced by gm_gp_norm)
-        if (D && p.aux && p.variant == GM_LOSS_W) lx += p.hyper[7] * p.aux[i];
+        // (DRAGAN carries the same kind of penalty rows on the NS loss, dra_gan.py:220-223: any
+        // separable variant with aux rows gets the term, like the fused head kernel)
+        if (D && p.aux) lx += p.hyper[7] * p.aux[i];
         acc += (double)lx + (double)lg;
         if (D && p.dax) { const float ax = act_grad(dx, x, p.out_act); p.dax[i] = ax; sbx += (double)ax; }
         if (p.dag) { const float ag = act_grad(dg, g, p.out_act); p.dag[i] = ag; sbg += (double)ag; }

@@ -966,11 +966,18 @@ class GANEngine:
         self.fG.rebind(); self.fD.rebind()
         self.fG.reset_state(); self.fD.reset_state()
         self.fG.grad.zero_(); self.fD.grad.zero_()
-        self.step0 = {"G": 0, "D": 0}
+        self.step0 = {"G": 0, "D": 0, "MI": 0}
+        self.run_config = {"variant": self.variant, "B": int(self.B), "D_steps": int(D_steps),
+                           "G_lr": float(G_lr), "D_lr": float(D_lr)}
         if resume is not None:
-            if self.variant in ("info", "be", "fisher"):
-                raise GMError("checkpoint resume is not wired for %s (extra optimizer / controller "
-                              "state)" % self.variant)
+            saved = resume.get("config")
+            if saved is not None and not resume.get("lenient", False):
+                diff = {k: (saved[k], self.run_config[k]) for k in self.run_config
+                        if k in saved and saved[k] != self.run_config[k]}
+                if diff:
+                    raise GMError("checkpoint was written by a run with different settings (saved, now): "
+                                  "%s -- Adam moments and the bias-correction schedule would not "
+                                  "continue that run; load_checkpoint(path, strict=False) overrides" % diff)
             for net, fp in (("G", self.fG), ("D", self.fD)):
                 st = resume[net]
                 if st["m"].numel() != fp.m.numel():
@@ -987,9 +994,18 @@ class GANEngine:
         if self.variant == "info":
             self.fQ.rebind(); self.fQ.reset_state(); self.fQ.grad.zero_()
             self.mi_m.zero_(); self.mi_v.zero_()
-            self.schedMI = torch.from_numpy(ops.adam_schedule(G_lr, max(1, n_iters))).to(dev)
+            if resume is not None:
+                # info_gan.py:146-148: the MI optimizer keeps its OWN moments for G's parameters and Q's
+                mi = resume["MI"]
+                self.mi_m.copy_(mi["m_G"]); self.mi_v.copy_(mi["v_G"])
+                self.fQ.m.copy_(mi["m_Q"]); self.fQ.v.copy_(mi["v_Q"])
+                self.step0["MI"] = int(mi["step"])
+            self.schedMI = torch.from_numpy(ops.adam_schedule(G_lr, max(1, n_iters),
+                                                              start=self.step0["MI"] + 1)).to(dev)
             self.lossMI = torch.zeros(max(1, n_iters), device=dev)
         self.aux.zero_()
+        if resume is not None and self.variant == "fisher":
+            self.aux.copy_(resume["fisher_aux"])     # lambda (fisher_gan.py:117-118,155-156) + moments
         self.ctr.zero_()
         self._drain()
         from collections import deque
@@ -1013,11 +1029,20 @@ class GANEngine:
         self._key = key
 
     def optim_state(self):
-        """Adam moments + step counts after the train() call that just finished (checkpointing)."""
+        """Everything the optimizers and controllers carry across steps, after the train() call that
+        just finished (checkpointing): Adam moments + step counts per optimizer, InfoGAN's third
+        optimizer, Fisher's lambda, BEGAN's K and plateau schedulers, and the run's settings."""
         torch.cuda.synchronize()
-        return {net: {"m": fp.m.detach().cpu().clone(), "v": fp.v.detach().cpu().clone(),
-                      "step": self.step0[net] + self.steps_planned[net]}
-                for net, fp in (("G", self.fG), ("D", self.fD))}
+        cpu = lambda t: t.detach().cpu().clone()
+        st = {net: {"m": cpu(fp.m), "v": cpu(fp.v), "step": self.step0[net] + self.steps_planned[net]}
+              for net, fp in (("G", self.fG), ("D", self.fD))}
+        st["config"] = dict(self.run_config)
+        if self.variant == "info":
+            st["MI"] = {"m_G": cpu(self.mi_m), "v_G": cpu(self.mi_v), "m_Q": cpu(self.fQ.m),
+                        "v_Q": cpu(self.fQ.v), "step": self.step0["MI"] + self.n_planned}
+        if self.variant == "fisher":
+            st["fisher_aux"] = cpu(self.aux)
+        return st
 
     def _ensure_graph(self):
         if not self.use_graph or self._graph_key == self._key:
@@ -1336,7 +1361,15 @@ class VAEEngine:
         self.fp.reset_state()
         self.fp.grad.zero_()
         self.step0 = 0
+        self.run_config = {"B": int(B), "lr": float(lr), "weight_decay": float(weight_decay)}
         if resume is not None:                       # see GANEngine.configure
+            saved = resume.get("config")
+            if saved is not None and not resume.get("lenient", False):
+                diff = {k: (saved[k], self.run_config[k]) for k in self.run_config
+                        if k in saved and saved[k] != self.run_config[k]}
+                if diff:
+                    raise GMError("checkpoint was written by a run with different settings (saved, now): "
+                                  "%s; load_checkpoint(path, strict=False) overrides" % diff)
             if resume["m"].numel() != self.fp.m.numel():
                 raise GMError("checkpoint optimizer state does not match this model")
             self.fp.m.copy_(resume["m"]); self.fp.v.copy_(resume["v"])
@@ -1358,7 +1391,7 @@ class VAEEngine:
     def optim_state(self):
         torch.cuda.synchronize()
         return {"m": self.fp.m.detach().cpu().clone(), "v": self.fp.v.detach().cpu().clone(),
-                "step": self.step0 + self.steps_planned}
+                "step": self.step0 + self.steps_planned, "config": dict(self.run_config)}
 
     def _graph(self, b, train, k=1):
         """hipGraph of k consecutive batches of size b (the device counter advances per batch)."""
@@ -1517,8 +1550,10 @@ class BEGANEngine(GANEngine):
         if self.world > 1:
             raise GMError("BEGAN's K controller needs global DX/DG means; data-parallel BEGAN is "
                           "not wired yet")
-        super().configure(n_iters, G_lr, D_lr, D_steps)
+        resume = kw.get("resume")
+        super().configure(n_iters, G_lr, D_lr, D_steps, resume=resume)
         self.gamma, self.lam, self.patience = float(GAMMA), float(LAMBDA), int(patience)
+        self.run_config.update(GAMMA=self.gamma, LAMBDA=self.lam, patience=self.patience)
         self.st.zero_()
         self.st[0] = float(K)
         self.st[4] = 1.0
@@ -1527,6 +1562,19 @@ class BEGANEngine(GANEngine):
         self.dst[0] = float("inf")                 # ReduceLROnPlateau.best (mode='min')
         self.dst[1], self.dst[2], self.dst[3], self.dst[4] = D_lr, G_lr, D_lr, G_lr
         self.ist.zero_()
+        if resume is not None:
+            # the controller K (be_gan.py:189-191) and both ReduceLROnPlateau schedulers (:133-136,
+            # :194-195: best, bad-epoch counts, current lr scales) continue where the run stopped;
+            # the K argument of this train() call is superseded by the saved K
+            be = resume["began"]
+            self.st.copy_(be["st"]); self.dst.copy_(be["dst"]); self.ist.copy_(be["ist"])
+
+    def optim_state(self):
+        st = super().optim_state()
+        cpu = lambda t: t.detach().cpu().clone()
+        st["began"] = {"st": cpu(self.st), "dst": cpu(self.dst), "ist": cpu(self.ist)}
+        st["config"] = dict(self.run_config)
+        return st
 
     def _D_rest(self, st, it, j):
         from . import ops_fused as of

@@ -71,6 +71,26 @@ def _lin(layer, x, act):
     return ops.fused_linear(x, layer.weight, layer.bias, act)
 
 
+def _stock_module(mod, n_linear=2):
+    """True iff `mod` is EXACTLY one of the module classes this package ships (not a user subclass
+    with its own forward / extra layers) with the expected nn.Linear children.  The fused engines
+    read the first Linear layers and hard-code relu-hidden MLPs; anything the user has changed in
+    the model (README.md:29-31 invites editing Generator / Discriminator) must take the general
+    autograd path instead of being silently trained as a 2-layer MLP."""
+    cls = type(mod)
+    if not cls.__dict__.get("_gm_stock_model", False):
+        return False
+    kids = list(mod.children())
+    return len(kids) == n_linear and all(type(k) is nn.Linear for k in kids)
+
+
+def stock_model(cls):
+    """Marks a module class shipped by this package (checked on the class itself, so a subclass
+    does not inherit the mark)."""
+    cls._gm_stock_model = True
+    return cls
+
+
 class _TwoLayer(nn.Module):
     """relu(first) -> out_act(second); attribute names are the reference's state_dict keys."""
     _names = ("linear", "second")
@@ -85,6 +105,7 @@ class _TwoLayer(nn.Module):
         return _lin(getattr(self, self._names[1]), h, self._out_act)
 
 
+@stock_model
 class Generator(_TwoLayer):
     """ns_gan.py:35-46."""
     _names = ("linear", "generate")
@@ -94,6 +115,7 @@ class Generator(_TwoLayer):
         self._build(z_dim, hidden_dim, image_size)
 
 
+@stock_model
 class Discriminator(_TwoLayer):
     """ns_gan.py:49-60 (sigmoid output)."""
     _names = ("linear", "discriminate")
@@ -103,6 +125,7 @@ class Discriminator(_TwoLayer):
         self._build(image_size, hidden_dim, output_dim)
 
 
+@stock_model
 class CriticReLU(Discriminator):
     """w_gp_gan.py:49-62 (ReLU output)."""
     _out_act = "relu"
@@ -143,6 +166,7 @@ class FlatAdam(torch.optim.Optimizer):
             self.offs.append(o)
             o += (p.numel() + 3) // 4 * 4
         self.t = 0
+        self.steps = [0] * len(params)          # per-parameter step counts (torch keeps one per parameter)
 
     def zero_grad(self, set_to_none=True):
         for p in self._ps:
@@ -150,22 +174,39 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        if all(p.grad is None for p in self._ps):
+        """One Adam step for every parameter that HAS a gradient; a parameter whose grad is None is
+        skipped entirely -- value, moments and its own step count stay put -- like
+        torch.optim.Adam does (frozen or unused parameters in user-written train_D / train_G).
+        Parameters are updated in runs of neighbours that share a step count: one launch in the
+        usual case (every parameter has a gradient on every step)."""
+        active = [p.grad is not None for p in self._ps]
+        if not any(active):
             return
-        for p, o in zip(self._ps, self.offs):
-            k = p.numel()
-            self.flat[o:o + k].copy_(p.data.reshape(-1))
-            if p.grad is None:
-                self.grad[o:o + k].zero_()
-            else:
+        for i, (p, o) in enumerate(zip(self._ps, self.offs)):
+            if active[i]:
+                k = p.numel()
+                self.flat[o:o + k].copy_(p.data.reshape(-1))
                 self.grad[o:o + k].copy_(p.grad.reshape(-1))
-        self.t += 1
+                self.steps[i] += 1
         lr = self.param_groups[0]["lr"]
-        sched = torch.from_numpy(ops.adam_schedule(lr, 1, start=self.t)).to(self.flat.device)
-        ops.adam(self.flat, self.grad, self.m, self.v, sched, weight_decay=self.wd,
-                 clamp=self.clamp)
-        for p, o in zip(self._ps, self.offs):
-            p.data.copy_(self.flat[o:o + p.numel()].view(p.shape))
+        ends = self.offs[1:] + [self.flat.numel()]
+        i, n = 0, len(self._ps)
+        while i < n:
+            if not active[i]:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and active[j + 1] and self.steps[j + 1] == self.steps[i]:
+                j += 1
+            lo, hi = self.offs[i], ends[j]
+            sched = torch.from_numpy(ops.adam_schedule(lr, 1, start=self.steps[i])).to(self.flat.device)
+            ops.adam(self.flat[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], sched,
+                     weight_decay=self.wd, clamp=self.clamp)
+            i = j + 1
+        self.t = max(self.steps)
+        for k, (p, o) in enumerate(zip(self._ps, self.offs)):
+            if active[k]:
+                p.data.copy_(self.flat[o:o + p.numel()].view(p.shape))
 
 
 class GANTrainer:
@@ -265,19 +306,28 @@ class GANTrainer:
         raise NotImplementedError(v)
 
     # ---- path selection -------------------------------------------------------------------
+    def _hook_is_stock(self, name):
+        """The hook `name` is the one this package ships (not overridden on the instance or in a
+        user subclass)."""
+        if name in self.__dict__:
+            return False
+        for base in type(self).__mro__:
+            if name in base.__dict__:              # the class that actually defines the hook
+                return bool(base.__dict__.get("_gm_stock_class", False))
+        return True
+
     def _stock(self):
         from .engine import GANEngine
         if self.variant not in GANEngine.SUPPORTED:
             return False
-        cls = type(self)
-        for name in self._STOCK:
-            if name in self.__dict__:
-                return False
-            for base in cls.__mro__:
-                if name in base.__dict__:          # the class that actually defines the hook
-                    if not base.__dict__.get("_gm_stock_class", False):
-                        return False
-                    break
+        hooks = self._STOCK + (("clip_D_weights",) if self.variant == "w" else ())
+        if not all(self._hook_is_stock(name) for name in hooks):
+            return False
+        m = self.model
+        if not (_stock_module(getattr(m, "G", None)) and _stock_module(getattr(m, "D", None))):
+            return False                               # edited / subclassed networks: general path
+        if self.variant == "info" and not _stock_module(getattr(m, "Q", None)):
+            return False
         it = self.train_iter
         ok = (isinstance(it, torch.utils.data.DataLoader)
               and isinstance(it.dataset, torch.utils.data.TensorDataset)
@@ -325,9 +375,16 @@ class GANTrainer:
                 self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
             return
         # GENERAL path: user-overridden hooks, same loop as the reference
+        if self.__dict__.get("_resume_optim") is not None:
+            raise GMError("load_checkpoint() restored optimizer state, but this trainer runs the general "
+                          "path (overridden hooks / edited networks), whose optimizers start fresh: "
+                          "resume is only defined on the fused engine")
         m = self.model
+        # WGAN's clamp (w_gan.py:158,241-243) is folded into the Adam kernel unless the user
+        # overrides clip_D_weights: then theirs is called after every critic step
+        user_clip = clip > 0 and hasattr(self, "clip_D_weights") and not self._hook_is_stock("clip_D_weights")
         G_opt = FlatAdam(m.G.parameters(), G_lr)
-        D_opt = FlatAdam(m.D.parameters(), D_lr, clamp=clip)
+        D_opt = FlatAdam(m.D.parameters(), D_lr, clamp=0.0 if user_clip else clip)
         kwD, kwG = train_D_kw or {}, train_G_kw or {}
         for _ in range(G_init):
             images = self.process_batch(self.train_iter)
@@ -348,6 +405,8 @@ class GANTrainer:
                     D_loss.backward()
                     self._after_D_backward()
                     D_opt.step()
+                    if user_clip:
+                        self.clip_D_weights(clip)
                     step.append(D_loss.item())
                 D_losses.append(np.mean(step))
                 G_opt.zero_grad()
@@ -385,10 +444,13 @@ class GANTrainer:
         step counts of the last train() call, the global CPU generator's state (= the cursor of the
         sampling / noise protocol) and the loss history.  After load_checkpoint() the next train()
         continues as if the run had never stopped."""
-        _save_checkpoint(self, savepath, ("Glosses", "Dlosses", "num_epochs"))
+        _save_checkpoint(self, savepath, tuple(n for n in ("Glosses", "Dlosses", "MIlosses", "K", "num_epochs")
+                                               if hasattr(self, n)))
 
-    def load_checkpoint(self, loadpath):
-        _load_checkpoint(self, loadpath)
+    def load_checkpoint(self, loadpath, strict=True):
+        """strict: refuse a checkpoint whose run settings (batch size, D_steps, learning rates ...)
+        differ from the next train() call's."""
+        _load_checkpoint(self, loadpath, strict)
 
     def load_model(self, loadpath):
         state = torch.load(loadpath)
@@ -407,36 +469,49 @@ def stock(cls):
 # ============================================================================================
 # Checkpoint / resume shared by all trainers
 # ============================================================================================
-CHECKPOINT_VERSION = 1
+CHECKPOINT_VERSION = 2
+
+
+def _plain(v):
+    """History values as plain Python numbers / lists (so the file loads with weights_only=True)."""
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    if isinstance(v, (np.floating, np.integer)):
+        return v.item()
+    if torch.is_tensor(v) and v.dim() == 0:
+        return v.item()
+    return v
 
 
 def _save_checkpoint(trainer, savepath, history):
     eng = getattr(trainer, "_engine", None)
     if eng is None or not hasattr(eng, "steps_planned"):
         raise GMError("save_checkpoint needs a finished train() call on the fused engine")
-    torch.save({"version": CHECKPOINT_VERSION, "name": trainer.name,
-                "model": {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()},
-                "optim": eng.optim_state(), "rng": torch.get_rng_state(),
-                "history": {n: getattr(trainer, n) for n in history}}, savepath)
+    state = {"version": CHECKPOINT_VERSION, "name": trainer.name,
+             "model": {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()},
+             "optim": eng.optim_state(), "rng": torch.get_rng_state(),
+             "history": {n: _plain(getattr(trainer, n)) for n in history}}
+    from . import dp
+    if dp.current()[1] == 0:                     # data parallel: replicas are identical, rank 0 writes
+        torch.save(state, savepath)
 
 
-def _load_checkpoint(trainer, loadpath):
-    if getattr(trainer, "variant", None) in ("be", "info", "fisher"):
-        raise GMError("checkpoint resume is not wired for this trainer (extra optimizer / "
-                      "controller state); use save_model / load_model")
-    ck = torch.load(loadpath, weights_only=False)
+def _load_checkpoint(trainer, loadpath, strict=True):
+    # plain tensors / numbers / containers only: no pickled code is executed
+    ck = torch.load(loadpath, weights_only=True)
     if ck.get("version") != CHECKPOINT_VERSION or ck.get("name") != trainer.name:
         raise GMError("not a checkpoint of a %s trainer" % trainer.name)
     trainer.model.load_state_dict(ck["model"])
     for n, v in ck["history"].items():
         setattr(trainer, n, list(v) if isinstance(v, list) else v)
-    trainer._resume_optim = ck["optim"]          # consumed by the next train()
+    trainer._resume_optim = dict(ck["optim"], lenient=not strict)   # consumed by the next train()
     torch.set_rng_state(ck["rng"])               # LAST: construction / loading drew nothing after
 
 
 # ============================================================================================
 # VAE (vae.py:47-223)
 # ============================================================================================
+@stock_model
 class Encoder(nn.Module):
     """vae.py:47-61."""
 
@@ -451,6 +526,7 @@ class Encoder(nn.Module):
         return _lin(self.mu, h, "id"), _lin(self.log_var, h, "id")
 
 
+@stock_model
 class Decoder(_TwoLayer):
     """vae.py:64-77."""
     _names = ("linear", "recon")
@@ -460,6 +536,7 @@ class Decoder(_TwoLayer):
         self._build(z_dim, hidden_dim, image_size)
 
 
+@stock_model
 class VAE(nn.Module):
     """vae.py:80-106."""
 
@@ -547,6 +624,14 @@ class VAETrainer:
                     if not base.__dict__.get("_gm_stock_class", False):
                         return False
                     break
+        m = self.model
+        enc, dec = getattr(m, "encoder", None), getattr(m, "decoder", None)
+        n_enc = 3 if isinstance(enc, Encoder) else 1       # VAE: linear, mu, log_var; AE: one layer
+        n_dec = 2 if isinstance(dec, Decoder) else 1
+        if not (_stock_module(enc, n_enc) and _stock_module(dec, n_dec)):
+            return False                               # edited / subclassed networks: general path
+        if not type(m).__dict__.get("_gm_stock_model", False):
+            return False                               # a subclass may have changed forward / reparameterize
         return (self._loader_ok(self.train_iter) and self._loader_ok(self.val_iter)
                 and self.train_iter.batch_size == self.val_iter.batch_size)
 
@@ -630,14 +715,17 @@ class VAETrainer:
                      if hasattr(self, n))
         _save_checkpoint(self, savepath, hist)
 
-    def load_checkpoint(self, loadpath):
-        _load_checkpoint(self, loadpath)
+    def load_checkpoint(self, loadpath, strict=True):
+        """strict: refuse a checkpoint whose run settings (batch size, D_steps, learning rates ...)
+        differ from the next train() call's."""
+        _load_checkpoint(self, loadpath, strict)
 
 
 # ============================================================================================
 # Autoencoder (ae.py:29-205; SURVEY.md 8f item 2) -- exported by src/ae.py as Encoder / Decoder /
 # Autoencoder / AutoencoderTrainer.  Runs on the VAE engine's machinery (engine.AEEngine).
 # ============================================================================================
+@stock_model
 class AEEncoder(nn.Module):
     """ae.py:29-39."""
 
@@ -649,6 +737,7 @@ class AEEncoder(nn.Module):
         return _lin(self.linear, x, "relu")
 
 
+@stock_model
 class AEDecoder(nn.Module):
     """ae.py:42-52."""
 
@@ -660,6 +749,7 @@ class AEDecoder(nn.Module):
         return _lin(self.linear, encoder_output, "sigmoid")
 
 
+@stock_model
 class Autoencoder(nn.Module):
     """ae.py:55-67."""
 
@@ -801,6 +891,7 @@ class Divergence:
 # General path only: K and the schedulers are host-side scalars updated from per-step losses
 # (be_gan.py:189-195), which is a host sync per step by construction of the algorithm.
 # ============================================================================================
+@stock_model
 class AEDiscriminator(_TwoLayer):
     """be_gan.py:63-76."""
     _names = ("encoder", "decoder")
@@ -865,7 +956,8 @@ class BEGANTrainerBase(GANTrainer):
             eng.use_graph = self.use_graph
             epoch_steps = int(np.ceil(len(self.train_iter) / D_steps))
             eng.configure(num_epochs * epoch_steps, G_lr, D_lr, D_steps, GAMMA=GAMMA, LAMBDA=LAMBDA,
-                          K=K, patience=5 * len(self.train_iter))
+                          K=K, patience=5 * len(self.train_iter),
+                          resume=self.__dict__.pop("_resume_optim", None))
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
@@ -911,6 +1003,7 @@ class BEGANTrainerBase(GANTrainer):
 # ============================================================================================
 # InfoGAN (info_gan.py:45-325).  General path (three optimizers, G updated by two of them).
 # ============================================================================================
+@stock_model
 class InfoGenerator(_TwoLayer):
     _names = ("linear", "generate")
 
@@ -919,6 +1012,7 @@ class InfoGenerator(_TwoLayer):
         self._build(z_dim + disc_dim + cont_dim, hidden_dim, image_size)
 
 
+@stock_model
 class InfoDiscriminator(_TwoLayer):
     _names = ("linear", "discriminator")
 
@@ -928,6 +1022,7 @@ class InfoDiscriminator(_TwoLayer):
         self._build(image_size, hidden_dim, output_dim)
 
 
+@stock_model
 class InfoQ(_TwoLayer):
     _names = ("linear", "inference")
     _out_act = "id"

@@ -202,8 +202,39 @@ def gen_bir():
                                 torch=torch.__version__))
 
 
+def gen_round2():
+    """Round-2 fixtures: the 50-step free-running NSGAN B=256 curve of SURVEY.md
+    8(d), and a full-size VAE B=512 epoch whose last training batch is the ragged 336
+    (50 000 mod 512) -- n_train = 512*3 + 336."""
+    tr, model = run_reference("ns", FULL, 256, dict(num_epochs=1), steps_cap=50)
+    arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+    for k, v in model.state_dict().items():
+        arrays["digest:" + k] = digest(v)
+    save("ns_full_b256_50steps", arrays, dict(variant="ns", cfg=FULL, batch=256, steps=50,
+                                              train_kw=dict(num_epochs=1), rng=rng_digest(),
+                                              torch=torch.__version__))
+    mod = ref_harness.load("vae")
+    n_train = 512 * 3 + 336
+    loaders = ref_harness.synthetic_loaders(512, n_train=n_train, n_val=FULL["n_val"],
+                                            n_test=FULL["n_test"], image_shape=FULL["image_shape"])
+    torch.manual_seed(1234)
+    model = mod.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = mod.VAETrainer(model, *loaders, viz=False)
+    with ref_harness.quiet():
+        tr.train(num_epochs=2)
+    arrays = {"recon_loss": np.array(tr.recon_loss), "kl_loss": np.array(tr.kl_loss),
+              "best_val_loss": np.array(tr.best_val_loss)}
+    for k, v in model.state_dict().items():
+        arrays["digest:" + k] = digest(v)
+    save("vae_full_b512_ragged", arrays, dict(variant="vae", cfg=FULL, batch=512, steps=8,
+                                              n_train=n_train, train_kw=dict(num_epochs=2),
+                                              rng=rng_digest(), torch=torch.__version__))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["ae"]:
+    if sys.argv[1:] == ["round2"]:
+        gen_round2()
+    elif sys.argv[1:] == ["ae"]:
         gen_ae()                 # only the ae.py fixtures (the others are unchanged)
     elif sys.argv[1:] == ["bir"]:
         gen_bir()
@@ -211,3 +242,4 @@ if __name__ == "__main__":
         main()
         gen_ae()
         gen_bir()
+        gen_round2()

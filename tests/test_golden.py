@@ -23,7 +23,7 @@ def load(name):
 
 SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
                if not os.path.basename(p).startswith(("vae", "ae_", "bir_")))
-FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256"]
+FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256", "ns_full_b256_50steps"]
 
 
 def run_port_gan(meta, batch, max_steps=None):
@@ -40,8 +40,8 @@ def run_port_gan(meta, batch, max_steps=None):
 
 def test_fixture_inventory():
     assert len(SMALL) == 16, SMALL          # 10 variants + 6 f-divergences
-    for n in FULL + ["vae_small", "vae_full_b512", "ae_small", "ae_full_b512", "bir_small",
-                     "bir_full_b256"]:
+    for n in FULL + ["vae_small", "vae_full_b512", "vae_full_b512_ragged", "ae_small", "ae_full_b512",
+                     "bir_small", "bir_full_b256"]:
         assert os.path.isfile(os.path.join(GOLDEN, n + ".npz")), n
 
 
@@ -71,7 +71,7 @@ def test_gan_full(name):
         np.testing.assert_allclose(digest(v), z["digest:" + k], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged"])
 def test_vae(name):
     z, meta = load(name)
     cfg = meta["cfg"]

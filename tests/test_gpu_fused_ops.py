@@ -1,0 +1,205 @@
+"""Per-op parity of the variant-specific fused kernels (csrc/gm_fused.hip) against torch -- each
+kernel on its own, through the C-ABI, so that two compensating errors cannot hide behind an
+end-to-end trainer test.  References are torch autograd in fp64 of the reference's own
+expressions:
+  WGAN-GP   w_gp_gan.py:195-218   (gm_interp, gm_gp_u, gm_gp_norm, gm_gp_dw2)
+  DRAGAN    dra_gan.py:198-223    (gm_std_all, gm_dragan_xhat, gm_dragan_rows, gm_dragan_head_bwd)
+  VAE       vae.py:100-106,203,212 (gm_vae_reparam, gm_vae_reparam_bwd, gm_sqerr_sigmoid_bwd)
+Tolerance: 2e-6 relative to the tensor's scale for element-wise outputs (fp32 kernels vs an fp64
+reference), 1e-5 for sums over the batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from generative_models_amd import ops, ops_fused as of  # noqa: E402
+
+DEV = "cuda"
+LAM = 10.0
+
+
+def rel(got, ref):
+    ref = ref.to(torch.float64)
+    return float((got.to(torch.float64) - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def critic(B=48, I=100, H=72, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return dict(B=B, I=I, H=H, W1=(r(H, I) / I ** 0.5), b1=r(H) * 0.1, w2=(r(1, H) / H ** 0.5),
+                b2=r(1) * 0.1 + 0.3, x=torch.rand(B, I, generator=g), gz=torch.rand(B, I, generator=g))
+
+
+@pytest.mark.parametrize("B,I", [(16, 64), (48, 100), (256, 784)])
+def test_interp(B, I):
+    """x_hat = eps*x + (1-eps)*G(z), eps [B,1] broadcast (w_gp_gan.py:197-201)."""
+    torch.manual_seed(1)
+    eps, x, g = torch.rand(B), torch.rand(B, I), torch.rand(B, I)
+    out = torch.empty(B, I, device=DEV)
+    of.interp(eps.to(DEV), ops.NO_SLOT, x.to(DEV), g.to(DEV), out)
+    ref = eps[:, None].double() * x.double() + (1 - eps[:, None].double()) * g.double()
+    assert rel(out.cpu(), ref) < 2e-6
+
+
+def test_wgangp_penalty_chain_vs_autograd():
+    """gp_u, gp_norm (incl. a zero-gradient row), gp_dw2 against autograd through the ReLU critic."""
+    c = critic()
+    B, I, H = c["B"], c["I"], c["H"]
+    f64 = lambda t: t.double().clone().requires_grad_(True)
+    W1, b1, w2, b2 = f64(c["W1"]), f64(c["b1"]), f64(c["w2"]), f64(c["b2"])
+    eps = torch.rand(B, 1, generator=torch.Generator().manual_seed(3)).double()
+    xh = (eps * c["x"].double() + (1 - eps) * c["gz"].double()).requires_grad_(True)
+    # two rows whose critic output is clamped by the output ReLU: their input gradient is exactly 0
+    with torch.no_grad():
+        b2_eff = b2.clone()
+    h = torch.relu(xh @ W1.t() + b1)
+    a2 = h @ w2.t() + b2_eff
+    dead = (a2.detach().view(-1) <= 0)
+    s = torch.relu(a2)
+    grads = torch.autograd.grad(s, xh, grad_outputs=torch.ones_like(s), create_graph=True)[0]
+    n = grads.norm(2, dim=1)
+    P = LAM * torch.mean((n - 1) ** 2)
+    dW1, dw2 = torch.autograd.grad(P, [W1, w2], allow_unused=True)
+
+    d = lambda t: t.detach().float().to(DEV).contiguous()
+    Hh, Sh = d(h), d(s.view(-1))
+    U = torch.empty(B, H, device=DEV)
+    of.gp_u(Sh, Hh, d(w2), U)
+    u_ref = ((a2.detach() > 0).double() * (h.detach() > 0).double() * w2.detach())
+    assert rel(U.cpu(), u_ref) < 2e-6
+    Gr = torch.empty(B, I, device=DEV)
+    ops.linear_bwd_dx(U, d(W1), Gr)                               # g = u W1
+    assert rel(Gr.cpu(), grads.detach()) < 5e-6
+    if dead.any():                                                # norm 0 -> gamma 0 (torch's subgradient)
+        assert float(Gr[dead.to(DEV)].abs().max()) == 0.0
+    Gam, pen = torch.empty(B, I, device=DEV), torch.empty(B, device=DEV)
+    inv_b = float(np.float32(1.0) / np.float32(B))
+    of.gp_norm(Gr, Gam, pen, LAM, inv_b)
+    n_d = n.detach()
+    gamma_ref = torch.where(n_d[:, None] > 0, (2 * LAM / B) * (n_d[:, None] - 1) * grads.detach() /
+                            n_d[:, None].clamp_min(1e-300), torch.zeros_like(grads.detach()))
+    assert rel(Gam.cpu(), gamma_ref) < 5e-6
+    assert rel(pen.cpu(), (n_d - 1) ** 2) < 5e-6
+    if dead.any():
+        assert float(Gam[dead.to(DEV)].abs().max()) == 0.0 and torch.all(pen[dead.to(DEV)] == 1.0)
+    # second backward: dP/dW1 = u^T gamma, dP/dw2 = sum_b m2 m1 . (gamma W1^T)
+    gW1 = torch.zeros(H, I, device=DEV)
+    ops.linear_bwd_dw(U, Gam, gW1, None, accumulate=True)
+    assert rel(gW1.cpu(), dW1) < 1e-5
+    T = torch.empty(B, H, device=DEV)
+    ops.linear_fwd(Gam, d(W1), None, T, "id")
+    gw2 = torch.full((1, H), 0.5, device=DEV)                     # accumulates on top of what is there
+    of.gp_dw2(Sh, Hh, T, gw2)
+    assert rel(gw2.cpu() - 0.5, dw2) < 1e-5
+
+
+def test_gp_norm_zero_row_is_exactly_zero():
+    B, I = 8, 40
+    g = torch.randn(B, I)
+    g[3] = 0.0
+    Gam, pen = torch.empty(B, I, device=DEV), torch.empty(B, device=DEV)
+    of.gp_norm(g.to(DEV), Gam, pen, LAM, 1.0 / B)
+    assert float(Gam[3].abs().max()) == 0.0 and float(pen[3]) == 1.0
+    assert torch.isfinite(Gam).all()
+
+
+@pytest.mark.parametrize("B,Z", [(16, 8), (512, 20), (336, 20)])
+def test_vae_reparam_forward_and_backward(B, Z):
+    """z = mu + eps*exp(lv/2), kl = sum 0.5(mu^2 + e^lv - lv - 1) and d(recon+kl)/d[mu|lv] from dz."""
+    torch.manual_seed(2)
+    ml, eps, dz = torch.randn(B, 2 * Z) * 0.5, torch.randn(B, Z), torch.randn(B, Z)
+    m64 = ml.double().requires_grad_(True)
+    mu, lv = m64[:, :Z], m64[:, Z:]
+    z_ref = mu + eps.double() * torch.exp(lv / 2)
+    kl_ref = torch.sum(0.5 * (mu ** 2 + torch.exp(lv) - lv - 1))
+    (z_ref * dz.double()).sum().add(kl_ref).backward()
+    z, kl = torch.empty(B, Z, device=DEV), torch.zeros(3, device=DEV)
+    of.vae_reparam(ml.to(DEV), eps.to(DEV), z, kl, B, Z, kl_slot=ops.slot(0, 0, 1, 0, 1))
+    assert rel(z.cpu(), z_ref.detach()) < 2e-6
+    kl_ref = float(kl_ref.detach())
+    assert abs(float(kl[1]) - kl_ref) <= 1e-5 * max(1.0, abs(kl_ref))
+    assert float(kl[0]) == 0.0 and float(kl[2]) == 0.0             # only its own slot
+    dml = torch.empty(B, 2 * Z, device=DEV)
+    of.vae_reparam_bwd(ml.to(DEV), eps.to(DEV), dz.to(DEV), dml, B, Z)
+    assert rel(dml.cpu(), m64.grad) < 5e-6
+
+
+@pytest.mark.parametrize("B,I", [(16, 64), (512, 784), (336, 784)])
+def test_sqerr_sigmoid_backward(B, I):
+    """recon = sum (x - sigmoid(a))^2 (vae.py:203): per-row partial sums and d recon / d a."""
+    torch.manual_seed(3)
+    x = (torch.rand(B, I) < 0.13).float()
+    a = (torch.randn(B, I)).double().requires_grad_(True)
+    xr = torch.sigmoid(a)
+    loss = torch.sum((x.double() - xr) ** 2)
+    loss.backward()
+    dA, part = torch.empty(B, I, device=DEV), torch.empty(B, device=DEV)
+    of.sqerr_sigmoid_bwd(x.to(DEV), xr.detach().float().to(DEV), dA, part, B)
+    assert rel(dA.cpu(), a.grad) < 5e-6
+    assert rel(part.cpu(), ((x.double() - xr.detach()) ** 2).sum(1)) < 5e-6
+    out = torch.zeros(2, device=DEV)
+    of.sum_finalize(part, B, out, out_slot=ops.slot(0, 0, 1, 0, 1))
+    assert abs(float(out[1]) - float(loss)) <= 1e-5 * float(loss) and float(out[0]) == 0.0
+
+
+@pytest.mark.parametrize("B,I", [(16, 64), (256, 784)])
+def test_std_all_is_the_unbiased_std_of_the_whole_batch(B, I):
+    """images.data.std() (dra_gan.py:204): over all B*I elements, Bessel-corrected."""
+    torch.manual_seed(4)
+    x = (torch.rand(B, I) < 0.13).float()
+    out = torch.empty(1, device=DEV)
+    of.std_all(x.to(DEV), B, out)
+    assert abs(float(out) - float(x.double().std())) < 1e-6
+
+
+def test_dragan_xhat():
+    """x_hat = delta*x + (1-delta)*(x + C*std*U)  (dra_gan.py:200-205)."""
+    B, I = 48, 100
+    torch.manual_seed(5)
+    x, delta, U = (torch.rand(B, I) < 0.13).float(), torch.rand(B), torch.rand(B, I)
+    std = x.std()
+    out = torch.empty(B, I, device=DEV)
+    of.dragan_xhat(x.to(DEV), delta.to(DEV), ops.NO_SLOT, U.to(DEV), ops.NO_SLOT,
+                   std.reshape(1).to(DEV), out, B)
+    ref = delta[:, None].double() * x.double() + (1 - delta[:, None].double()) * (x.double() + std.double() * U.double())
+    assert rel(out.cpu(), ref) < 2e-6
+
+
+def test_dragan_penalty_chain_vs_autograd():
+    """gm_gp_u (sigmoid critic: m2 = 1) + dX GEMM + gm_dragan_rows + gm_dragan_head_bwd + the three
+    accumulating GEMMs of engine._issue_dra_backward against autograd's double backward through the
+    SIGMOID critic (the sigma'' path)."""
+    c = critic(seed=7)
+    B, I, H = c["B"], c["I"], c["H"]
+    f64 = lambda t: t.double().clone().requires_grad_(True)
+    W1, b1, w2, b2 = f64(c["W1"]), f64(c["b1"]), f64(c["w2"]), f64(c["b2"])
+    xh = (c["x"].double() + 0.3 * c["gz"].double()).requires_grad_(True)
+    h = torch.relu(xh @ W1.t() + b1)
+    s = torch.sigmoid(h @ w2.t() + b2)
+    grads = torch.autograd.grad(s, xh, grad_outputs=torch.ones_like(s), create_graph=True)[0]
+    n = grads.norm(2, dim=1)
+    P = LAM * torch.mean((n - 1) ** 2)
+    dW1, db1, dw2, db2 = torch.autograd.grad(P, [W1, b1, w2, b2])
+
+    d = lambda t: t.detach().float().to(DEV).contiguous()
+    Xh, Hh, Sh = d(xh), d(h), d(s.view(-1))
+    U, V = torch.empty(B, H, device=DEV), torch.empty(B, I, device=DEV)
+    of.gp_u(Sh, Hh, d(w2), U)                                     # m1 . w2
+    ops.linear_bwd_dx(U, d(W1), V)                                # v = (m1 . w2) W1
+    dv, da2, pen = torch.empty(B, I, device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    inv_b = float(np.float32(1.0) / np.float32(B))
+    of.dragan_rows(Sh, V, dv, da2, pen, LAM, inv_b, B)
+    assert rel(pen.cpu(), (n.detach() - 1) ** 2) < 1e-5
+    gW1, gb1 = torch.zeros(H, I, device=DEV), torch.zeros(H, device=DEV)
+    gw2, gb2 = torch.zeros(1, H, device=DEV), torch.zeros(1, device=DEV)
+    ops.linear_bwd_dw(U, dv, gW1, None, accumulate=True)          # (m1 . w2)^T dv
+    T = torch.empty(B, H, device=DEV)
+    ops.linear_fwd(dv, d(W1), None, T, "id")                      # du = dv W1^T
+    dA1 = torch.empty(B, H, device=DEV)
+    of.dragan_head_bwd(Hh, T, da2, d(w2), gw2, gb2, dA1, B)
+    ops.linear_bwd_dw(dA1, Xh, gW1, gb1, accumulate=True)         # da1^T x_hat, sum da1
+    assert rel(gW1.cpu(), dW1) < 2e-5
+    assert rel(gb1.cpu(), db1) < 2e-5
+    assert rel(gw2.cpu(), dw2) < 2e-5
+    assert rel(gb2.cpu(), db2) < 2e-5

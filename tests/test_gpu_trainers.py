@@ -126,6 +126,50 @@ def test_engine_vs_oracle(variant, kw, cfg):
         lclose(p_tr.MIlosses, o_tr.MIlosses, "info MIlosses")
 
 
+TF_CASES = [("ns", {}), ("mm", dict(G_init=0)), ("w", {}), ("ls", {}), ("ra", {}), ("fisher", {}),
+            ("wgp", {}), ("dra", {}), ("be", {}), ("info", {})] + [("f", dict(method=m)) for m in port.F_METHODS]
+
+
+@pytest.mark.parametrize("variant,kw", TF_CASES, ids=["%s%d" % (v, i) for i, (v, _) in enumerate(TF_CASES)])
+def test_teacher_forced_single_step_gradients(variant, kw):
+    """ONE D+G iteration from identical parameters, images and noise: the gradient buffers the fused
+    engine leaves behind (dL_D/dD-params of the critic step, dL_G/dG-params of the generator step on
+    the updated critic; InfoGAN: the MI step's G and Q gradients) against the oracle's autograd
+    gradients, tensor by tensor.  Catches a compensating error pair that a loss curve would hide."""
+    cfg = SMALL
+    grads = {}
+
+    def tap(kind, tr, info):
+        m = tr.model
+        if kind == "D":
+            grads["D"] = [p.grad.detach().clone() for p in m.D.parameters()]
+        elif kind == "G" and variant != "info":
+            grads["G"] = [p.grad.detach().clone() for p in m.G.parameters()]
+        elif kind == "Q":
+            grads["G"] = [p.grad.detach().clone() for p in m.G.parameters()]
+            grads["Q"] = [p.grad.detach().clone() for p in m.Q.parameters()]
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build(variant, cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    okw = dict(kw)
+    o = port.GANPort(variant, o_model, loaders[0], method=okw.pop("method", "jensen_shannon"), tap=tap)
+    o.train(num_epochs=1, D_steps=1, max_steps=1, **okw)
+    p_tr, p_model, _ = run_product(variant, cfg, cfg["batch"], dict(num_epochs=1, D_steps=1, **kw), capped=1)
+    eng = p_tr._engine
+    assert eng is not None and len(p_tr.Glosses) == 1
+    torch.cuda.synchronize()
+    for net, fp in (("D", eng.fD), ("G", eng.fG)) + ((("Q", eng.fQ),) if variant == "info" else ()):
+        assert len(fp.params) == len(grads[net])
+        for p_, off, ref in zip(fp.params, fp.offsets, grads[net]):
+            got = fp.grad[off:off + p_.numel()].view(p_.shape).cpu()
+            # relative to the tensor's scale, plus 2e-7 absolute: the critic's output-bias gradient
+            # is a sum of two nearly cancelling halves (e.g. WGAN: -mean(s'x) + mean(s'g))
+            aerr = float((got - ref).abs().max())
+            tol = (2e-3 if variant == "be" else 2e-5) * float(ref.abs().max()) + 2e-7
+            # BEGAN: sign() gradients flip where |D(x)-x| crosses 0 within fp32 rounding
+            assert aerr <= tol, (variant, net, tuple(p_.shape), aerr, tol)
+
+
 def test_eager_equals_graph():
     """The hipGraph replay and the eager launch sequence are the same kernels: bitwise equal."""
     a = run_product("ns", SMALL, 16, dict(num_epochs=2), use_graph=True)
@@ -169,10 +213,30 @@ def test_engine_vs_reference_golden(name):
     cfg, variant = meta["cfg"], meta["variant"]
     full = "steps" in meta
     batch = meta["batch"] if full else cfg["batch"]
-    p_tr, p_model, _ = run_product(variant, cfg, batch, meta["train_kw"],
-                                   capped=meta["steps"] if full else None)
-    lclose(p_tr.Glosses, z["Glosses"], name + " Glosses")
-    lclose(p_tr.Dlosses, z["Dlosses"], name + " Dlosses")
+    p_tr, p_model, p_rng = run_product(variant, cfg, batch, meta["train_kw"],
+                                       capped=meta["steps"] if full else None)
+    # the global CPU generator ends where the reference left it (digest recorded by gen_golden)
+    import hashlib
+    assert hashlib.sha256(p_rng.numpy().tobytes()).hexdigest() == meta["rng"], "RNG stream position"
+    if name.endswith("50steps"):
+        # 50-step FREE-RUNNING NSGAN B=256 curve.  Two fp32 summation orders of the
+        # same math drift apart chaotically on this horizon (survey probe: 1.6e-5 between 1 and 8
+        # CPU threads of the reference itself), so the bound here is stated, not the 1e-5 of the
+        # short horizons: first 24 steps <= 1e-5, all 50 steps <= 5e-5; the measured value is
+        # written to gpurun_out/parity_50step.json and quoted in DESIGN.md.
+        g, d = np.asarray(p_tr.Glosses), np.asarray(p_tr.Dlosses)
+        eg = np.abs(g - z["Glosses"]) / np.maximum(1, np.abs(z["Glosses"]))
+        ed = np.abs(d - z["Dlosses"]) / np.maximum(1, np.abs(z["Dlosses"]))
+        out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        if os.path.isdir(out):
+            json.dump({"max_rel_err_G_50": float(eg.max()), "max_rel_err_D_50": float(ed.max()),
+                       "max_rel_err_G_24": float(eg[:24].max()), "max_rel_err_D_24": float(ed[:24].max())},
+                      open(os.path.join(out, "parity_50step.json"), "w"))
+        assert max(eg[:24].max(), ed[:24].max()) <= TOL, (eg[:24].max(), ed[:24].max())
+        assert max(eg.max(), ed.max()) <= 5e-5, (eg.max(), ed.max())
+    else:
+        lclose(p_tr.Glosses, z["Glosses"], name + " Glosses")
+        lclose(p_tr.Dlosses, z["Dlosses"], name + " Dlosses")
     sd = p_model.state_dict()
     if full:
         from oracle.gen_golden import digest
@@ -269,14 +333,17 @@ def test_vae_engine_vs_oracle(cfg, n_train):
         assert (a.cpu() - b).abs().max().item() <= 5e-5, k
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged"])
 def test_vae_engine_vs_reference_golden(name):
+    """vae_full_b512_ragged: 3 full batches of 512 + the ragged 336 (= 50 000 mod 512), 2 epochs."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     cfg = meta["cfg"]
     batch = meta.get("batch", cfg.get("batch"))
-    p, p_model, _ = run_vae_product(cfg, batch, meta.get("n_train", cfg["n_train"]),
-                                    meta["train_kw"]["num_epochs"])
+    p, p_model, p_rng = run_vae_product(cfg, batch, meta.get("n_train", cfg["n_train"]),
+                                        meta["train_kw"]["num_epochs"])
+    import hashlib
+    assert hashlib.sha256(p_rng.numpy().tobytes()).hexdigest() == meta["rng"], "RNG stream position"
     ref = z["recon_loss"]
     got = np.array(p.recon_loss)
     assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
@@ -372,8 +439,9 @@ def test_ae_general_path_when_hook_overridden():
 # must equal one uninterrupted train(2) bit for bit -- weights, Adam moments and schedule position,
 # the RNG-protocol cursor and the loss history all travel in the checkpoint.
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,kw", [("ns", {}), ("w", dict(D_steps=2)), ("wgp", dict(D_steps=1))],
-                         ids=["ns", "w", "wgp"])
+@pytest.mark.parametrize("variant,kw", [("ns", {}), ("w", dict(D_steps=2)), ("wgp", dict(D_steps=1)),
+                                        ("fisher", {}), ("info", {}), ("be", {}), ("dra", dict(D_steps=1))],
+                         ids=["ns", "w", "wgp", "fisher", "info", "be", "dra"])
 def test_gan_checkpoint_resume_is_bitwise_uninterrupted(variant, kw, tmp_path):
     import contextlib, io
     full, full_model, full_rng = run_product(variant, SMALL, 16, dict(num_epochs=2, **kw))
@@ -394,12 +462,38 @@ def test_gan_checkpoint_resume_is_bitwise_uninterrupted(variant, kw, tmp_path):
     torch.cuda.synchronize()
     assert tr2.num_epochs == 2
     assert tr2.Glosses == full.Glosses and tr2.Dlosses == full.Dlosses
+    if variant == "info":                                  # third optimizer's moments travelled
+        assert tr2.MIlosses == full.MIlosses
+    if variant == "be":                                    # K controller + plateau schedulers travelled
+        assert tr2.K == full.K
     assert torch.equal(torch.get_rng_state(), full_rng)
     for (k, a), (_, b) in zip(model2.state_dict().items(), full_model.state_dict().items()):
         assert torch.equal(a, b), k
     # the reference's own weights-only checkpoint still loads
     tr2.save_model(str(tmp_path / "w.pt"))
     assert list(torch.load(str(tmp_path / "w.pt")).keys()) == list(full_model.state_dict().keys())
+
+
+def test_checkpoint_refuses_a_run_with_other_settings(tmp_path):
+    """nothing checked D_steps / lr / batch size against the saved run."""
+    import contextlib, io
+    from generative_models_amd._lib import GMError
+    tr1, _ = build_product("w", SMALL, 16)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr1.train(num_epochs=1, D_steps=2)
+    path = str(tmp_path / "ck.pt")
+    tr1.save_checkpoint(path)
+    ck = torch.load(path, weights_only=True)               # plain tensors / numbers only
+    assert all(isinstance(x, float) for x in ck["history"]["Glosses"])
+    tr2, _ = build_product("w", SMALL, 16)
+    tr2.load_checkpoint(path)
+    with pytest.raises(GMError, match="different settings"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr2.train(num_epochs=1, D_steps=3)
+    tr3, _ = build_product("w", SMALL, 16)
+    tr3.load_checkpoint(path, strict=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr3.train(num_epochs=1, D_steps=3)                 # explicit override: allowed
 
 
 @pytest.mark.parametrize("kind", ["vae", "ae"])
