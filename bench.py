@@ -532,7 +532,10 @@ def main():
                                    "784-400-20 MLPs, N=50000 synthetic Bernoulli images, parity-mode "
                                    "RNG protocol, Adam 2e-4, D_steps=1",
                        "global_batch": B_global,
-                       "launch": ("hipGraph/iteration" if (world == 1 and not force_dp) else "hipGraph per segment + 2 RCCL all-reduces/iteration") if eng.use_graph else "eager",
+                       "launch": ("hipGraph/iteration" if (world == 1 and not force_dp) else
+                                  ("hipGraph/iteration incl. 2 in-graph peer all-reduces (+Adam) over hipIpc/xGMI mappings"
+                                   if eng._peer() else "hipGraph per segment + 2 RCCL all-reduces/iteration"))
+                       if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgm_hip.so")
-SOURCES = ("gm_gemm.hip", "gm_ops.hip", "gm_fused.hip")
+SOURCES = ("gm_gemm.hip", "gm_ops.hip", "gm_fused.hip", "gm_comm.hip")
 HOST_SOURCES = ("gm_hostrng.cpp",)       # host-only C++ (RNG protocol replay): g++, linked in
 
 

@@ -141,6 +141,14 @@ _SIGNATURES = {
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_mt19937_skip": (c_int, [_P, c_int64, ctypes.c_uint64]),
+    "gm_comm_create": (c_int, [c_int, c_int, c_int64, POINTER(c_void_p), _P]),
+    "gm_comm_connect": (c_int, [_P, _P]),
+    "gm_comm_destroy": (c_int, [_P]),
+    "gm_comm_error": (c_int, [_P, POINTER(c_int)]),
+    "gm_allreduce_f32": (c_int, [_P, _P, _P, c_int64]),
+    "gm_allreduce_adam_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float, _P]),
+    "gm_allreduce_scalars": (c_int, [_P, _P, _P, c_int]),
     "gm_stage_in": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int]),
     "gm_host_device_ptr": (c_int, [_P, POINTER(c_void_p)]),
     "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),

@@ -1,0 +1,323 @@
+// gm_comm.hip -- gradient exchange of the data-parallel step as KERNELS inside the iteration's
+// hipGraph (the reference has no distributed code at all).
+//
+// Round 1 exchanged the two gradient buckets of a D+G step (D 1.26 MB, G 1.29 MB) with two
+// host-launched RCCL all-reduces between three segment graphs: 114 us per iteration on ONE rank
+// against 71 us for the single-GPU graph -- the step is too short for host-launched collectives.
+// Here every rank maps the other ranks' exchange buffers (hipIpc handles over the xGMI peer
+// mappings; fine-grained device memory) and the all-reduce is three small kernels in the graph:
+//   stage : my gradient bucket -> my exchange buffer `in[parity]`
+//   reduce: signal "in ready" to every peer (remote 8-byte stores), wait for theirs; every rank sums
+//           ITS slice of the bucket over ranks 0..W-1 in rank order (identical bits everywhere)
+//           into its `out[parity]`                                            (reduce-scatter)
+//   gather: signal "out ready", wait; read every slice from its owner, write the reduced gradient
+//           back and -- optionally -- apply Adam to the parameters right there     (all-gather)
+// xGMI is point-to-point: each rank moves 2 * (W-1)/W of the bucket over W-1 links in parallel
+// (0.32 MB per link at W = 8) instead of W-1 ring hops.  Flags are monotonically increasing sequence
+// numbers kept in device memory (the graph replays without arguments); exchange buffers are double
+// buffered by sequence parity, which makes one flag wait per phase sufficient (see the comment at
+// `reduce_kernel`).  Every wait is bounded: on expiry the kernel raises the communicator's error
+// flag and carries on, so a lost peer shows up as a Python exception at the next read-back, never as
+// a hung GPU.
+#include "gm_common.h"
+
+#include <cstring>
+
+namespace {
+
+constexpr int MAXW = 8;
+constexpr int64_t FLAG_BYTES = 4096;             // [phase 0..3][source rank] u64, padded
+constexpr int64_t SCAL_FLOATS = 64;              // scalar exchange: 2 parities x up to 16 values (+pad)
+constexpr unsigned long long SPIN_LIMIT = 1ull << 24;
+
+struct Region {            // layout of one rank's exchange region (byte offsets)
+    int64_t flags, scal, in, out, total;
+};
+Region layout(int64_t n_floats) {
+    Region r;
+    const int64_t nb = ((n_floats * 4 + 255) / 256) * 256;
+    r.flags = 0;
+    r.scal = FLAG_BYTES;
+    r.in = r.scal + 2 * SCAL_FLOATS * 4 * MAXW;   // [parity][rank][16 floats]
+    r.in = ((r.in + 255) / 256) * 256;
+    r.out = r.in + 2 * nb;
+    r.total = r.out + 2 * nb;
+    return r;
+}
+
+struct Comm {
+    int rank, world;
+    int64_t n_floats;
+    Region lay;
+    char* base[MAXW];          // mapped exchange regions (base[rank] = my own allocation)
+    bool opened[MAXW];
+    unsigned long long* seq;   // device: number of completed all-reduces; [1]: copy for the gather phase
+    unsigned long long* sseq;  // device: number of completed scalar exchanges
+    int* err;                  // device: set when a bounded wait expired
+};
+
+struct CommP {
+    int rank, world;
+    char* base[MAXW];
+    Region lay;
+    unsigned long long* seq;
+    unsigned long long* sseq;
+    int* err;
+};
+
+__device__ __forceinline__ unsigned long long* flag_ptr(const CommP& c, int owner, int phase, int src) {
+    return reinterpret_cast<unsigned long long*>(c.base[owner] + c.lay.flags) + (phase * MAXW + src) * 8;
+}
+
+// signal phase `phase` of sequence s to every peer (a remote 8-byte store into THEIR flag array),
+// then wait until every peer's signal for the same phase has arrived in MINE.
+__device__ void signal_and_wait(const CommP& c, int phase, unsigned long long s) {
+    if (threadIdx.x < (unsigned)c.world && (int)threadIdx.x != c.rank) {
+        const int peer = threadIdx.x;
+        if (blockIdx.x == 0) {
+            __threadfence_system();               // my earlier stores (previous kernel) are out
+            __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_ACQUIRE,
+                                 __HIP_MEMORY_SCOPE_SYSTEM) < s) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicExch(c.err, 1); break; }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();                       // acquire side for the whole workgroup
+}
+
+__device__ __forceinline__ void slice_of(int64_t n4, int world, int r, int64_t* lo, int64_t* hi) {
+    const int64_t per = (n4 + world - 1) / world;
+    *lo = per * r < n4 ? per * r : n4;
+    *hi = per * (r + 1) < n4 ? per * (r + 1) : n4;
+}
+
+// stage: grad -> in[parity].  n is padded to a multiple of 4 by the caller's buffers.
+__global__ __launch_bounds__(256) void stage_kernel(CommP c, const float* __restrict__ g, int64_t n) {
+    const unsigned long long s = c.seq[0] + 1;
+    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4;          // floats4 per parity buffer
+    float4* dst = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.in) + (s & 1) * nb4;
+    const float4* src = reinterpret_cast<const float4*>(g);
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+// reduce-scatter.  Why one wait per phase is enough with double-buffered exchange buffers: a peer
+// overwrites its in[parity] again only in the stage kernel of sequence s+2, which it reaches after
+// its gather phase of s+1, which waited for MY reduce signal of s+1, which I send after this kernel.
+__global__ __launch_bounds__(256) void reduce_kernel(CommP c, int64_t n) {
+    const unsigned long long s = c.seq[0] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.seq[1] = s;        // the gather phase reads seq[1]
+    signal_and_wait(c, 0, s);
+    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4, n4 = n >> 2;
+    int64_t lo, hi;
+    slice_of(n4, c.world, c.rank, &lo, &hi);
+    float4* out = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.out) + (s & 1) * nb4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < c.world; ++r) {                       // rank order: same bits on every rank
+            const float4 v = (reinterpret_cast<const float4*>(c.base[r] + c.lay.in) + (s & 1) * nb4)[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        out[i] = a;
+    }
+}
+
+struct AdamP {
+    float* p; float* m; float* v;
+    const float* sched; gm_slot sched_slot;
+    float omb1, b2, omb2, eps, wd, clamp;
+    const float* lr_scale;
+    int enabled;
+};
+
+// all-gather (+ Adam): every element comes from its slice owner's out[parity]
+__global__ __launch_bounds__(256) void gather_kernel(CommP c, float* __restrict__ g, int64_t n, AdamP ad) {
+    const unsigned long long s = c.seq[1];
+    signal_and_wait(c, 1, s);
+    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4, n4 = n >> 2;
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (ad.enabled) {
+        const int64_t si = gm_slot_index(ad.sched_slot);
+        step_size = ad.sched[2 * si] * (ad.lr_scale ? ad.lr_scale[0] : 1.0f);
+        bc2_sqrt = ad.sched[2 * si + 1];
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int r = 0; r < c.world; ++r) {
+        int64_t lo, hi;
+        slice_of(n4, c.world, r, &lo, &hi);
+        const float4* src = reinterpret_cast<const float4*>(c.base[r] + c.lay.out) + (s & 1) * nb4;
+        for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
+            const float4 G = src[i];
+            reinterpret_cast<float4*>(g)[i] = G;
+            if (ad.enabled) {
+                float4 P = reinterpret_cast<float4*>(ad.p)[i];
+                float4 M = reinterpret_cast<float4*>(ad.m)[i];
+                float4 V = reinterpret_cast<float4*>(ad.v)[i];
+                adam_update(P.x, G.x, M.x, V.x, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.y, G.y, M.y, V.y, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.z, G.z, M.z, V.z, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.w, G.w, M.w, V.w, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                reinterpret_cast<float4*>(ad.p)[i] = P;
+                reinterpret_cast<float4*>(ad.m)[i] = M;
+                reinterpret_cast<float4*>(ad.v)[i] = V;
+            }
+        }
+    }
+    // last: publish the completed sequence number.  Nobody in THIS kernel reads seq[0]; the next
+    // stage kernel does, after the kernel boundary.
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.seq[0] = s;
+}
+
+// Scalar exchange: vals[0..k) <- sum over ranks (rank order) of every rank's vals[0..k), k <= 16.
+// One workgroup: write mine into every peer's slot array (remote stores), signal, wait, sum locally.
+__global__ __launch_bounds__(64) void scalars_kernel(CommP c, float* __restrict__ vals, int k) {
+    const unsigned long long s = c.sseq[0] + 1;
+    const int par = (int)(s & 1);
+    if ((int)threadIdx.x < k) {
+        const float v = vals[threadIdx.x];
+        for (int r = 0; r < c.world; ++r) {
+            float* slot = reinterpret_cast<float*>(c.base[r] + c.lay.scal) + ((par * MAXW + c.rank) * 16);
+            __hip_atomic_store(slot + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    signal_and_wait(c, 2, s);
+    if ((int)threadIdx.x < k) {
+        float a = 0.f;
+        for (int r = 0; r < c.world; ++r) {
+            const float* slot = reinterpret_cast<const float*>(c.base[c.rank] + c.lay.scal) + ((par * MAXW + r) * 16);
+            a += __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        vals[threadIdx.x] = a;
+    }
+    if (threadIdx.x == 0) c.sseq[0] = s;
+}
+
+CommP params_of(const Comm* cm) {
+    CommP p{};
+    p.rank = cm->rank; p.world = cm->world; p.lay = cm->lay; p.seq = cm->seq; p.sseq = cm->sseq; p.err = cm->err;
+    for (int i = 0; i < MAXW; ++i) p.base[i] = cm->base[i];
+    return p;
+}
+
+#define GM_HIPC(call)                                             \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) {                                  \
+            gm_set_error(hipGetErrorString(e__));                 \
+            return -(int)e__;                                     \
+        }                                                         \
+    } while (0)
+
+}  // namespace
+
+extern "C" int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void* handle_out64) {
+    GM_CHECK_ARG(comm_out && handle_out64 && world >= 1 && world <= MAXW && rank >= 0 && rank < world && n_floats > 0);
+    Comm* cm = new Comm();
+    cm->rank = rank; cm->world = world; cm->n_floats = n_floats; cm->lay = layout(n_floats);
+    for (int i = 0; i < MAXW; ++i) { cm->base[i] = nullptr; cm->opened[i] = false; }
+    void* p = nullptr;
+    // fine-grained device memory: stores by a peer over xGMI are visible to this GPU's loads without
+    // a kernel boundary; plain hipMalloc as a fallback (single-GPU multi-process tests)
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)cm->lay.total, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); GM_HIPC(hipMalloc(&p, (size_t)cm->lay.total)); }
+    GM_HIPC(hipMemset(p, 0, (size_t)cm->lay.total));
+    cm->base[rank] = static_cast<char*>(p);
+    void* ctr = nullptr;
+    GM_HIPC(hipMalloc(&ctr, 64));
+    GM_HIPC(hipMemset(ctr, 0, 64));
+    cm->seq = static_cast<unsigned long long*>(ctr);
+    cm->sseq = cm->seq + 2;
+    cm->err = reinterpret_cast<int*>(cm->seq + 4);
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    if (world > 1) GM_HIPC(hipIpcGetMemHandle(&h, p));
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle travels as 64 bytes");
+    std::memset(handle_out64, 0, 64);
+    std::memcpy(handle_out64, &h, sizeof(h));
+    GM_HIPC(hipDeviceSynchronize());
+    *comm_out = cm;
+    return 0;
+}
+
+extern "C" int gm_comm_connect(void* comm, const void* all_handles) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && (all_handles || cm->world == 1));
+    for (int r = 0; r < cm->world; ++r) {
+        if (r == cm->rank) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char*>(all_handles) + 64 * r, sizeof(h));
+        void* p = nullptr;
+        GM_HIPC(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        cm->base[r] = static_cast<char*>(p);
+        cm->opened[r] = true;
+    }
+    return 0;
+}
+
+extern "C" int gm_comm_destroy(void* comm) {
+    Comm* cm = static_cast<Comm*>(comm);
+    if (!cm) return 0;
+    for (int r = 0; r < cm->world; ++r)
+        if (cm->opened[r]) (void)hipIpcCloseMemHandle(cm->base[r]);
+    if (cm->base[cm->rank]) (void)hipFree(cm->base[cm->rank]);
+    if (cm->seq) (void)hipFree(cm->seq);
+    delete cm;
+    return 0;
+}
+
+extern "C" int gm_comm_error(void* comm, int* flag_out) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && flag_out);
+    GM_HIPC(hipMemcpy(flag_out, cm->err, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const AdamP& ad) {
+    GM_CHECK_ARG(cm && buf && n > 0 && n <= cm->n_floats && n % 4 == 0);
+    GM_CHECK_ARG((reinterpret_cast<uintptr_t>(buf) & 15) == 0);
+    const CommP p = params_of(cm);
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    int rblocks = (int)((n / 4 / cm->world + 255) / 256);     // a slice per rank: fewer pollers
+    if (rblocks > 64) rblocks = 64;
+    if (rblocks < 1) rblocks = 1;
+    hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
+    hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, s, p, buf, n, ad);
+    GM_LAUNCH_RET();
+}
+
+extern "C" int gm_allreduce_f32(void* comm, void* stream, float* buf, int64_t n) {
+    AdamP ad{};
+    return allreduce_impl(static_cast<Comm*>(comm), (hipStream_t)stream, buf, n, ad);
+}
+
+extern "C" int gm_allreduce_adam_f32(void* comm, void* stream, float* grad, int64_t n, float* p,
+                                     float* m, float* v, const float* sched, gm_slot sched_slot,
+                                     double beta1, double beta2, double eps, double weight_decay,
+                                     float clamp, const float* lr_scale) {
+    GM_CHECK_ARG(p && m && v && sched);
+    GM_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    AdamP ad{};
+    ad.p = p; ad.m = m; ad.v = v; ad.sched = sched; ad.sched_slot = sched_slot;
+    ad.omb1 = (float)(1.0 - beta1); ad.b2 = (float)beta2; ad.omb2 = (float)(1.0 - beta2);
+    ad.eps = (float)eps; ad.wd = (float)weight_decay; ad.clamp = clamp; ad.lr_scale = lr_scale;
+    ad.enabled = 1;
+    return allreduce_impl(static_cast<Comm*>(comm), (hipStream_t)stream, grad, n, ad);
+}
+
+extern "C" int gm_allreduce_scalars(void* comm, void* stream, float* vals, int k) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && vals && k > 0 && k <= 16);
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params_of(cm), vals, k);
+    GM_LAUNCH_RET();
+}

@@ -296,6 +296,11 @@ class GANEngine:
         self.use_graph = use_graph
         self.force_segments = False    # tests: exercise the DP launch structure on one rank
         import os
+        # data-parallel gradient exchange: "peer" = kernels inside the iteration graph over hipIpc /
+        # xGMI peer mappings (csrc/gm_comm.hip; falls back to "rccl" if its self-check fails);
+        # "rccl" = host-launched torch.distributed all-reduces between per-segment graphs
+        self.comm_mode = os.environ.get("GM_DP_COMM", "peer")
+        self._comms = None
         self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
@@ -357,6 +362,14 @@ class GANEngine:
     def _single(self):
         return self.world == 1 and not self.force_segments
 
+    def _peer(self):
+        """Data parallel with the in-graph peer exchange (one hipGraph per iteration, Adam applied by
+        the all-gather kernel)."""
+        return not self._single() and self.comm_mode == "peer"
+
+    def _one_graph(self):
+        return self._single() or self._peer()
+
     def _tick_in_head(self):
         """The per-graph tick rides in the generator step's head_bwd kernel."""
         return self.use_graph and self.fold_tick and self.fuse_head and not self.dag
@@ -398,10 +411,10 @@ class GANEngine:
         pending = []
         for j in range(d):
             pending.append(lambda st, it, j=j: self._issue_D_pre(st, it, j))
-            seg(pending, self.fD.grad)
+            seg(pending, ("D", j))
             pending = [lambda st, it, j=j: self._issue_D_post(st, it, j)]
         pending.append(lambda st, it: self._issue_G_pre(st, it))
-        seg(pending, self.fG.grad)
+        seg(pending, ("G", 0))
         tail = [lambda st, it: self._issue_G_post(st, it)]
         if self.variant == "info":
             tail.append(lambda st, it: self._issue_Q(st, it))
@@ -413,25 +426,44 @@ class GANEngine:
         return segs
 
     def _issue_iteration(self, st, it):
-        """Single-process form: all segments back to back (one hipGraph when use_graph)."""
+        """All segments back to back (one hipGraph when use_graph): single GPU, or data parallel with
+        the in-graph peer exchange."""
         for run, ar in self._segments():
             run(st, it)
             if ar is not None:
-                self._allreduce(ar)
+                self._allreduce(ar, st, it)
 
-    def _allreduce(self, flat):
-        if self.world > 1 or self.force_segments:
-            from . import dp
-            dp.allreduce_sum_(flat, self.pg)
+    def _allreduce(self, ar, st=None, it=0):
+        """Gradient exchange after a backward segment.  ar = ("D", j) | ("G", 0)."""
+        if self._single():
+            return
+        net, j = ar
+        fp = self.fD if net == "D" else self.fG
+        if self._peer():
+            # all-reduce + optim.Adam.step in the all-gather kernel (ns_gan.py:139,156)
+            if net == "D":
+                slot, clamp = self._slot(it, self.D_steps, j, 0, 1), self.clip
+                sched, scale = self.schedD, self._lr_scale("D")
+            else:
+                slot, clamp = self._G_sched_slot(it), 0.0
+                sched, scale = self.schedG, self._lr_scale("G")
+            self._comms[net].allreduce_adam(fp.grad, fp.flat, fp.m, fp.v, sched, slot, clamp=clamp,
+                                            lr_scale=scale, stream=st)
+            return
+        from . import dp
+        dp.allreduce_sum_(fp.grad, self.pg)
+
+    def _lr_scale(self, net):
+        return None                                 # BEGAN: the plateau schedulers' device-side scale
 
     def _issue_D(self, st, it, j):
         self._issue_D_pre(st, it, j)
-        self._allreduce(self.fD.grad)
+        self._allreduce(("D", j), st, it)
         self._issue_D_post(st, it, j)
 
     def _issue_G(self, st, it):
         self._issue_G_pre(st, it)
-        self._allreduce(self.fG.grad)
+        self._allreduce(("G", 0), st, it)
         self._issue_G_post(st, it)
 
     # ---- pieces of one critic step (composed sequentially, or as parallel graph branches) -----
@@ -567,8 +599,8 @@ class GANEngine:
             ops.adam(self.fQ.flat, self.fQ.grad, self.fQ.m, self.fQ.v, self.schedMI, s_slot, stream=st)
 
     def _issue_D_post(self, st, it, j):
-        if self._adam_in_epilogue("D"):
-            return                                  # already applied by head_bwd / dW1 epilogues
+        if self._adam_in_epilogue("D") or self._peer():
+            return                  # already applied by the gradient epilogues / the all-gather kernel
         ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
                  self._slot(it, self.D_steps, j, 0, 1), clamp=self.clip, stream=st)
 
@@ -670,7 +702,7 @@ class GANEngine:
         self._G_dw1(st, it)
 
     def _issue_G_post(self, st, it):
-        if self._adam_in_epilogue("G"):
+        if self._adam_in_epilogue("G") or self._peer():
             return
         ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
                  self._G_sched_slot(it), stream=st)
@@ -1008,6 +1040,8 @@ class GANEngine:
             self.aux.copy_(resume["fisher_aux"])     # lambda (fisher_gan.py:117-118,155-156) + moments
         self.ctr.zero_()
         self._drain()
+        if self._peer() and self._comms is None:
+            self._setup_peer_comm()
         from collections import deque
         self.n_planned = n_iters
         self._pending, self._cursor, self._uploaded, self._next_it = deque(), 0, 0, 0
@@ -1027,6 +1061,29 @@ class GANEngine:
         # schedule / loss buffers are re-created per train(): pointers change => recapture
         self._graph_key = None
         self._key = key
+
+    def _setup_peer_comm(self):
+        """One communicator per optimizer bucket (own flags and sequence numbers).  Every rank runs
+        the self-check; unless ALL ranks pass, every rank falls back to RCCL."""
+        from . import dp
+        try:
+            comms = {"D": dp.PeerComm(self.fD.n, self.world, self.rank, self.pg),
+                     "G": dp.PeerComm(self.fG.n, self.world, self.rank, self.pg)}
+            ok = all(c.selfcheck(self.device) for c in comms.values())
+        except Exception:                            # noqa: BLE001  (no IPC / no peer access here)
+            comms, ok = None, False
+        if self.world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if dist.get_backend(self.pg) == "nccl":
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            ok = bool(flag.item())
+        if ok:
+            self._comms = comms
+        else:
+            self.comm_mode = "rccl"
+            self._graph_key = None
 
     def optim_state(self):
         """Everything the optimizers and controllers carry across steps, after the train() call that
@@ -1048,7 +1105,7 @@ class GANEngine:
         if not self.use_graph or self._graph_key == self._key:
             return
         torch.cuda.synchronize()
-        if self.world == 1 and not self.force_segments:
+        if self._one_graph():
             if self.dag:
                 import ctypes
                 from . import _lib
@@ -1127,7 +1184,7 @@ class GANEngine:
 
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
-        if self.use_graph and self.world == 1 and not self.force_segments:
+        if self.use_graph and self._one_graph():
             for size, g in self.graphs_by_size:           # largest first: 8, 4, 2, 1 iterations
                 while k >= size:
                     g.launch()
@@ -1137,7 +1194,7 @@ class GANEngine:
                 for g, ar in self.seg_graphs:
                     g.launch()
                     if ar is not None:
-                        self._allreduce(ar)
+                        self._allreduce(ar)           # rccl: host-launched between the segment graphs
         else:
             st = ops.stream_ptr()
             self._issue_stage_in(st, it, k)
@@ -1226,8 +1283,12 @@ class GANEngine:
         lg_t = self.lossG[self.g_off + it0:self.g_off + it1]
         ld_t = self.lossD[it0 * d:it1 * d]
         if self.world > 1:       # per-rank partial means (1/B_global scaling) -> global means
+            import torch.distributed as dist
             from . import dp
-            lg_t, ld_t = lg_t.clone(), ld_t.clone()
+            if self._comms is not None:
+                self._comms["D"].check(); self._comms["G"].check()
+            cpu = dist.get_backend(self.pg) != "nccl"           # gloo control plane: host tensors
+            lg_t, ld_t = (lg_t.cpu() if cpu else lg_t.clone()), (ld_t.cpu() if cpu else ld_t.clone())
             dp.allreduce_sum_(lg_t, self.pg)
             dp.allreduce_sum_(ld_t, self.pg)
         lg = lg_t.cpu().numpy()
@@ -1589,7 +1650,12 @@ class BEGANEngine(GANEngine):
         ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
         ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
 
+    def _lr_scale(self, net):
+        return self.st[4:5] if net == "D" else self.st[5:6]
+
     def _issue_D_post(self, st, it, j):
+        if self._peer():
+            return
         ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
                  self._slot(it, self.D_steps, j, 0, 1), lr_scale=self.st[4:5], stream=st)
 
@@ -1609,6 +1675,8 @@ class BEGANEngine(GANEngine):
                           stream=st)
 
     def _issue_G_post(self, st, it):
+        if self._peer():
+            return
         ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
                  self._G_sched_slot(it), lr_scale=self.st[5:6], stream=st)
 

@@ -301,6 +301,27 @@ int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 
+/* ---- C1 (NEW: the reference has no distributed code): gradient exchange of
+ * the data-parallel step between the ranks of one node, as kernels that live inside the iteration's
+ * hipGraph (csrc/gm_comm.hip).  Every rank creates a communicator (an exchange region in fine-grained
+ * device memory), the 64-byte IPC handles are exchanged by the host (torch.distributed
+ * all_gather_object), gm_comm_connect maps the peers.  gm_allreduce_f32: in-place SUM over ranks of
+ * buf[0..n) (n % 4 == 0, 16-byte aligned), identical bits on every rank; gm_allreduce_adam_f32: same,
+ * with optim.Adam.step (ns_gan.py:139,156) applied to (p, m, v) by the kernel that writes the reduced
+ * gradient; gm_allreduce_scalars: up to 16 floats (the pre-reductions of the losses that are not a
+ * mean of per-sample terms: ra_gan.py:204, fisher_gan.py:214-223, dra_gan.py:204, be_gan.py:189-195).
+ * Waits are bounded; gm_comm_error reports an expired one. */
+int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void* handle_out64);
+int gm_comm_connect(void* comm, const void* all_handles /* world x 64 bytes, rank order */);
+int gm_comm_destroy(void* comm);
+int gm_comm_error(void* comm, int* flag_out);
+int gm_allreduce_f32(void* comm, void* stream, float* buf, int64_t n);
+int gm_allreduce_adam_f32(void* comm, void* stream, float* grad, int64_t n, float* p, float* m,
+                          float* v, const float* sched, gm_slot sched_slot, double beta1,
+                          double beta2, double eps, double weight_decay, float clamp,
+                          const float* lr_scale_or_null);
+int gm_allreduce_scalars(void* comm, void* stream, float* vals, int k);
+
 /* ---- HOST helper (no device work): first B entries of torch.randperm(n, generator=
  * Generator().manual_seed(seed)) in O(B): RandomSampler.__iter__ (torch/utils/data/sampler.py:160-185)
  * feeding process_batch (ns_gan.py:222-226).  mt19937 seeded with the low 32 bits of `seed`,

@@ -1,0 +1,172 @@
+"""Data-parallel path on the MI355X: the peer-to-peer gradient exchange
+(csrc/gm_comm.hip, dp.PeerComm) and the N-rank engine, exercised with SEVERAL RANKS ON ONE GPU --
+the exchange goes through hipIpc mappings exactly as it does between GPUs of a node (there over
+xGMI), the control plane is gloo.  N ranks must reproduce 1 rank up to fp32 summation order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(os.path.dirname(HERE), "generative_models_amd", "src")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                      RANK=str(rank), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, SRC)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _comm_worker(rank, world, port, q):
+    dist = _init(rank, world, port)
+    from generative_models_amd import dp, ops
+    dev = torch.device("cuda", 0)
+    n = 314404
+    comm = dp.PeerComm(n, world, rank)
+    ok = comm.selfcheck(dev)
+    g = torch.Generator().manual_seed(100)
+    res = []
+    for rnd in range(3):                               # changing data: a stale mapping would show
+        bufs = [torch.randn(n, generator=g) for _ in range(world)]
+        mine = bufs[rank].to(dev)
+        comm.allreduce(mine)
+        torch.cuda.synchronize()
+        want = bufs[0].clone()
+        for r in range(1, world):
+            want += bufs[r]                            # rank order, fp32: bit-identical expected
+        res.append(bool(torch.equal(mine.cpu(), want)))
+    # all-reduce + Adam == Adam on the summed gradient
+    grads = [torch.randn(n, generator=g) * 1e-2 for _ in range(world)]
+    p0 = torch.randn(n, generator=g)
+    gsum = grads[0].clone()
+    for r in range(1, world):
+        gsum += grads[r]
+    sched = torch.from_numpy(ops.adam_schedule(2e-4, 2)).to(dev)
+    pa, ma, va = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb, mb, vb = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    ga = grads[rank].to(dev)
+    for step in range(2):
+        comm.allreduce_adam(ga, pa, ma, va, sched, ops.slot(0, 0, step, 0, 1), clamp=0.01)
+        ops.adam(pb, gsum.to(dev), mb, vb, sched, ops.slot(0, 0, step, 0, 1), clamp=0.01)
+        torch.cuda.synchronize()
+        res.append(bool(torch.equal(ga.cpu(), gsum)))
+        ga = grads[rank].to(dev)
+    res.append(bool(torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)))
+    comm.check()
+    q.put((rank, ok, res))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_peer_allreduce_between_processes(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, res in out:
+        assert ok, "selfcheck failed on rank %d" % rank
+        assert all(res), (rank, res)
+
+
+SMALL = dict(image_size=64, hidden_dim=48, z_dim=8, batch=16, n_train=160, n_val=48, n_test=48,
+             image_shape=(1, 8, 8))
+MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "ls": ("ls_gan", "LSGAN", "LSGANTrainer"),
+        "w": ("w_gan", "WGAN", "WGANTrainer"), "wgp": ("w_gp_gan", "WGPGAN", "WGPGANTrainer"),
+        "mm": ("mm_gan", "MMGAN", "MMGANTrainer"), "f": ("f_gan", "fGAN", "fGANTrainer")}
+
+
+def _train_worker(rank, world, port, variant, kw, q):
+    dist = _init(rank, world, port) if world > 1 else None
+    if world == 1:
+        sys.path.insert(0, os.path.dirname(HERE))
+        sys.path.insert(0, SRC)
+        torch.cuda.set_device(0)
+    import contextlib
+    import importlib
+    import io
+    from oracle import port as oport
+    mod_name, model_name, trainer_name = MODS[variant]
+    mod = importlib.import_module(mod_name)
+    cfg = SMALL
+    loaders = oport.synthetic_loaders(cfg["batch"], n_train=cfg["n_train"], n_val=cfg["n_val"],
+                                      n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    model = getattr(mod, model_name)(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
+                                     z_dim=cfg["z_dim"])
+    tr = getattr(mod, trainer_name)(model, *loaders, viz=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**kw)
+    torch.cuda.synchronize()
+    eng = tr._engine
+    out = dict(rank=rank, G=list(tr.Glosses), D=list(tr.Dlosses), mode=eng.comm_mode, world=eng.world,
+               params={k: v.cpu().numpy() for k, v in model.state_dict().items()},
+               rng=torch.get_rng_state().numpy().tobytes())
+    q.put(out)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_world(world, variant, kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("variant,kw", [("ns", dict(num_epochs=2)), ("ls", dict(num_epochs=1)),
+                                        ("w", dict(num_epochs=1, D_steps=2)),
+                                        ("wgp", dict(num_epochs=1, D_steps=1)),
+                                        ("mm", dict(num_epochs=1, G_init=2)),
+                                        ("f", dict(num_epochs=1, method="pearson"))],
+                         ids=["ns", "ls", "w", "wgp", "mm", "f"])
+def test_two_rank_engine_equals_one_rank(variant, kw):
+    """The ENGINE's N > 1 path (row shards, 1/B_global scaling, in-graph peer all-reduce + Adam) on
+    two ranks == the single-rank fused engine: losses 1e-5, parameters 2e-5 (fp32 summation order),
+    identical replicas, identical RNG stream position on every rank."""
+    one = _run_world(1, variant, kw)[0]
+    two = _run_world(2, variant, kw)
+    assert all(o["world"] == 2 and o["mode"] == "peer" for o in two), [o["mode"] for o in two]
+    for o in two:
+        assert o["rng"] == one["rng"]
+        g, d = np.array(o["G"]), np.array(o["D"])
+        assert np.max(np.abs(g - np.array(one["G"])) / np.maximum(1, np.abs(one["G"]))) <= 1e-5
+        assert np.max(np.abs(d - np.array(one["D"])) / np.maximum(1, np.abs(one["D"]))) <= 1e-5
+        for k, v in o["params"].items():
+            assert np.max(np.abs(v - one["params"][k])) <= 2e-5, k
+    for k, v in two[0]["params"].items():                 # replicas stay bit-identical
+        assert np.array_equal(v, two[1]["params"][k]), k
