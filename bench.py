@@ -336,8 +336,7 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     trainer = getattr(m, cls + "Trainer")(model, loader, None, None, viz=False)
     data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
     eng = gm_engine.GANEngine(variant, trainer.model, data, B_global, dev, use_graph=use_graph,
-                              world_size=world, rank=rank)
-    eng.force_segments = force_dp
+                              world_size=world, rank=rank, force_dp=force_dp)
     eng.configure(W + reps * K, lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
     marks = []

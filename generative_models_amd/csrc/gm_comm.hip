@@ -4,21 +4,25 @@
 // Round 1 exchanged the two gradient buckets of a D+G step (D 1.26 MB, G 1.29 MB) with two
 // host-launched RCCL all-reduces between three segment graphs: 114 us per iteration on ONE rank
 // against 71 us for the single-GPU graph -- the step is too short for host-launched collectives.
-// Here every rank maps the other ranks' exchange buffers (hipIpc handles over the xGMI peer
-// mappings; fine-grained device memory) and the all-reduce is three small kernels in the graph:
-//   stage : my gradient bucket -> my exchange buffer `in[parity]`
+// Here every rank maps the other ranks' exchange regions (hipIpc handles over the xGMI peer
+// mappings; fine-grained device memory).  The gradient bucket itself LIVES in the region (`in`: the
+// backward kernels write dW/db straight into it -- dp.PeerComm.grad_buffer), so the all-reduce is two
+// small kernels in the graph:
 //   reduce: signal "in ready" to every peer (remote 8-byte stores), wait for theirs; every rank sums
 //           ITS slice of the bucket over ranks 0..W-1 in rank order (identical bits everywhere)
-//           into its `out[parity]`                                            (reduce-scatter)
+//           into its `out`                                                     (reduce-scatter)
 //   gather: signal "out ready", wait; read every slice from its owner, write the reduced gradient
 //           back and -- optionally -- apply Adam to the parameters right there     (all-gather)
+// (a bucket that lives elsewhere is first copied in by a third kernel, `stage`).
 // xGMI is point-to-point: each rank moves 2 * (W-1)/W of the bucket over W-1 links in parallel
 // (0.32 MB per link at W = 8) instead of W-1 ring hops.  Flags are monotonically increasing sequence
-// numbers kept in device memory (the graph replays without arguments); exchange buffers are double
-// buffered by sequence parity, which makes one flag wait per phase sufficient (see the comment at
-// `reduce_kernel`).  Every wait is bounded: on expiry the kernel raises the communicator's error
-// flag and carries on, so a lost peer shows up as a Python exception at the next read-back, never as
-// a hung GPU.
+// numbers kept in device memory (the graph replays without arguments).  One wait per phase is
+// enough, with single buffers: I overwrite `in` (next backward) only after my gather, which waited
+// for every peer's "out ready", which a peer sends after its reduce kernel -- the only reader of my
+// `in` -- has completed; I overwrite `out` only in my next reduce, after every peer's next "in
+// ready", which it sends after its gather -- the only reader of my `out` -- has completed.
+// Every wait is bounded: on expiry the kernel raises the communicator's error flag and carries on,
+// so a lost peer shows up as a Python exception at the next read-back, never as a hung GPU.
 #include "gm_common.h"
 
 #include <cstring>
@@ -40,8 +44,8 @@ Region layout(int64_t n_floats) {
     r.scal = FLAG_BYTES;
     r.in = r.scal + 2 * SCAL_FLOATS * 4 * MAXW;   // [parity][rank][16 floats]
     r.in = ((r.in + 255) / 256) * 256;
-    r.out = r.in + 2 * nb;
-    r.total = r.out + 2 * nb;
+    r.out = r.in + nb;
+    r.total = r.out + nb;
     return r;
 }
 
@@ -70,24 +74,31 @@ __device__ __forceinline__ unsigned long long* flag_ptr(const CommP& c, int owne
 }
 
 // signal phase `phase` of sequence s to every peer (a remote 8-byte store into THEIR flag array),
-// then wait until every peer's signal for the same phase has arrived in MINE.
+// then wait until every peer's signal for the same phase has arrived in MINE.  ONE lane per
+// workgroup does the fences and the polling (a system-scope fence by every thread of every workgroup
+// was measured at 22 us per kernel); the workgroup barrier hands the acquire to the other lanes.
 __device__ void signal_and_wait(const CommP& c, int phase, unsigned long long s) {
-    if (threadIdx.x < (unsigned)c.world && (int)threadIdx.x != c.rank) {
-        const int peer = threadIdx.x;
+    if (c.world == 1) return;                     // uniform: nothing to exchange
+    if (threadIdx.x == 0) {
         if (blockIdx.x == 0) {
-            __threadfence_system();               // my earlier stores (previous kernel) are out
-            __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);      // system scope: the previous kernel's stores are out
+            for (int peer = 0; peer < c.world; ++peer)
+                if (peer != c.rank)
+                    __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        unsigned long long spins = 0;
-        while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_ACQUIRE,
-                                 __HIP_MEMORY_SCOPE_SYSTEM) < s) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > SPIN_LIMIT) { atomicExch(c.err, 1); break; }
+        for (int peer = 0; peer < c.world; ++peer) {
+            if (peer == c.rank) continue;
+            unsigned long long spins = 0;
+            while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_SYSTEM) < s) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPIN_LIMIT) { atomicExch(c.err, 1); break; }
+            }
         }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);          // system scope: see what the peers published
     }
     __syncthreads();
-    __threadfence_system();                       // acquire side for the whole workgroup
 }
 
 __device__ __forceinline__ void slice_of(int64_t n4, int world, int r, int64_t* lo, int64_t* hi) {
@@ -96,32 +107,28 @@ __device__ __forceinline__ void slice_of(int64_t n4, int world, int r, int64_t* 
     *hi = per * (r + 1) < n4 ? per * (r + 1) : n4;
 }
 
-// stage: grad -> in[parity].  n is padded to a multiple of 4 by the caller's buffers.
+// stage: a bucket that does not live in the exchange region -> in
 __global__ __launch_bounds__(256) void stage_kernel(CommP c, const float* __restrict__ g, int64_t n) {
-    const unsigned long long s = c.seq[0] + 1;
-    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4;          // floats4 per parity buffer
-    float4* dst = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.in) + (s & 1) * nb4;
+    float4* dst = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.in);
     const float4* src = reinterpret_cast<const float4*>(g);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
-// reduce-scatter.  Why one wait per phase is enough with double-buffered exchange buffers: a peer
-// overwrites its in[parity] again only in the stage kernel of sequence s+2, which it reaches after
-// its gather phase of s+1, which waited for MY reduce signal of s+1, which I send after this kernel.
+// reduce-scatter
 __global__ __launch_bounds__(256) void reduce_kernel(CommP c, int64_t n) {
     const unsigned long long s = c.seq[0] + 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) c.seq[1] = s;        // the gather phase reads seq[1]
     signal_and_wait(c, 0, s);
-    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4, n4 = n >> 2;
+    const int64_t n4 = n >> 2;
     int64_t lo, hi;
     slice_of(n4, c.world, c.rank, &lo, &hi);
-    float4* out = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.out) + (s & 1) * nb4;
+    float4* out = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.out);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = 0; r < c.world; ++r) {                       // rank order: same bits on every rank
-            const float4 v = (reinterpret_cast<const float4*>(c.base[r] + c.lay.in) + (s & 1) * nb4)[i];
+            const float4 v = reinterpret_cast<const float4*>(c.base[r] + c.lay.in)[i];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         out[i] = a;
@@ -140,7 +147,7 @@ struct AdamP {
 __global__ __launch_bounds__(256) void gather_kernel(CommP c, float* __restrict__ g, int64_t n, AdamP ad) {
     const unsigned long long s = c.seq[1];
     signal_and_wait(c, 1, s);
-    const int64_t nb4 = ((n * 4 + 255) / 256) * 64 / 4, n4 = n >> 2;
+    const int64_t n4 = n >> 2;
     float step_size = 0.f, bc2_sqrt = 1.f;
     if (ad.enabled) {
         const int64_t si = gm_slot_index(ad.sched_slot);
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void gather_kernel(CommP c, float* __restrict_
     for (int r = 0; r < c.world; ++r) {
         int64_t lo, hi;
         slice_of(n4, c.world, r, &lo, &hi);
-        const float4* src = reinterpret_cast<const float4*>(c.base[r] + c.lay.out) + (s & 1) * nb4;
+        const float4* src = reinterpret_cast<const float4*>(c.base[r] + c.lay.out);
         for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
             const float4 G = src[i];
             reinterpret_cast<float4*>(g)[i] = G;
@@ -272,6 +279,14 @@ extern "C" int gm_comm_destroy(void* comm) {
     return 0;
 }
 
+extern "C" int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && ptr_out && n_floats_out);
+    *ptr_out = cm->base[cm->rank] + cm->lay.in;
+    *n_floats_out = cm->n_floats;
+    return 0;
+}
+
 extern "C" int gm_comm_error(void* comm, int* flag_out) {
     Comm* cm = static_cast<Comm*>(comm);
     GM_CHECK_ARG(cm && flag_out);
@@ -283,15 +298,19 @@ static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const 
     GM_CHECK_ARG(cm && buf && n > 0 && n <= cm->n_floats && n % 4 == 0);
     GM_CHECK_ARG((reinterpret_cast<uintptr_t>(buf) & 15) == 0);
     const CommP p = params_of(cm);
+    // one 16-byte element per thread where the bucket allows it (a D+G step's buckets are ~80k
+    // float4: 256 workgroups of 256 threads, one pass).  Waiting workgroups poll flags in THEIR OWN
+    // memory (peers store remotely), so many pollers cost no xGMI traffic.
     int blocks = (int)((n / 4 + 255) / 256);
-    if (blocks > 256) blocks = 256;
+    if (blocks > 320) blocks = 320;
     if (blocks < 1) blocks = 1;
-    int rblocks = (int)((n / 4 / cm->world + 255) / 256);     // a slice per rank: fewer pollers
-    if (rblocks > 64) rblocks = 64;
+    int rblocks = (int)((n / 4 / cm->world + 255) / 256);     // a slice per rank
+    if (rblocks > 320) rblocks = 320;
     if (rblocks < 1) rblocks = 1;
-    hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
+    if (reinterpret_cast<char*>(buf) != cm->base[cm->rank] + cm->lay.in)    // the bucket lives elsewhere
+        hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
     hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, s, p, buf, n, ad);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
     GM_LAUNCH_RET();
 }
 

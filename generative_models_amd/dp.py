@@ -82,6 +82,23 @@ class PeerComm:
             _lib.call("gm_comm_connect", self.h, blob)
             dist.barrier(group=group)               # every rank has mapped every region
 
+    def grad_buffer(self):
+        """The region's own bucket as a torch tensor (zero copy): gradients written here by the
+        backward kernels are exchanged in place, without a staging copy."""
+        import ctypes
+
+        from . import _lib
+        ptr, n = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.call("gm_comm_buffer", self.h, ctypes.byref(ptr), ctypes.byref(n))
+
+        class _Region:                               # keeps the communicator alive with the tensor
+            owner = self
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f4", "data": (ptr.value, False),
+                                        "version": 2}
+        t = torch.as_tensor(_Region(), device=torch.device("cuda", torch.cuda.current_device()))
+        t.zero_()
+        return t
+
     def allreduce(self, buf, n=None, stream=None):
         from . import _lib, ops
         _lib.call("gm_allreduce_f32", self.h, stream or ops.stream_ptr(), buf.data_ptr(),

@@ -37,9 +37,11 @@ class FlatParams:
     re-points `.data` at views of it, so one Adam launch / one all-reduce bucket covers the net.
     The nn.Linear modules stay the parameter holders (state_dict keys)."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, grad_alloc=None):
         # an element may be a tuple of parameters: packed back to back with no padding between
         # them (e.g. the VAE's mu / log_var heads, used as ONE [2Z, H] matrix by the kernels)
+        # grad_alloc(n): where the flat gradient bucket lives (data parallel: inside the peer
+        # exchange region, so that it is all-reduced in place)
         self.params, offs, n = [], [], 0
         for item in params:
             group = item if isinstance(item, (tuple, list)) else (item,)
@@ -51,7 +53,7 @@ class FlatParams:
         self.n = n
         self.offsets = offs
         self.flat = torch.zeros(n, device=device)
-        self.grad = torch.zeros(n, device=device)
+        self.grad = torch.zeros(n, device=device) if grad_alloc is None else grad_alloc(n)
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
         self.views, self.gviews = [], []
@@ -269,7 +271,8 @@ class GANEngine:
     SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info", "be", "dra")
 
     def __init__(self, variant, model, data, B, device, method=None, use_graph=True,
-                 world_size=1, rank=0, process_group=None):
+                 world_size=1, rank=0, process_group=None, force_dp=False):
+        """force_dp: run the data-parallel launch structure on one rank (diagnostics / tests)."""
         assert variant in self.SUPPORTED, variant
         self.variant, self.model, self.device = variant, model, device
         self.method = method
@@ -283,8 +286,20 @@ class GANEngine:
         self.data = data                   # [N, I] fp32 on device
         self.N, self.I = data.shape
         G, D = model.G, model.D
-        self.fG = FlatParams(G.parameters(), device)
-        self.fD = FlatParams(D.parameters(), device)
+        import os
+        # data-parallel gradient exchange: "peer" = kernels inside the iteration graph over hipIpc /
+        # xGMI peer mappings (csrc/gm_comm.hip; falls back to "rccl" if its self-check fails);
+        # "rccl" = host-launched torch.distributed all-reduces between per-segment graphs
+        self.comm_mode = os.environ.get("GM_DP_COMM", "peer")
+        self.force_segments = bool(force_dp)
+        self._comms = None
+        if (world_size > 1 or force_dp) and self.comm_mode == "peer":
+            self._setup_peer_comm(sum(_align4(p.numel()) for p in D.parameters()),
+                                  sum(_align4(p.numel()) for p in G.parameters()))
+        alloc = (lambda net: (lambda n: self._comms[net].grad_buffer()[:n])) if self._comms else \
+            (lambda net: None)
+        self.fG = FlatParams(G.parameters(), device, grad_alloc=alloc("G"))
+        self.fD = FlatParams(D.parameters(), device, grad_alloc=alloc("D"))
         g1, g2 = list(G.children())[:2]
         d1, d2 = list(D.children())[:2]
         self.G1, self.G2 = _Linear(self.fG, g1), _Linear(self.fG, g2)
@@ -294,13 +309,6 @@ class GANEngine:
         self.Hd_dim = self.D1.W.shape[0]
         assert self.D2.W.shape[0] == 1 or variant == "be", "score-based critics (BEGAN: autoencoder)"
         self.use_graph = use_graph
-        self.force_segments = False    # tests: exercise the DP launch structure on one rank
-        import os
-        # data-parallel gradient exchange: "peer" = kernels inside the iteration graph over hipIpc /
-        # xGMI peer mappings (csrc/gm_comm.hip; falls back to "rccl" if its self-check fails);
-        # "rccl" = host-launched torch.distributed all-reduces between per-segment graphs
-        self.comm_mode = os.environ.get("GM_DP_COMM", "peer")
-        self._comms = None
         self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
         self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
@@ -1040,8 +1048,6 @@ class GANEngine:
             self.aux.copy_(resume["fisher_aux"])     # lambda (fisher_gan.py:117-118,155-156) + moments
         self.ctr.zero_()
         self._drain()
-        if self._peer() and self._comms is None:
-            self._setup_peer_comm()
         from collections import deque
         self.n_planned = n_iters
         self._pending, self._cursor, self._uploaded, self._next_it = deque(), 0, 0, 0
@@ -1062,13 +1068,14 @@ class GANEngine:
         self._graph_key = None
         self._key = key
 
-    def _setup_peer_comm(self):
-        """One communicator per optimizer bucket (own flags and sequence numbers).  Every rank runs
-        the self-check; unless ALL ranks pass, every rank falls back to RCCL."""
+    def _setup_peer_comm(self, nD, nG):
+        """One communicator per optimizer bucket (own flags and sequence numbers); the flat gradient
+        buffers are placed inside them.  Every rank runs the self-check; unless ALL ranks pass,
+        every rank falls back to RCCL."""
         from . import dp
         try:
-            comms = {"D": dp.PeerComm(self.fD.n, self.world, self.rank, self.pg),
-                     "G": dp.PeerComm(self.fG.n, self.world, self.rank, self.pg)}
+            comms = {"D": dp.PeerComm(nD, self.world, self.rank, self.pg),
+                     "G": dp.PeerComm(nG, self.world, self.rank, self.pg)}
             ok = all(c.selfcheck(self.device) for c in comms.values())
         except Exception:                            # noqa: BLE001  (no IPC / no peer access here)
             comms, ok = None, False
@@ -1083,7 +1090,6 @@ class GANEngine:
             self._comms = comms
         else:
             self.comm_mode = "rccl"
-            self._graph_key = None
 
     def optim_state(self):
         """Everything the optimizers and controllers carry across steps, after the train() call that
@@ -1591,9 +1597,9 @@ class BEGANEngine(GANEngine):
     the reference's four `.item()` syncs per step disappear."""
 
     def __init__(self, model, data, B, device, use_graph=True, world_size=1, rank=0,
-                 process_group=None):
+                 process_group=None, force_dp=False):
         super().__init__("be", model, data, B, device, use_graph=use_graph, world_size=world_size,
-                         rank=rank, process_group=process_group)
+                         rank=rank, process_group=process_group, force_dp=force_dp)
         Bl, I = self.Bl, self.I
         z = lambda *s, **k: torch.zeros(*s, device=device, **k)
         self.Yd, self.dY, self.rows = z(2 * Bl, I), z(2 * Bl, I), z(2 * Bl)

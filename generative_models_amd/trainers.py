@@ -351,7 +351,8 @@ class GANTrainer:
             world, rank, group = dp.current()
             self._engine = GANEngine(self.variant, self.model, data, it.batch_size, dev,
                                      method=self.method, use_graph=self.use_graph,
-                                     world_size=world, rank=rank, process_group=group)
+                                     world_size=world, rank=rank, process_group=group,
+                                     force_dp=getattr(self, "force_dp", False))
             self._engine_key = key
         return self._engine
 
@@ -930,7 +931,8 @@ class BEGANTrainerBase(GANTrainer):
             imgs = it.dataset.tensors[0]
             data = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
             self._engine = BEGANEngine(self.model, data, it.batch_size, dev, use_graph=self.use_graph,
-                                       world_size=world, rank=rank, process_group=group)
+                                       world_size=world, rank=rank, process_group=group,
+                                       force_dp=getattr(self, "force_dp", False))
             self._engine_key = key
         return self._engine
 

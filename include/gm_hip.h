@@ -315,6 +315,9 @@ int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void*
 int gm_comm_connect(void* comm, const void* all_handles /* world x 64 bytes, rank order */);
 int gm_comm_destroy(void* comm);
 int gm_comm_error(void* comm, int* flag_out);
+/* The region's own bucket (n_floats fp32, 256-byte aligned): a gradient buffer placed here is
+ * all-reduced without a staging copy. */
+int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out);
 int gm_allreduce_f32(void* comm, void* stream, float* buf, int64_t n);
 int gm_allreduce_adam_f32(void* comm, void* stream, float* grad, int64_t n, float* p, float* m,
                           float* v, const float* sched, gm_slot sched_slot, double beta1,

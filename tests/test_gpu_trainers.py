@@ -548,11 +548,13 @@ def test_dp_launch_structure_single_rank_rccl():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port_no = s.getsockname()[1]; s.close()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_no)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["GM_DP_COMM"] = "rccl"
     try:
         ref = run_product("ls", SMALL, 16, dict(num_epochs=2))
         tr, model = build_product("ls", SMALL, 16)
+        tr.force_dp = True
         eng = tr._get_engine()
-        eng.force_segments = True
+        assert eng.force_segments and eng.comm_mode == "rccl"
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
             tr.train(num_epochs=2)
@@ -565,7 +567,30 @@ def test_dp_launch_structure_single_rank_rccl():
         for (k, a), (_, b) in zip(model.state_dict().items(), ref[1].state_dict().items()):
             assert (a - b).abs().max().item() <= 1e-6, k
     finally:
+        os.environ.pop("GM_DP_COMM", None)
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant,kw", [("ls", dict(num_epochs=2)), ("w", dict(num_epochs=1, D_steps=2)),
+                                        ("wgp", dict(num_epochs=1, D_steps=1))], ids=["ls", "w", "wgp"])
+def test_dp_peer_structure_single_rank(variant, kw):
+    """The data-parallel launch structure with the in-graph peer exchange (gradient buckets inside
+    the exchange region, reduce + gather(+Adam) kernels in the ONE hipGraph per iteration) on a
+    single rank: must equal the single-GPU fused run (a one-rank sum is the identity; Adam runs in
+    the gather kernel instead of the gradient epilogues)."""
+    ref = run_product(variant, SMALL, 16, kw)
+    tr, model = build_product(variant, SMALL, 16)
+    tr.force_dp = True
+    eng = tr._get_engine()
+    assert eng._peer() and eng._comms is not None and eng.fD.grad.data_ptr() != 0
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**kw)
+    torch.cuda.synchronize()
+    lclose(tr.Glosses, ref[0].Glosses, "peer-structure Glosses", tol=1e-6)
+    lclose(tr.Dlosses, ref[0].Dlosses, "peer-structure Dlosses", tol=1e-6)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref[1].state_dict().items()):
+        assert (a - b).abs().max().item() <= 1e-6, k
 
 
 # ---------------------------------------------------------------------------------------------
