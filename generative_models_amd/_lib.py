@@ -83,6 +83,12 @@ _SIGNATURES = {
                                  c_int]),
     "gm_gan_loss": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, POINTER(c_float), c_int,
                             c_float, _P, Slot, _P, _P, _P, _P]),
+    "gm_gan_loss_phase": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, POINTER(c_float), c_int,
+                                  c_float, _P, Slot, _P, _P, _P, _P, c_int, _P, c_float]),
+    "gm_l1_rows_dp": (c_int, [_P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P]),
+    "gm_began_dloss_dp": (c_int, [_P, _P, c_int, c_int, _P, _P, Slot]),
+    "gm_std_sums": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "gm_std_from_sums": (c_int, [_P, _P, c_int64, _P]),
     "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, ctypes.c_double, ctypes.c_double,
                         ctypes.c_double, ctypes.c_double, c_float]),
     "gm_interp": (c_int, [_P, _P, Slot, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int]),

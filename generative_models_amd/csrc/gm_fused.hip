@@ -551,13 +551,15 @@ extern "C" int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const f
 // rows (or all rows when K is null), -K/B for the rest (d(DX - K*DG)/dY, be_gan.py:225-236).
 __global__ __launch_bounds__(256) void l1_rows_kernel(const float* __restrict__ Y, int64_t ldy,
                                                      const float* __restrict__ X, int64_t ldx,
-                                                     int R, int I, int B, const float* __restrict__ K,
+                                                     int R, int I, int B, int Bscale,
+                                                     const float* __restrict__ K,
                                                      float* __restrict__ dY, int64_t lddy,
                                                      float* __restrict__ rowsum) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wave;
     if (r >= R) return;
-    const float coef = (K != nullptr && r >= B) ? (-K[0]) / (float)B : 1.0f / (float)B;
+    // Bscale: rows of the GLOBAL batch (the mean's denominator; = B on one GPU)
+    const float coef = (K != nullptr && r >= B) ? (-K[0]) / (float)Bscale : 1.0f / (float)Bscale;
     float acc = 0.f;
     for (int i = lane; i < I; i += 64) {
         const float d = Y[(int64_t)r * ldy + i] - X[(int64_t)r * ldx + i];
@@ -568,18 +570,23 @@ __global__ __launch_bounds__(256) void l1_rows_kernel(const float* __restrict__ 
     if (lane == 0) rowsum[r] = acc;
 }
 
+extern "C" int gm_l1_rows_dp(void* stream, const float* Y, int64_t ldy, const float* X, int64_t ldx,
+                             int R, int I, int B, int B_global, const float* K_dev, float* dY,
+                             int64_t lddy, float* rowsum) {
+    GM_CHECK_ARG(Y && X && dY && rowsum && R > 0 && I > 0 && B > 0 && B_global >= B);
+    hipLaunchKernelGGL(l1_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, Y, ldy, X,
+                       ldx, R, I, B, B_global, K_dev, dY, lddy, rowsum);
+    GM_LAUNCH_RET();
+}
 extern "C" int gm_l1_rows(void* stream, const float* Y, int64_t ldy, const float* X, int64_t ldx,
                           int R, int I, int B, const float* K_dev, float* dY, int64_t lddy,
                           float* rowsum) {
-    GM_CHECK_ARG(Y && X && dY && rowsum && R > 0 && I > 0 && B > 0);
-    hipLaunchKernelGGL(l1_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, Y, ldy, X,
-                       ldx, R, I, B, K_dev, dY, lddy, rowsum);
-    GM_LAUNCH_RET();
+    return gm_l1_rows_dp(stream, Y, ldy, X, ldx, R, I, B, B, K_dev, dY, lddy, rowsum);
 }
 
 // DX = mean(rows[0:B]), DG = mean(rows[B:2B]), D_loss = DX - K*DG  (be_gan.py:225-236)
 __global__ __launch_bounds__(256) void began_dloss_kernel(const float* __restrict__ rows, int B,
-                                                         float* __restrict__ st,
+                                                         int Bscale, float* __restrict__ st,
                                                          float* __restrict__ loss_out,
                                                          gm_slot loss_slot) {
     __shared__ double sh[4];
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(256) void began_dloss_kernel(const float* __restric
         __syncthreads();
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
         __syncthreads();
-        m[k] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)B);
+        m[k] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)Bscale);
     }
     if (threadIdx.x == 0) {
         st[1] = m[0];
@@ -601,12 +608,16 @@ __global__ __launch_bounds__(256) void began_dloss_kernel(const float* __restric
     }
 }
 
+extern "C" int gm_began_dloss_dp(void* stream, const float* rows, int B, int B_global, float* state,
+                                 float* loss_out, gm_slot loss_slot) {
+    GM_CHECK_ARG(rows && state && loss_out && B > 0 && B_global >= B);
+    hipLaunchKernelGGL(began_dloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, B, B_global,
+                       state, loss_out, loss_slot);
+    GM_LAUNCH_RET();
+}
 extern "C" int gm_began_dloss(void* stream, const float* rows, int B, float* state, float* loss_out,
                               gm_slot loss_slot) {
-    GM_CHECK_ARG(rows && state && loss_out && B > 0);
-    hipLaunchKernelGGL(began_dloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, B, state,
-                       loss_out, loss_slot);
-    GM_LAUNCH_RET();
+    return gm_began_dloss_dp(stream, rows, B, B, state, loss_out, loss_slot);
 }
 
 // End of a BEGAN iteration (be_gan.py:189-195): convergence measure, K <- clip(K + lambda*(gamma*DX
@@ -655,6 +666,43 @@ extern "C" int gm_began_update(void* stream, float* state, double* dstate, int64
 //   head  : gw2 += colsum(m1 . T) + da2^T h ; gb2 += sum da2 ; da1 = (da2 w2) . m1   (T = dv W1^T)
 // ------------------------------------------------------------------------------------------
 // out[0] = unbiased std over n = R*I elements (two fp64 sums; one workgroup)
+// Data parallel: images.data.std() is over the GLOBAL batch (dra_gan.py:204) -> every rank
+// contributes (sum x, sum x^2) of its rows; after the scalar all-reduce std_from_sums finishes.
+__global__ __launch_bounds__(1024) void std_sums_kernel(const float* __restrict__ X, int64_t ldx, int R,
+                                                       int I, float* __restrict__ out2) {
+    __shared__ double sh[2][16];
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t n = (int64_t)R * I;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)X[(i / I) * ldx + (i % I)];
+        s1 += v; s2 += v * v;
+    }
+    s1 = gm_wave_sum_d(s1); s2 = gm_wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < 16; ++q) { a += sh[0][q]; b += sh[1][q]; }
+        out2[0] = (float)a; out2[1] = (float)b;
+    }
+}
+__global__ void std_from_sums_kernel(const float* __restrict__ sums2, int64_t n, float* __restrict__ out) {
+    const double a = (double)sums2[0], b = (double)sums2[1];
+    const double mean = a / (double)n;
+    const double var = (b - (double)n * mean * mean) / (double)(n - 1);
+    out[0] = (float)sqrt(var > 0.0 ? var : 0.0);
+}
+extern "C" int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2) {
+    GM_CHECK_ARG(X && out2 && R > 0 && I > 0 && ldx >= I);
+    hipLaunchKernelGGL(std_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, X, ldx, R, I, out2);
+    GM_LAUNCH_RET();
+}
+extern "C" int gm_std_from_sums(void* stream, const float* sums2, int64_t n_total, float* out) {
+    GM_CHECK_ARG(sums2 && out && n_total > 1);
+    hipLaunchKernelGGL(std_from_sums_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums2, n_total, out);
+    GM_LAUNCH_RET();
+}
+
 __global__ __launch_bounds__(1024) void std_all_kernel(const float* __restrict__ X, int64_t ldx, int R,
                                                       int I, float* __restrict__ out) {
     __shared__ double sh[2][16];

@@ -120,6 +120,16 @@ struct LossP {
     float* dag;
     float* aux;
     float* db;      // optional: d loss / d (head bias) = sum(dax) + sum(dag), fp64-accumulated
+    // data parallel: the two losses that are not a mean of per-sample terms are
+    // evaluated in phases around scalar all-reduces (gm_allreduce_scalars) of `pre`:
+    //   RaGAN  1: pre[0] = sum_local sg            | 2: mean(sg) known: dax, pre[1] = sum_local du,
+    //          pre[4] = sum_local dax, loss        | 3: sum(du) known: dag, db
+    //   Fisher 1: pre[0..3] = local moment sums    | 2: everything else from the global moments
+    // phase 0 = the whole loss in one launch (one GPU).  loss_scale: 1 on the rank that reports a
+    // loss computed identically everywhere (Fisher), 0 on the others (losses are summed over ranks).
+    int phase;
+    float* pre;
+    float loss_scale;
 };
 
 __device__ double block_sum(double v, double* sh) {
@@ -142,22 +152,39 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
 
     if (p.variant == GM_LOSS_RA && D) {
         // ra_gan.py:204-205  L = -mean(log(sig(sx - mean(sg)) + eps) + log(sig(1 - sg) + eps)) / 2
-        double s1 = 0.0;
-        for (int i = t; i < B; i += 256) s1 += (double)p.sg[i];
-        const float mg = (float)(block_sum(s1, sh) * (double)ib);
-        double sq = 0.0, sbx = 0.0, sbg = 0.0;
-        for (int i = t; i < B; i += 256) {
-            const float u = gm_sigmoid(p.sx[i] - mg);
-            const float v = gm_sigmoid(1.f - p.sg[i]);
-            acc += (double)(logf(u + EPS) + logf(v + EPS));
-            const float gu = (-0.5f * ib) / (u + EPS);       // dL/du
-            const float du = (gu * (1.f - u)) * u;           // through the inner sigmoid
-            const float ax = act_grad(du, p.sx[i], p.out_act);
-            p.dax[i] = ax;
-            sbx += (double)ax;
-            sq += (double)du;
+        float mg, sum_du, bx = 0.f;
+        if (p.phase <= 1) {
+            double s1 = 0.0;
+            for (int i = t; i < B; i += 256) s1 += (double)p.sg[i];
+            const double tot1 = block_sum(s1, sh);
+            if (p.phase == 1) { if (t == 0) p.pre[0] = (float)tot1; return; }
+            mg = (float)(tot1 * (double)ib);
+        } else {
+            mg = p.pre[0] * ib;                               // pre[0]: sum of sg over ALL ranks
         }
-        const float sum_du = (float)block_sum(sq, sh);        // d/dmg = -sum_du ; dmg/dsg_j = 1/B
+        if (p.phase <= 2) {
+            double sq = 0.0, sbx = 0.0;
+            for (int i = t; i < B; i += 256) {
+                const float u = gm_sigmoid(p.sx[i] - mg);
+                const float v = gm_sigmoid(1.f - p.sg[i]);
+                acc += (double)(logf(u + EPS) + logf(v + EPS));
+                const float gu = (-0.5f * ib) / (u + EPS);       // dL/du
+                const float du = (gu * (1.f - u)) * u;           // through the inner sigmoid
+                const float ax = act_grad(du, p.sx[i], p.out_act);
+                p.dax[i] = ax;
+                sbx += (double)ax;
+                sq += (double)du;
+            }
+            sum_du = (float)block_sum(sq, sh);                // d/dmg = -sum_du ; dmg/dsg_j = 1/B
+            const double tot = block_sum(acc, sh);
+            bx = (float)block_sum(sbx, sh);
+            if (t == 0) p.loss_out[gm_slot_index(p.loss_slot)] = -(float)(tot * (double)ib) / 2.f;
+            if (p.phase == 2) { if (t == 0) { p.pre[1] = sum_du; p.pre[4] = bx; } return; }
+        } else {
+            sum_du = p.pre[1];                                // sum of du over ALL ranks
+            bx = p.pre[4];
+        }
+        double sbg = 0.0;
         for (int i = t; i < B; i += 256) {
             const float v = gm_sigmoid(1.f - p.sg[i]);
             const float gv = (-0.5f * ib) / (v + EPS);
@@ -166,26 +193,30 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
             p.dag[i] = ag;
             sbg += (double)ag;
         }
-        const double tot = block_sum(acc, sh);
-        const float bx = (float)block_sum(sbx, sh), bg = (float)block_sum(sbg, sh);
-        if (t == 0) {
-            p.loss_out[gm_slot_index(p.loss_slot)] = -(float)(tot * (double)ib) / 2.f;
-            if (p.db) p.db[0] = bx + bg;
-        }
+        const float bg = (float)block_sum(sbg, sh);
+        if (t == 0 && p.db) p.db[0] = bx + bg;
         return;
     }
 
     if (p.variant == GM_LOSS_FISHER && D) {
         // fisher_gan.py:214-223; aux[0] = lambda (updated in place: :155-156), aux[1..4] = moments
-        double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
-        for (int i = t; i < B; i += 256) {
-            const float x = p.sx[i], g = p.sg[i];
-            a1 += x; a2 += (double)(x * x); b1 += g; b2 += (double)(g * g);
+        float m1x, m2x, m1g, m2g;
+        if (p.phase <= 1) {
+            double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+            for (int i = t; i < B; i += 256) {
+                const float x = p.sx[i], g = p.sg[i];
+                a1 += x; a2 += (double)(x * x); b1 += g; b2 += (double)(g * g);
+            }
+            const double t1 = block_sum(a1, sh), t2 = block_sum(a2, sh), t3 = block_sum(b1, sh), t4 = block_sum(b2, sh);
+            if (p.phase == 1) {
+                if (t == 0) { p.pre[0] = (float)t1; p.pre[1] = (float)t2; p.pre[2] = (float)t3; p.pre[3] = (float)t4; }
+                return;
+            }
+            m1x = (float)(t1 * (double)ib); m2x = (float)(t2 * (double)ib);
+            m1g = (float)(t3 * (double)ib); m2g = (float)(t4 * (double)ib);
+        } else {                                              // sums over ALL ranks
+            m1x = p.pre[0] * ib; m2x = p.pre[1] * ib; m1g = p.pre[2] * ib; m2g = p.pre[3] * ib;
         }
-        const float m1x = (float)(block_sum(a1, sh) * (double)ib);
-        const float m2x = (float)(block_sum(a2, sh) * (double)ib);
-        const float m1g = (float)(block_sum(b1, sh) * (double)ib);
-        const float m2g = (float)(block_sum(b2, sh) * (double)ib);
         const float lam = p.aux[0], rho = p.hyper[0];
         const float omega = 1.f - (0.5f * m2x + 0.5f * m2g);
         const float loss = -((m1x - m1g) + lam * omega - (rho / 2.f) * (omega * omega));
@@ -202,7 +233,7 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
         __syncthreads();
         if (t == 0) {
             if (p.db) p.db[0] = bx + bg;
-            p.loss_out[gm_slot_index(p.loss_slot)] = loss;
+            p.loss_out[gm_slot_index(p.loss_slot)] = loss * p.loss_scale;
             p.aux[0] = lam + rho * (-omega);                  // lambda += rho * lambda.grad
             p.aux[1] = m1x; p.aux[2] = m1g; p.aux[3] = m2x; p.aux[4] = m2g;
         }
@@ -239,10 +270,33 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(LossP p) {
 
 }  // namespace
 
+static int gan_loss_impl(void* stream, int variant, int gen_mode, const float* sx,
+                         const float* sg, int B, int out_act, const float* hyper, int n_hyper,
+                         float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
+                         float* aux_io, float* db_out, int phase, float* pre, float loss_scale);
+
 extern "C" int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx,
                            const float* sg, int B, int out_act, const float* hyper, int n_hyper,
                            float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
                            float* aux_io, float* db_out) {
+    return gan_loss_impl(stream, variant, gen_mode, sx, sg, B, out_act, hyper, n_hyper, inv_b, loss_out,
+                         loss_slot, dax, dag, aux_io, db_out, 0, nullptr, 1.0f);
+}
+
+extern "C" int gm_gan_loss_phase(void* stream, int variant, int gen_mode, const float* sx,
+                                 const float* sg, int B, int out_act, const float* hyper, int n_hyper,
+                                 float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
+                                 float* aux_io, float* db_out, int phase, float* pre, float loss_scale) {
+    GM_CHECK_ARG(phase >= 1 && phase <= 3 && pre);
+    GM_CHECK_ARG(!gen_mode && (variant == GM_LOSS_RA || variant == GM_LOSS_FISHER));
+    return gan_loss_impl(stream, variant, gen_mode, sx, sg, B, out_act, hyper, n_hyper, inv_b, loss_out,
+                         loss_slot, dax, dag, aux_io, db_out, phase, pre, loss_scale);
+}
+
+static int gan_loss_impl(void* stream, int variant, int gen_mode, const float* sx,
+                         const float* sg, int B, int out_act, const float* hyper, int n_hyper,
+                         float inv_b, float* loss_out, gm_slot loss_slot, float* dax, float* dag,
+                         float* aux_io, float* db_out, int phase, float* pre, float loss_scale) {
     GM_CHECK_ARG(sg && loss_out && B > 0 && n_hyper >= 0 && n_hyper <= 8);
     GM_CHECK_ARG(variant >= GM_LOSS_NS && variant <= GM_LOSS_F_JS);
     GM_CHECK_ARG(gen_mode || (sx && dax && dag));
@@ -252,7 +306,7 @@ extern "C" int gm_gan_loss(void* stream, int variant, int gen_mode, const float*
     p.sx = sx; p.sg = sg; p.inv_b = inv_b;
     for (int i = 0; i < n_hyper; ++i) p.hyper[i] = hyper[i];
     p.loss_out = loss_out; p.loss_slot = loss_slot; p.dax = dax; p.dag = dag; p.aux = aux_io;
-    p.db = db_out;
+    p.db = db_out; p.phase = phase; p.pre = pre; p.loss_scale = loss_scale;
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     GM_LAUNCH_RET();
 }

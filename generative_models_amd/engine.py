@@ -341,6 +341,7 @@ class GANEngine:
         self.rowloss = z(2 * Bl)
         self.done_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.aux = z(8)                    # Fisher lambda + moments
+        self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
         if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
             self.U, self.Gr, self.Gam, self.T = z(Bl, Hd), z(Bl, I), z(Bl, I), z(Bl, Hd)
@@ -464,6 +465,14 @@ class GANEngine:
     def _lr_scale(self, net):
         return None                                 # BEGAN: the plateau schedulers' device-side scale
 
+    def _dp(self):
+        return not self._single()
+
+    def _exchange_scalars(self, st, vals, k):
+        """SUM over ranks of vals[0..k) inside the graph (the pre-reductions of the losses that are not
+        a mean of per-sample terms)."""
+        self._comms["D"].allreduce_scalars(vals, k, stream=st)
+
     def _issue_D(self, st, it, j):
         self._issue_D_pre(st, it, j)
         self._allreduce(("D", j), st, it)
@@ -542,9 +551,24 @@ class GANEngine:
                             self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
-            ops.gan_loss(self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD,
-                         dS[:Bl], dS[Bl:], hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot,
-                         aux=aux, db=D2.gb, stream=st)
+            loss = lambda **kw: ops.gan_loss(
+                self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD, dS[:Bl], dS[Bl:],
+                hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot, aux=aux, db=D2.gb, stream=st, **kw)
+            if self._dp() and self.variant == "ra":
+                # mean(D(G(z))) and sum(du) span the GLOBAL batch (ra_gan.py:204)
+                loss(phase=1, pre=self.pre)
+                self._exchange_scalars(st, self.pre, 1)
+                loss(phase=2, pre=self.pre)
+                self._exchange_scalars(st, self.pre[1:], 1)
+                loss(phase=3, pre=self.pre)
+            elif self._dp() and self.variant == "fisher":
+                # the four moments span the GLOBAL batch; lambda's ascent is then identical on every
+                # rank (fisher_gan.py:214-223,155-156); rank 0 reports the (global) loss
+                loss(phase=1, pre=self.pre)
+                self._exchange_scalars(st, self.pre, 4)
+                loss(phase=2, pre=self.pre, loss_scale=1.0 if self.rank == 0 else 0.0)
+            else:
+                loss()
             ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
             ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
         if grouped:
@@ -763,9 +787,17 @@ class GANEngine:
         Bl, d, R = self.Bl, self.D_steps, self.R
         D1, D2 = self.D1, self.D2
         x = self.X2[:Bl]
-        of.std_all(x, Bl, self.stdv, stream=st)                                   # images.data.std()
-        of.dragan_xhat(x, self.delta_ring.view(-1), self._slot(it, d, j, R * d, self.B),
-                       self.U_ring.view(-1), self._slot(it, d, j, R * d, self.B * self.I),
+        if self._dp():
+            # images.data.std() is over the GLOBAL batch (dra_gan.py:204): (sum x, sum x^2) of my rows,
+            # summed over ranks, then the unbiased std of B*I elements
+            of.std_sums(x, Bl, self.pre[8:], stream=st)
+            self._exchange_scalars(st, self.pre[8:], 2)
+            of.std_from_sums(self.pre[8:], self.B * self.I, self.stdv, stream=st)
+        else:
+            of.std_all(x, Bl, self.stdv, stream=st)                               # images.data.std()
+        r0 = self.rank * Bl                                                        # my rows of the draws
+        of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.B),
+                       self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.B * self.I),
                        self.stdv, self.Xh, Bl, stream=st)
         ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
         ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "sigmoid", M=Bl, stream=st)
@@ -1215,15 +1247,12 @@ class GANEngine:
         something else after run() returns (train(): the epoch-end loss read-back); never past
         what configure() planned.  Without it the host draws exactly what this call consumes, so a
         caller that times run() times its draws too."""
-        if self.world > 1 and self.variant == "dra":
-            raise GMError("DRAGAN perturbs with the std of the GLOBAL batch; its data-parallel form "
-                          "needs a pre-all-reduce of (sum x, sum x^2) (SURVEY.md 8e): not wired yet")
-        if self.world > 1 and self.variant == "info":
+        if self._dp() and self.variant == "info":
             raise GMError("InfoGAN's three-optimizer step is not wired for data parallelism yet")
-        if self.world > 1 and self.variant in ("ra", "fisher"):
-            raise GMError("RaGAN / FisherGAN losses are not a mean of per-sample terms; their "
-                          "data-parallel form needs a scalar pre-all-reduce (SURVEY.md 8e) and is "
-                          "not implemented: run them on one GPU")
+        if self._dp() and self.variant in ("ra", "fisher", "dra", "be") and not self._peer():
+            raise GMError("%s needs scalar pre-reductions over the global batch inside the step "
+                          "(SURVEY.md 8e); they are exchanged by the in-graph peer communicator "
+                          "(GM_DP_COMM=peer), which is not active here" % self.variant)
         if it_start != self._next_it:
             raise GMError("run(): iterations are consumed in order (next is %d, got %d)"
                           % (self._next_it, it_start))
@@ -1614,9 +1643,6 @@ class BEGANEngine(GANEngine):
 
     def configure(self, n_iters, G_lr, D_lr, D_steps, GAMMA=0.5, LAMBDA=1e-3, K=0.0, patience=0,
                   **kw):
-        if self.world > 1:
-            raise GMError("BEGAN's K controller needs global DX/DG means; data-parallel BEGAN is "
-                          "not wired yet")
         resume = kw.get("resume")
         super().configure(n_iters, G_lr, D_lr, D_steps, resume=resume)
         self.gamma, self.lam, self.patience = float(GAMMA), float(LAMBDA), int(patience)
@@ -1650,8 +1676,13 @@ class BEGANEngine(GANEngine):
         X2, Hd, Yd, dY, dHd = self.X2, self.Hd, self.Yd, self.dY, self.dHd
         ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)            # encoder
         ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=2 * Bl, stream=st)              # decoder
-        of.l1_rows(Yd, X2, 2 * Bl, Bl, self.st, dY, self.rows, stream=st)          # K = st[0]
-        of.began_dloss(self.rows, Bl, self.st, self.lossD, self._slot(it, d, j, 0, 1), stream=st)
+        of.l1_rows(Yd, X2, 2 * Bl, Bl, self.st, dY, self.rows, B_global=self.B, stream=st)   # K = st[0]
+        of.began_dloss(self.rows, Bl, self.st, self.lossD, self._slot(it, d, j, 0, 1), B_global=self.B,
+                       stream=st)
+        if self._dp():
+            # DX, DG are means over the GLOBAL batch (be_gan.py:189-195): the per-rank partial means
+            # in st[1:3] are summed over ranks before the K controller / plateau schedulers read them
+            self._exchange_scalars(st, self.st[1:], 2)
         ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
         ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
         ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
@@ -1672,7 +1703,7 @@ class BEGANEngine(GANEngine):
         Hd, Yd, dY, dHd, Xg = self.Hd, self.Yd, self.dY, self.dHd, self.Xg2
         ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
         ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=Bl, stream=st)
-        of.l1_rows(Yd, Xg, Bl, Bl, None, dY, self.rows, stream=st)
+        of.l1_rows(Yd, Xg, Bl, Bl, None, dY, self.rows, B_global=self.B, stream=st)
         of.sum_finalize(self.rows, Bl, self.lossG, scale=self.inv_b,
                         out_slot=self._slot(it, 1, self.g_off, 0, 1), stream=st)
         ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)

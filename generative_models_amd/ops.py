@@ -198,10 +198,21 @@ def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
 
 
 def gan_loss(variant, gen_mode, sx, sg, B, out_act, loss_out, dax, dag, hyper=(), inv_b=None,
-             loss_slot=NO_SLOT, aux=None, db=None, stream=None):
-    """Adversarial loss + d(loss)/d(pre-activation score).  SURVEY.md appendix A.2."""
+             loss_slot=NO_SLOT, aux=None, db=None, stream=None, phase=0, pre=None, loss_scale=1.0):
+    """Adversarial loss + d(loss)/d(pre-activation score).  SURVEY.md appendix A.2.
+    phase / pre / loss_scale: the data-parallel, phased form of the RaGAN / Fisher critic losses
+    (gm_gan_loss_phase)."""
     h = (ctypes.c_float * 8)(*([float(x) for x in hyper] + [0.0] * (8 - len(hyper))))
     inv_b = float(np.float32(1.0) / np.float32(B)) if inv_b is None else float(inv_b)
+    if phase:
+        _lib.call("gm_gan_loss_phase", stream or stream_ptr(), LOSS[variant] if isinstance(variant, str) else variant,
+                  1 if gen_mode else 0, sx.data_ptr() if sx is not None else None, sg.data_ptr(), B,
+                  ACT[out_act] if not isinstance(out_act, int) else out_act, h, len(hyper), inv_b,
+                  loss_out.data_ptr(), loss_slot, dax.data_ptr() if dax is not None else None,
+                  dag.data_ptr() if dag is not None else None,
+                  aux.data_ptr() if aux is not None else None, db.data_ptr() if db is not None else None,
+                  phase, pre.data_ptr(), loss_scale)
+        return
     _lib.call("gm_gan_loss", stream or stream_ptr(), LOSS[variant] if isinstance(variant, str) else variant,
               1 if gen_mode else 0, sx.data_ptr() if sx is not None else None, sg.data_ptr(), B,
               ACT[out_act] if not isinstance(out_act, int) else out_act, h, len(hyper), inv_b,

@@ -106,21 +106,30 @@ def info_q_loss(q, noise, noise_slot, B, z_dim, disc_dim, cont_dim, dq, loss_out
               dq.data_ptr(), _ld(dq), loss_out.data_ptr(), loss_slot)
 
 
-def l1_rows(Y, X, R, B, K_dev, dY, rowsum, stream=None):
-    """Per-row L1 error + gradient (BEGAN, be_gan.py:225-236,256)."""
-    _lib.call("gm_l1_rows", stream or stream_ptr(), Y.data_ptr(), _ld(Y), X.data_ptr(), _ld(X), R,
-              Y.shape[1], B, K_dev.data_ptr() if K_dev is not None else None, dY.data_ptr(), _ld(dY),
-              rowsum.data_ptr())
+def l1_rows(Y, X, R, B, K_dev, dY, rowsum, B_global=None, stream=None):
+    """Per-row L1 error + gradient (BEGAN, be_gan.py:225-236,256).  B_global: the mean's
+    denominator when this rank holds B of B_global rows."""
+    _lib.call("gm_l1_rows_dp", stream or stream_ptr(), Y.data_ptr(), _ld(Y), X.data_ptr(), _ld(X), R,
+              Y.shape[1], B, B if B_global is None else B_global,
+              K_dev.data_ptr() if K_dev is not None else None, dY.data_ptr(), _ld(dY), rowsum.data_ptr())
 
 
-def began_dloss(rows, B, state, loss_out, loss_slot, stream=None):
-    _lib.call("gm_began_dloss", stream or stream_ptr(), rows.data_ptr(), B, state.data_ptr(),
-              loss_out.data_ptr(), loss_slot)
+def began_dloss(rows, B, state, loss_out, loss_slot, B_global=None, stream=None):
+    _lib.call("gm_began_dloss_dp", stream or stream_ptr(), rows.data_ptr(), B,
+              B if B_global is None else B_global, state.data_ptr(), loss_out.data_ptr(), loss_slot)
 
 
 def began_update(state, dstate, istate, gamma, lam, patience, tick, stream=None):
     _lib.call("gm_began_update", stream or stream_ptr(), state.data_ptr(), dstate.data_ptr(),
               istate.data_ptr(), gamma, lam, patience, tick.data_ptr() if tick is not None else None)
+
+
+def std_sums(X, R, out2, stream=None):
+    _lib.call("gm_std_sums", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out2.data_ptr())
+
+
+def std_from_sums(sums2, n_total, out, stream=None):
+    _lib.call("gm_std_from_sums", stream or stream_ptr(), sums2.data_ptr(), n_total, out.data_ptr())
 
 
 def std_all(X, R, out, stream=None):

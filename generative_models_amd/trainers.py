@@ -369,11 +369,15 @@ class GANTrainer:
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
-                eng.run(epoch_steps, it_start=it0, horizon=num_epochs * epoch_steps)
+                # viz draws from the global generator at every epoch end (ns_gan.py:168,234): the host
+                # replay must then not run ahead into the next epoch's draws
+                eng.run(epoch_steps, it_start=it0,
+                        horizon=None if self.viz else num_epochs * epoch_steps)
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)     # one sync per epoch
                 if self.variant == "info":
                     self.MIlosses.extend(eng.mi_losses(it0, it0 + epoch_steps))
                 self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+                self._viz_epoch(epoch)
             return
         # GENERAL path: user-overridden hooks, same loop as the reference
         if self.__dict__.get("_resume_optim") is not None:
@@ -416,6 +420,29 @@ class GANTrainer:
                 G_loss.backward()
                 G_opt.step()
             self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+            self._viz_epoch(epoch)
+
+    # ---- visualisation (ns_gan.py:166-170, 228-281) ---------------------
+    viz_dir = None          # default: ../viz/<name>/ like the reference (scripts run from src/)
+
+    def _viz_epoch(self, epoch):
+        if self.viz:
+            self.generate_images(epoch)
+            try:
+                import matplotlib.pyplot as plt
+                plt.show()
+            except Exception:                                # noqa: BLE001
+                pass
+
+    def generate_images(self, epoch, num_outputs=36, save=True):
+        """ns_gan.py:228-262: a grid of generator samples, saved as ../viz/<name>/reconst_<epoch>.png."""
+        from . import viz
+        return viz.generate_images(self, epoch, num_outputs, save, self.viz_dir)
+
+    def viz_loss(self):
+        """ns_gan.py:264-281."""
+        from . import viz
+        viz.viz_loss(self)
 
     def _after_D_backward(self):
         """Fisher GAN's hand-rolled lambda ascent (fisher_gan.py:155-156); no-op otherwise."""
@@ -963,10 +990,12 @@ class BEGANTrainerBase(GANTrainer):
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
-                eng.run(epoch_steps, it_start=it0, horizon=num_epochs * epoch_steps)
+                eng.run(epoch_steps, it_start=it0,
+                        horizon=None if self.viz else num_epochs * epoch_steps)
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)
                 self.K = eng.K_value()
                 self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+                self._viz_epoch(epoch)
             return
         from torch.optim.lr_scheduler import ReduceLROnPlateau
         m = self.model

@@ -108,6 +108,16 @@ int gm_linear_bwd_dw_adam(void* stream, const float* dA, int64_t lda, const floa
 int gm_gan_loss(void* stream, int variant, int gen_mode, const float* sx, const float* sg, int B,
                 int out_act, const float* hyper, int n_hyper, float inv_b, float* loss_out,
                 gm_slot loss_slot, float* dax, float* dag, float* aux_io, float* db_out);
+/* Data-parallel form of the two critic losses that are not a mean of per-sample terms:
+ * RaGAN's mean(D(G(z))) inside the sigmoid (ra_gan.py:204) and Fisher's moments / lambda ascent
+ * (fisher_gan.py:214-223,155-156) span the GLOBAL batch.  The loss runs in phases around
+ * gm_allreduce_scalars of `pre` (device float[8]): Ra 1 | exchange pre[0] | 2 | exchange pre[1] | 3;
+ * Fisher 1 | exchange pre[0..3] | 2.  loss_scale: 1 on the rank that reports a loss every rank
+ * computes identically (Fisher), 0 elsewhere -- per-rank loss slots are summed over ranks. */
+int gm_gan_loss_phase(void* stream, int variant, int gen_mode, const float* sx, const float* sg, int B,
+                      int out_act, const float* hyper, int n_hyper, float inv_b, float* loss_out,
+                      gm_slot loss_slot, float* dax, float* dag, float* aux_io, float* db_out,
+                      int phase, float* pre, float loss_scale);
 
 /* ---- K7 (+K8): Adam over one flat parameter buffer, exactly torch's _single_tensor_adam
  * (SURVEY.md section 3.5).  sched: device float2 table {step_size = lr/bc1, bc2_sqrt} indexed by
@@ -197,6 +207,12 @@ int gm_l1_rows(void* stream, const float* Y, int64_t ldy, const float* X, int64_
                int B, const float* K_dev, float* dY, int64_t lddy, float* rowsum);
 int gm_began_dloss(void* stream, const float* rows, int B, float* state, float* loss_out,
                    gm_slot loss_slot);
+/* data parallel: B rows of this rank out of B_global (the means' denominator); DX / DG in the state
+ * are then PARTIAL means: gm_allreduce_scalars(state + 1, 2) makes them global before began_update */
+int gm_l1_rows_dp(void* stream, const float* Y, int64_t ldy, const float* X, int64_t ldx, int R, int I,
+                  int B, int B_global, const float* K_dev, float* dY, int64_t lddy, float* rowsum);
+int gm_began_dloss_dp(void* stream, const float* rows, int B, int B_global, float* state,
+                      float* loss_out, gm_slot loss_slot);
 int gm_began_update(void* stream, float* state, double* dstate, int64_t* istate, float gamma,
                     float lambda, int64_t patience, int64_t* tick);
 /* gm_adam with a device-resident learning-rate scale (a power of two: exact). */
@@ -265,6 +281,9 @@ int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, const float
  * second backward; head_bwd: the w2/b2 accumulations and da1.  Penalty rows are added to the loss by
  * gm_head_fwd_loss / gm_gan_loss with weight hyper[7]. */
 int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out);
+/* data parallel: (sum x, sum x^2) of this rank's rows -> scalar all-reduce -> std of the global batch */
+int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2);
+int gm_std_from_sums(void* stream, const float* sums2, int64_t n_total, float* out);
 int gm_dragan_xhat(void* stream, const float* x, int64_t ldx, const float* delta, gm_slot delta_slot,
                    const float* U, gm_slot u_slot, const float* std_dev, float C, float* out,
                    int64_t ldo, int B, int I);

@@ -213,6 +213,32 @@ def gen_round2():
     save("ns_full_b256_50steps", arrays, dict(variant="ns", cfg=FULL, batch=256, steps=50,
                                               train_kw=dict(num_epochs=1), rng=rng_digest(),
                                               torch=torch.__version__))
+    # viz=True (ns_gan.py:166-170): one extra compute_noise(36, z) draw per epoch end moves the RNG
+    # stream -- the fixture pins losses, parameters and the final generator state with viz on
+    mod_name, model_name, trainer_name = port.REFERENCE_NAMES["ns"]
+    mod = ref_harness.load(mod_name)
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:          # the reference writes ../viz/<name>/ relative to cwd
+        os.makedirs(os.path.join(tmp, "src"))
+        os.chdir(os.path.join(tmp, "src"))
+        try:
+            loaders = ref_harness.synthetic_loaders(SMALL["batch"], n_train=SMALL["n_train"],
+                                                    n_val=SMALL["n_val"], n_test=SMALL["n_test"],
+                                                    image_shape=SMALL["image_shape"])
+            torch.manual_seed(1234)
+            model = getattr(mod, model_name)(image_size=SMALL["image_size"], hidden_dim=SMALL["hidden_dim"],
+                                             z_dim=SMALL["z_dim"])
+            tr = getattr(mod, trainer_name)(model, *loaders, viz=True)
+            with ref_harness.quiet():
+                tr.train(num_epochs=3)
+        finally:
+            os.chdir(cwd)
+    arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+    for k, v in model.state_dict().items():
+        arrays["param:" + k] = v.numpy()
+    save("ns_small_viz", arrays, dict(variant="ns", cfg=SMALL, train_kw=dict(num_epochs=3), viz=True,
+                                      rng=rng_digest(), torch=torch.__version__))
     mod = ref_harness.load("vae")
     n_train = 512 * 3 + 336
     loaders = ref_harness.synthetic_loaders(512, n_train=n_train, n_val=FULL["n_val"],

@@ -60,8 +60,10 @@ def build_product(variant, cfg, batch, loaders=None, use_graph=True):
     return tr, model
 
 
-def run_product(variant, cfg, batch, train_kw, use_graph=True, capped=None):
+def run_product(variant, cfg, batch, train_kw, use_graph=True, capped=None, viz_dir=None):
     tr, model = build_product(variant, cfg, batch, use_graph=use_graph)
+    if viz_dir is not None:                                # ns_gan.py:166-170 with viz=True
+        tr.viz, tr.viz_dir = True, viz_dir
     if capped is not None:
         class Capped(torch.utils.data.DataLoader):
             def __len__(self):
@@ -213,8 +215,22 @@ def test_engine_vs_reference_golden(name):
     cfg, variant = meta["cfg"], meta["variant"]
     full = "steps" in meta
     batch = meta["batch"] if full else cfg["batch"]
+    viz_dir = None
+    if meta.get("viz"):                                    # fixture written with viz=True
+        import tempfile
+        viz_dir = tempfile.mkdtemp()
     p_tr, p_model, p_rng = run_product(variant, cfg, batch, meta["train_kw"],
-                                       capped=meta["steps"] if full else None)
+                                       capped=meta["steps"] if full else None, viz_dir=viz_dir)
+    if viz_dir is not None:
+        # one sample grid per epoch, written off the step stream: 6x6 images of
+        # shape x shape with torchvision's 2-pixel padding
+        import struct
+        side = int(cfg["image_size"] ** 0.5)
+        for e in range(1, meta["train_kw"]["num_epochs"] + 1):
+            png = open(os.path.join(viz_dir, p_tr.name, "reconst_%d.png" % e), "rb").read()
+            assert png[:8] == b"\x89PNG\r\n\x1a\n"
+            w, h = struct.unpack(">II", png[16:24])
+            assert (w, h) == (6 * (side + 2) + 2, 6 * (side + 2) + 2)
     # the global CPU generator ends where the reference left it (digest recorded by gen_golden)
     import hashlib
     assert hashlib.sha256(p_rng.numpy().tobytes()).hexdigest() == meta["rng"], "RNG stream position"
