@@ -144,6 +144,8 @@ _SIGNATURES = {
                                    c_int]),
     "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,
                                _P, c_int64, _P, Slot]),
+    "gm_info_q_loss_dp": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
+                                  _P, c_int64, _P, Slot]),
     "gm_act_bwd": (c_int, [_P, _P, _P, _P, c_int64, c_int]),
     "gm_randperm_prefix": (c_int, [ctypes.c_uint64, c_int64, c_int, _P]),
     "gm_mt19937_skip": (c_int, [_P, c_int64, ctypes.c_uint64]),

@@ -484,13 +484,14 @@ extern "C" int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, cons
 __global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restrict__ q, int64_t ldq,
                                                          const float* __restrict__ noise,
                                                          gm_slot noise_slot, int64_t ldn, int B,
-                                                         int zd, int nd, int nc, float lambda,
+                                                         int Bscale, int zd, int nd, int nc, float lambda,
                                                          float* __restrict__ dq, int64_t lddq,
                                                          float* __restrict__ loss_out,
                                                          gm_slot loss_slot) {
     __shared__ double sh[4];
     const float* nz = noise + gm_slot_offset(noise_slot);
-    const float inv_b = 1.0f / (float)B, inv_bc = 1.0f / (float)(B * nc);
+    // Bscale: rows of the GLOBAL batch (both means' denominator; = B on one GPU)
+    const float inv_b = 1.0f / (float)Bscale, inv_bc = 1.0f / (float)(Bscale * nc);
     double acc_d = 0.0, acc_c = 0.0;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* qr = q + (int64_t)b * ldq;
@@ -529,15 +530,22 @@ __global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restric
     if (threadIdx.x == 0) loss_out[gm_slot_index(loss_slot)] = lambda * (outv[0] + outv[1]);
 }
 
+extern "C" int gm_info_q_loss_dp(void* stream, const float* q, int64_t ldq, const float* noise,
+                                 gm_slot noise_slot, int64_t ldn, int B, int B_global, int z_dim,
+                                 int disc_dim, int cont_dim, float lambda, float* dq, int64_t lddq,
+                                 float* loss_out, gm_slot loss_slot) {
+    GM_CHECK_ARG(q && noise && dq && loss_out && B > 0 && B_global >= B && disc_dim > 0 && cont_dim > 0 && z_dim >= 0);
+    hipLaunchKernelGGL(info_q_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
+                       noise_slot, ldn, B, B_global, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
+                       loss_slot);
+    GM_LAUNCH_RET();
+}
 extern "C" int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise,
                               gm_slot noise_slot, int64_t ldn, int B, int z_dim, int disc_dim,
                               int cont_dim, float lambda, float* dq, int64_t lddq, float* loss_out,
                               gm_slot loss_slot) {
-    GM_CHECK_ARG(q && noise && dq && loss_out && B > 0 && disc_dim > 0 && cont_dim > 0 && z_dim >= 0);
-    hipLaunchKernelGGL(info_q_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
-                       noise_slot, ldn, B, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
-                       loss_slot);
-    GM_LAUNCH_RET();
+    return gm_info_q_loss_dp(stream, q, ldq, noise, noise_slot, ldn, B, B, z_dim, disc_dim, cont_dim, lambda,
+                             dq, lddq, loss_out, loss_slot);
 }
 
 // ------------------------------------------------------------------------------------------

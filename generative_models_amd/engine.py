@@ -294,8 +294,11 @@ class GANEngine:
         self.force_segments = bool(force_dp)
         self._comms = None
         if (world_size > 1 or force_dp) and self.comm_mode == "peer":
-            self._setup_peer_comm(sum(_align4(p.numel()) for p in D.parameters()),
-                                  sum(_align4(p.numel()) for p in G.parameters()))
+            sizes = {"D": sum(_align4(p.numel()) for p in D.parameters()),
+                     "G": sum(_align4(p.numel()) for p in G.parameters())}
+            if variant == "info":                    # third optimizer: G u Q (info_gan.py:146-148)
+                sizes["Q"] = sum(_align4(p.numel()) for p in model.Q.parameters())
+            self._setup_peer_comm(sizes)
         alloc = (lambda net: (lambda n: self._comms[net].grad_buffer()[:n])) if self._comms else \
             (lambda net: None)
         self.fG = FlatParams(G.parameters(), device, grad_alloc=alloc("G"))
@@ -352,7 +355,7 @@ class GANEngine:
             # InfoGAN (info_gan.py:78-148): auxiliary net Q and a third optimizer over G u Q that
             # keeps its OWN Adam moments for G's parameters
             Q = model.Q
-            self.fQ = FlatParams(Q.parameters(), device)
+            self.fQ = FlatParams(Q.parameters(), device, grad_alloc=alloc("Q"))
             q1, q2 = list(Q.children())[:2]
             self.Q1, self.Q2 = _Linear(self.fQ, q1), _Linear(self.fQ, q2)
             self.mi_m, self.mi_v = torch.zeros_like(self.fG.m), torch.zeros_like(self.fG.v)
@@ -609,7 +612,7 @@ class GANEngine:
         ops.linear_fwd(Xg, Q1.W, Q1.b, self.Hq, "relu", M=Bl, stream=st)
         ops.linear_fwd(self.Hq, Q2.W, Q2.b, self.Qo, "id", M=Bl, stream=st)
         of.info_q_loss(self.Qo, zbase, z_slot, Bl, self.zd, self.nd, self.nc, self.dQo, self.lossMI,
-                       s_slot, stream=st)
+                       s_slot, B_global=self.B, stream=st)
         fused = self.fuse_adam and self._single()
         if fused:
             adam = self._adam_args("MI", s_slot)
@@ -626,7 +629,14 @@ class GANEngine:
         ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
         dw(self.dXg, Hg, g2)
         dw(self.dHg, zbase, g1, x_slot=z_slot)
-        if not fused:
+        if self._peer():
+            # MI_optimizer.step (info_gan.py:148,207): G's gradient bucket with the MI optimizer's OWN
+            # moments, and Q's bucket -- all-reduce + Adam in the gather kernels
+            self._comms["G"].allreduce_adam(self.fG.grad, self.fG.flat, self.mi_m, self.mi_v, self.schedMI,
+                                            s_slot, stream=st)
+            self._comms["Q"].allreduce_adam(self.fQ.grad, self.fQ.flat, self.fQ.m, self.fQ.v, self.schedMI,
+                                            s_slot, stream=st)
+        elif not fused:
             ops.adam(self.fG.flat, self.fG.grad, self.mi_m, self.mi_v, self.schedMI, s_slot, stream=st)
             ops.adam(self.fQ.flat, self.fQ.grad, self.fQ.m, self.fQ.v, self.schedMI, s_slot, stream=st)
 
@@ -1100,14 +1110,13 @@ class GANEngine:
         self._graph_key = None
         self._key = key
 
-    def _setup_peer_comm(self, nD, nG):
+    def _setup_peer_comm(self, sizes):
         """One communicator per optimizer bucket (own flags and sequence numbers); the flat gradient
         buffers are placed inside them.  Every rank runs the self-check; unless ALL ranks pass,
         every rank falls back to RCCL."""
         from . import dp
         try:
-            comms = {"D": dp.PeerComm(nD, self.world, self.rank, self.pg),
-                     "G": dp.PeerComm(nG, self.world, self.rank, self.pg)}
+            comms = {k: dp.PeerComm(n, self.world, self.rank, self.pg) for k, n in sizes.items()}
             ok = all(c.selfcheck(self.device) for c in comms.values())
         except Exception:                            # noqa: BLE001  (no IPC / no peer access here)
             comms, ok = None, False
@@ -1247,12 +1256,10 @@ class GANEngine:
         something else after run() returns (train(): the epoch-end loss read-back); never past
         what configure() planned.  Without it the host draws exactly what this call consumes, so a
         caller that times run() times its draws too."""
-        if self._dp() and self.variant == "info":
-            raise GMError("InfoGAN's three-optimizer step is not wired for data parallelism yet")
-        if self._dp() and self.variant in ("ra", "fisher", "dra", "be") and not self._peer():
-            raise GMError("%s needs scalar pre-reductions over the global batch inside the step "
-                          "(SURVEY.md 8e); they are exchanged by the in-graph peer communicator "
-                          "(GM_DP_COMM=peer), which is not active here" % self.variant)
+        if self._dp() and self.variant in ("ra", "fisher", "dra", "be", "info") and not self._peer():
+            raise GMError("%s needs exchanges inside the step (scalar pre-reductions over the global "
+                          "batch / a third gradient bucket, SURVEY.md 8e); they run on the in-graph peer "
+                          "communicator (GM_DP_COMM=peer), which is not active here" % self.variant)
         if it_start != self._next_it:
             raise GMError("run(): iterations are consumed in order (next is %d, got %d)"
                           % (self._next_it, it_start))
@@ -1333,7 +1340,13 @@ class GANEngine:
         return G, D
 
     def mi_losses(self, it0, it1):
-        return [float(x) for x in self.lossMI[it0:it1].cpu().numpy()]
+        t = self.lossMI[it0:it1]
+        if self.world > 1:                           # per-rank partial means -> global
+            import torch.distributed as dist
+            from . import dp
+            t = t.cpu() if dist.get_backend(self.pg) != "nccl" else t.clone()
+            dp.allreduce_sum_(t, self.pg)
+        return [float(x) for x in t.cpu().numpy()]
 
 
 class VAEEngine:

@@ -99,11 +99,11 @@ def head_bwd(H, dS, w2, rowloss, dH, gw2, gb2, loss_out, loss_slot, inv_b, gen_m
 
 
 def info_q_loss(q, noise, noise_slot, B, z_dim, disc_dim, cont_dim, dq, loss_out, loss_slot,
-                lam=1.0, stream=None):
+                lam=1.0, B_global=None, stream=None):
     """InfoGAN train_Q loss (info_gan.py:295-302) + d loss / d q."""
-    _lib.call("gm_info_q_loss", stream or stream_ptr(), q.data_ptr(), _ld(q), noise.data_ptr(),
-              noise_slot, z_dim + disc_dim + cont_dim, B, z_dim, disc_dim, cont_dim, lam,
-              dq.data_ptr(), _ld(dq), loss_out.data_ptr(), loss_slot)
+    _lib.call("gm_info_q_loss_dp", stream or stream_ptr(), q.data_ptr(), _ld(q), noise.data_ptr(),
+              noise_slot, z_dim + disc_dim + cont_dim, B, B if B_global is None else B_global, z_dim,
+              disc_dim, cont_dim, lam, dq.data_ptr(), _ld(dq), loss_out.data_ptr(), loss_slot)
 
 
 def l1_rows(Y, X, R, B, K_dev, dY, rowsum, B_global=None, stream=None):

@@ -299,6 +299,10 @@ int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, const float* T
 int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise, gm_slot noise_slot,
                    int64_t ldn, int B, int z_dim, int disc_dim, int cont_dim, float lambda, float* dq,
                    int64_t lddq, float* loss_out, gm_slot loss_slot);
+/* data parallel: this rank's B rows of a global batch of B_global (both means' denominator) */
+int gm_info_q_loss_dp(void* stream, const float* q, int64_t ldq, const float* noise, gm_slot noise_slot,
+                      int64_t ldn, int B, int B_global, int z_dim, int disc_dim, int cont_dim, float lambda,
+                      float* dq, int64_t lddq, float* loss_out, gm_slot loss_slot);
 
 /* ---- elementwise activation backward for the general autograd path:
  * dA = dY * act'(Y)  (Relu/SigmoidBackward, ns_gan.py:44-45). */

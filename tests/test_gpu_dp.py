@@ -101,7 +101,8 @@ MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "ls": ("ls_gan", "LSGAN", "LS
         "w": ("w_gan", "WGAN", "WGANTrainer"), "wgp": ("w_gp_gan", "WGPGAN", "WGPGANTrainer"),
         "mm": ("mm_gan", "MMGAN", "MMGANTrainer"), "f": ("f_gan", "fGAN", "fGANTrainer"),
         "ra": ("ra_gan", "RaNSGAN", "RaNSGANTrainer"), "fisher": ("fisher_gan", "FisherGAN", "FisherGANTrainer"),
-        "dra": ("dra_gan", "DRAGAN", "DRAGANTrainer"), "be": ("be_gan", "BEGAN", "BEGANTrainer")}
+        "dra": ("dra_gan", "DRAGAN", "DRAGANTrainer"), "be": ("be_gan", "BEGAN", "BEGANTrainer"),
+        "info": ("info_gan", "InfoGAN", "InfoGANTrainer")}
 
 
 def _train_worker(rank, world, port, variant, kw, q):
@@ -120,14 +121,17 @@ def _train_worker(rank, world, port, variant, kw, q):
     loaders = oport.synthetic_loaders(cfg["batch"], n_train=cfg["n_train"], n_val=cfg["n_val"],
                                       n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
     torch.manual_seed(1234)
-    model = getattr(mod, model_name)(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
-                                     z_dim=cfg["z_dim"])
+    mkw = dict(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+    if variant == "info":
+        mkw.update(disc_dim=10, cont_dim=10)
+    model = getattr(mod, model_name)(**mkw)
     tr = getattr(mod, trainer_name)(model, *loaders, viz=False)
     with contextlib.redirect_stdout(io.StringIO()):
         tr.train(**kw)
     torch.cuda.synchronize()
     eng = tr._engine
-    out = dict(rank=rank, G=list(tr.Glosses), D=list(tr.Dlosses), mode=eng.comm_mode, world=eng.world,
+    out = dict(rank=rank, G=list(tr.Glosses), D=list(tr.Dlosses), MI=list(getattr(tr, "MIlosses", [])),
+               mode=eng.comm_mode, world=eng.world,
                params={k: v.cpu().numpy() for k, v in model.state_dict().items()},
                rng=torch.get_rng_state().numpy().tobytes())
     q.put(out)
@@ -158,8 +162,9 @@ def _run_world(world, variant, kw):
                                         # not a mean of per-sample terms: scalar pre-reductions over the
                                         # global batch inside the step
                                         ("ra", dict(num_epochs=1)), ("fisher", dict(num_epochs=1)),
-                                        ("dra", dict(num_epochs=1, D_steps=1)), ("be", dict(num_epochs=2))],
-                         ids=["ns", "ls", "w", "wgp", "mm", "f", "ra", "fisher", "dra", "be"])
+                                        ("dra", dict(num_epochs=1, D_steps=1)), ("be", dict(num_epochs=2)),
+                                        ("info", dict(num_epochs=1))],       # three optimizers, MI bucket
+                         ids=["ns", "ls", "w", "wgp", "mm", "f", "ra", "fisher", "dra", "be", "info"])
 def test_two_rank_engine_equals_one_rank(variant, kw):
     """The ENGINE's N > 1 path (row shards, 1/B_global scaling, in-graph peer all-reduce + Adam) on
     two ranks == the single-rank fused engine: losses 1e-5, parameters 2e-5 (fp32 summation order),
@@ -172,6 +177,9 @@ def test_two_rank_engine_equals_one_rank(variant, kw):
         g, d = np.array(o["G"]), np.array(o["D"])
         assert np.max(np.abs(g - np.array(one["G"])) / np.maximum(1, np.abs(one["G"]))) <= 1e-5
         assert np.max(np.abs(d - np.array(one["D"])) / np.maximum(1, np.abs(one["D"]))) <= 1e-5
+        if variant == "info":
+            mi = np.array(o["MI"])
+            assert np.max(np.abs(mi - np.array(one["MI"])) / np.maximum(1, np.abs(one["MI"]))) <= 1e-5
         ptol = 1.5e-4 if variant == "be" else 2e-5         # BEGAN: sign() gradients, one Adam step
         for k, v in o["params"].items():
             assert np.max(np.abs(v - one["params"][k])) <= ptol, k
