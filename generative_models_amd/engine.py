@@ -1354,13 +1354,15 @@ class VAEEngine:
     batch size (full batches and the ragged last one, 50 000 mod 512 = 336), a device step counter
     selecting index rows / eps rows / Adam-schedule rows / loss slots."""
 
-    def __init__(self, model, device, use_graph=True):
+    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
+                 force_dp=False):
         self.model, self.device, self.use_graph = model, device, use_graph
         enc, dec = model.encoder, model.decoder
-        self.fp = FlatParams([enc.linear.weight, enc.linear.bias,
-                              (enc.mu.weight, enc.log_var.weight), (enc.mu.bias, enc.log_var.bias),
-                              dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias],
-                             device)
+        plist = [enc.linear.weight, enc.linear.bias,
+                 (enc.mu.weight, enc.log_var.weight), (enc.mu.bias, enc.log_var.bias),
+                 dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias]
+        self._dp_init(plist, world_size, rank, process_group, force_dp)
+        self.fp = FlatParams(plist, device, grad_alloc=self._grad_alloc)
         fp = self.fp
         self.E1, self.D1, self.D2 = _Linear(fp, enc.linear), _Linear(fp, dec.linear), \
             _Linear(fp, dec.recon)
@@ -1381,6 +1383,56 @@ class VAEEngine:
         self._common_init(device)
 
     has_eps = True              # the VAE draws eps per batch (vae.py:104); the plain AE does not
+
+    # ---- data parallel: every batch's rows are split over the ranks; the losses are
+    # SUMS (vae.py:203,212), so the gradient all-reduce is a plain sum with no 1/N and the per-rank
+    # loss slots add up to the reference's values -------------------------------------------------
+    def _dp_init(self, plist, world, rank, pg, force_dp):
+        import os
+        self.world, self.rank, self.pg, self.force_dp = world, rank, pg, bool(force_dp)
+        self.comm, self._grad_alloc = None, None
+        if world > 1 or force_dp:
+            if os.environ.get("GM_DP_COMM", "peer") != "peer":
+                raise GMError("data-parallel VAE / AE exchange gradients with the in-graph peer "
+                              "communicator (GM_DP_COMM=peer)")
+            from . import dp
+            n = 0
+            for item in plist:
+                for q in (item if isinstance(item, (tuple, list)) else (item,)):
+                    n += q.numel()
+                n = _align4(n)
+            self.comm = dp.PeerComm(n, world, rank, pg)
+            ok = self.comm.selfcheck(self.device)
+            if world > 1:
+                import torch.distributed as dist
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                if dist.get_backend(pg) == "nccl":
+                    flag = flag.to(self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+                ok = bool(flag.item())
+            if not ok:
+                raise GMError("peer exchange self-check failed: data-parallel VAE / AE needs hipIpc peer "
+                              "mappings between the ranks' GPUs")
+            self._grad_alloc = lambda k: self.comm.grad_buffer()[:k]
+
+    def _dp(self):
+        return self.world > 1 or self.force_dp
+
+    def _rows(self, b):
+        """Rows [lo, hi) of a batch of b rows owned by this rank (ragged batches split as evenly as
+        integer division allows)."""
+        return b * self.rank // self.world, b * (self.rank + 1) // self.world
+
+    def read_losses(self, buf, lo, n):
+        """Loss slots [lo, lo+n) summed over ranks (each rank holds its rows' partial sums)."""
+        t = buf[lo:lo + n]
+        if self.world > 1:
+            import torch.distributed as dist
+            from . import dp
+            self.comm.check()
+            t = t.cpu() if dist.get_backend(self.pg) != "nccl" else t.clone()
+            dp.allreduce_sum_(t, self.pg)
+        return t.cpu().numpy()
 
     def _common_init(self, device):
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
@@ -1420,10 +1472,13 @@ class VAEEngine:
         eps_slot = self._slot(t, 1, 0, R, B * Z)
         loss_slot = self._slot(t, 1, 0, 0, 1)
         recon_out, kl_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
-        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
+        lo, hi = self._rows(b)                       # this rank's rows of the batch
+        b = hi - lo
+        ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], self.X, B=b, idx_slot=idx_slot, stream=st)
         ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
         ops.linear_fwd(self.He, ML.W, ML.b, self.ml, "id", M=b, stream=st)
-        of.vae_reparam(self.ml, self.eps_ring.view(-1), self.Zs, kl_out, b, Z, eps_slot=eps_slot,
+        eps_base = self.eps_ring.view(-1)[lo * Z:]
+        of.vae_reparam(self.ml, eps_base, self.Zs, kl_out, b, Z, eps_slot=eps_slot,
                        kl_slot=loss_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
@@ -1431,7 +1486,7 @@ class VAEEngine:
         of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
-            if self.fuse_adam:
+            if self.fuse_adam and not self._dp():
                 # Adam (weight_decay 1e-5, vae.py:139-142) folded into every dW epilogue; each dX
                 # GEMM reads a layer's weights BEFORE that layer's dW launch updates them
                 adam = dict(sched=self.sched, sched_slot=sched_slot)
@@ -1452,15 +1507,23 @@ class VAEEngine:
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
             ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
             dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
-            of.vae_reparam_bwd(self.ml, self.eps_ring.view(-1), self.dZ, self.dml, b, Z,
+            of.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
                                eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             dw2((self.dml, self.He, ML), (self.dHe, self.X, E1))
-            if not self.fuse_adam:
-                ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
-                         weight_decay=self.wd, stream=st)
+            self._optimizer_step(st, sched_slot)
         if self.use_graph:
             ops.tick(self.ctr, 1, stream=st)
+
+    def _optimizer_step(self, st, sched_slot):
+        """optimizer.step() (vae.py:162) when it is not fused into the dW epilogues: data parallel ->
+        gradient SUM over ranks + Adam in the exchange's gather kernel."""
+        if self._dp():
+            self.comm.allreduce_adam(self.fp.grad, self.fp.flat, self.fp.m, self.fp.v, self.sched, sched_slot,
+                                     weight_decay=self.wd, stream=st)
+        elif not self.fuse_adam:
+            ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
+                     weight_decay=self.wd, stream=st)
 
     def configure(self, B, n_train_steps, lr, weight_decay, resume=None):
         dev = self.device
@@ -1586,11 +1649,13 @@ class AEEngine(VAEEngine):
 
     has_eps = False
 
-    def __init__(self, model, device, use_graph=True):
+    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
+                 force_dp=False):
         self.model, self.device, self.use_graph = model, device, use_graph
         enc, dec = model.encoder, model.decoder
-        self.fp = FlatParams([enc.linear.weight, enc.linear.bias, dec.linear.weight,
-                              dec.linear.bias], device)
+        plist = [enc.linear.weight, enc.linear.bias, dec.linear.weight, dec.linear.bias]
+        self._dp_init(plist, world_size, rank, process_group, force_dp)
+        self.fp = FlatParams(plist, device, grad_alloc=self._grad_alloc)
         self.E1, self.D2 = _Linear(self.fp, enc.linear), _Linear(self.fp, dec.linear)
         self.H, self.I = enc.linear.weight.shape
         self.Z = 1                                   # dummy width of the (unused) eps ring
@@ -1611,7 +1676,9 @@ class AEEngine(VAEEngine):
         E1, D2 = self.E1, self.D2
         idx_slot = self._slot(t, 1, 0, self.R, self.B)
         loss_slot = self._slot(t, 1, 0, 0, 1)
-        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
+        lo, hi = self._rows(b)                       # this rank's rows of the batch
+        b = hi - lo
+        ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], self.X, B=b, idx_slot=idx_slot, stream=st)
         ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
         ops.linear_fwd(self.He, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
         of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
@@ -1619,15 +1686,13 @@ class AEEngine(VAEEngine):
                         stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
-            adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
+            adam = dict(sched=self.sched, sched_slot=sched_slot) if (self.fuse_adam and not self._dp()) else None
             # dH reads the decoder weights before the paired dW launch updates them
             ops.linear_bwd_dx(self.dA, D2.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             ops.linear_bwd_dw_adam_pair(dict(dA=self.dA, X=self.He, lin=D2, adam=adam, M=b),
                                         dict(dA=self.dHe, X=self.X, lin=E1, adam=adam, M=b),
                                         weight_decay=self.wd if adam is not None else 0.0, stream=st)
-            if adam is None:
-                ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
-                         weight_decay=self.wd, stream=st)
+            self._optimizer_step(st, sched_slot)
         if self.use_graph:
             ops.tick(self.ctr, 1, stream=st)
 

@@ -681,7 +681,11 @@ class VAETrainer:
             from .engine import VAEEngine
             dev = next(self.model.parameters()).device
             if self._engine is None:
-                self._engine = VAEEngine(self.model, dev, use_graph=self.use_graph)
+                from . import dp
+                world, rank, group = dp.current()
+                self._engine = VAEEngine(self.model, dev, use_graph=self.use_graph, world_size=world,
+                                         rank=rank, process_group=group,
+                                         force_dp=getattr(self, "force_dp", False))
             eng = self._engine
             eng.use_graph = self.use_graph
             B = self.train_iter.batch_size
@@ -697,9 +701,9 @@ class VAETrainer:
                 eng.run_pass(tdata, _epoch_order(self.train_iter), True, t0)
                 self.model.eval()
                 eng.run_pass(vdata, _epoch_order(self.val_iter), False, 0)
-                recon = [float(x) for x in eng.recon[t0:t0 + steps].cpu().numpy()]   # one sync
-                kl = [float(x) for x in eng.kl[t0:t0 + steps].cpu().numpy()]
-                vr, vk = eng.vrecon[:nval].cpu().numpy(), eng.vkl[:nval].cpu().numpy()
+                recon = [float(x) for x in eng.read_losses(eng.recon, t0, steps)]     # one sync
+                kl = [float(x) for x in eng.read_losses(eng.kl, t0, steps)]
+                vr, vk = eng.read_losses(eng.vrecon, 0, nval), eng.read_losses(eng.vkl, 0, nval)
                 val_loss = np.mean([float(a + b) for a, b in zip(vr, vk)])
                 self._end_epoch(epoch, num_epochs, recon, kl, val_loss, deepcopy, quiet)
             return
@@ -827,7 +831,11 @@ class AutoencoderTrainer(VAETrainer):
             from .engine import AEEngine
             dev = next(self.model.parameters()).device
             if self._engine is None:
-                self._engine = AEEngine(self.model, dev, use_graph=self.use_graph)
+                from . import dp
+                world, rank, group = dp.current()
+                self._engine = AEEngine(self.model, dev, use_graph=self.use_graph, world_size=world,
+                                        rank=rank, process_group=group,
+                                        force_dp=getattr(self, "force_dp", False))
             eng = self._engine
             eng.use_graph = self.use_graph
             steps = len(self.train_iter)
@@ -842,8 +850,8 @@ class AutoencoderTrainer(VAETrainer):
                 eng.run_pass(tdata, _epoch_order(self.train_iter), True, t0)
                 self.model.eval()
                 eng.run_pass(vdata, _epoch_order(self.val_iter), False, 0)
-                recon = [float(x) for x in eng.recon[t0:t0 + steps].cpu().numpy()]   # one sync
-                val_loss = np.mean([float(x) for x in eng.vrecon[:nval].cpu().numpy()])
+                recon = [float(x) for x in eng.read_losses(eng.recon, t0, steps)]     # one sync
+                val_loss = np.mean([float(x) for x in eng.read_losses(eng.vrecon, 0, nval)])
                 self._end_epoch_ae(epoch, num_epochs, recon, val_loss, deepcopy, quiet)
             return
         # GENERAL path (compute_batch / evaluate overridden)

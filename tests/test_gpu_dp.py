@@ -185,3 +185,69 @@ def test_two_rank_engine_equals_one_rank(variant, kw):
             assert np.max(np.abs(v - one["params"][k])) <= ptol, k
     for k, v in two[0]["params"].items():                 # replicas stay bit-identical
         assert np.array_equal(v, two[1]["params"][k]), k
+
+
+def _vae_worker(rank, world, port, kind, q):
+    dist = _init(rank, world, port) if world > 1 else None
+    if world == 1:
+        sys.path.insert(0, os.path.dirname(HERE))
+        sys.path.insert(0, SRC)
+        torch.cuda.set_device(0)
+    import contextlib
+    import io
+    from oracle import port as oport
+    cfg = SMALL
+    loaders = oport.synthetic_loaders(cfg["batch"], n_train=150, n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                      image_shape=tuple(cfg["image_shape"]))      # 150: ragged last batch of 6
+    torch.manual_seed(1234)
+    if kind == "vae":
+        import vae
+        model = vae.VAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+        tr = vae.VAETrainer(model, *loaders, viz=False)
+    else:
+        import ae
+        model = ae.Autoencoder(image_size=cfg["image_size"], hidden_dim=cfg["z_dim"])
+        tr = ae.AutoencoderTrainer(model, *loaders, viz=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=2)
+    torch.cuda.synchronize()
+    q.put(dict(rank=rank, recon=list(tr.recon_loss), kl=list(getattr(tr, "kl_loss", [])),
+               best=float(tr.best_val_loss), world=tr._engine.world,
+               params={k: v.cpu().numpy() for k, v in model.state_dict().items()},
+               rng=torch.get_rng_state().numpy().tobytes()))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["vae", "ae"])
+def test_two_rank_vae_equals_one_rank(kind):
+    """vae.py / ae.py under data parallelism: every batch's rows (incl. the ragged last one) split
+    over two ranks, gradient SUM without 1/N (the losses are sums, vae.py:203,212), per-rank loss
+    slots add up to the single-rank values."""
+    def run(world):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_vae_worker, args=(r, world, port, kind, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return out
+    one = run(1)[0]
+    two = run(2)
+    for o in two:
+        assert o["world"] == 2 and o["rng"] == one["rng"]
+        for key in ("recon", "kl"):
+            a, b = np.array(o[key]), np.array(one[key])
+            assert a.shape == b.shape
+            if a.size:
+                assert np.max(np.abs(a - b) / np.maximum(1, np.abs(b))) <= 2e-5, key
+        assert abs(o["best"] - one["best"]) <= 2e-5 * abs(one["best"])
+        for k, v in o["params"].items():
+            assert np.max(np.abs(v - one["params"][k])) <= 2e-5, k
+    for k, v in two[0]["params"].items():
+        assert np.array_equal(v, two[1]["params"][k]), k
