@@ -39,7 +39,8 @@ class HeadBwdArgs(ctypes.Structure):
                 ("with_adam", c_int), ("mW", c_void_p), ("vW", c_void_p), ("mb", c_void_p),
                 ("vb", c_void_p), ("sched", c_void_p), ("sched_slot", Slot),
                 ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
-                ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p)]
+                ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p),
+                ("gw2_add", c_void_p)]
 
 
 
@@ -113,6 +114,12 @@ _SIGNATURES = {
                                            c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
                                            POINTER(HeadBwdArgs)]),
+    "gm_linear_bwd_dw_adam_head_ex": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
+                                              c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
+                                              POINTER(HeadBwdArgs), c_int]),
+    "gm_gp_dw2_store": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
+    "gm_head_gp": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_int]),
     "gm_head_bwd_fused": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, Slot,
                                   c_float, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, Slot,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_double,

@@ -100,7 +100,7 @@ extern "C" int gm_gp_norm(void* stream, const float* g, int64_t ldg, float* gam,
 __global__ __launch_bounds__(256) void gp_dw2_kernel(const float* __restrict__ s,
                                                     const float* __restrict__ h, int64_t ldh,
                                                     const float* __restrict__ t, int64_t ldt,
-                                                    float* __restrict__ gw2, int B, int H) {
+                                                    float* __restrict__ gw2, int B, int H, int store) {
     __shared__ float sh[8][33];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
     float acc = 0.f;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gp_dw2_kernel(const float* __restrict__ s
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) v += sh[r][threadIdx.x & 31];
-        gw2[c] += v;
+        gw2[c] = store ? v : (gw2[c] + v);
     }
 }
 
@@ -121,7 +121,39 @@ extern "C" int gm_gp_dw2(void* stream, const float* s, const float* h, int64_t l
                          int64_t ldt, float* gw2, int B, int H) {
     GM_CHECK_ARG(s && h && t && gw2 && B > 0 && H > 0);
     hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, s, h,
-                       ldh, t, ldt, gw2, B, H);
+                       ldh, t, ldt, gw2, B, H, 0);
+    GM_LAUNCH_RET();
+}
+extern "C" int gm_gp_dw2_store(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
+                               int64_t ldt, float* out, int B, int H) {
+    GM_CHECK_ARG(s && h && t && out && B > 0 && H > 0);
+    hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, s, h,
+                       ldh, t, ldt, out, B, H, 1);
+    GM_LAUNCH_RET();
+}
+
+// One wave per row: the N = 1 critic layer on x_hat (a dot product, not an MFMA launch) and u.
+__global__ __launch_bounds__(256) void head_gp_kernel(const float* __restrict__ h, int64_t ldh,
+                                                     const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ s,
+                                                     float* __restrict__ u, int64_t ldu, int B, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float* hr = h + (int64_t)b * ldh;
+    float acc = 0.f;
+    for (int i = lane; i < H; i += 64) acc = fmaf(hr[i], w2[i], acc);
+    acc = gm_wave_sum(acc);
+    const float sv = fmaxf(acc + b2[0], 0.f);
+    if (lane == 0) s[b] = sv;
+    float* ur = u + (int64_t)b * ldu;
+    for (int i = lane; i < H; i += 64) ur[i] = (sv > 0.f && hr[i] > 0.f) ? w2[i] : 0.f;
+}
+extern "C" int gm_head_gp(void* stream, const float* h, int64_t ldh, const float* w2, const float* b2,
+                          float* s, float* u, int64_t ldu, int B, int H) {
+    GM_CHECK_ARG(h && w2 && b2 && s && u && B > 0 && H > 0 && ldh >= H && ldu >= H);
+    hipLaunchKernelGGL(head_gp_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, ldh, w2,
+                       b2, s, u, ldu, B, H);
     GM_LAUNCH_RET();
 }
 

@@ -59,6 +59,8 @@ struct GemmP {
     const float* aux;         // dx: output of the layer below [M,N]
     int64_t ldaux;
     float* db;                // dw: bias gradient (virtual ones column n == N_real)
+    int ones_from;            // dw: the ones column is 1 for reduction rows >= ones_from, 0 before (a
+                              //     stacked reduction whose first rows must not reach the bias gradient)
     int n_real;               // dw: number of real columns of B (N = n_real + 1 when db)
     int epi;
     int accumulate;
@@ -140,13 +142,13 @@ __device__ __forceinline__ float4 quad_transpose(float4 v, int lane) {
     return v;
 }
 
-__device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, int ones_col) {
-    const bool okx = x < X;
-    const float fill = (x == ones_col) ? 1.f : 0.f;
-    v.x = (kb + 0 < K) ? (okx ? v.x : fill) : 0.f;
-    v.y = (kb + 1 < K) ? (okx ? v.y : fill) : 0.f;
-    v.z = (kb + 2 < K) ? (okx ? v.z : fill) : 0.f;
-    v.w = (kb + 3 < K) ? (okx ? v.w : fill) : 0.f;
+__device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, int ones_col,
+                                         int ones_from = 0) {
+    const bool okx = x < X, oc = (x == ones_col);
+    v.x = (kb + 0 < K) ? (okx ? v.x : ((oc && kb + 0 >= ones_from) ? 1.f : 0.f)) : 0.f;
+    v.y = (kb + 1 < K) ? (okx ? v.y : ((oc && kb + 1 >= ones_from) ? 1.f : 0.f)) : 0.f;
+    v.z = (kb + 2 < K) ? (okx ? v.z : ((oc && kb + 2 >= ones_from) ? 1.f : 0.f)) : 0.f;
+    v.w = (kb + 3 < K) ? (okx ? v.w : ((oc && kb + 3 >= ones_from) ? 1.f : 0.f)) : 0.f;
     return v;
 }
 
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
     auto fix_b = [&](float4 v, int c) -> float4 {
         const int kb = 8 * c + 4 * h;
         if (MODE == MODE_FWD) return fix_kc(v, n0 + r, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, n0 + r, b_cols, kb, p.K, ones_col);
+        return fix_xc(XV ? quad_transpose(v, lane) : v, n0 + r, b_cols, kb, p.K, ones_col, p.ones_from);
     };
 
     f32x16 acc;
@@ -695,7 +697,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     auto fix_b = [&](float4 v, int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
         if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col);
+        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, p.ones_from);
     };
 
     f32x4 acc[MI][NI];
@@ -1132,7 +1134,7 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam, const HeadBwdP* head = nullptr);
+                   const gm_adam_epi* adam, const HeadBwdP* head = nullptr, int ones_from = 0);
 static int dw_fill(const float* dA, int64_t lda, const float* X, int64_t ldx, gm_slot x_slot,
                    float* dW, float* db, int M, int K, int N, int accumulate,
                    const gm_adam_epi* adam, GemmP* out, bool* xvec);
@@ -1165,6 +1167,17 @@ extern "C" int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t
                                           const float* sched, gm_slot sched_slot, double beta1,
                                           double beta2, double eps, double weight_decay, float clamp,
                                           const gm_head_bwd_args* head) {
+    return gm_linear_bwd_dw_adam_head_ex(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, pW, mW, vW, pb, mb,
+                                         vb, sched, sched_slot, beta1, beta2, eps, weight_decay, clamp, head, 0);
+}
+
+extern "C" int gm_linear_bwd_dw_adam_head_ex(void* stream, const float* dA, int64_t lda,
+                                             const float* X, int64_t ldx, gm_slot x_slot, float* dW,
+                                             float* db, int M, int K, int N, float* pW, float* mW,
+                                             float* vW, float* pb, float* mb, float* vb,
+                                             const float* sched, gm_slot sched_slot, double beta1,
+                                             double beta2, double eps, double weight_decay, float clamp,
+                                             const gm_head_bwd_args* head, int ones_from) {
     GM_CHECK_ARG(head);
     // sched == NULL: plain gradients (data-parallel runs all-reduce before the optimizer step)
     GM_CHECK_ARG(!sched || (db && pW && mW && vW && pb && mb && vb));
@@ -1181,7 +1194,7 @@ extern "C" int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t
         a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
         a.enabled = 1;
     }
-    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp);
+    return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp, ones_from);
 }
 
 static int dw_adam_fill(const gm_dw_adam_args& a, GemmP* p, bool* xvec) {
@@ -1218,11 +1231,13 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam, const HeadBwdP* head) {
+                   const gm_adam_epi* adam, const HeadBwdP* head, int ones_from) {
     GemmP p{};
     bool xvec = false;
     const int rc = dw_fill(dA, lda, X, ldx, x_slot, dW, db, M, K, N, accumulate, adam, &p, &xvec);
     if (rc) return rc;
+    GM_CHECK_ARG(ones_from >= 0 && ones_from <= M);
+    p.ones_from = ones_from;
     Rider r;
     r.head = head;
     return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, r);

@@ -15,6 +15,8 @@ struct HeadBwdP {
     int R, B, Hd, gen_mode;
     gm_adam_epi adam;                       // optional: Adam on (w2, b2) right here (pW=w2, pb=b2)
     int64_t* tick;                          // optional: *tick += 1 after the loss slot is written
+    const float* gw2_add;                   // optional: added to gw2 before it is stored / stepped (the
+                                            // gradient penalty's second-backward share, w_gp_gan.py:215)
 };
 
 // 16 columns x 64 row-groups per 1024-thread workgroup: 25 workgroups for Hd=400, 8 rows per thread
@@ -43,6 +45,7 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid)
         if (rg == 0 && c < p.Hd) {
             float v = 0.f;
             for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
+            if (p.gw2_add) v += p.gw2_add[c];
             p.gw2[c] = v;
             if (p.adam.enabled) {          // every thread of this block read w2[c] before the barrier
                 const int64_t si = gm_slot_index(p.adam.sched_slot);
@@ -115,6 +118,7 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out) {
         e.wd = (float)a.weight_decay; e.clamp = a.clamp; e.enabled = 1;
     }
     p.tick = a.tick;
+    p.gw2_add = a.gw2_add;
     p.H = a.H; p.ldh = a.ldh; p.dS = a.dS; p.w2 = a.w2; p.rowloss = a.rowloss; p.dH = a.dH;
     p.lddh = a.lddh; p.gw2 = a.gw2; p.gb2 = a.gb2; p.loss_out = a.loss_out;
     p.loss_slot = a.loss_slot; p.inv_b = a.inv_b; p.gen_mode = a.gen_mode; p.B = a.B;

@@ -331,14 +331,18 @@ class GANEngine:
         z = lambda *s: torch.zeros(*s, device=dev)
         # rows [0,Bl): real batch, [Bl,2Bl): G(z) of the critic step, [2Bl,3Bl): G(z) of the
         # generator step -- contiguous so that both generator forwards can be ONE 2Bl-row launch
-        self.XX = z(3 * Bl, I)
+        # WGAN-GP: the penalty's gamma rows sit right BEFORE [x ; G(zD)] (and u right before dH) so
+        # that dW1 = [u ; dH]^T [gamma ; X2] is ONE weight-gradient GEMM over 3B rows
+        self.XX4 = z(4 * Bl, I)
+        self.XX = self.XX4[Bl:]
         self.X2, self.Xg2 = self.XX[:2 * Bl], self.XX[2 * Bl:]
         self.HG = z(2 * Bl, H)
         self.Hg, self.Hg2 = self.HG[:Bl], self.HG[Bl:]
         self.Hd = z(2 * Bl, Hd)
         self.S2 = z(2 * Bl)                # scores
         self.dS = z(2 * Bl)                # d loss / d pre-activation score
-        self.dHd = z(2 * Bl, Hd)
+        self.DU = z(3 * Bl, Hd)
+        self.dHd = self.DU[Bl:]
         self.dXg = z(Bl, I)
         self.dHg = z(Bl, H)
         self.rowloss = z(2 * Bl)
@@ -347,7 +351,12 @@ class GANEngine:
         self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
         if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
-            self.U, self.Gr, self.Gam, self.T = z(Bl, Hd), z(Bl, I), z(Bl, I), z(Bl, Hd)
+            self.Gr, self.T = z(Bl, I), z(Bl, Hd)
+            if variant == "wgp":
+                self.U, self.Gam = self.DU[:Bl], self.XX4[:Bl]
+                self.gw2_pen = z(Hd)
+            else:
+                self.U, self.Gam = z(Bl, Hd), z(Bl, I)
             self.pen = z(Bl)
         if variant == "dra":
             self.da2, self.dA1, self.stdv = z(Bl), z(Bl, Hd), z(1)
@@ -392,8 +401,17 @@ class GANEngine:
         if not (self.fuse_adam and self._single()) or self.dag:
             return False
         if net == "D":
-            return self.fuse_head and self.variant not in ("ra", "fisher", "wgp", "dra")
+            return self.fuse_head and self.variant not in ("ra", "fisher", "dra") and \
+                (self.variant != "wgp" or self._wgp_stacked())
         return True
+
+    def _wgp_stacked(self):
+        """WGAN-GP critic step with the second backward folded into the first-order launches: the
+        layer-1 weight gradient as one stacked GEMM (+Adam), the w2 share added in the head's
+        backward, D(x_hat)'s head + u as one kernel."""
+        import os
+        return self.variant == "wgp" and self.fuse_head and self.group_head and not self.dag and \
+            os.environ.get("GM_WGP_STACK", "1") != "0"
 
     def _slot(self, it, mul, add, ring, stride, post=False):
         """Graph mode: resolved on device from the counter; eager mode: resolved here.
@@ -543,11 +561,16 @@ class GANEngine:
             if self.group_head and not self.dag:
                 # head backward + first-layer weight gradient (+ both Adam steps when they are
                 # fused: one GPU, nothing accumulates into these gradients later): ONE launch
-                ops.linear_bwd_dw_adam_head(
-                    dHd, X2, D1, adam,
-                    dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
-                         loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam),
-                    M=2 * Bl, stream=st)
+                head = dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
+                            loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam)
+                if self._wgp_stacked():
+                    # dW1 = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows (the penalty rows do not reach
+                    # db1), gw2 += the penalty's share (computed by _issue_gp_forward)
+                    head["gw2_add"] = self.gw2_pen
+                    ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
+                                                stream=st)
+                else:
+                    ops.linear_bwd_dw_adam_head(dHd, X2, D1, adam, head, M=2 * Bl, stream=st)
                 grouped = True
             else:
                 of.head_bwd(Hd, dS, D2.W, self.rowloss, None, D2.gW, D2.gb, self.lossD, loss_slot,
@@ -581,7 +604,7 @@ class GANEngine:
                                    M=2 * Bl, stream=st)
         else:
             ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
-        if self.variant == "wgp":
+        if self.variant == "wgp" and not self._wgp_stacked():
             self._issue_gp_backward(st)
         if self.variant == "dra":
             self._issue_dra_backward(st)
@@ -786,10 +809,18 @@ class GANEngine:
         ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
                       stream=st)
         ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
-        ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "relu", M=Bl, stream=st)
-        ops_gp.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)                  # u = m2*(m1.w2)
+        if self._wgp_stacked():
+            ops_gp.head_gp(self.Hh, D2.W, D2.b, self.Sh, self.U, stream=st)     # D(x_hat), u: one launch
+        else:
+            ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "relu", M=Bl, stream=st)
+            ops_gp.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)              # u = m2*(m1.w2)
         ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                # g = u W1
         ops_gp.gp_norm(self.Gr, self.Gam, self.pen, self.gp_lambda, self.inv_b, stream=st)
+        if self._wgp_stacked():
+            # second backward, w2's share, BEFORE the stacked dW1 launch steps W1:
+            # t = gamma W1^T, gw2_pen = sum_b m2 m1 . t   (w_gp_gan.py:215)
+            ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)
+            ops_gp.gp_dw2_store(self.Sh, self.Hh, self.T, self.gw2_pen, stream=st)
 
     # -- DRAGAN penalty: dra_gan.py:198-223; sigmoid critic => second-order terms --
     def _issue_dra_forward(self, st, it, j):

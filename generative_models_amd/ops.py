@@ -147,6 +147,8 @@ def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
     a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, 0.0
     tick = head.get("tick")
     a.tick = tick.data_ptr() if tick is not None else None
+    add = head.get("gw2_add")
+    a.gw2_add = add.data_ptr() if add is not None else None
     return a
 
 
@@ -165,26 +167,27 @@ def linear_bwd_dx_head(dA, W, dX, head, below=None, epi="id", M=None, stream=Non
 
 
 def linear_bwd_dw_adam_head(dA, X, lin, adam, head, M=None, x_slot=NO_SLOT, betas=(0.9, 0.999),
-                            eps=1e-8, weight_decay=0.0, stream=None):
+                            eps=1e-8, weight_decay=0.0, ones_from=0, stream=None):
     """linear_bwd_dw_adam and the critic head's backward (ops_fused.head_bwd with Adam on the head
     layer) as ONE launch.  head: dict(H, dS, lin (head _Linear), rowloss, loss_out, loss_slot,
-    inv_b, B, adam (dict(sched, sched_slot, clamp))); dH must already be written by head_fwd_loss."""
+    inv_b, B, adam (dict(sched, sched_slot, clamp)), gw2_add=None); dH must already be written by
+    head_fwd_loss.  ones_from: the first rows of the (stacked) reduction that do not reach db."""
     import ctypes
     N, K = lin.gW.shape
     M = dA.shape[0] if M is None else M
     a = _head_args(head, betas, eps)
     if adam is None:                            # plain gradients (the head's dict has adam=None too)
-        _lib.call("gm_linear_bwd_dw_adam_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
+        _lib.call("gm_linear_bwd_dw_adam_head_ex", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
                   _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
                   lin.gb.data_ptr(), M, K, N, None, None, None, None, None, None, None, NO_SLOT,
-                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a))
+                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a), ones_from)
         return
-    _lib.call("gm_linear_bwd_dw_adam_head", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
+    _lib.call("gm_linear_bwd_dw_adam_head_ex", stream or stream_ptr(), _chk(dA, "dA").data_ptr(),
               _ld(dA), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
               lin.gb.data_ptr(), M, K, N, lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(),
               lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr(), adam["sched"].data_ptr(),
               adam["sched_slot"], betas[0], betas[1], eps, weight_decay, adam.get("clamp", 0.0),
-              ctypes.byref(a))
+              ctypes.byref(a), ones_from)
 
 
 def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):

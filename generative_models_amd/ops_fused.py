@@ -31,6 +31,20 @@ def gp_dw2(s, h, t, gw2, stream=None):
               _ld(t), gw2.data_ptr(), B, H)
 
 
+def gp_dw2_store(s, h, t, out, stream=None):
+    """out[n] = sum_b [s_b>0][h[b,n]>0] t[b,n] (gp_dw2 without the accumulation)."""
+    B, H = h.shape
+    _lib.call("gm_gp_dw2_store", stream or stream_ptr(), s.data_ptr(), h.data_ptr(), _ld(h), t.data_ptr(),
+              _ld(t), out.data_ptr(), B, H)
+
+
+def head_gp(h, w2, b2, s, u, stream=None):
+    """D(x_hat)'s N = 1 layer + the seed of the input gradient in one launch (w_gp_gan.py:202-212)."""
+    B, H = u.shape
+    _lib.call("gm_head_gp", stream or stream_ptr(), h.data_ptr(), _ld(h), w2.data_ptr(), b2.data_ptr(),
+              s.data_ptr(), u.data_ptr(), _ld(u), B, H)
+
+
 def vae_reparam(ml, eps, z, kl_out, B, Z, eps_slot=NO_SLOT, kl_slot=NO_SLOT, stream=None):
     _lib.call("gm_vae_reparam", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
               eps_slot, z.data_ptr(), _ld(z), kl_out.data_ptr(), kl_slot, B, Z)

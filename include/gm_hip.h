@@ -149,6 +149,14 @@ int gm_gp_norm(void* stream, const float* g, int64_t ldg, float* gamma, int64_t 
  * is gm_linear_bwd_dw(u, gamma, accumulate) and t = gamma*W1^T is gm_linear_fwd). */
 int gm_gp_dw2(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
               int64_t ldt, float* gw2, int B, int H);
+/* same, STORING the sum (out[n] = ...) instead of accumulating */
+int gm_gp_dw2_store(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
+                    int64_t ldt, float* out, int B, int H);
+/* K10 prologue in one launch: the critic's N = 1 output layer on x_hat and the vector the input
+ * gradient starts from -- s[b] = relu(h[b,:].w2 + b2), u[b,n] = [s_b>0][h[b,n]>0] w2[n]
+ * (w_gp_gan.py:202-212: D(x_hat) and autograd.grad's seed through the ReLU critic). */
+int gm_head_gp(void* stream, const float* h, int64_t ldh, const float* w2, const float* b2, float* s,
+               float* u, int64_t ldu, int B, int H);
 
 /* ---- K14: VAE.  ml = [mu | log_var] (B x 2Z, the two encoder heads packed side by side).
  * reparam: z = mu + eps*exp(lv/2) (vae.py:100-106), kl_out[slot] = sum 0.5*(mu^2+exp(lv)-lv-1)
@@ -236,6 +244,7 @@ typedef struct gm_head_bwd_args {
     const float* sched; gm_slot sched_slot;
     double beta1, beta2, eps, weight_decay; float clamp;
     int64_t* tick;
+    const float* gw2_add;                 /* optional [Hd]: added to gw2 before it is stored / stepped */
 } gm_head_bwd_args;
 int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const float* X,
                                int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
@@ -243,6 +252,15 @@ int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const
                                const float* sched, gm_slot sched_slot, double beta1, double beta2,
                                double eps, double weight_decay, float clamp,
                                const gm_head_bwd_args* head);
+/* Same with a STACKED reduction: the first `ones_from` rows of dA / X contribute to dW but not to db
+ * (WGAN-GP, w_gp_gan.py:207-218: dW1 = [u ; dH]^T [gamma ; X] in one GEMM -- the penalty's second
+ * backward has no bias term). */
+int gm_linear_bwd_dw_adam_head_ex(void* stream, const float* dA, int64_t lda, const float* X,
+                                  int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
+                                  float* pW, float* mW, float* vW, float* pb, float* mb, float* vb,
+                                  const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                                  double eps, double weight_decay, float clamp,
+                                  const gm_head_bwd_args* head, int ones_from);
 /* gm_linear_bwd_dx carrying the head's backward workgroups (generator step: the single scalar
  * workgroup that writes the loss and ticks the iteration counter). */
 int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W, float* dX,

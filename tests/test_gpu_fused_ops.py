@@ -203,3 +203,44 @@ def test_dragan_penalty_chain_vs_autograd():
     assert rel(gb1.cpu(), db1) < 2e-5
     assert rel(gw2.cpu(), dw2) < 2e-5
     assert rel(gb2.cpu(), db2) < 2e-5
+
+
+def test_head_gp_and_stacked_weight_gradient():
+    """The fused WGAN-GP critic step's building blocks: gm_head_gp (D(x_hat)'s N = 1 layer + u in one
+    launch) == linear + relu + gp_u; gm_gp_dw2_store == gp_dw2 on a zeroed buffer; the stacked
+    weight-gradient GEMM [u ; dH]^T [gamma ; X] with ones_from == the two separate GEMMs, and its
+    bias gradient only sees the dH rows."""
+    torch.manual_seed(6)
+    B, I, H = 48, 100, 72
+    h = torch.relu(torch.randn(B, H)).to(DEV)
+    w2, b2 = (torch.randn(1, H) / H ** 0.5).to(DEV), torch.tensor([0.05], device=DEV)
+    s, u = torch.empty(B, device=DEV), torch.empty(B, H, device=DEV)
+    of.head_gp(h, w2, b2, s, u)
+    s_ref = torch.relu(h.double() @ w2.double().t() + b2.double()).view(-1)
+    assert rel(s.cpu(), s_ref.cpu()) < 2e-6
+    u_ref = (s_ref[:, None] > 0).double() * (h.double() > 0).double() * w2.double()
+    assert torch.equal(u.cpu().double(), u_ref.cpu())
+    t = torch.randn(B, H, device=DEV)
+    a, b = torch.zeros(1, H, device=DEV), torch.full((1, H), 7.0, device=DEV)
+    of.gp_dw2(s, h, t, a)
+    of.gp_dw2_store(s, h, t, b)
+    assert torch.equal(a, b)
+    # stacked dW: rows [0, B) = (u, gamma) penalty rows, rows [B, 3B) = (dH, X) first-order rows
+    from types import SimpleNamespace
+    gam, X = torch.randn(B, I, device=DEV), torch.rand(2 * B, I, device=DEV)
+    dH = torch.randn(2 * B, H, device=DEV) * 0.1
+    DU, XX = torch.cat([u, dH]).contiguous(), torch.cat([gam, X]).contiguous()
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    lin = SimpleNamespace(W=z(H, I), b=z(H), gW=z(H, I), gb=z(H), mW=z(H * I), vW=z(H * I), mb=z(H), vb=z(H))
+    head_lin = SimpleNamespace(W=w2.clone(), b=b2.clone(), gW=z(1, H), gb=z(1), mW=z(H), vW=z(H), mb=z(1), vb=z(1))
+    dS, rl, lo = torch.randn(2 * B, device=DEV) / B, torch.rand(2 * B, device=DEV), z(1)
+    Hd = torch.relu(torch.randn(2 * B, H, device=DEV))
+    add = torch.randn(H, device=DEV)
+    head = dict(H=Hd, dS=dS, lin=head_lin, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT, inv_b=1.0 / B,
+                B=B, adam=None, gw2_add=add)
+    ops.linear_bwd_dw_adam_head(DU, XX, lin, None, head, M=3 * B, ones_from=B)
+    gW_ref = u.double().t() @ gam.double() + dH.double().t() @ X.double()
+    assert rel(lin.gW.cpu(), gW_ref.cpu()) < 2e-6
+    assert rel(lin.gb.cpu(), dH.double().sum(0).cpu()) < 2e-6          # no bias share from the u rows
+    gw2_ref = dS.double() @ Hd.double() + add.double()
+    assert rel(head_lin.gW.view(-1).cpu(), gw2_ref.cpu()) < 2e-6
