@@ -107,6 +107,9 @@ _SIGNATURES = {
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
     "gm_linear_fwd_gather": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
                                      c_int, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
+    "gm_linear_fwd_gather_bits": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
+                                          c_int, _P, c_int, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
+    "gm_gather_rows_bits": (c_int, [_P, _P, c_int, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
     "gm_linear_bwd_dx_head": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                       c_int, c_int, POINTER(HeadBwdArgs)]),
     "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),

@@ -10,6 +10,11 @@ struct GatherP {
     const int64_t* idx; gm_slot idx_slot;
     float* out; int64_t ld_out;
     int B, row_elems, vec;
+    // bit-packed resident dataset (utils.py:31 binarises MNIST, so a pixel is
+    // one bit): row r = words[r * wpr .. ), pixel i = bit (i & 31) of word i >> 5.  98 B/row instead
+    // of 3136 B: the one batch-proportional HBM read stream of the step shrinks 32x; the gather
+    // expands to the fp32 rows the GEMMs consume.
+    const uint32_t* bits; int wpr;
 };
 
 // bid: index among the gather workgroups; every workgroup has blockDim.x / 64 waves = rows.
@@ -21,8 +26,22 @@ static __device__ __forceinline__ void gather_body(const GatherP& p, int bid) {
     if (b >= p.B) return;
     int64_t r = ix[b];
     if (r < 0 || r >= p.n_rows) r = 0;     // never fault on a corrupt index; parity tests catch it
-    const float* src = p.data + r * (int64_t)p.row_elems;
     float* dst = p.out + (int64_t)b * p.ld_out;
+    if (p.bits) {
+        const uint32_t* w = p.bits + r * (int64_t)p.wpr;
+        if (p.vec) {                        // 4 pixels = 4 bits of one word (row_elems % 4 == 0)
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int q = lane; q < (p.row_elems >> 2); q += 64) {
+                const uint32_t v = w[q >> 3] >> (4 * (q & 7));
+                d4[q] = make_float4((float)(v & 1u), (float)((v >> 1) & 1u), (float)((v >> 2) & 1u),
+                                    (float)((v >> 3) & 1u));
+            }
+        } else {
+            for (int i = lane; i < p.row_elems; i += 64) dst[i] = (float)((w[i >> 5] >> (i & 31)) & 1u);
+        }
+        return;
+    }
+    const float* src = p.data + r * (int64_t)p.row_elems;
     if (p.vec) {
         const int n4 = p.row_elems >> 2;
         const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -50,5 +69,19 @@ static inline int gm_gather_fill(const float* data, int64_t n_rows, const int64_
     g->vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) &&
              ((reinterpret_cast<uintptr_t>(data) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    g->bits = nullptr; g->wpr = 0;
+    return 0;
+}
+
+// `data` is really the bit-packed dataset (see GatherP): words_per_row uint32 per row
+static inline int gm_gather_fill_bits(const uint32_t* bits, int words_per_row, int64_t n_rows,
+                                      const int64_t* idx, gm_slot idx_slot, float* out, int64_t ld_out,
+                                      int B, int row_elems, GatherP* g) {
+    GM_CHECK_ARG(bits && idx && out && B > 0 && row_elems > 0 && ld_out >= row_elems && n_rows > 0);
+    GM_CHECK_ARG(words_per_row * 32 >= row_elems);
+    g->data = nullptr; g->n_rows = n_rows; g->idx = idx; g->idx_slot = idx_slot; g->out = out;
+    g->ld_out = ld_out; g->B = B; g->row_elems = row_elems;
+    g->vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    g->bits = bits; g->wpr = words_per_row;
     return 0;
 }

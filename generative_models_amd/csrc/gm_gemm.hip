@@ -1060,16 +1060,37 @@ extern "C" int gm_linear_fwd(void* stream, const float* X, int64_t ldx, gm_slot 
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);
 }
 
+static int fwd_gather_impl(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                           const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                           int K, int N, int act, const GatherP& g, float* out);
+
 extern "C" int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
                                     const float* W, const float* bias, float* Y, int64_t ldy, int M,
                                     int K, int N, int act, const float* data, int64_t n_rows,
                                     const int64_t* idx, gm_slot idx_slot, float* out,
                                     int64_t ld_out, int B, int row_elems) {
-    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
-    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
     GatherP g{};
     const int rc = gm_gather_fill(data, n_rows, idx, idx_slot, out, ld_out, B, row_elems, &g);
     if (rc) return rc;
+    return fwd_gather_impl(stream, X, ldx, x_slot, W, bias, Y, ldy, M, K, N, act, g, out);
+}
+
+extern "C" int gm_linear_fwd_gather_bits(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                         const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                         int K, int N, int act, const uint32_t* bits, int words_per_row,
+                                         int64_t n_rows, const int64_t* idx, gm_slot idx_slot, float* out,
+                                         int64_t ld_out, int B, int row_elems) {
+    GatherP g{};
+    const int rc = gm_gather_fill_bits(bits, words_per_row, n_rows, idx, idx_slot, out, ld_out, B, row_elems, &g);
+    if (rc) return rc;
+    return fwd_gather_impl(stream, X, ldx, x_slot, W, bias, Y, ldy, M, K, N, act, g, out);
+}
+
+static int fwd_gather_impl(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                           const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                           int K, int N, int act, const GatherP& g, float* out) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
     // the gathered rows must not be an operand or the output of this GEMM
     GM_CHECK_ARG(out != Y && out != X);
     GemmP p{};

@@ -283,7 +283,13 @@ class GANEngine:
         self.world, self.rank, self.pg = world_size, rank, process_group
         assert B % world_size == 0, "global batch must divide across ranks"
         self.Bl = B // world_size          # rows this rank computes
-        self.data = data                   # [N, I] fp32 on device
+        # resident dataset [N, I]: 1 bit per pixel when it is binary (the reference's MNIST is,
+        # utils.py:31; GM_PACKED=0 keeps fp32 rows), else fp32
+        import os as _os
+        if not isinstance(data, ops.PackedData) and _os.environ.get("GM_PACKED", "1") != "0" \
+                and ops.PackedData.is_binary(data):
+            data = ops.PackedData(data)
+        self.data = data
         self.N, self.I = data.shape
         G, D = model.G, model.D
         import os

@@ -92,6 +92,12 @@ def linear_fwd_gather(x, W, b, y, act, data, idx, out, M=None, B=None, x_slot=NO
     M = x.shape[0] if M is None else M
     n_rows, row = data.shape
     B = out.shape[0] if B is None else B
+    if isinstance(data, PackedData):                 # 1 bit / pixel resident dataset
+        _lib.call("gm_linear_fwd_gather_bits", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
+                  x_slot, _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
+                  _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act], data.data_ptr(), data.wpr,
+                  n_rows, idx.data_ptr(), idx_slot, out.data_ptr(), _ld(out), B, row)
+        return y
     _lib.call("gm_linear_fwd_gather", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
               x_slot, _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
               _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act], _chk(data, "data").data_ptr(),
@@ -190,11 +196,47 @@ def linear_bwd_dw_adam_head(dA, X, lin, adam, head, M=None, x_slot=NO_SLOT, beta
               ctypes.byref(a), ones_from)
 
 
+class PackedData:
+    """Device-resident dataset at 1 bit per pixel.  utils.py:31,34 binarises
+    MNIST with torch.bernoulli, so every pixel is exactly 0.0 or 1.0: a row of 784 pixels is 25
+    uint32 words (100 B) instead of 3136 B.  The gather kernels expand the selected rows back to the
+    fp32 rows the GEMMs read; nothing else ever touches the dataset."""
+
+    def __init__(self, images_2d):
+        """images_2d: [N, I] tensor (any device) holding only 0.0 / 1.0."""
+        x = images_2d.detach()
+        self.shape = tuple(x.shape)
+        n, i = self.shape
+        self.wpr = (i + 31) // 32
+        b = (x.to("cpu") != 0).numpy()
+        packed = np.packbits(b, axis=1, bitorder="little")            # pixel i -> bit (i & 7) of byte i >> 3
+        pad = self.wpr * 4 - packed.shape[1]
+        if pad:
+            packed = np.concatenate([packed, np.zeros((n, pad), dtype=np.uint8)], axis=1)
+        words = np.ascontiguousarray(packed).view("<u4")              # little-endian: pixel i = bit i & 31
+        dev = images_2d.device if images_2d.is_cuda else torch.device("cuda")
+        self.bits = torch.from_numpy(words.view(np.int32).copy()).to(dev)
+
+    @staticmethod
+    def is_binary(images):
+        return bool(((images == 0) | (images == 1)).all())
+
+    def data_ptr(self):
+        return self.bits.data_ptr()
+
+    def nbytes(self):
+        return self.bits.numel() * 4
+
+
 def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
-    """out[b,:] = data[idx[b],:]  (process_batch, ns_gan.py:222-226)."""
+    """out[b,:] = data[idx[b],:]  (process_batch, ns_gan.py:222-226).  data: fp32 [N, I] or PackedData."""
     n_rows, row = data.shape
     B = out.shape[0] if B is None else B
     assert idx.dtype == torch.int64 and idx.is_cuda
+    if isinstance(data, PackedData):
+        _lib.call("gm_gather_rows_bits", stream or stream_ptr(), data.data_ptr(), data.wpr, n_rows,
+                  idx.data_ptr(), idx_slot, out.data_ptr(), _ld(out), B, row)
+        return out
     _lib.call("gm_gather_rows", stream or stream_ptr(), data.data_ptr(), n_rows, idx.data_ptr(),
               idx_slot, out.data_ptr(), _ld(out), B, row)
     return out

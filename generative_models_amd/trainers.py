@@ -667,9 +667,14 @@ class VAETrainer:
         cache = self.__dict__.setdefault("_data_cache", {})
         key = id(loader.dataset)
         if key not in cache:
+            import os
             imgs = loader.dataset.tensors[0]
             dev = next(self.model.parameters()).device
-            cache[key] = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
+            flat = imgs.reshape(imgs.shape[0], -1)
+            if os.environ.get("GM_PACKED", "1") != "0" and ops.PackedData.is_binary(flat):
+                cache[key] = ops.PackedData(flat.to(dev))        # 1 bit / pixel
+            else:
+                cache[key] = flat.to(dev, torch.float32).contiguous()
         return cache[key]
 
     def train(self, num_epochs, lr=1e-3, weight_decay=1e-5, quiet=False):

@@ -273,6 +273,15 @@ int gm_linear_fwd_gather(void* stream, const float* X, int64_t ldx, gm_slot x_sl
                          const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
                          const float* data, int64_t n_rows, const int64_t* idx, gm_slot idx_slot,
                          float* out, int64_t ld_out, int B, int row_elems);
+/* Same with the BIT-PACKED resident dataset (utils.py:31 binarises MNIST): row r
+ * = bits[r*words_per_row ...], pixel i = bit (i & 31) of word i >> 5; the gather expands to fp32 rows. */
+int gm_linear_fwd_gather_bits(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                              const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                              const uint32_t* bits, int words_per_row, int64_t n_rows, const int64_t* idx,
+                              gm_slot idx_slot, float* out, int64_t ld_out, int B, int row_elems);
+int gm_gather_rows_bits(void* stream, const uint32_t* bits, int words_per_row, int64_t n_rows,
+                        const int64_t* idx, gm_slot idx_slot, float* out, int64_t ld_out, int B,
+                        int row_elems);
 /* Two gm_linear_bwd_dw_adam calls over the same batch rows as ONE launch (the generator step's two
  * weight gradients are independent once d loss / d hidden is known).  Falls back to two launches
  * when the pair cannot share a tile configuration.  sched == NULL in an argument block: plain

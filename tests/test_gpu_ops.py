@@ -554,3 +554,29 @@ def test_dx_with_scalar_head_riding(B, I, Hd):
     torch.cuda.synchronize()
     assert ctr.item() == 2
     assert torch.equal(dX, dX_ref) and torch.equal(loss, ref_loss) and loss[1].item() != 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# Bit-packed resident dataset (utils.py:31 binarises MNIST): the gather from
+# 1 bit / pixel rows must equal the gather from the fp32 rows, on its own and riding in a GEMM launch
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,I,B", [(500, 784, 256), (77, 64, 16), (40, 100, 24), (33, 37, 9)])
+def test_packed_dataset_gather_equals_fp32_gather(N, I, B):
+    torch.manual_seed(N + I)
+    data = torch.bernoulli(torch.full((N, I), 0.3)).cuda()
+    packed = ops.PackedData(data)
+    assert packed.shape == (N, I) and packed.wpr == (I + 31) // 32
+    assert packed.nbytes() * 8 < data.numel() * 4 or I < 32        # ~32x smaller
+    idx = torch.randint(0, N, (B,), device="cuda")
+    a, b = torch.empty(B, I, device="cuda"), torch.full((B, I), -1.0, device="cuda")
+    ops.gather_rows(data, idx, a)
+    ops.gather_rows(packed, idx, b)
+    assert torch.equal(a, data[idx]) and torch.equal(b, a)
+    # riding in the generator's first forward launch (engine: gm_linear_fwd_gather_bits)
+    x, W, bias = torch.randn(2 * B, 20, device="cuda"), torch.randn(48, 20, device="cuda"), torch.zeros(48, device="cuda")
+    y1, y2 = torch.empty(2 * B, 48, device="cuda"), torch.empty(2 * B, 48, device="cuda")
+    o1, o2 = torch.empty(B, I, device="cuda"), torch.full((B, I), -1.0, device="cuda")
+    ops.linear_fwd_gather(x, W, bias, y1, "relu", data, idx, o1)
+    ops.linear_fwd_gather(x, W, bias, y2, "relu", packed, idx, o2)
+    assert torch.equal(y1, y2) and torch.equal(o1, o2) and torch.equal(o2, data[idx])
+    assert not ops.PackedData.is_binary(torch.rand(4, 4))

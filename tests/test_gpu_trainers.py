@@ -181,6 +181,20 @@ def test_eager_equals_graph():
         assert torch.equal(x, y), k
 
 
+def test_fp32_resident_dataset_equals_bit_packed(monkeypatch):
+    """GM_PACKED=0 keeps the dataset as fp32 rows (3136 B/row); the default packs a binary dataset to
+    1 bit/pixel.  Same batches either way -> bitwise the same run."""
+    a = run_product("ns", SMALL, 16, dict(num_epochs=2))
+    from generative_models_amd import ops
+    assert isinstance(a[0]._engine.data, ops.PackedData)
+    monkeypatch.setenv("GM_PACKED", "0")
+    b = run_product("ns", SMALL, 16, dict(num_epochs=2))
+    assert torch.is_tensor(b[0]._engine.data)
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
+
+
 def test_run_to_run_determinism():
     a = run_product("ls", SMALL, 16, dict(num_epochs=1))
     b = run_product("ls", SMALL, 16, dict(num_epochs=1))
