@@ -97,6 +97,8 @@ _SIGNATURES = {
     "gm_gp_norm": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_float, c_float, c_float, c_int,
                            c_int]),
     "gm_gp_dw2": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
+    "gm_bir_reparam": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
+    "gm_bir_mmd": (c_int, [_P, _P, c_int64, _P, Slot, _P, _P, c_int64, c_int, c_int, c_float]),
     "gm_vae_reparam": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, Slot, c_int, c_int]),
     "gm_vae_reparam_bwd": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int64, c_int,
                                    c_int]),

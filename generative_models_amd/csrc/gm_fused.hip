@@ -158,6 +158,88 @@ extern "C" int gm_head_gp(void* stream, const float* h, int64_t ldh, const float
 }
 
 // ------------------------------------------------------------------------------------------
+// BIR-VAE (bir_vae.py:86-97, 180-221).
+//   reparameterize: z = mu + eps, eps ~ N(0, set_var) drawn by the HOST from numpy's global RNG
+//   maximum_mean_discrepancy: k(a,b) = exp(-mean_d((a-b)^2)/dim) = exp(-|a-b|^2/dim^2);
+//     mmd = sum_ij k(x_i,x_j) + sum_ij k(z_i,z_j) - 2 sum_ij k(x_i,z_j),  x = torch.randn(z.shape)
+//   One wave per latent row m: partial[m] = sum_j k(x_m,x_j) + sum_j k(z_m,z_j) - 2 sum_i k(x_i,z_m)
+//   and d(lambda*mmd)/dz_m = lambda*(4/dim^2) * [sum_i k(x_i,z_m)(z_m-x_i) - sum_j k(z_m,z_j)(z_m-z_j)]
+//   (the z-z term appears twice in the double sum: once through each argument).  O(B^2 Z) work,
+//   26 MFLOP at B=256, Z=20: a latency-sized kernel, not a GEMM.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bir_reparam_kernel(const float* __restrict__ mu, int64_t ldmu,
+                                                         const float* __restrict__ eps, gm_slot eps_slot,
+                                                         float* __restrict__ z, int64_t ldz, int B, int Z) {
+    const float* e = eps + gm_slot_offset(eps_slot);
+    const int64_t n = (int64_t)B * Z, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int b = (int)(i / Z), c = (int)(i % Z);
+        z[(int64_t)b * ldz + c] = mu[(int64_t)b * ldmu + c] + e[i];
+    }
+}
+extern "C" int gm_bir_reparam(void* stream, const float* mu, int64_t ldmu, const float* eps,
+                              gm_slot eps_slot, float* z, int64_t ldz, int B, int Z) {
+    GM_CHECK_ARG(mu && eps && z && B > 0 && Z > 0 && ldmu >= Z && ldz >= Z);
+    int blocks = (int)(((int64_t)B * Z + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(bir_reparam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mu, ldmu, eps,
+                       eps_slot, z, ldz, B, Z);
+    GM_LAUNCH_RET();
+}
+
+constexpr int BIR_MAXZ = 64;
+__global__ __launch_bounds__(256) void bir_mmd_kernel(const float* __restrict__ z, int64_t ldz,
+                                                     const float* __restrict__ prior, gm_slot prior_slot,
+                                                     float* __restrict__ partial, float* __restrict__ dz,
+                                                     int64_t lddz, int B, int Z, float lambda) {
+    const float* x = prior + gm_slot_offset(prior_slot);          // [B, Z] contiguous
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= B) return;
+    const float inv_d = 1.0f / (float)Z;
+    float zm[BIR_MAXZ], xm[BIR_MAXZ], g[BIR_MAXZ];
+#pragma unroll 4
+    for (int d = 0; d < Z; ++d) { zm[d] = z[(int64_t)m * ldz + d]; xm[d] = x[(int64_t)m * Z + d]; g[d] = 0.f; }
+    float s_xx = 0.f, s_zz = 0.f, s_xz = 0.f;
+    for (int j = lane; j < B; j += 64) {
+        const float* zj = z + (int64_t)j * ldz;
+        const float* xj = x + (int64_t)j * Z;
+        float dxx = 0.f, dzz = 0.f, dxz = 0.f;
+        for (int d = 0; d < Z; ++d) {
+            const float a = xm[d] - xj[d], b = zm[d] - zj[d], c = xj[d] - zm[d];
+            dxx += a * a; dzz += b * b; dxz += c * c;
+        }
+        // torch: mean over dim (sum * 1/dim ... as a division), then div by dim, exp(-.)
+        const float kxx = expf(-((dxx / (float)Z) / (float)Z));
+        const float kzz = expf(-((dzz / (float)Z) / (float)Z));
+        const float kxz = expf(-((dxz / (float)Z) / (float)Z));
+        s_xx += kxx; s_zz += kzz; s_xz += kxz;
+        if (dz) {
+            for (int d = 0; d < Z; ++d) g[d] += kxz * (zm[d] - xj[d]) - kzz * (zm[d] - zj[d]);
+        }
+    }
+    (void)inv_d;
+    // the three sums are O(B) each and nearly cancel: combine them in double
+    const double t_xx = gm_wave_sum_d((double)s_xx), t_zz = gm_wave_sum_d((double)s_zz),
+                 t_xz = gm_wave_sum_d((double)s_xz);
+    if (lane == 0) partial[m] = (float)((t_xx + t_zz) - 2.0 * t_xz);
+    if (dz) {
+        const float coef = lambda * (4.0f / ((float)Z * (float)Z));
+        for (int d = 0; d < Z; ++d) {
+            const float t = gm_wave_sum(g[d]);
+            if (lane == 0) dz[(int64_t)m * lddz + d] = coef * t;
+        }
+    }
+}
+extern "C" int gm_bir_mmd(void* stream, const float* z, int64_t ldz, const float* prior, gm_slot prior_slot,
+                          float* partial, float* dz, int64_t lddz, int B, int Z, float lambda) {
+    GM_CHECK_ARG(z && prior && partial && B > 0 && Z > 0 && Z <= BIR_MAXZ && ldz >= Z && (!dz || lddz >= Z));
+    hipLaunchKernelGGL(bir_mmd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, ldz, prior,
+                       prior_slot, partial, dz, lddz, B, Z, lambda);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
 // K14a VAE reparameterise + KL  (vae.py:100-106, 210-212).  ml = [mu | log_var] (B x 2Z).
 //   z = mu + eps*exp(lv/2);  kl = sum 0.5*(mu^2 + exp(lv) - lv - 1)
 //   kl gradient seeds: dml_kl = [mu | 0.5*(exp(lv) - 1)]

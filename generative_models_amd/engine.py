@@ -1632,25 +1632,10 @@ class VAEEngine:
             lo = done * B
             hi = min(n, lo + cnt * B)
             s["idx"].view(-1)[:hi - lo].copy_(perm[lo:hi])    # rows of B indices, last one ragged
-            if self.has_eps:
-                # torch.randn(mu.shape) per batch (vae.py:104): the full batches of the chunk in
-                # one C call (HostReplay), a ragged last batch on its own
-                nfull = sum(1 for b in sizes if b == B)
-                from ._lib import DRAW_NORMAL
-                replay = HostReplay.available() and B * Z >= 16
-                if replay and nfull:
-                    replay = HostReplay.run([HostReplay.op(DRAW_NORMAL, B * Z, s["eps"], B * Z * 4)], nfull)
-                for k, b in enumerate(sizes):
-                    if replay and b == B:
-                        continue
-                    if replay and b * Z >= 16 and HostReplay.run(
-                            [HostReplay.op(DRAW_NORMAL, b * Z, s["eps"][k], 0)], 1):
-                        continue
-                    s["eps"][k].view(-1)[:b * Z].normal_()
+            self._draw_chunk(s, sizes)
             r = t % R
             self.idx_ring[r:r + cnt].copy_(s["idx"][:cnt], non_blocking=True)
-            if self.has_eps:
-                self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
+            self._upload_chunk(s, r, cnt)
             ev = torch.cuda.Event()
             ev.record()
             s["event"] = ev
@@ -1672,6 +1657,31 @@ class VAEEngine:
                     k += 1
             done += cnt
         return nb
+
+    def _torch_normal_rows(self, dst, sizes):
+        """torch.randn(b, Z) per batch of the chunk (global CPU generator, in order) into dst[k]: the
+        full batches in one C call (HostReplay), a ragged last batch on its own."""
+        B, Z = self.B, self.Z
+        nfull = sum(1 for b in sizes if b == B)
+        from ._lib import DRAW_NORMAL
+        replay = HostReplay.available() and B * Z >= 16
+        if replay and nfull:
+            replay = HostReplay.run([HostReplay.op(DRAW_NORMAL, B * Z, dst, B * Z * 4)], nfull)
+        for k, b in enumerate(sizes):
+            if replay and b == B:
+                continue
+            if replay and b * Z >= 16 and HostReplay.run([HostReplay.op(DRAW_NORMAL, b * Z, dst[k], 0)], 1):
+                continue
+            dst[k].view(-1)[:b * Z].normal_()
+
+    def _draw_chunk(self, s, sizes):
+        """HOST draws of the chunk's batches, in the reference's order (vae.py:104)."""
+        if self.has_eps:
+            self._torch_normal_rows(s["eps"], sizes)
+
+    def _upload_chunk(self, s, r, cnt):
+        if self.has_eps:
+            self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
 
     def alloc_val(self, n):
         if getattr(self, "vrecon", None) is None or self.vrecon.numel() < n:
@@ -1729,6 +1739,104 @@ class AEEngine(VAEEngine):
             ops.linear_bwd_dw_adam_pair(dict(dA=self.dA, X=self.He, lin=D2, adam=adam, M=b),
                                         dict(dA=self.dHe, X=self.X, lin=E1, adam=adam, M=b),
                                         weight_decay=self.wd if adam is not None else 0.0, stream=st)
+            self._optimizer_step(st, sched_slot)
+        if self.use_graph:
+            ops.tick(self.ctr, 1, stream=st)
+
+
+class BIRVAEEngine(VAEEngine):
+    """bir_vae.py:119-232: encoder 784->400->mu, z = mu + eps with eps ~
+    N(0, set_var) from NUMPY's global RNG (drawn on the host exactly as the reference does,
+    bir_vae.py:92-94 -- a variance used as a standard deviation is part of the contract), decoder,
+    loss = sum (x - x_hat)^2 + 1000 * MMD(z) with the Gaussian-kernel MMD against
+    x = torch.randn(z.shape) (:203, global torch CPU generator).  `kl` / `vkl` hold the MMD terms."""
+
+    LAMBDA = 1000.0
+
+    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
+                 force_dp=False):
+        if world_size > 1 or force_dp:
+            raise GMError("BIR-VAE's MMD couples every pair of rows of the batch: it does not shard on "
+                          "the batch axis (run it on one GPU)")
+        self.model, self.device, self.use_graph = model, device, use_graph
+        enc, dec = model.encoder, model.decoder
+        plist = [enc.linear.weight, enc.linear.bias, enc.mu.weight, enc.mu.bias,
+                 dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias]
+        self._dp_init(plist, 1, 0, None, False)
+        self.fp = FlatParams(plist, device)
+        fp = self.fp
+        self.E1, self.MU = _Linear(fp, enc.linear), _Linear(fp, enc.mu)
+        self.D1, self.D2 = _Linear(fp, dec.linear), _Linear(fp, dec.recon)
+        self.Z, self.H = enc.mu.weight.shape
+        self.I = enc.linear.weight.shape[1]
+        self.set_var = float(model.set_var)
+        self._common_init(device)
+
+    def _alloc(self, B):
+        if self._bufB == B:
+            return
+        dev, I, H, Z = self.device, self.I, self.H, self.Z
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.X, self.He, self.Mu, self.Zs = z(B, I), z(B, H), z(B, Z), z(B, Z)
+        self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
+        self.dHdec, self.dZ, self.dZm, self.dHe = z(B, H), z(B, Z), z(B, Z), z(B, H)
+        self.part, self.partm = z(B), z(B)
+        self._bufB = B
+        self.graphs = {}
+
+    def configure(self, B, n_train_steps, lr, weight_decay, resume=None):
+        super().configure(B, n_train_steps, lr, weight_decay, resume=resume)
+        self.prior_ring = torch.zeros(self.R, B, self.Z, device=self.device)
+        for s in self.stage:
+            s["prior"] = torch.zeros(self.R, B, self.Z).pin_memory()
+
+    def _draw_chunk(self, s, sizes):
+        import numpy as np
+        Z = self.Z
+        for k, b in enumerate(sizes):
+            # model(images) -> reparameterize: np.random.normal(0, set_var, mu.shape).float()
+            e = np.random.normal(loc=0.0, scale=self.set_var, size=(b, Z))
+            s["eps"][k].view(-1)[:b * Z].copy_(torch.from_numpy(e).float().view(-1))
+        # maximum_mean_discrepancy: torch.randn(z.shape) -- a different generator, order-independent
+        self._torch_normal_rows(s["prior"], sizes)
+
+    def _upload_chunk(self, s, r, cnt):
+        self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
+        self.prior_ring[r:r + cnt].copy_(s["prior"][:cnt], non_blocking=True)
+
+    def _issue(self, st, t, b, train):
+        from . import ops_fused as of
+        R, B, Z = self.R, self.B, self.Z
+        E1, MU, D1, D2 = self.E1, self.MU, self.D1, self.D2
+        idx_slot = self._slot(t, 1, 0, R, B)
+        eps_slot = self._slot(t, 1, 0, R, B * Z)
+        loss_slot = self._slot(t, 1, 0, 0, 1)
+        recon_out, mmd_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
+        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
+        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        ops.linear_fwd(self.He, MU.W, MU.b, self.Mu, "id", M=b, stream=st)
+        of.bir_reparam(self.Mu, self.eps_ring.view(-1), self.Zs, b, Z, eps_slot=eps_slot, stream=st)
+        ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
+        ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
+        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
+        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
+        of.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
+                   self.LAMBDA, prior_slot=eps_slot, stream=st)
+        of.sum_finalize(self.partm, b, mmd_out, scale=self.LAMBDA, out_slot=loss_slot, stream=st)
+        if train:
+            sched_slot = self._slot(t, 1, 0, 0, 1)
+            adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
+            dw2 = lambda a1, a2: ops.linear_bwd_dw_adam_pair(
+                dict(dA=a1[0], X=a1[1], lin=a1[2], adam=adam, M=b),
+                dict(dA=a2[0], X=a2[1], lin=a2[2], adam=adam, M=b),
+                weight_decay=self.wd if adam is not None else 0.0, stream=st)
+            # every dX reads a layer's weights BEFORE that layer's dW(+Adam) launch updates them
+            ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
+            # d loss / d z = decoder path + d(1000 * mmd)/dz ; z = mu + eps -> d/d mu is the same
+            ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, add=self.dZm, add_scale=1.0, stream=st)
+            dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
+            ops.linear_bwd_dx(self.dZ, MU.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
+            dw2((self.dZ, self.He, MU), (self.dHe, self.X, E1))
             self._optimizer_step(st, sched_slot)
         if self.use_graph:
             ops.tick(self.ctr, 1, stream=st)

@@ -45,6 +45,19 @@ def head_gp(h, w2, b2, s, u, stream=None):
               s.data_ptr(), u.data_ptr(), _ld(u), B, H)
 
 
+def bir_reparam(mu, eps, z, B, Z, eps_slot=NO_SLOT, stream=None):
+    """z = mu + eps (bir_vae.py:86-97; eps drawn on the host from numpy's global RNG)."""
+    _lib.call("gm_bir_reparam", stream or stream_ptr(), mu.data_ptr(), _ld(mu), eps.data_ptr(), eps_slot,
+              z.data_ptr(), _ld(z), B, Z)
+
+
+def bir_mmd(z, prior, partial, dz, B, Z, lam, prior_slot=NO_SLOT, stream=None):
+    """Row shares of the Gaussian-kernel MMD (bir_vae.py:201-221) and d(lam*mmd)/dz (dz may be None)."""
+    _lib.call("gm_bir_mmd", stream or stream_ptr(), z.data_ptr(), _ld(z), prior.data_ptr(), prior_slot,
+              partial.data_ptr(), dz.data_ptr() if dz is not None else None,
+              _ld(dz) if dz is not None else 0, B, Z, lam)
+
+
 def vae_reparam(ml, eps, z, kl_out, B, Z, eps_slot=NO_SLOT, kl_slot=NO_SLOT, stream=None):
     _lib.call("gm_vae_reparam", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
               eps_slot, z.data_ptr(), _ld(z), kl_out.data_ptr(), kl_slot, B, Z)

@@ -759,6 +759,188 @@ class VAETrainer:
 
 
 # ============================================================================================
+# BIR-VAE (bir_vae.py:37-232; SURVEY.md 8f item 2, second half) -- exported by src/bir_vae.py as
+# Encoder / Decoder / BIRVAE / BIRVAETrainer.  Fused path: engine.BIRVAEEngine.
+# ============================================================================================
+@stock_model
+class BIREncoder(nn.Module):
+    """bir_vae.py:37-51: 784 -> 400 (relu) -> mu."""
+
+    def __init__(self, image_size, hidden_dim, z_dim):
+        super().__init__()
+        self.linear = nn.Linear(image_size, hidden_dim)
+        self.mu = nn.Linear(hidden_dim, z_dim)
+
+    def forward(self, x):
+        return _lin(self.mu, _lin(self.linear, x, "relu"), "id")
+
+
+@stock_model
+class BIRDecoder(_TwoLayer):
+    """bir_vae.py:54-66."""
+    _names = ("linear", "recon")
+
+    def __init__(self, z_dim, hidden_dim, image_size):
+        super().__init__()
+        self._build(z_dim, hidden_dim, image_size)
+
+
+@stock_model
+class BIRVAE(nn.Module):
+    """bir_vae.py:69-97.  I: how many bits are let through; set_var = 1 / 4**(I / z_dim)."""
+
+    def __init__(self, image_size=784, hidden_dim=400, z_dim=20, I=13.3):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.z_dim, self.I = image_size, hidden_dim, z_dim, I
+        self.encoder = BIREncoder(image_size=image_size, hidden_dim=hidden_dim, z_dim=z_dim)
+        self.decoder = BIRDecoder(z_dim=z_dim, hidden_dim=hidden_dim, image_size=image_size)
+        self.shape = int(image_size ** 0.5)
+        self.set_var = 1 / (4 ** (I / z_dim))
+
+    def forward(self, x):
+        mu = self.encoder(x)
+        z = self.reparameterize(mu)
+        return self.decoder(z), z
+
+    def reparameterize(self, mu):
+        """bir_vae.py:86-97: eps from NUMPY's global RNG with scale = set_var (the reference passes a
+        variance as the standard deviation; part of the contract)."""
+        eps = to_cuda(torch.from_numpy(np.random.normal(loc=0.0, scale=self.set_var,
+                                                        size=tuple(mu.shape))).float())
+        return mu + eps
+
+
+@stock
+class BIRVAETrainer(VAETrainer):
+    """bir_vae.py:99-232: the VAE loop with loss = sum (x - x_hat)^2 + 1000 * MMD(z)."""
+    _gm_stock_class = True
+    _hook_names = ("compute_batch", "evaluate", "maximum_mean_discrepancy", "compute_kernel")
+
+    def __init__(self, model, train_iter, val_iter, test_iter, viz=False):
+        self.model = to_cuda(model)
+        self.name = model.__class__.__name__
+        self.train_iter, self.val_iter, self.test_iter = train_iter, val_iter, test_iter
+        self.best_val_loss = 1e10
+        self.debugging_image, _ = next(iter(test_iter))          # bir_vae.py:110 (consumes RNG)
+        self.viz = viz
+        self.mmd_loss, self.recon_loss = [], []
+        self.num_epochs = 0
+        self._engine = None
+        self.use_graph = True
+
+    def _stock(self):
+        m = self.model
+        if not (_stock_module(getattr(m, "encoder", None), 2) and _stock_module(getattr(m, "decoder", None), 2)
+                and type(m).__dict__.get("_gm_stock_model", False)):
+            return False
+        cls = type(self)
+        for name in self._hook_names:
+            if name in self.__dict__:
+                return False
+            for base in cls.__mro__:
+                if name in base.__dict__:
+                    if not base.__dict__.get("_gm_stock_class", False):
+                        return False
+                    break
+        return (self._loader_ok(self.train_iter) and self._loader_ok(self.val_iter)
+                and self.train_iter.batch_size == self.val_iter.batch_size)
+
+    # ---- reference-visible hooks (general path) ---------------------------------------------
+    def compute_kernel(self, x, y):
+        """bir_vae.py:210-221."""
+        x_size, y_size, dim = x.size(0), y.size(0), x.size(1)
+        tx = x.unsqueeze(1).expand(x_size, y_size, dim)
+        ty = y.unsqueeze(0).expand(x_size, y_size, dim)
+        return torch.exp(-torch.div(torch.mean(torch.pow(tx - ty, 2), dim=2), dim))
+
+    def maximum_mean_discrepancy(self, z):
+        """bir_vae.py:201-208 (the prior sample is drawn on the CPU generator, then moved: the
+        reference's own code mixes a CPU tensor with z and only runs on CPU)."""
+        x = to_cuda(torch.randn(z.shape))
+        return self.compute_kernel(x, x).sum() + self.compute_kernel(z, z).sum() \
+            - 2 * self.compute_kernel(x, z).sum()
+
+    def compute_batch(self, batch, LAMBDA=1000.):
+        """bir_vae.py:180-199."""
+        images, _ = batch
+        images = to_cuda(images.view(images.shape[0], -1))
+        outputs, z = self.model(images)
+        return torch.sum((images - outputs) ** 2), LAMBDA * self.maximum_mean_discrepancy(z)
+
+    def evaluate(self, iterator):
+        """bir_vae.py:223-232."""
+        loss = []
+        for batch in iterator:
+            mse, mmd = self.compute_batch(batch)
+            loss.append((mse + mmd).item())
+        return np.mean(loss)
+
+    def train(self, num_epochs, lr=1e-3, weight_decay=1e-5, quiet=False):
+        """bir_vae.py:119-178.  (The reference never increments num_epochs here; neither do we.)"""
+        from copy import deepcopy
+        if self._stock():
+            if not torch.cuda.is_available():
+                raise GMError("no MI355X visible: the fused step engine has no CPU fallback")
+            from .engine import BIRVAEEngine
+            dev = next(self.model.parameters()).device
+            if self._engine is None:
+                from . import dp
+                world, rank, group = dp.current()
+                self._engine = BIRVAEEngine(self.model, dev, use_graph=self.use_graph, world_size=world,
+                                            rank=rank, process_group=group)
+            eng = self._engine
+            eng.use_graph = self.use_graph
+            steps = len(self.train_iter)
+            eng.configure(self.train_iter.batch_size, num_epochs * steps, lr, weight_decay,
+                          resume=self.__dict__.pop("_resume_optim", None))
+            tdata, vdata = self._device_data(self.train_iter), self._device_data(self.val_iter)
+            nval = len(self.val_iter)
+            eng.alloc_val(nval)
+            for epoch in range(1, num_epochs + 1):
+                self.model.train()
+                t0 = (epoch - 1) * steps
+                eng.run_pass(tdata, _epoch_order(self.train_iter), True, t0)
+                self.model.eval()
+                eng.run_pass(vdata, _epoch_order(self.val_iter), False, 0)
+                recon = [float(x) for x in eng.read_losses(eng.recon, t0, steps)]     # one sync
+                mmd = [float(x) for x in eng.read_losses(eng.kl, t0, steps)]
+                vr, vm = eng.read_losses(eng.vrecon, 0, nval), eng.read_losses(eng.vkl, 0, nval)
+                val_loss = np.mean([float(a + b) for a, b in zip(vr, vm)])
+                self._end_epoch_bir(epoch, num_epochs, recon, mmd, val_loss, deepcopy, quiet)
+            return
+        opt = FlatAdam([p for p in self.model.parameters() if p.requires_grad], lr,
+                       weight_decay=weight_decay)
+        for epoch in range(1, num_epochs + 1):
+            self.model.train()
+            recon, mmd = [], []
+            for batch in self.train_iter:
+                opt.zero_grad()
+                a, b = self.compute_batch(batch)
+                (a + b).backward()
+                opt.step()
+                recon.append(a.item())
+                mmd.append(b.item())
+            self.model.eval()
+            val_loss = self.evaluate(self.val_iter)
+            self._end_epoch_bir(epoch, num_epochs, recon, mmd, val_loss, deepcopy, quiet)
+
+    def _end_epoch_bir(self, epoch, num_epochs, recon, mmd, val_loss, deepcopy, quiet):
+        self.mmd_loss.extend(mmd)
+        self.recon_loss.extend(recon)
+        if val_loss < self.best_val_loss:
+            self.best_model = deepcopy(self.model)
+            self.best_val_loss = val_loss
+        if not quiet:
+            tot = [float(np.float32(a) + np.float32(b)) for a, b in zip(recon, mmd)]
+            print("Epoch[%d/%d], Total Loss: %.4f, MSE Loss: %.4f, MMD Loss: %.4f, Val Loss: %.4f"
+                  % (epoch, num_epochs, np.mean(tot), np.mean(recon), np.mean(mmd), val_loss))
+
+    def save_checkpoint(self, savepath):
+        raise GMError("BIR-VAE checkpoints would also have to carry numpy's global RNG state; use "
+                      "save_model / load_model")
+
+
+# ============================================================================================
 # Autoencoder (ae.py:29-205; SURVEY.md 8f item 2) -- exported by src/ae.py as Encoder / Decoder /
 # Autoencoder / AutoencoderTrainer.  Runs on the VAE engine's machinery (engine.AEEngine).
 # ============================================================================================

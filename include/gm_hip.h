@@ -158,6 +158,15 @@ int gm_gp_dw2_store(void* stream, const float* s, const float* h, int64_t ldh, c
 int gm_head_gp(void* stream, const float* h, int64_t ldh, const float* w2, const float* b2, float* s,
                float* u, int64_t ldu, int B, int H);
 
+/* ---- BIR-VAE (bir_vae.py:86-97, 180-221).  reparam: z = mu + eps with the
+ * host-drawn numpy noise (scale = set_var, :92-94).  mmd: partial[m] = row m's share of
+ * sum k(x,x) + sum k(z,z) - 2 sum k(x,z) with the Gaussian kernel exp(-mean_d((a-b)^2)/dim) over the
+ * prior sample x = torch.randn(z.shape) (:203), and (dz != NULL) dz = d(lambda*mmd)/dz. */
+int gm_bir_reparam(void* stream, const float* mu, int64_t ldmu, const float* eps, gm_slot eps_slot,
+                   float* z, int64_t ldz, int B, int Z);
+int gm_bir_mmd(void* stream, const float* z, int64_t ldz, const float* prior, gm_slot prior_slot,
+               float* partial, float* dz, int64_t lddz, int B, int Z, float lambda);
+
 /* ---- K14: VAE.  ml = [mu | log_var] (B x 2Z, the two encoder heads packed side by side).
  * reparam: z = mu + eps*exp(lv/2) (vae.py:100-106), kl_out[slot] = sum 0.5*(mu^2+exp(lv)-lv-1)
  * (vae.py:210-212).  reparam_bwd: d(recon+kl)/d[mu|lv] from dz.  sqerr: per-row sums of

@@ -244,3 +244,31 @@ def test_head_gp_and_stacked_weight_gradient():
     assert rel(lin.gb.cpu(), dH.double().sum(0).cpu()) < 2e-6          # no bias share from the u rows
     gw2_ref = dS.double() @ Hd.double() + add.double()
     assert rel(head_lin.gW.view(-1).cpu(), gw2_ref.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("B,Z", [(256, 20), (37, 6), (100, 64)])
+def test_bir_mmd_matches_fp64_autograd(B, Z):
+    """gm_bir_mmd: Gaussian-kernel MMD of bir_vae.py:201-221 and d(lam * mmd)/dz vs fp64 autograd."""
+    torch.manual_seed(B + Z)
+    z = (torch.randn(B, Z) * 0.7 + 0.2).cuda()
+    x = torch.randn(B, Z).cuda()
+    part, dz, out = torch.zeros(B, device="cuda"), torch.zeros(B, Z, device="cuda"), torch.zeros(1, device="cuda")
+    lam = 1000.0
+    of.bir_mmd(z, x.view(-1), part, dz, B, Z, lam)
+    of.sum_finalize(part, B, out, scale=lam)
+    torch.cuda.synchronize()
+    zd = z.double().cpu().requires_grad_(True)
+    xd = x.double().cpu()
+
+    def kern(a, b):
+        return torch.exp(-((a.unsqueeze(1) - b.unsqueeze(0)) ** 2).mean(2) / Z)
+    mmd = lam * (kern(xd, xd).sum() + kern(zd, zd).sum() - 2 * kern(xd, zd).sum())
+    mmd.backward()
+    assert abs(out.item() - mmd.item()) <= 1e-4 * max(10.0, abs(mmd.item())), (out.item(), mmd.item())
+    g = zd.grad
+    assert (dz.cpu().double() - g).abs().max().item() <= 2e-5 * max(1.0, g.abs().max().item())
+    # forward only (evaluate): dz untouched
+    dz.fill_(7.0)
+    of.bir_mmd(z, x.view(-1), part, None, B, Z, lam)
+    torch.cuda.synchronize()
+    assert bool((dz == 7.0).all())

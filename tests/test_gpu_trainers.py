@@ -383,6 +383,87 @@ def test_vae_engine_vs_reference_golden(name):
 
 
 # ---------------------------------------------------------------------------------------------
+# BIR-VAE (bir_vae.py; SURVEY.md 8f item 2, second half): numpy + torch global generators
+# ---------------------------------------------------------------------------------------------
+def run_bir_product(cfg, batch, n_train, epochs, use_graph=True, np_seed=77):
+    import bir_vae
+    loaders = port.synthetic_loaders(batch, n_train=n_train, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    np.random.seed(np_seed)
+    model = bir_vae.BIRVAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"],
+                           z_dim=cfg["z_dim"])
+    tr = bir_vae.BIRVAETrainer(model, *loaders, viz=False)
+    tr.use_graph = use_graph
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=epochs)
+    torch.cuda.synchronize()
+    assert tr._engine is not None, "fused BIR-VAE engine was not used"
+    return tr, model, torch.get_rng_state()
+
+
+@pytest.mark.parametrize("name", ["bir_small", "bir_full_b256"])
+def test_bir_vae_engine_vs_reference_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    p, p_model, p_rng = run_bir_product(cfg, meta["batch"], meta["n_train"],
+                                        meta["train_kw"]["num_epochs"], np_seed=meta["np_seed"])
+    import hashlib
+    assert hashlib.sha256(p_rng.numpy().tobytes()).hexdigest() == meta["rng"], "RNG stream position"
+    ref, got = z["recon_loss"], np.array(p.recon_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
+    # 1000 * (three O(B^2) sums that nearly cancel): the reference's own fp32 pairwise sums carry
+    # ~1e-7 * B^2 * 1000 of rounding; same bound as the oracle's test in test_golden.py
+    ref, got = z["mmd_loss"], np.array(p.mmd_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(10, np.abs(ref))) <= 1e-4, (got[:4], ref[:4])
+    assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 2e-5 * abs(float(z["best_val_loss"]))
+    for k, v in p_model.state_dict().items():
+        if "param:" + k in z:
+            assert np.abs(v.cpu().numpy() - z["param:" + k]).max() <= 5e-5, k
+
+
+def test_bir_vae_engine_vs_oracle_eager_and_graph():
+    cfg = SMALL
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=150, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    np.random.seed(5)
+    o_model = port.build("bir", cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    o = port.BIRVAEPort(o_model, *loaders)
+    o.train(2)
+    o_rng, o_np = torch.get_rng_state(), np.random.get_state()[1].copy()
+    for use_graph in (True, False):
+        p, p_model, p_rng = run_bir_product(cfg, cfg["batch"], 150, 2, use_graph=use_graph, np_seed=5)
+        assert torch.equal(o_rng, p_rng)
+        assert np.array_equal(o_np, np.random.get_state()[1]), "numpy generator position"
+        lclose(np.array(p.recon_loss) / 100, np.array(o.recon_loss) / 100, "bir recon")
+        ref, got = np.array(o.mmd_loss), np.array(p.mmd_loss)
+        assert np.max(np.abs(got - ref) / np.maximum(10, np.abs(ref))) <= 1e-4
+        for (k, a), (_, b) in zip(p_model.state_dict().items(), o_model.state_dict().items()):
+            assert (a.cpu() - b).abs().max().item() <= 5e-5, k
+
+
+def test_bir_vae_user_hook_takes_general_path():
+    import bir_vae
+    cfg = SMALL
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=96, n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+
+    class Mine(bir_vae.BIRVAETrainer):
+        def compute_batch(self, batch, LAMBDA=10.):
+            return super().compute_batch(batch, LAMBDA=LAMBDA)
+
+    torch.manual_seed(3)
+    np.random.seed(3)
+    model = bir_vae.BIRVAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+    tr = Mine(model, *loaders)
+    tr.train(1, quiet=True)
+    assert tr._engine is None and len(tr.recon_loss) == len(loaders[0])
+    assert np.isfinite(tr.best_val_loss)
+
+
+# ---------------------------------------------------------------------------------------------
 # Autoencoder (ae.py) on the VAE engine's machinery
 # ---------------------------------------------------------------------------------------------
 def run_ae_product(cfg, hidden, batch, n_train, epochs, use_graph=True):
