@@ -171,9 +171,14 @@ _SIGNATURES = {
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float, _P]),
     "gm_allreduce_scalars": (c_int, [_P, _P, _P, c_int]),
     "gm_stage_in": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int]),
+    "gm_stage_in_gated": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int, _P, Slot, ctypes.c_double]),
     "gm_host_device_ptr": (c_int, [_P, POINTER(c_void_p)]),
     "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),
     "gm_host_replay_threads": (c_int, [c_int]),
+    "gm_fill_submit": (c_int64, [_P, c_int64, POINTER(DrawOp), c_int, c_int, _P, c_int64]),
+    "gm_fill_wait": (c_int, [c_int64]),
+    "gm_fill_completed": (c_int64, []),
+    "gm_fill_reset": (c_int, []),
     "gm_host_replay_flavour": (c_int, [c_int]),
     "gm_graph_begin": (c_int, [_P]),
     "gm_graph_end": (c_int, [_P, POINTER(c_void_p)]),

@@ -662,7 +662,10 @@ __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_
 // MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
 // (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
 // rounds of one workgroup per CU): one round, 6 fragment loads per 32 MFMAs instead of 4 per 16.
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
+// OF: the ones column starts at reduction row p.ones_from (WGAN-GP's stacked dW only); compiled out
+// otherwise -- the four extra compares per fragment cost the generator's dW pair 1.2 us when they ran
+// unconditionally.
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by) {
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -697,7 +700,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     auto fix_b = [&](float4 v, int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
         if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, p.ones_from);
+        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
     };
 
     f32x4 acc[MI][NI];
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <int MODE, bool VEC, int G, bool XV, int MI, int NI>
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
     __shared__ float red[16 * 32 * 32];
@@ -784,13 +787,13 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body(hp, bid);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y - hrows);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF>(p, red, blockIdx.x, blockIdx.y - hrows);
 }
 
-template <bool VEC, int G, bool XV, int MI, int NI>
+template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
-    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI>(p, hp, hrows, hblocks);
+    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF>(p, hp, hrows, hblocks);
 }
 
 // The generator step's dX GEMM carrying the one scalar workgroup of the head (loss + tick): the
@@ -938,12 +941,12 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int hblocks = gm_head_bwd_blocks(*head);
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
-#define GM_LH(V, GG, X) do {                                                                       \
-        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
-#define GM_LH_G(V, X) GM_LH(V, 1, X)
+#define GM_LH(V, GG, X, OFV) do {                                                                  \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
+#define GM_LH_G(V, X) do { if (p.ones_from > 0) GM_LH(V, 1, X, true); else GM_LH(V, 1, X, false); } while (0)
                 if (xv) GM_LH_G(false, true); else GM_LH_G(false, false);   // VEC is a k-contiguous notion
 #undef GM_LH_G
 #undef GM_LH
@@ -1257,7 +1260,7 @@ static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, i
     bool xvec = false;
     const int rc = dw_fill(dA, lda, X, ldx, x_slot, dW, db, M, K, N, accumulate, adam, &p, &xvec);
     if (rc) return rc;
-    GM_CHECK_ARG(ones_from >= 0 && ones_from <= M);
+    GM_CHECK_ARG(ones_from >= 0 && ones_from <= M && (ones_from == 0 || head));
     p.ones_from = ones_from;
     Rider r;
     r.head = head;

@@ -633,3 +633,113 @@ extern "C" int gm_host_replay(void* torch_cpu_rng_state, int64_t state_bytes, co
     mt_store(m, g);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fill worker: gm_host_replay jobs run by ONE persistent native thread, in submission order, on a
+// generator state buffer the caller keeps alive -- the Python side only enqueues (microseconds, no
+// interpreter lock hand-off between the thread that launches graphs and the one that draws).  After
+// a job's ring slots are written the worker advances the fill gate (gm_stage_in_gated) with a release
+// store.  A failed job is sticky: later jobs are not run (their gate never opens; the submitter sees
+// the error at gm_fill_wait and opens the gates itself).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct FillJob {
+    int64_t id;
+    void* state;
+    int64_t state_bytes;
+    std::vector<gm_draw_op> ops;
+    int n_iters;
+    int64_t* gate;
+    int64_t gate_value;
+};
+
+struct FillWorker {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<FillJob> q;                    // FIFO (small: a handful of jobs in flight)
+    size_t head = 0;
+    int64_t submitted = 0;
+    std::atomic<int64_t> completed{0};
+    std::atomic<int> rc{0};
+    std::thread th;
+
+    FillWorker() : th([this] { loop(); }) { th.detach(); }
+
+    void loop() {
+        for (;;) {
+            FillJob job;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                // a short spin before sleeping: consecutive sub-chunks arrive microseconds apart
+                for (int spin = 0; head == q.size() && spin < 2000; ++spin) {
+                    l.unlock();
+                    _mm_pause();
+                    l.lock();
+                }
+                cv_job.wait(l, [this] { return head < q.size(); });
+                job = std::move(q[head++]);
+                if (head == q.size()) { q.clear(); head = 0; }
+            }
+            if (rc.load() == 0) {
+                const int r = gm_host_replay(job.state, job.state_bytes, job.ops.data(), (int)job.ops.size(),
+                                             job.n_iters);
+                if (r != 0) rc.store(r);
+                else if (job.gate) __atomic_store_n(job.gate, job.gate_value, __ATOMIC_RELEASE);
+            }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                completed.store(job.id);
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+FillWorker* fill_worker() {
+    static FillWorker* w = new FillWorker();   // never destroyed: the thread outlives static teardown
+    return w;
+}
+
+}  // namespace
+
+extern "C" int64_t gm_fill_submit(void* torch_cpu_rng_state, int64_t state_bytes, const gm_draw_op* ops,
+                                  int n_ops, int n_iters, int64_t* gate, int64_t gate_value) {
+    if (!torch_cpu_rng_state || !ops || n_ops <= 0 || n_iters <= 0) {
+        gm_set_error("gm_fill_submit: bad arguments");
+        return GM_EINVAL;
+    }
+    FillWorker* w = fill_worker();
+    FillJob job;
+    job.state = torch_cpu_rng_state; job.state_bytes = state_bytes;
+    job.ops.assign(ops, ops + n_ops);
+    job.n_iters = n_iters; job.gate = gate; job.gate_value = gate_value;
+    int64_t id;
+    {
+        std::lock_guard<std::mutex> l(w->mu);
+        id = job.id = ++w->submitted;
+        w->q.push_back(std::move(job));
+    }
+    w->cv_job.notify_one();
+    return id;
+}
+
+extern "C" int64_t gm_fill_completed(void) { return fill_worker()->completed.load(); }
+
+extern "C" int gm_fill_wait(int64_t id) {
+    FillWorker* w = fill_worker();
+    if (w->completed.load() < id) {
+        std::unique_lock<std::mutex> l(w->mu);
+        w->cv_done.wait(l, [&] { return w->completed.load() >= id; });
+    }
+    return w->rc.load();
+}
+
+// Clears a sticky error once every submitted job has been retired (the run that hit it is over).
+extern "C" int gm_fill_reset(void) {
+    FillWorker* w = fill_worker();
+    std::unique_lock<std::mutex> l(w->mu);
+    w->cv_done.wait(l, [&] { return w->completed.load() >= w->submitted; });
+    w->rc.store(0);
+    return 0;
+}

@@ -25,7 +25,8 @@ import torch
 from . import ops
 from ._lib import GMError
 
-CHUNK = 64          # iterations prefetched per host->device upload
+CHUNK = 64          # iterations prefetched per host->device upload (VAE / AE passes)
+GAN_RING = 128      # iterations of draws the GAN engines' host / device rings hold
 
 
 def _align4(n):
@@ -204,9 +205,10 @@ class HostReplay:
     def call(state, ops, n_iters):
         """Advance the serialized generator `state` (uint8 tensor) through n_iters iterations of the
         program.  Returns the C return code (0 ok, GM_EUNSUPPORTED: shape outside the restated paths)."""
+        import ctypes
         from . import _lib
-        arr = (_lib.DrawOp * len(ops))(*ops)
-        return _lib.load().gm_host_replay(state.data_ptr(), state.numel(), arr, len(ops), n_iters)
+        arr = ops if isinstance(ops, ctypes.Array) else (_lib.DrawOp * len(ops))(*ops)
+        return _lib.load().gm_host_replay(state.data_ptr(), state.numel(), arr, len(arr), n_iters)
 
     @classmethod
     def run(cls, ops, n_iters):
@@ -262,6 +264,25 @@ class HostReplay:
             if torch.equal(st, s1) and all(torch.equal(out[k], ref[k]) for k in out):
                 return flavour
         return False
+
+
+class _FillJob:
+    """A sub-chunk of draws queued on the native fill worker (gm_fill_submit); the same surface as
+    the prefetch pool's future."""
+    __slots__ = ("id",)
+
+    def __init__(self, job_id):
+        self.id = job_id
+
+    def done(self):
+        from . import _lib
+        return _lib.load().gm_fill_completed() >= self.id
+
+    def result(self):
+        from . import _lib
+        rc = _lib.load().gm_fill_wait(self.id)
+        if rc != 0:
+            raise GMError("host draw replay failed on the fill worker (rc=%d)" % rc)
 
 
 class GANEngine:
@@ -329,7 +350,17 @@ class GANEngine:
         self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
-        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))   # iterations / graph
+        # iterations per graph (largest captured size; powers of two below it are captured too).  A
+        # graph boundary costs ~14 us of idle GPU plus the ~9 us stage-in of its draws (measured,
+        # profiles/r02_experiments.md): 32 iterations per graph amortise that to < 1 us / iteration
+        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
+        # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
+        self.gated = os.environ.get("GM_GATED", "1") != "0"
+        if os.environ.get("GM_RAMP"):
+            self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
+        if os.environ.get("GM_FIRST_PIECE"):
+            self.FIRST_PIECE = max(1, int(os.environ["GM_FIRST_PIECE"]))
+        self._gate = None
         self._standalone_G = False
         self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
@@ -871,7 +902,10 @@ class GANEngine:
         ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
-    AHEAD = 3           # sub-chunks of host draws that may be in flight ahead of the launches
+    AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
+    RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
+    FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
+    GATE_TIMEOUT_S = 20.0
 
     def _alloc_rings(self, R):
         """Device rings of R iterations and PINNED host rings of the same layout.  The host replay
@@ -919,10 +953,28 @@ class GANEngine:
             _lib.call("gm_host_device_ptr", h.data_ptr(), ctypes.byref(devp))
             segs.append(_lib.StageSeg(devp.value, dv.data_ptr(), h.numel() * h.element_size() // R))
         self._segs = (_lib.StageSeg * len(segs))(*segs)
+        if getattr(self, "_gate", None) is None:
+            # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
+            # configure(), [1] = raised by a stage-in kernel whose wait timed out.  Allocated once per
+            # engine: captured graphs hold its address.
+            self._gate = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self._gate_np = self._gate.numpy()
+            gp = ctypes.c_void_p()
+            _lib.call("gm_host_device_ptr", self._gate.data_ptr(), ctypes.byref(gp))
+            self._gate_dev = gp.value
         self._views = {}
         for r in range(R):                            # every slot a sub-chunk can start at: built once
             self._host_views(r)
         self._replay_ok = HostReplay.available()
+        # native fill worker (gm_fill_submit): usable when the C replay covers this variant's draws --
+        # probed by running one iteration's program on a COPY of the generator state (the ring slots it
+        # scribbles on are rewritten before anything reads them)
+        import os
+        self._native_fill = False
+        if self._replay_ok and os.environ.get("GM_NATIVE_FILL", "1") != "0":
+            probe = torch.get_rng_state().clone()
+            self._native_fill = HostReplay.call(probe, self._host_views(0)["program"], 1) == 0
+        self._rng_state, self._rng_owned = None, False
 
     def _host_views(self, r):
         """Views of the host rings starting at ring slot r (what one sub-chunk's draws write), with
@@ -940,7 +992,9 @@ class GANEngine:
                 if k in h:
                     v[k] = h[k][r * per:]
             v["idx_np"] = v["idx"].numpy()
-            v["program"] = self._program(v)
+            from ._lib import DrawOp
+            prog = self._program(v)
+            v["program"] = (DrawOp * len(prog))(*prog)          # built once: one C call per sub-chunk
             self._views[r] = v
         return v
 
@@ -980,7 +1034,11 @@ class GANEngine:
     def _issue_stage_in(self, st, it, k):
         """First launch of a graph of k iterations: their ring slots, host ring -> device ring."""
         from . import _lib
-        _lib.call("gm_stage_in", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k)
+        if self.gated:
+            _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k,
+                      self._gate_dev, self._slot(it, 1, 0, 0, 1), self.GATE_TIMEOUT_S)
+        else:
+            _lib.call("gm_stage_in", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k)
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -1057,6 +1115,7 @@ class GANEngine:
         s = self._host_views(c0 % self.R)
         if self._replay_ok:
             if HostReplay.run(s["program"], n_it):
+                self._gate_np[0] = c0 + n_it         # plain 8-byte store after the ring writes (x86 TSO)
                 if self._trace is not None:
                     import time
                     self._trace.append(("filled", n_it, time.perf_counter()))
@@ -1067,6 +1126,7 @@ class GANEngine:
             for j in range(d):
                 self._draw_D(s, i * d + j)
             self._draw_G(s, i)
+        self._gate_np[0] = c0 + n_it
         return s
 
     # -- public: run `n_iters` iterations starting a fresh train() ----------------------------
@@ -1129,15 +1189,20 @@ class GANEngine:
         self._drain()
         from collections import deque
         self.n_planned = n_iters
-        self._pending, self._cursor, self._uploaded, self._next_it = deque(), 0, 0, 0
+        self._fills, self._cursor, self._next_it = deque(), 0, 0
         self._launched, self._ramp = deque(), []
+        if self._gate is not None:
+            torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
+            self._gate_np[:] = 0
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
         self._event_pool = []
         # DRAGAN prefetches a B x 784 uniform tensor per critic step: keep its ring small
-        R = max(1, min(16 if self.variant == "dra" else CHUNK, n_iters))
+        import os
+        ring = int(os.environ.get("GM_RING", GAN_RING))
+        R = max(1, min(16 if self.variant == "dra" else ring, n_iters))
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
-               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen())
+               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated)
         self.D_steps = D_steps
         if getattr(self, "_ring_key", None) != (D_steps, R, self._batch_gen()):
             self._alloc_rings(R)
@@ -1232,39 +1297,129 @@ class GANEngine:
 
     def _drain(self):
         """Wait for host fills still in flight (configure / error paths)."""
-        pend = getattr(self, "_pending", None)
+        pend = getattr(self, "_fills", None)
+        failed = False
         while pend:
             _, _, fut = pend.popleft()
             try:
                 fut.result()
             except Exception:                         # noqa: BLE001  (a failed fill of a dead run)
-                pass
+                failed = True
+        if getattr(self, "_rng_owned", False):
+            self._release_rng()
+        if failed and getattr(self, "_native_fill", False):
+            from . import _lib
+            _lib.load().gm_fill_reset()
 
-    class _Done:
-        """A fill that ran on the calling thread (same interface as the pool's future)."""
-
-        def __init__(self, value):
-            self.value = value
-
-        def result(self):
-            return self.value
-
-    def _pump(self, limit, inline=False):
-        """Keep up to AHEAD sub-chunks of host draws in flight, never past `limit`.  The first
-        sub-chunks of a run that starts cold are short (`_ramp`: 1, then 3 iterations) so that the
-        GPU starts after one iteration's worth of draws; inline=True draws the next sub-chunk on
-        the calling thread (no hand-off latency at the start of a run)."""
-        pool = _prefetch_pool()
-        while len(self._pending) < self.AHEAD and self._cursor < limit:
+    def _pump(self, limit, upto=None):
+        """Submit sub-chunks of host draws, in order, never past `limit`, while fewer than
+        AHEAD * SUB iterations are submitted-and-unfinished (upto: stop once iteration `upto` is
+        covered; those sub-chunks are submitted even if that means waiting for ring slots).  The first
+        sub-chunks of a run that starts cold are short (`_ramp`) so that the fill gate of the first
+        graph opens after one or two iterations' worth of draws.  Native fill worker: one C call per
+        sub-chunk, no Python thread involved; otherwise the prefetch thread runs _fill."""
+        unfinished = sum(n for _, n, f in self._fills if not f.done())     # (once: pessimistic inside the loop)
+        while self._cursor < limit and (upto is None or self._cursor < upto):
+            if unfinished >= self.AHEAD * self.SUB:
+                break
             it = self._cursor
-            want = self._ramp.pop(0) if self._ramp else self.SUB
+            want = self._ramp[0] if self._ramp else self.SUB
             n = min(want, self.SUB, self.R - it % self.R, limit - it)
-            if inline:
-                self._pending.append((it, n, self._Done(self._fill(it, n))))
-                inline = False
+            if self._native_fill:
+                if not self._slots_free_now(it, n, wait=upto is not None):
+                    break
+                fut = self._submit_native(it, n)
             else:
-                self._pending.append((it, n, pool.submit(self._fill, it, n)))
+                fut = _prefetch_pool().submit(self._fill, it, n)
+            if self._ramp:
+                self._ramp.pop(0)
+            self._fills.append((it, n, fut))
             self._cursor += n
+            unfinished += n
+
+    def _slots_free_now(self, c0, n, wait):
+        """Main-thread form of _wait_slots_free: True when the ring slots of [c0, c0+n) can be
+        rewritten (the launch that last staged them in has completed); wait=True blocks for it."""
+        need = c0 + n - self.R
+        if need <= 0:
+            return True
+        for it_end, e in self._launched:
+            if it_end >= need:
+                if not e.query():
+                    if not wait:
+                        return False
+                    e.synchronize()
+                while self._launched and self._launched[0][0] < need:
+                    self._event_pool.append(self._launched.popleft()[1])
+                return True
+        if wait:                                      # cannot happen: iterations < c0 + n - R precede every piece being launched
+            raise GMError("host ring: iteration %d was never launched" % (need - 1))
+        return False
+
+    def _submit_native(self, c0, n):
+        from . import _lib
+        if not self._rng_owned:
+            # the generator state lives in this buffer while jobs are in flight; torch's global
+            # generator gets it back in _release_rng
+            self._rng_state = torch.get_rng_state()
+            self._rng_owned = True
+        prog = self._host_views(c0 % self.R)["program"]
+        job = _lib.load().gm_fill_submit(self._rng_state.data_ptr(), self._rng_state.numel(), prog, len(prog),
+                                         n, self._gate.data_ptr(), c0 + n)
+        if job <= 0:
+            _lib.check(int(job), "gm_fill_submit")
+        return _FillJob(job)
+
+    def _release_rng(self):
+        """Hand the generator state back to torch once no draw job is outstanding."""
+        if self._rng_owned and not self._fills:
+            torch.set_rng_state(self._rng_state)
+            self._rng_owned = False
+
+    def _reap(self, block=False, upto=None):
+        """Retire finished fills (re-raises what a worker hit).  block: wait for the oldest one;
+        upto: wait for every fill that covers iterations < upto."""
+        fl = self._fills
+        while fl and (block or fl[0][2].done() or (upto is not None and fl[0][0] < upto)):
+            fl.popleft()[2].result()
+            block = False
+
+    def _plan(self, it, n, cold):
+        """Split iterations [it, it+n) into graph launches: powers of two up to graph_iters, never
+        across the end of the ring (a stage-in copies contiguous slots), ascending inside each ring
+        segment.  cold (nothing drawn ahead): the first piece is at most FIRST_PIECE iterations --
+        the GPU idles until its draws exist -- and no piece is more than 4x what precedes it (the
+        host draws ~5x faster than the GPU consumes, so later gates are open on arrival)."""
+        cap = 1
+        while cap * 2 <= min(self.graph_iters, self.R):
+            cap *= 2
+        out, done = [], 0
+        while n > 0:
+            seg = min(n, self.R - it % self.R)
+            q, r = divmod(seg, cap)
+            pieces = [1 << i for i in range(cap.bit_length()) if (r >> i) & 1] + [cap] * q
+            if cold:
+                fixed = []
+                for s_ in pieces:
+                    stack = [s_]
+                    while stack:
+                        x = stack.pop()
+                        bound = self.FIRST_PIECE if done == 0 else 4 * done
+                        if x > bound and x > 1:
+                            stack += [x // 2, x // 2]
+                        else:
+                            fixed.append(x)
+                            done += x
+                pieces = fixed
+            out += pieces
+            it += seg
+            n -= seg
+        return out
+
+    def _check_gate(self):
+        if self._gate is not None and self._gate_np[1] != 0:
+            raise GMError("a stage-in kernel gave up waiting for the host draws of its iterations "
+                          "(%g s): results of this run are invalid" % self.GATE_TIMEOUT_S)
 
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
@@ -1306,26 +1461,33 @@ class GANEngine:
             raise GMError("run(): configure() planned %d iterations" % self.n_planned)
         limit = min(self.n_planned, max(end, horizon or 0))
         it = it_start
-        cold = not self._pending and self._cursor == it_start     # nothing drawn ahead
+        cold = not self._fills and self._cursor == it_start       # nothing drawn ahead
+        gated = self.gated
         if cold:
-            self._ramp = [1, 3]
+            self._ramp = list(self.RAMP)
         trace = self._trace
         if trace is not None:
             import time
             trace.append(("run", it_start, time.perf_counter()))
+        self._check_gate()
         try:
-            while it < end:
-                if it >= self._uploaded:
-                    self._pump(limit, inline=cold)
-                    cold = False
-                    c0, n, fut = self._pending.popleft()
-                    fut.result()                      # re-raises anything the worker hit
-                    if trace is not None:
-                        trace.append(("got", c0, time.perf_counter()))
-                    self._uploaded = c0 + n           # drawn into the host ring
-                    self._pump(limit)                 # next draws overlap the launches below
-                k = min(end, self._uploaded) - it
+            for k in self._plan(it_start, n_iters, cold):
+                # the draws of [it, it+k) must be SUBMITTED before their graph is enqueued; gated: the
+                # graph's stage-in kernel waits for them on the fill gate, so the launch (~50 us of
+                # host time) overlaps the draws; ungated: wait for them here
+                self._reap()
+                self._pump(limit, upto=it + k)
+                while self._cursor < it + k:
+                    self._reap(block=True)
+                    self._pump(limit, upto=it + k)
+                if not gated:
+                    self._reap(upto=it + k)
+                    self._pump(limit)                 # further draws overlap the launch below
+                if trace is not None:
+                    trace.append(("got", it, time.perf_counter()))
                 self._launch(it, k)
+                if gated:
+                    self._pump(limit)                 # (gated: the launch itself overlaps this piece's draws)
                 ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
                 ev.record()
                 self._launched.append((it + k, ev))
@@ -1334,7 +1496,13 @@ class GANEngine:
                 if trace is not None:
                     trace.append(("launched", it + k, time.perf_counter()))
                 it += k
+            self._reap(upto=end)                      # a failed draw surfaces here, not as a GPU time-out
+            self._pump(limit)
+            self._reap()
+            self._release_rng()                       # (draws still ahead of `end`: the state stays with them)
         except BaseException:
+            if self._gate is not None:
+                self._gate_np[0] = 1 << 62            # open every gate: nothing on the GPU waits for draws that will not come
             self._drain()
             raise
         self._next_it = end
@@ -1372,6 +1540,7 @@ class GANEngine:
             dp.allreduce_sum_(ld_t, self.pg)
         lg = lg_t.cpu().numpy()
         ld = ld_t.cpu().numpy().reshape(-1, d)
+        self._check_gate()
         G = [float(x) for x in lg]
         D = [float(np.mean([float(v) for v in row])) for row in ld]
         return G, D

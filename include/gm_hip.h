@@ -357,6 +357,15 @@ typedef struct gm_stage_seg {
     int64_t bytes_per_iter;
 } gm_stage_seg;
 int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters);
+/* The same with a FILL GATE: the launch may be enqueued before the host has finished writing the
+ * iterations' slots (ns_gan.py:218-226 draws them on the host one step at a time; here the host
+ * writes a sub-chunk and then advances gate[0] = number of iterations written since configure).
+ * Every workgroup waits (system-scope acquire loads of pinned host memory) until
+ * gate[0] >= it + n_iters, it = index of `it_slot` (the absolute iteration); after timeout_s seconds
+ * it raises gate[1] = 1 and proceeds -- the host must check gate[1] before trusting results.
+ * gate: device-visible address (gm_host_device_ptr) of two int64 in pinned host memory. */
+int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
+                      const int64_t* gate, gm_slot it_slot, double timeout_s);
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 
@@ -424,6 +433,20 @@ int gm_host_replay(void* torch_cpu_rng_state, int64_t state_bytes, const gm_draw
  * (normal_fill_16<float>), 1 = avx_mathfun.h polynomials with the mul+add pairs contracted to FMAs,
  * 2 = same without contraction.  Python picks the one that reproduces torch bit for bit. */
 int gm_host_replay_flavour(int flavour);
+/* HOST: the same replay as a job for the library's fill worker (one persistent native thread, jobs run
+ * in submission order on the caller-owned generator state buffer, which must stay valid until the job
+ * is retired).  After the job's writes the worker stores *gate = gate_value (release) -- the fill gate
+ * of gm_stage_in_gated -- when gate is non-null.  Returns the job id (> 0) or a negative error.
+ * gm_fill_wait(id): block until job id is retired, returns the worker's sticky error (0 = none; after
+ * an error later jobs are retired without running and without opening their gates).
+ * gm_fill_completed(): id of the last retired job.  gm_fill_reset(): wait for everything submitted and
+ * clear the sticky error.  Replaces one Python thread hop + two generator-state copies per sub-chunk
+ * of ns_gan.py:183,208,222-226-style draws. */
+int64_t gm_fill_submit(void* torch_cpu_rng_state, int64_t state_bytes, const gm_draw_op* ops, int n_ops,
+                       int n_iters, int64_t* gate, int64_t gate_value);
+int gm_fill_wait(int64_t id);
+int64_t gm_fill_completed(void);
+int gm_fill_reset(void);
 /* HOST: size of the worker pool of gm_host_replay's Box-Muller stage (1 = caller only). */
 int gm_host_replay_threads(int n_threads);
 

@@ -103,6 +103,7 @@ def _stub(variant, B, Z, N, d, world=1, rank=0, joint=False, I=24, info=None, R=
     e.world, e.rank, e.Bl = world, rank, B // world
     e.z_joint, e.R = joint, R
     e._trace, e._views, e._launched = None, {}, deque()
+    e._gate_np = np.zeros(2, dtype=np.int64)
     if info:
         e.zd, e.nd, e.nc = info
     z = lambda *s, **k: torch.zeros(*s, **k)
@@ -182,3 +183,45 @@ def test_replay_threads_do_not_change_results():
     finally:
         _lib.call("gm_host_replay_threads", 1)
     assert torch.equal(a, b)
+
+
+def test_fill_worker_matches_inline_replay_and_opens_gate():
+    """gm_fill_submit: jobs run in order on the caller's state buffer, results bit-identical to
+    gm_host_replay called inline, gate advanced after each job; an unsupported job is sticky and
+    leaves later gates closed until gm_fill_reset."""
+    import ctypes
+    from generative_models_amd import _lib
+    lib = _lib.load()
+    assert HostReplay.available()
+    torch.manual_seed(21)
+    s0 = torch.get_rng_state()
+    B, Z, N = 64, 20, 5000
+    ref_idx, ref_z = torch.empty(6, B, dtype=torch.int64), torch.empty(6, B, Z)
+    prog = lambda idx, z: [HostReplay.op(DRAW_SAMPLER, B, idx, B * 8, a=N),
+                           HostReplay.op(DRAW_NORMAL, B * Z, z, B * Z * 4)]
+    st_ref = s0.clone()
+    assert HostReplay.call(st_ref, prog(ref_idx, ref_z), 6) == 0
+    idx, z = torch.empty(6, B, dtype=torch.int64), torch.empty(6, B, Z)
+    st = s0.clone()
+    gate = torch.zeros(2, dtype=torch.int64)
+    jobs = []
+    for c0, n in ((0, 1), (1, 2), (3, 3)):                      # three sub-chunks, in order
+        p = prog(idx[c0:], z[c0:])
+        arr = (_lib.DrawOp * len(p))(*p)
+        jobs.append(lib.gm_fill_submit(st.data_ptr(), st.numel(), arr, len(p), n, gate.data_ptr(), c0 + n))
+    assert jobs == sorted(jobs) and jobs[0] > 0
+    assert lib.gm_fill_wait(jobs[-1]) == 0
+    assert lib.gm_fill_completed() >= jobs[-1]
+    assert int(gate[0]) == 6
+    assert torch.equal(idx, ref_idx) and torch.equal(z, ref_z) and torch.equal(st, st_ref)
+    # sticky failure: normal_ on < 16 elements is outside the restated paths
+    small = torch.empty(8)
+    bad = [HostReplay.op(DRAW_NORMAL, 8, small, 0)]
+    j1 = lib.gm_fill_submit(st.data_ptr(), st.numel(), (_lib.DrawOp * 1)(*bad), 1, 1, gate.data_ptr(), 100)
+    p = prog(idx, z)
+    j2 = lib.gm_fill_submit(st.data_ptr(), st.numel(), (_lib.DrawOp * 2)(*p), 2, 1, gate.data_ptr(), 200)
+    assert lib.gm_fill_wait(j2) == _lib.GM_EUNSUPPORTED and lib.gm_fill_wait(j1) == _lib.GM_EUNSUPPORTED
+    assert int(gate[0]) == 6 and torch.equal(st, st_ref)      # neither job ran / opened a gate
+    assert lib.gm_fill_reset() == 0
+    j3 = lib.gm_fill_submit(st.data_ptr(), st.numel(), (_lib.DrawOp * 2)(*p), 2, 1, gate.data_ptr(), 7)
+    assert lib.gm_fill_wait(j3) == 0 and int(gate[0]) == 7
