@@ -327,7 +327,8 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     """W warm-up + reps x K timed iterations of the fused engine.  Returns (engine, [seconds])."""
     import importlib
     from generative_models_amd import engine as gm_engine
-    mod, cls = {"ns": ("ns_gan", "NSGAN"), "ls": ("ls_gan", "LSGAN"), "wgp": ("w_gp_gan", "WGPGAN")}[variant]
+    mod, cls = {"ns": ("ns_gan", "NSGAN"), "ls": ("ls_gan", "LSGAN"), "wgp": ("w_gp_gan", "WGPGAN"),
+                "dra": ("dra_gan", "DRAGAN")}[variant]
     m = importlib.import_module(mod)
     ds = synthetic_dataset()
     loader = torch.utils.data.DataLoader(ds, batch_size=B_global, shuffle=True)
@@ -403,10 +404,13 @@ def dominant_gemm_roofline(M, K, N, reps=50):
             "frac": ach / PEAK_FP32_MFMA_TFLOPS}
 
 
-def other_configs(dev, steps, warmup, reps, cpu=True):
-    """BASELINE.json configs 3/4/5 on one MI355X, >= 200 timed steps each."""
+def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
+    """BASELINE.json configs 3/4/5 on one MI355X, >= 200 timed steps each (+ DRAGAN,
+    the variant whose per-step host draw is the largest: B x 784 uniforms).  only: one of
+    wgp_b256 / ns_b1024 / ls_b1024 / dra_b256 / vae_b512 (profiling runs)."""
     K, W = max(steps, 200), max(warmup, 20)
     out = []
+    want = lambda tag: only is None or only == tag
 
     def gan(name, variant, B, lrs, flop_per_image, cpu_variant):
         eng, secs = bench_gan(variant, B, W, K, reps, dev, lrs=lrs)
@@ -421,13 +425,26 @@ def other_configs(dev, steps, warmup, reps, cpu=True):
         del eng
         out.append(e)
 
-    gan("WGAN-GP MNIST bs=256 D_steps=1 (BASELINE.json configs[2]; w_gp_gan.py __main__)", "wgp", 256,
-        (1e-4, 1e-4), 8_836_000, "wgp")
-    gan("NSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ns", 1024,
-        (2e-4, 2e-4), FLOP_PER_IMAGE, "ns")
-    gan("LSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ls", 1024,
-        (1e-4, 1e-4), FLOP_PER_IMAGE, "ls")
-    for with_eval in (False, True):
+    if want("wgp_b256"):
+        gan("WGAN-GP MNIST bs=256 D_steps=1 (BASELINE.json configs[2]; w_gp_gan.py __main__)", "wgp", 256,
+            (1e-4, 1e-4), 8_836_000, "wgp")
+    if want("ns_b1024"):
+        gan("NSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ns", 1024,
+            (2e-4, 2e-4), FLOP_PER_IMAGE, "ns")
+    if want("ls_b1024"):
+        gan("LSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ls", 1024,
+            (1e-4, 1e-4), FLOP_PER_IMAGE, "ls")
+    if want("dra_b256"):
+        # not a BASELINE.json config: the variant with the heaviest host protocol (dra_gan.py:200-205
+        # draws B x 784 uniforms per critic step on the CPU generator) -- VERDICT r1 item 9
+        eng, secs = bench_gan("dra", 256, W, K, reps, dev, lrs=(1e-4, 1e-4))
+        dt = float(np.median(secs))
+        out.append({"workload": "DRAGAN MNIST bs=256 D_steps=1 (dra_gan.py; host draws 256 x 784 uniforms per step)",
+                    "img_s": K * 256 / dt, "ms_per_step": dt / K * 1e3, "steps": K,
+                    "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs]})
+        log("DRAGAN bs=256: %.0f img/s" % (K * 256 / dt))
+        del eng
+    for with_eval in ((False, True) if want("vae_b512") else ()):
         img_s, ms, n = bench_vae(512, dev, with_eval)
         e = {"workload": "VAE MNIST bs=512 full epochs incl. the ragged 336 batch, %s "
                          "(BASELINE.json configs[3])" % ("train + per-epoch 10k-image validation pass"
@@ -465,6 +482,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 3/4/5 section")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--only", default=None, help="profiling: run ONE of the extra configs (wgp_b256, ns_b1024, "
+                    "ls_b1024, dra_b256, vae_b512) and print its entry instead of the contract line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -489,6 +508,9 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     W, K, reps = args.warmup, args.steps, max(1, args.reps)
+    if args.only:
+        print(json.dumps(other_configs(dev, min(K, 400), W, min(reps, 3), cpu=False, only=args.only)))
+        return
     B_global = B_PER_GPU * world
     eng, secs = bench_gan("ns", B_global, W, K, reps, dev, world=world, rank=rank,
                           use_graph=not args.no_graph, force_dp=force_dp)

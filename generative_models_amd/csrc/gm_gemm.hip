@@ -71,6 +71,7 @@ struct GemmP {
     int xr, xc, tm, tn;
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
+    int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
@@ -771,7 +772,18 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];
-    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, blockIdx.x, blockIdx.y);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.x16) {
+        // workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): XCD (xi, xj) of
+        // the xr x xc arrangement owns a pr x pc block of tiles, so its private L2 pulls 1/xr of the
+        // A rows and 1/xc of the B rows over the fabric instead of all of both
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int pr = (p.tm + p.xr - 1) / p.xr, pc = (p.tn + p.xc - 1) / p.xc;
+        by = (xcd / p.xc) * pr + j / pc;
+        bx = (xcd % p.xc) * pc + j % pc;
+        if (j >= pr * pc || by >= p.tm || bx >= p.tn) return;   // workgroup-uniform
+    }
+    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, bx, by);
 }
 
 // The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
@@ -1007,6 +1019,25 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
                 if (rc) return rc;
                 return launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
+            }
+        }
+        {
+            static int x16_on = -1;
+            if (x16_on < 0) { const char* e = getenv("GM_XCD16"); x16_on = e ? atoi(e) : 0; }
+            const int gtm = (int)grid.y, gtn = (int)grid.x;                  // tiles of the chosen shape
+            if (x16_on && gtm * gtn >= 64) {
+                const int th = (wide == 2) ? 64 : (wide == 3 ? 16 : 32), tw = (wide == 1) ? 64 : 32;
+                int best = 1 << 30, bxr = 0;
+                for (int xr = 1; xr <= 8; xr <<= 1) {
+                    const int xc = 8 / xr;
+                    if (xr > gtm || xc > gtn) continue;
+                    const int cost = ((gtm + xr - 1) / xr) * th + ((gtn + xc - 1) / xc) * tw;   // operand rows per XCD
+                    if (cost < best) { best = cost; bxr = xr; }
+                }
+                if (bxr) {
+                    p.x16 = 1; p.xr = bxr; p.xc = 8 / bxr; p.tm = gtm; p.tn = gtn;
+                    grid = dim3(8 * ((gtm + p.xr - 1) / p.xr) * ((gtn + p.xc - 1) / p.xc), 1);
+                }
             }
         }
 #define GM_L16(V, W, GG, X) do {                                                                   \

@@ -45,9 +45,13 @@ struct StageP {
     const int64_t* gate;
     gm_slot it_slot;
     uint64_t timeout;
+    int64_t* publish;       // optional: workgroup (0,0) stores the absolute iteration of it_slot here (a
+                            // stable base for a second stage-in that runs concurrently with iterations
+                            // that advance the step counter)
 };
 
 __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
+    if (p.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.publish = gm_slot_index(p.it_slot);
     if (p.gate) {
         if (threadIdx.x == 0) {
             // RELAXED system-scope loads: the gate and the rings are fine-grained (uncached) host
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
 }
 
 static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
-                         const int64_t* gate, gm_slot it_slot, double timeout_s) {
+                         const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish = nullptr,
+                         int max_blocks = 256) {
     GM_CHECK_ARG(segs && n_segs > 0 && n_segs <= GM_STAGE_MAX_SEGS && n_iters > 0);
     StageP p{};
     int64_t most = 0;
@@ -97,11 +102,11 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
         if (segs[i].bytes_per_iter > most) most = segs[i].bytes_per_iter;
     }
     p.n_segs = n_segs; p.slot = slot; p.n_iters = n_iters;
-    p.gate = gate; p.it_slot = it_slot;
+    p.gate = gate; p.it_slot = it_slot; p.publish = publish;
     p.timeout = (uint64_t)(timeout_s * 1e8);          // wall_clock64(): 100 MHz
     int64_t blocks = (most * n_iters / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256) blocks = 256;
+    if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0,
                        (hipStream_t)stream, p);
     GM_LAUNCH_RET();
@@ -112,9 +117,11 @@ extern "C" int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, g
 }
 
 extern "C" int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot,
-                                 int n_iters, const int64_t* gate, gm_slot it_slot, double timeout_s) {
-    GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0);
-    return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s);
+                                 int n_iters, const int64_t* gate, gm_slot it_slot, double timeout_s,
+                                 int64_t* publish, int max_blocks) {
+    GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0 && max_blocks >= 1);
+    return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s, publish,
+                         max_blocks > 256 ? 256 : max_blocks);
 }
 
 // Device-side address of pinned host memory (hipHostMalloc / torch pin_memory()).

@@ -356,6 +356,11 @@ class GANEngine:
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
         self.gated = os.environ.get("GM_GATED", "1") != "0"
+        # forked tail stage-in: measured 72.4 -> 81.7 us / iteration (a graph with a parallel branch leaves
+        # the linear-chain fast path of the runtime, as the DAG experiment of round 1 did): off
+        self.split_stage = os.environ.get("GM_SPLIT_STAGE", "0") != "0"
+        self.stage_base = torch.zeros(1, dtype=torch.int64, device=device)
+        self._stage_side, self._stage_events = None, []
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -903,6 +908,7 @@ class GANEngine:
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
+    STAGE_HEAD = 4      # iterations a long graph stages in serially; the rest overlaps their kernels
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
     FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
     GATE_TIMEOUT_S = 20.0
@@ -1031,14 +1037,31 @@ class GANEngine:
             prog.append(op(DRAW_NORMAL, B * Z, s["zG"][0], gs, **rows(Z)))    # ns_gan.py:208
         return prog
 
-    def _issue_stage_in(self, st, it, k):
-        """First launch of a graph of k iterations: their ring slots, host ring -> device ring."""
+    def _issue_stage_in(self, st, it, k, first=0, base=None, publish=None, max_blocks=256):
+        """Stage-in of iterations [it+first, it+first+k): host ring -> device ring (first launch of a
+        graph).  base: device word holding `it` to resolve the slots from instead of the step counter
+        (the forked tail stage-in of a long graph); publish: device word this launch stores `it` to."""
         from . import _lib
-        if self.gated:
-            _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k,
-                      self._gate_dev, self._slot(it, 1, 0, 0, 1), self.GATE_TIMEOUT_S)
+        if base is not None:
+            ring_slot = ops.slot(base.data_ptr(), 1, first, self.R, 1)
+            it_slot = ops.slot(base.data_ptr(), 1, first, 0, 1)
         else:
-            _lib.call("gm_stage_in", st, self._segs, len(self._segs), self._slot(it, 1, 0, self.R, 1), k)
+            ring_slot, it_slot = self._slot(it, 1, first, self.R, 1), self._slot(it, 1, first, 0, 1)
+        if self.gated:
+            _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
+                      it_slot, self.GATE_TIMEOUT_S, publish.data_ptr() if publish is not None else None,
+                      max_blocks)
+        else:
+            _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
+
+    def _stage_stream(self):
+        if self._stage_side is None:
+            import ctypes
+            from . import _lib
+            h = ctypes.c_void_p()
+            _lib.call("gm_stream_create", ctypes.byref(h))
+            self._stage_side = h
+        return self._stage_side
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -1272,9 +1295,28 @@ class GANEngine:
                 # graphs of graph_iters, ..., 4, 2, 1 iterations (the device counter advances inside
                 # every iteration): any run length is a handful of launches
                 def body(k):
+                    # long graphs stage in their first STAGE_HEAD iterations up front and the rest on a
+                    # forked branch that overlaps those iterations' kernels (the PCIe reads of a
+                    # 32-iteration stage-in take ~60 us -- 1.9 us per iteration when serial)
+                    head = self.STAGE_HEAD if (self.gated and self.split_stage and k >= 2 * self.STAGE_HEAD) else k
+
                     def fn(st):
-                        self._issue_stage_in(st, 0, k)
-                        for _ in range(k):
+                        if head == k:
+                            self._issue_stage_in(st, 0, k)
+                        else:
+                            from . import _lib
+                            side = self._stage_stream()
+                            e0, e1 = ops.Event(), ops.Event()
+                            self._stage_events += [e0, e1]
+                            self._issue_stage_in(st, 0, head, publish=self.stage_base)
+                            e0.record(st)
+                            _lib.call("gm_stream_wait_event", side, e0.h)
+                            self._issue_stage_in(side, 0, k - head, first=head, base=self.stage_base,
+                                                 max_blocks=32)
+                            e1.record(side)
+                        for i in range(k):
+                            if i == head and head < k:
+                                _lib.call("gm_stream_wait_event", st, e1.h)
                             self._issue_iteration(st, 0)
                     return fn
                 self.graph = ops.Graph().capture(body(1))

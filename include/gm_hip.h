@@ -363,9 +363,14 @@ int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot
  * Every workgroup waits (system-scope acquire loads of pinned host memory) until
  * gate[0] >= it + n_iters, it = index of `it_slot` (the absolute iteration); after timeout_s seconds
  * it raises gate[1] = 1 and proceeds -- the host must check gate[1] before trusting results.
- * gate: device-visible address (gm_host_device_ptr) of two int64 in pinned host memory. */
+ * gate: device-visible address (gm_host_device_ptr) of two int64 in pinned host memory.
+ * publish (optional, device memory): workgroup (0,0) stores `it` there -- a second stage-in that runs
+ * on a forked branch of the graph, concurrently with iterations that advance the step counter, resolves
+ * its slots from that word instead.  max_blocks (1..256): workgroups per segment (a concurrent
+ * stage-in should leave the CUs to the iteration kernels). */
 int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
-                      const int64_t* gate, gm_slot it_slot, double timeout_s);
+                      const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish,
+                      int max_blocks);
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 

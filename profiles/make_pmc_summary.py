@@ -23,11 +23,11 @@ def load(prefix, c):
     return agg
 
 
-def main(prefix, tag):
+def main(prefix, tag, outdir=None, what="NSGAN bs=256, `bench.py --steps 60 --warmup 20`"):
     f, w = load(prefix, "FETCH_SIZE"), load(prefix, "WRITE_SIZE")
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = outdir or os.path.dirname(os.path.abspath(__file__))
     lines = ["# PMC pass (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, --kernel-trace)", "",
-             "NSGAN bs=256, `bench.py --steps 60 --warmup 20`.  Counter unit: KiB per dispatch.  Per",
+             what + ".  Counter unit: KiB per dispatch.  Per",
              "MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports HALF the bytes of wide coalesced",
              "reads, so `read_bytes = 2 * FETCH_SIZE * 1024` (calibration, earlier round-1 pass with a standalone",
              "gather: `gather_rows_kernel` reads 256 x 3136 B = 784 KiB and showed FETCH ~427 -> x2 = 853 KiB; its",
@@ -42,17 +42,18 @@ def main(prefix, tag):
         fr, wr = tot / n, wt / max(wn, 1)
         lines.append("| `%s` | %d | %d | %.1f | %.2f | %.1f | %.2f |" % (k[0], k[1], n, fr, 2 * fr * 1024 / 1e6, wr, wr * 1024 / 1e6))
         out["%s|%d" % k] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "dispatches": n}
-    lines += ["", "Reading: every GEMM pulls its operands into (almost) each of the 8 XCD-private L2s: the layer-1",
+    if tag == "r01":
+        lines += ["", "Reading: every GEMM pulls its operands into (almost) each of the 8 XCD-private L2s: the layer-1",
               "critic forward on 2B rows (`gemm16_kernel<0, true, 16, 1, false, 2, 2>`, grid 212992) moves ~23 MB",
               "over the fabric for 2.85 MB of unique operands (8 x 2.85 = 22.8 MB); the layer-1 weight gradient",
               "that also carries the head's backward and both Adam steps (`gemm16_dw_head_kernel`) reads 26 MB",
               "(2.4 MB of operands x 8 + 3.8 MB of Adam state + 0.8 MB for the head) and writes 5.0 MB (gradient +",
               "p, m, v).  The XCD-aware remap that cuts the replication ~2.4x did not shorten the kernels",
-              "(r01_experiments.md): at B=256 they are latency / MFMA-chain bound per CU, not fabric bound."]
+                  "(r01_experiments.md): at B=256 they are latency / MFMA-chain bound per CU, not fabric bound."]
     open(os.path.join(here, tag + "_pmc_fetch_write.md"), "w").write("\n".join(lines) + "\n")
     json.dump(out, open(os.path.join(here, tag + "_pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines[7:]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])

@@ -1,5 +1,5 @@
 """Condense a rocprofv3 `--kernel-trace --stats --output-format csv` run (gpurun_out/<dir>) into the
-small markdown + csv kept under profiles/.  Usage: python profiles/make_summary.py <run_dir> <tag>"""
+small markdown + csv kept under profiles/.  Usage: python profiles/make_summary.py <run_dir> <tag> [outdir]"""
 import csv
 import os
 import sys
@@ -12,11 +12,12 @@ def short(name):
     return name.split("(")[0]
 
 
-def main(run_dir, tag):
+def main(run_dir, tag, outdir=None):
+    outdir = outdir or os.path.dirname(os.path.abspath(__file__))
     stats = [f for f in os.listdir(run_dir) if f.endswith("kernel_stats.csv")][0]
     rows = list(csv.DictReader(open(os.path.join(run_dir, stats))))
     trace = [f for f in os.listdir(run_dir) if f.endswith("kernel_trace.csv")]
-    out_csv = os.path.join(os.path.dirname(__file__), tag + "_kernel_stats.csv")
+    out_csv = os.path.join(outdir, tag + "_kernel_stats.csv")
     with open(out_csv, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "pct", "min_us", "max_us"])
@@ -35,7 +36,7 @@ def main(run_dir, tag):
         t = list(csv.DictReader(open(os.path.join(run_dir, trace[0]))))
         agg = {}
         for r in t:
-            if "gemm_kernel" not in r["Kernel_Name"]:
+            if "gemm" not in r["Kernel_Name"]:
                 continue
             key = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "?")),
                    r.get("Grid_Size_Y", ""))
@@ -47,9 +48,9 @@ def main(run_dir, tag):
                   "| kernel | grid | calls | avg us |", "|---|---|---|---|"]
         for k, (n, tot) in sorted(agg.items()):
             lines.append("| `%s` | %s x %s | %d | %.2f |" % (k[0], k[1], k[2], n, tot / n / 1e3))
-    open(os.path.join(os.path.dirname(__file__), tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(outdir, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

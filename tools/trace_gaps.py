@@ -7,7 +7,9 @@ from collections import OrderedDict
 
 
 def short(n):
-    n = n.replace("void ", "")
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    if n.startswith("at::native") or "at::native" in n[:40]:
+        return "torch: " + n.split("<")[0].split("::")[-1]
     return n.split("(")[0][:70]
 
 
