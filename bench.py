@@ -532,7 +532,7 @@ def main():
         # x2 gfx950 correction + WRITE_SIZE per dispatch; PMC counters cannot be read from inside this
         # process) -- the source file is named next to the number
         traffic, traffic_src = None, None
-        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r02_nsgan_b256_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]

@@ -245,16 +245,18 @@ extern "C" int gm_bir_mmd(void* stream, const float* z, int64_t ldz, const float
 //   kl gradient seeds: dml_kl = [mu | 0.5*(exp(lv) - 1)]
 // Single workgroup (B*Z <= ~20k elements); kl written to kl_out[slot].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vae_reparam_kernel(const float* __restrict__ ml, int64_t ldml,
-                                                         const float* __restrict__ eps,
-                                                         gm_slot eps_slot, float* __restrict__ z,
-                                                         int64_t ldz, float* __restrict__ kl_out,
-                                                         gm_slot kl_slot, int B, int Z) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void vae_reparam_kernel(const float* __restrict__ ml, int64_t ldml,
+                                                          const float* __restrict__ eps,
+                                                          gm_slot eps_slot, float* __restrict__ z,
+                                                          int64_t ldz, float* __restrict__ kl_out,
+                                                          gm_slot kl_slot, int B, int Z) {
+    // one 1024-thread workgroup: two expf per element make this a latency chain, so 16 waves split it
+    // (256 threads: 20.6 us at B*Z = 10240, a sixth of the VAE step; profiles/r02_vae_b512_summary.md)
+    __shared__ double sh[16];
     const float* e = eps + gm_slot_offset(eps_slot);
     double acc = 0.0;
     const int n = B * Z;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
         const int b = i / Z, c = i % Z;
         const float mu = ml[(int64_t)b * ldml + c], lv = ml[(int64_t)b * ldml + Z + c];
         z[(int64_t)b * ldz + c] = mu + e[i] * expf(lv / 2.f);
@@ -263,14 +265,18 @@ __global__ __launch_bounds__(256) void vae_reparam_kernel(const float* __restric
     acc = gm_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) kl_out[gm_slot_index(kl_slot)] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];                 // fixed order
+        kl_out[gm_slot_index(kl_slot)] = (float)t;
+    }
 }
 
 extern "C" int gm_vae_reparam(void* stream, const float* ml, int64_t ldml, const float* eps,
                               gm_slot eps_slot, float* z, int64_t ldz, float* kl_out,
                               gm_slot kl_slot, int B, int Z) {
     GM_CHECK_ARG(ml && eps && z && kl_out && B > 0 && Z > 0 && ldml >= 2 * Z);
-    hipLaunchKernelGGL(vae_reparam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ml, ldml, eps,
+    hipLaunchKernelGGL(vae_reparam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ml, ldml, eps,
                        eps_slot, z, ldz, kl_out, kl_slot, B, Z);
     GM_LAUNCH_RET();
 }
@@ -342,22 +348,32 @@ extern "C" int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, c
 // out[slot] = scale * sum_{i<n} partial[i]   (single workgroup, fp64 accumulate, fixed order)
 __global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restrict__ partial, int n,
                                                           float scale, float* __restrict__ out,
-                                                          gm_slot out_slot) {
+                                                          gm_slot out_slot, int64_t* tick) {
     __shared__ double sh[4];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += (double)partial[i];
     acc = gm_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         out[gm_slot_index(out_slot)] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * (double)scale);
+        if (tick) *tick += 1;                       // after the slot is resolved: last launch of a step
+    }
 }
 
 extern "C" int gm_sum_finalize(void* stream, const float* partial, int n, float scale, float* out,
                                gm_slot out_slot) {
     GM_CHECK_ARG(partial && out && n > 0);
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n,
-                       scale, out, out_slot);
+                       scale, out, out_slot, (int64_t*)nullptr);
+    GM_LAUNCH_RET();
+}
+
+extern "C" int gm_sum_finalize_tick(void* stream, const float* partial, int n, float scale, float* out,
+                                    gm_slot out_slot, int64_t* tick) {
+    GM_CHECK_ARG(partial && out && n > 0 && tick);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n,
+                       scale, out, out_slot, tick);
     GM_LAUNCH_RET();
 }
 

@@ -1689,7 +1689,7 @@ class VAEEngine:
         import os
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
-        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "8")))
+        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))   # batches per graph
 
     def _alloc(self, B):
         if self._bufB == B:
@@ -1731,7 +1731,6 @@ class VAEEngine:
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
         of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
-        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             if self.fuse_adam and not self._dp():
@@ -1760,8 +1759,9 @@ class VAEEngine:
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             dw2((self.dml, self.He, ML), (self.dHe, self.X, E1))
             self._optimizer_step(st, sched_slot)
-        if self.use_graph:
-            ops.tick(self.ctr, 1, stream=st)
+        # the reconstruction sum is the step's LAST launch and carries the counter tick
+        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
+                        tick=self.ctr if self.use_graph else None, stream=st)
 
     def _optimizer_step(self, st, sched_slot):
         """optimizer.step() (vae.py:162) when it is not fused into the dW epilogues: data parallel ->
@@ -1940,8 +1940,6 @@ class AEEngine(VAEEngine):
         ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
         ops.linear_fwd(self.He, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
         of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
-        of.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
-                        stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             adam = dict(sched=self.sched, sched_slot=sched_slot) if (self.fuse_adam and not self._dp()) else None
@@ -1951,8 +1949,8 @@ class AEEngine(VAEEngine):
                                         dict(dA=self.dHe, X=self.X, lin=E1, adam=adam, M=b),
                                         weight_decay=self.wd if adam is not None else 0.0, stream=st)
             self._optimizer_step(st, sched_slot)
-        if self.use_graph:
-            ops.tick(self.ctr, 1, stream=st)
+        of.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
+                        tick=self.ctr if self.use_graph else None, stream=st)
 
 
 class BIRVAEEngine(VAEEngine):
@@ -2030,7 +2028,6 @@ class BIRVAEEngine(VAEEngine):
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
         of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
-        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot, stream=st)
         of.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
                    self.LAMBDA, prior_slot=eps_slot, stream=st)
         of.sum_finalize(self.partm, b, mmd_out, scale=self.LAMBDA, out_slot=loss_slot, stream=st)
@@ -2049,8 +2046,8 @@ class BIRVAEEngine(VAEEngine):
             ops.linear_bwd_dx(self.dZ, MU.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             dw2((self.dZ, self.He, MU), (self.dHe, self.X, E1))
             self._optimizer_step(st, sched_slot)
-        if self.use_graph:
-            ops.tick(self.ctr, 1, stream=st)
+        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
+                        tick=self.ctr if self.use_graph else None, stream=st)
 
 
 class BEGANEngine(GANEngine):

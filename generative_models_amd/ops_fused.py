@@ -74,7 +74,13 @@ def sqerr_sigmoid_bwd(x, xr, dA, partial, B, stream=None):
               _ld(xr), dA.data_ptr(), _ld(dA), partial.data_ptr(), B, I)
 
 
-def sum_finalize(partial, n, out, scale=1.0, out_slot=NO_SLOT, stream=None):
+def sum_finalize(partial, n, out, scale=1.0, out_slot=NO_SLOT, tick=None, stream=None):
+    """out[slot] = scale * sum(partial[:n]) (fp64, fixed order).  tick: device step counter to advance
+    (this is then the last launch of the step)."""
+    if tick is not None:
+        _lib.call("gm_sum_finalize_tick", stream or stream_ptr(), partial.data_ptr(), n, scale,
+                  out.data_ptr(), out_slot, tick.data_ptr())
+        return
     _lib.call("gm_sum_finalize", stream or stream_ptr(), partial.data_ptr(), n, scale,
               out.data_ptr(), out_slot)
 

@@ -181,6 +181,10 @@ int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, const float*
 /* out[slot] = scale * sum(partial[0..n)) in a fixed order (deterministic loss reductions). */
 int gm_sum_finalize(void* stream, const float* partial, int n, float scale, float* out,
                     gm_slot out_slot);
+/* The same as the LAST launch of a step: also advances the device step counter `tick` by one (every
+ * slot of the step has been resolved by then), saving the separate gm_tick launch. */
+int gm_sum_finalize_tick(void* stream, const float* partial, int n, float scale, float* out,
+                         gm_slot out_slot, int64_t* tick);
 
 /* ---- fused critic head (output_dim == 1, separable loss variants): replaces the N=1 GEMV
  * (`self.discriminate`, ns_gan.py:59), the loss lines of train_D / train_G (appendix A.2) and, in

@@ -1,0 +1,47 @@
+"""The package caps torch's intra-op pool at the container's CPU quota (generative_models_amd/__init__.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_quota_parsers(tmp_path, monkeypatch):
+    import builtins
+    import generative_models_amd as gm
+    real_open = builtins.open
+    files = {"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}
+
+    def fake_open(path, *a, **k):
+        if path in files:
+            p = tmp_path / "f"
+            p.write_text(files[path])
+            return real_open(p, *a, **k)
+        if str(path).startswith("/sys/fs/cgroup"):
+            raise OSError(path)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert gm._cpu_quota_cores() == 16.0
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert gm._cpu_quota_cores() is None
+    del files["/sys/fs/cgroup/cpu.max"]
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "400000\n"
+    files["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000\n"
+    assert gm._cpu_quota_cores() == 4.0
+
+
+def test_cap_applies(monkeypatch):
+    import torch
+    import generative_models_amd as gm
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(2, before))
+        monkeypatch.setattr(gm, "_cpu_quota_cores", lambda: 1.5)
+        gm._respect_cpu_quota()
+        assert torch.get_num_threads() == 1
+        torch.set_num_threads(max(2, before))
+        monkeypatch.setenv("GM_KEEP_THREADS", "1")
+        gm._respect_cpu_quota()
+        assert torch.get_num_threads() == max(2, before)
+    finally:
+        torch.set_num_threads(before)
