@@ -97,7 +97,8 @@ def gemm_variant(kind, M, K, N):
         mi, ni = 1, 2
     b = lambda v: "true" if v else "false"
     if kind == "dwh":
-        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d>" % (g, b(xv), mi, ni)
+        # last argument: ones column with a row offset (WGAN-GP's stacked weight gradient only)
+        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, false>" % (g, b(xv), mi, ni)
     if kind == "dxh":
         assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_dx_head_kernel<%d, %d, %d>" % (g, mi, ni)

@@ -580,3 +580,49 @@ def test_packed_dataset_gather_equals_fp32_gather(N, I, B):
     ops.linear_fwd_gather(x, W, bias, y2, "relu", packed, idx, o2)
     assert torch.equal(y1, y2) and torch.equal(o1, o2) and torch.equal(o2, data[idx])
     assert not ops.PackedData.is_binary(torch.rand(4, 4))
+
+
+def test_stage_in_gate_waits_for_the_host_and_times_out_without_hanging():
+    """gm_stage_in_gated: the kernel copies only after the fill counter in pinned host memory covers
+    its iterations; a counter that never advances ends in a bounded wait + the time-out flag (the GPU
+    is never left hanging on a host that died)."""
+    import ctypes
+    import threading
+    import time
+    from generative_models_amd import _lib
+    R, n = 8, 64
+    host = torch.zeros(R, n).pin_memory()
+    dev = torch.full((R, n), -1.0, device="cuda")
+    gate = torch.zeros(2, dtype=torch.int64).pin_memory()
+    hp, gp = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.call("gm_host_device_ptr", host.data_ptr(), ctypes.byref(hp))
+    _lib.call("gm_host_device_ptr", gate.data_ptr(), ctypes.byref(gp))
+    segs = (_lib.StageSeg * 1)(_lib.StageSeg(hp.value, dev.data_ptr(), n * 4))
+    st = ops.stream_ptr()
+    it = 3                                              # iterations [3, 5) -> ring slots 3, 4
+
+    def launch(timeout_s):
+        _lib.call("gm_stage_in_gated", st, segs, 1, ops.slot(0, 0, it, R, 1), 2, gp.value,
+                  ops.slot(0, 0, it, 0, 1), timeout_s, None, 256)
+
+    # 1. the host fills AFTER the launch: the kernel must wait for it
+    def fill():
+        time.sleep(0.05)
+        host[3:5] = torch.arange(2 * n, dtype=torch.float32).view(2, n)
+        gate.numpy()[0] = 5                            # iterations < 5 are written
+    th = threading.Thread(target=fill)
+    launch(5.0)
+    th.start()
+    torch.cuda.synchronize()
+    th.join()
+    assert int(gate[1]) == 0
+    assert torch.equal(dev[3:5].cpu(), host[3:5]) and bool((dev[:3] == -1).all()) and bool((dev[5:] == -1).all())
+    # 2. the fill never comes: bounded wait, flag raised, the stream keeps working
+    it = 6
+    t0 = time.perf_counter()
+    launch(0.05)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(gate[1]) == 1 and 0.04 < dt < 2.0, (int(gate[1]), dt)
+    x = torch.ones(4, device="cuda") * 2
+    assert float(x.sum()) == 8.0
