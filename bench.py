@@ -579,10 +579,21 @@ def main():
                     "ns", B_PER_GPU, seconds_target=5.0, compute_only=True, cores=line["cpu_baseline"]["cores"])
             if not args.no_configs:
                 line["configs"] = other_configs(dev, min(K, 400), W, min(reps, 3), cpu=not args.no_cpu_baseline)
-        print(json.dumps(line))
+        out_line = json.dumps(line)
+    else:
+        out_line = None
     if force_dp or world > 1:
         torch.distributed.barrier()          # rank 0 may still be in its reporting section
         torch.distributed.destroy_process_group()
+    if out_line is not None:
+        # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit,
+        # AFTER the result: push it out first so that the JSON line is the last thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                            # noqa: BLE001
+            pass
+        print(out_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ namespace {
 constexpr int MAXW = 8;
 constexpr int64_t FLAG_BYTES = 4096;             // [phase 0..3][source rank] u64, padded
 constexpr int64_t SCAL_FLOATS = 64;              // scalar exchange: 2 parities x up to 16 values (+pad)
-constexpr unsigned long long SPIN_LIMIT = 1ull << 24;
+constexpr unsigned long long WAIT_TICKS = 10ull * 100000000ull;   // bounded waits: 10 s of the 100 MHz wall clock
 
 struct Region {            // layout of one rank's exchange region (byte offsets)
     int64_t flags, scal, in, out, total;
@@ -87,13 +87,21 @@ __device__ void signal_and_wait(const CommP& c, int phase, unsigned long long s)
                     __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        for (int peer = 0; peer < c.world; ++peer) {
+        // once a wait has expired the run is lost anyway: later waits return at once instead of
+        // costing another time-out each (a broken peer mapping must not stall start-up for minutes)
+        bool dead = __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const unsigned long long t0 = wall_clock64();
+        for (int peer = 0; peer < c.world && !dead; ++peer) {
             if (peer == c.rank) continue;
-            unsigned long long spins = 0;
+            unsigned int spins = 0;
             while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_SYSTEM) < s) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPIN_LIMIT) { atomicExch(c.err, 1); break; }
+                if ((++spins & 255u) == 0 && wall_clock64() - t0 > WAIT_TICKS) {
+                    atomicExch(c.err, 1);
+                    dead = true;
+                    break;
+                }
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);          // system scope: see what the peers published

@@ -73,14 +73,37 @@ class PeerComm:
         self.world, self.rank, self.n = world, rank, int(n_floats)
         self.h = ctypes.c_void_p()
         handle = ctypes.create_string_buffer(64)
-        _lib.call("gm_comm_create", rank, world, self.n, ctypes.byref(self.h), handle)
+        # Collective-safe construction: a rank whose allocation / IPC export / mapping fails must not
+        # leave the others blocked in a collective -- every step's outcome is agreed on before the
+        # next one, and then EVERY rank raises.
+        err = None
+        try:
+            _lib.call("gm_comm_create", rank, world, self.n, ctypes.byref(self.h), handle)
+        except Exception as e:                       # noqa: BLE001
+            err = e
         if world > 1:
             import torch.distributed as dist
             got = [None] * world
-            dist.all_gather_object(got, bytes(handle.raw), group=group)
-            blob = ctypes.create_string_buffer(b"".join(got), 64 * world)
-            _lib.call("gm_comm_connect", self.h, blob)
-            dist.barrier(group=group)               # every rank has mapped every region
+            dist.all_gather_object(got, None if err is not None else bytes(handle.raw), group=group)
+            if any(g is None for g in got):
+                self.close()
+                raise _lib.GMError("peer communicator: exchange region could not be created / exported on "
+                                   "rank(s) %s%s" % ([i for i, g in enumerate(got) if g is None],
+                                                     (": %s" % err) if err is not None else ""))
+            try:
+                blob = ctypes.create_string_buffer(b"".join(got), 64 * world)
+                _lib.call("gm_comm_connect", self.h, blob)
+            except Exception as e:                   # noqa: BLE001
+                err = e
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None, group=group)      # also: every rank has mapped every region
+            if not all(oks):
+                self.close()
+                raise _lib.GMError("peer communicator: hipIpc mapping failed on rank(s) %s%s"
+                                   % ([i for i, g in enumerate(oks) if not g],
+                                      (": %s" % err) if err is not None else ""))
+        elif err is not None:
+            raise err
 
     def grad_buffer(self):
         """The region's own bucket as a torch tensor (zero copy): gradients written here by the
