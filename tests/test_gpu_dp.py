@@ -25,23 +25,38 @@ def _free_port():
     return p
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, real=False):
+    """real: one GPU per rank and RCCL as the control plane (a node with >= `world` GPUs: the exchange
+    then crosses xGMI links); otherwise every rank on GPU 0 with gloo."""
+    local = rank if real else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
-                      RANK=str(rank), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      RANK=str(rank), LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, SRC)
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    if real:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     return dist
 
 
-def _comm_worker(rank, world, port, q):
-    dist = _init(rank, world, port)
+needs_2_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2,
+                                  reason="needs >= 2 GPUs (peer mappings over xGMI)")
+
+
+def _comm_worker(rank, world, port, q, real=False):
+    dist = _init(rank, world, port, real)
     from generative_models_amd import dp, ops
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     n = 314404
-    comm = dp.PeerComm(n, world, rank)
+    try:
+        comm = dp.PeerComm(n, world, rank)
+    except Exception as e:                            # noqa: BLE001  (collective: every rank raises)
+        q.put((rank, False, ["PeerComm: %r" % (e,)]))
+        dist.destroy_process_group()
+        return
     ok = comm.selfcheck(dev)
     g = torch.Generator().manual_seed(100)
     res = []
@@ -78,12 +93,11 @@ def _comm_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_peer_allreduce_between_processes(world):
+def _comm_case(world, real):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, real)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=180) for _ in range(world)]
@@ -91,8 +105,19 @@ def test_peer_allreduce_between_processes(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, res in out:
-        assert ok, "selfcheck failed on rank %d" % rank
+        assert ok, "communicator / selfcheck failed on rank %d: %s" % (rank, res)
         assert all(res), (rank, res)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_peer_allreduce_between_processes(world):
+    _comm_case(world, real=False)
+
+
+@needs_2_gpus
+def test_peer_allreduce_between_gpus():
+    """One rank per GPU, up to 8: the exchange crosses the xGMI links (skipped on 1-GPU boxes)."""
+    _comm_case(min(torch.cuda.device_count(), 8), real=True)
 
 
 SMALL = dict(image_size=64, hidden_dim=48, z_dim=8, batch=16, n_train=160, n_val=48, n_test=48,
@@ -105,8 +130,8 @@ MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "ls": ("ls_gan", "LSGAN", "LS
         "info": ("info_gan", "InfoGAN", "InfoGANTrainer")}
 
 
-def _train_worker(rank, world, port, variant, kw, q):
-    dist = _init(rank, world, port) if world > 1 else None
+def _train_worker(rank, world, port, variant, kw, q, real=False):
+    dist = _init(rank, world, port, real) if world > 1 else None
     if world == 1:
         sys.path.insert(0, os.path.dirname(HERE))
         sys.path.insert(0, SRC)
@@ -140,11 +165,11 @@ def _train_worker(rank, world, port, variant, kw, q):
         dist.destroy_process_group()
 
 
-def _run_world(world, variant, kw):
+def _run_world(world, variant, kw, real=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q, real)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
@@ -184,6 +209,26 @@ def test_two_rank_engine_equals_one_rank(variant, kw):
         for k, v in o["params"].items():
             assert np.max(np.abs(v - one["params"][k])) <= ptol, k
     for k, v in two[0]["params"].items():                 # replicas stay bit-identical
+        assert np.array_equal(v, two[1]["params"][k]), k
+
+
+@needs_2_gpus
+@pytest.mark.parametrize("variant,kw", [("ns", dict(num_epochs=2))], ids=["ns"])
+def test_two_gpu_engine_equals_one_rank(variant, kw):
+    """The same comparison with ONE GPU PER RANK and RCCL as control plane (skipped on 1-GPU boxes):
+    either exchange mode is acceptable here (peer mappings, or the RCCL fallback if the self-check
+    refused them)."""
+    one = _run_world(1, variant, kw)[0]
+    two = _run_world(2, variant, kw, real=True)
+    for o in two:
+        assert o["world"] == 2 and o["rng"] == one["rng"]
+        g, d = np.array(o["G"]), np.array(o["D"])
+        assert np.max(np.abs(g - np.array(one["G"])) / np.maximum(1, np.abs(one["G"]))) <= 1e-5
+        assert np.max(np.abs(d - np.array(one["D"])) / np.maximum(1, np.abs(one["D"]))) <= 1e-5
+        ptol = 1.5e-4 if variant == "be" else 2e-5
+        for k, v in o["params"].items():
+            assert np.max(np.abs(v - one["params"][k])) <= ptol, k
+    for k, v in two[0]["params"].items():
         assert np.array_equal(v, two[1]["params"][k]), k
 
 
