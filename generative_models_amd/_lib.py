@@ -108,6 +108,8 @@ _SIGNATURES = {
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
+    "gm_linear_fwd_interp": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int,
+                                     _P, Slot, _P, c_int64, _P, c_int64, c_int]),
     "gm_linear_fwd_gather": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
                                      c_int, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
     "gm_linear_fwd_gather_bits": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,

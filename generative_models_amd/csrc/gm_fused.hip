@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ e
     if (b >= B) return;
     const float ev = e[b];
     const float om = 1.f - ev;
-    for (int i = lane; i < I; i += 64)
-        out[(int64_t)b * ldo + i] = ev * x[(int64_t)b * ldx + i] + om * g[(int64_t)b * ldg + i];
+    for (int i = lane; i < I; i += 64)      // two roundings and an add, never contracted (as torch computes it)
+        out[(int64_t)b * ldo + i] = __fadd_rn(__fmul_rn(ev, x[(int64_t)b * ldx + i]),
+                                              __fmul_rn(om, g[(int64_t)b * ldg + i]));
 }
 
 extern "C" int gm_interp(void* stream, const float* eps, gm_slot eps_slot, const float* x,
@@ -66,53 +67,94 @@ extern "C" int gm_gp_u(void* stream, const float* s, const float* h, int64_t ldh
 //     pen[b] = (n_b - 1)^2 ;  gamma_b = lambda * inv_b * 2 (n_b - 1) * g_b / n_b  (0 when n_b = 0,
 //     torch's norm sub-gradient).  One wave per row.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, int64_t ldg,
-                                                     float* __restrict__ gam, int64_t ldm,
-                                                     float* __restrict__ pen, float lambda,
-                                                     float inv_b, float k, int B, int I) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
+template <bool VEC4>
+__global__ __launch_bounds__(64) void gp_norm_kernel(const float* __restrict__ g, int64_t ldg,
+                                                    float* __restrict__ gam, int64_t ldm,
+                                                    float* __restrict__ pen, float lambda,
+                                                    float inv_b, float k, int B, int I) {
+    // one wave per row AND per workgroup (B workgroups spread over the CUs: a latency chain, not
+    // bandwidth); VEC4 (I % 4 == 0, I <= 1024, aligned rows): the row stays in registers between the
+    // norm and the scaling -- one round of 16-byte loads instead of two passes of dword loads
+    const int lane = threadIdx.x, b = blockIdx.x;
     const float* row = g + (int64_t)b * ldg;
+    float* o = gam + (int64_t)b * ldm;
     float ss = 0.f;
-    for (int i = lane; i < I; i += 64) ss += row[i] * row[i];
+    float4 v[4];
+    if (VEC4) {
+        const int n4 = I >> 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4*>(row)[min(lane + 64 * j, n4 - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < n4)
+                ss += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    } else {
+        for (int i = lane; i < I; i += 64) ss += row[i] * row[i];
+    }
     ss = gm_wave_sum(ss);
     const float n = sqrtf(ss);
     const float dn = n - k;
     if (lane == 0) pen[b] = dn * dn;
     const float coef = (n > 0.f) ? (lambda * (inv_b * (2.f * dn))) / n : 0.f;
-    float* o = gam + (int64_t)b * ldm;
-    for (int i = lane; i < I; i += 64) o[i] = row[i] * coef;
+    if (VEC4) {
+        const int n4 = I >> 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < n4)
+                reinterpret_cast<float4*>(o)[lane + 64 * j] =
+                    make_float4(v[j].x * coef, v[j].y * coef, v[j].z * coef, v[j].w * coef);
+    } else {
+        for (int i = lane; i < I; i += 64) o[i] = row[i] * coef;
+    }
 }
 
 extern "C" int gm_gp_norm(void* stream, const float* g, int64_t ldg, float* gam, int64_t ldm,
                           float* pen, float lambda, float inv_b, float k, int B, int I) {
     GM_CHECK_ARG(g && gam && pen && B > 0 && I > 0);
-    hipLaunchKernelGGL(gp_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                       gam, ldm, pen, lambda, inv_b, k, B, I);
+    const bool vec4 = (I % 4 == 0) && I <= 1024 && (ldg % 4 == 0) && (ldm % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gam)) & 15) == 0;
+    if (vec4) hipLaunchKernelGGL(gp_norm_kernel<true>, dim3(B), dim3(64), 0, (hipStream_t)stream, g, ldg,
+                                 gam, ldm, pen, lambda, inv_b, k, B, I);
+    else hipLaunchKernelGGL(gp_norm_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, g, ldg,
+                            gam, ldm, pen, lambda, inv_b, k, B, I);
     GM_LAUNCH_RET();
 }
 
 // ------------------------------------------------------------------------------------------
 // K12 tail: gw2[n] += sum_b [s_b>0][h[b,n]>0] * t[b,n]       (dP/dw2, A.3)
-// 32 columns per workgroup, 8 row-groups, fixed-order LDS combine (deterministic).
+// 32 columns per workgroup, 32 row-groups (1024 threads: 8 rows each at B = 256 -- with 8 row-groups a
+// thread walked 32 dependent rows and the launch took 9.5 us), fixed-order LDS combine (deterministic).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_dw2_kernel(const float* __restrict__ s,
-                                                    const float* __restrict__ h, int64_t ldh,
-                                                    const float* __restrict__ t, int64_t ldt,
-                                                    float* __restrict__ gw2, int B, int H, int store) {
-    __shared__ float sh[8][33];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+__global__ __launch_bounds__(1024) void gp_dw2_kernel(const float* __restrict__ s,
+                                                     const float* __restrict__ h, int64_t ldh,
+                                                     const float* __restrict__ t, int64_t ldt,
+                                                     float* __restrict__ gw2, int B, int H, int store) {
+    __shared__ float sh[32][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
     float acc = 0.f;
-    if (c < H)
-        for (int b = rg; b < B; b += 8)
+    if (c < H) {
+        int b = rg;
+        for (; b + 96 < B; b += 128) {                       // four independent rows in flight
+            const float s0 = s[b], s1 = s[b + 32], s2 = s[b + 64], s3 = s[b + 96];
+            const float h0 = h[(int64_t)b * ldh + c], h1 = h[(int64_t)(b + 32) * ldh + c];
+            const float h2 = h[(int64_t)(b + 64) * ldh + c], h3 = h[(int64_t)(b + 96) * ldh + c];
+            const float t0 = t[(int64_t)b * ldt + c], t1 = t[(int64_t)(b + 32) * ldt + c];
+            const float t2 = t[(int64_t)(b + 64) * ldt + c], t3 = t[(int64_t)(b + 96) * ldt + c];
+            if (s0 > 0.f && h0 > 0.f) acc += t0;
+            if (s1 > 0.f && h1 > 0.f) acc += t1;
+            if (s2 > 0.f && h2 > 0.f) acc += t2;
+            if (s3 > 0.f && h3 > 0.f) acc += t3;
+        }
+        for (; b < B; b += 32)
             if (s[b] > 0.f && h[(int64_t)b * ldh + c] > 0.f) acc += t[(int64_t)b * ldt + c];
-    sh[rg][threadIdx.x & 31] = acc;
+    }
+    sh[rg][col] = acc;
     __syncthreads();
     if (rg == 0 && c < H) {
         float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v += sh[r][threadIdx.x & 31];
+        for (int r = 0; r < 32; ++r) v += sh[r][col];
         gw2[c] = store ? v : (gw2[c] + v);
     }
 }
@@ -120,40 +162,74 @@ __global__ __launch_bounds__(256) void gp_dw2_kernel(const float* __restrict__ s
 extern "C" int gm_gp_dw2(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
                          int64_t ldt, float* gw2, int B, int H) {
     GM_CHECK_ARG(s && h && t && gw2 && B > 0 && H > 0);
-    hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, s, h,
+    hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(1024), 0, (hipStream_t)stream, s, h,
                        ldh, t, ldt, gw2, B, H, 0);
     GM_LAUNCH_RET();
 }
 extern "C" int gm_gp_dw2_store(void* stream, const float* s, const float* h, int64_t ldh, const float* t,
                                int64_t ldt, float* out, int B, int H) {
     GM_CHECK_ARG(s && h && t && out && B > 0 && H > 0);
-    hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, s, h,
+    hipLaunchKernelGGL(gp_dw2_kernel, dim3((H + 31) / 32), dim3(1024), 0, (hipStream_t)stream, s, h,
                        ldh, t, ldt, out, B, H, 1);
     GM_LAUNCH_RET();
 }
 
-// One wave per row: the N = 1 critic layer on x_hat (a dot product, not an MFMA launch) and u.
-__global__ __launch_bounds__(256) void head_gp_kernel(const float* __restrict__ h, int64_t ldh,
-                                                     const float* __restrict__ w2,
-                                                     const float* __restrict__ b2, float* __restrict__ s,
-                                                     float* __restrict__ u, int64_t ldu, int B, int H) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
+// One wave per row (and per workgroup): the N = 1 critic layer on x_hat (a dot product, not an MFMA
+// launch) and u.  VEC4: h and w2 rows in registers (16-byte loads), u written from them.
+template <bool VEC4>
+__global__ __launch_bounds__(64) void head_gp_kernel(const float* __restrict__ h, int64_t ldh,
+                                                    const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ s,
+                                                    float* __restrict__ u, int64_t ldu, int B, int H) {
+    const int lane = threadIdx.x, b = blockIdx.x;
     const float* hr = h + (int64_t)b * ldh;
+    float* ur = u + (int64_t)b * ldu;
     float acc = 0.f;
-    for (int i = lane; i < H; i += 64) acc = fmaf(hr[i], w2[i], acc);
+    float4 hv[2], wv[2];
+    if (VEC4) {
+        const int n4 = H >> 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = min(lane + 64 * j, n4 - 1);
+            hv[j] = reinterpret_cast<const float4*>(hr)[i4];
+            wv[j] = reinterpret_cast<const float4*>(w2)[i4];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (lane + 64 * j < n4) {
+                acc = fmaf(hv[j].x, wv[j].x, acc); acc = fmaf(hv[j].y, wv[j].y, acc);
+                acc = fmaf(hv[j].z, wv[j].z, acc); acc = fmaf(hv[j].w, wv[j].w, acc);
+            }
+    } else {
+        for (int i = lane; i < H; i += 64) acc = fmaf(hr[i], w2[i], acc);
+    }
     acc = gm_wave_sum(acc);
     const float sv = fmaxf(acc + b2[0], 0.f);
     if (lane == 0) s[b] = sv;
-    float* ur = u + (int64_t)b * ldu;
-    for (int i = lane; i < H; i += 64) ur[i] = (sv > 0.f && hr[i] > 0.f) ? w2[i] : 0.f;
+    if (VEC4) {
+        const int n4 = H >> 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (lane + 64 * j < n4) {
+                float4 d;
+                d.x = (sv > 0.f && hv[j].x > 0.f) ? wv[j].x : 0.f; d.y = (sv > 0.f && hv[j].y > 0.f) ? wv[j].y : 0.f;
+                d.z = (sv > 0.f && hv[j].z > 0.f) ? wv[j].z : 0.f; d.w = (sv > 0.f && hv[j].w > 0.f) ? wv[j].w : 0.f;
+                reinterpret_cast<float4*>(ur)[lane + 64 * j] = d;
+            }
+    } else {
+        for (int i = lane; i < H; i += 64) ur[i] = (sv > 0.f && hr[i] > 0.f) ? w2[i] : 0.f;
+    }
 }
 extern "C" int gm_head_gp(void* stream, const float* h, int64_t ldh, const float* w2, const float* b2,
                           float* s, float* u, int64_t ldu, int B, int H) {
     GM_CHECK_ARG(h && w2 && b2 && s && u && B > 0 && H > 0 && ldh >= H && ldu >= H);
-    hipLaunchKernelGGL(head_gp_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, ldh, w2,
-                       b2, s, u, ldu, B, H);
+    const bool vec4 = (H % 4 == 0) && H <= 512 && (ldh % 4 == 0) && (ldu % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w2) |
+                        reinterpret_cast<uintptr_t>(u)) & 15) == 0;
+    if (vec4) hipLaunchKernelGGL(head_gp_kernel<true>, dim3(B), dim3(64), 0, (hipStream_t)stream, h, ldh, w2,
+                                 b2, s, u, ldu, B, H);
+    else hipLaunchKernelGGL(head_gp_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, h, ldh, w2,
+                            b2, s, u, ldu, B, H);
     GM_LAUNCH_RET();
 }
 

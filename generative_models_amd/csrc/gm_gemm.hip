@@ -72,6 +72,12 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
+    // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
+    // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
+    const float* ip_eps; gm_slot ip_slot;
+    const float* ip_x; int64_t ip_ldx;
+    float* ip_out; int64_t ip_ldo;
+    int ip_rows;
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
@@ -161,6 +167,12 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
         if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
         else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
         p.C[(int64_t)m * p.ldc + n] = v;
+        if (p.ip_out && m < p.ip_rows) {
+            // two roundings and an add, never contracted: torch's eps * x + (1 - eps) * g
+            const float ev = (p.ip_eps + gm_slot_offset(p.ip_slot))[m];
+            p.ip_out[(int64_t)m * p.ip_ldo + n] =
+                __fadd_rn(__fmul_rn(ev, p.ip_x[(int64_t)m * p.ip_ldx + n]), __fmul_rn(1.f - ev, v));
+        }
     } else if (MODE == MODE_DX) {
         if (p.add) v += p.add_scale * p.add[(int64_t)m * p.ldadd + n];
         if (p.epi == GM_ACT_RELU) {
@@ -1089,6 +1101,25 @@ extern "C" int gm_linear_fwd(void* stream, const float* X, int64_t ldx, gm_slot 
     p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
     p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = act;
     p.a_slot = x_slot; p.b_slot = no_slot();
+    const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
+                     (x_slot.stride % 4 == 0);
+    return launch<MODE_FWD>((hipStream_t)stream, p, vec);
+}
+
+extern "C" int gm_linear_fwd_interp(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                    const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                    int K, int N, int act, const float* eps, gm_slot eps_slot,
+                                    const float* x_real, int64_t ld_real, float* x_hat, int64_t ld_hat,
+                                    int rows) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
+    GM_CHECK_ARG(eps && x_real && x_hat && rows > 0 && rows <= M && ld_real >= N && ld_hat >= N);
+    GemmP p{};
+    p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
+    p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = act;
+    p.a_slot = x_slot; p.b_slot = no_slot();
+    p.ip_eps = eps; p.ip_slot = eps_slot; p.ip_x = x_real; p.ip_ldx = ld_real;
+    p.ip_out = x_hat; p.ip_ldo = ld_hat; p.ip_rows = rows;
     const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
                      (x_slot.stride % 4 == 0);
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);

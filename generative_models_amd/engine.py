@@ -579,7 +579,20 @@ class GANEngine:
                                   stream=st, **self._gather_args(it, j))
         else:
             ops.linear_fwd(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot, stream=st)
-        ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
+        if self._interp_in_gen():
+            # WGAN-GP: x_hat = eps*x + (1-eps)*G(zD) written by this launch's epilogue for its first
+            # Bl rows (the real rows were gathered by the previous launch's rider)
+            r0 = self.rank * Bl
+            ops.linear_fwd_interp(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", self.eps_ring.view(-1)[r0:],
+                                  self._slot(it, d, j, R * d, self.B), self.XX[:Bl], self.Xh, Bl, M=rows,
+                                  stream=st)
+        else:
+            ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
+
+    def _interp_in_gen(self):
+        import os
+        # (the DAG experiment runs the gather on a side stream, concurrently with this launch)
+        return self.variant == "wgp" and not self.dag and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
 
     def _D_rest(self, st, it, j):
         Bl, d = self.Bl, self.D_steps
@@ -848,8 +861,9 @@ class GANEngine:
         D1, D2 = self.D1, self.D2
         r0 = self.rank * Bl
         eps_slot = self._slot(it, d, j, R * d, self.B)
-        ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
-                      stream=st)
+        if not self._interp_in_gen():
+            ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
+                          stream=st)
         ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
         if self._wgp_stacked():
             ops_gp.head_gp(self.Hh, D2.W, D2.b, self.Sh, self.U, stream=st)     # D(x_hat), u: one launch

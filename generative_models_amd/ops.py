@@ -42,6 +42,20 @@ def linear_fwd(x, W, b, y, act, M=None, x_slot=NO_SLOT, stream=None):
     return y
 
 
+def linear_fwd_interp(x, W, b, y, act, eps, eps_slot, x_real, x_hat, rows, M=None, x_slot=NO_SLOT,
+                      stream=None):
+    """linear_fwd + WGAN-GP's x_hat = eps*x_real + (1-eps)*y for the first `rows` output rows
+    (w_gp_gan.py:197-201), written by the same launch."""
+    N, K = W.shape
+    M = x.shape[0] if M is None else M
+    _lib.call("gm_linear_fwd_interp", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x), x_slot,
+              _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
+              _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act] if not isinstance(act, int) else act,
+              eps.data_ptr(), eps_slot, _chk(x_real, "x_real").data_ptr(), _ld(x_real),
+              _chk(x_hat, "x_hat").data_ptr(), _ld(x_hat), rows)
+    return y
+
+
 def linear_bwd_dx(dA, W, dX, below=None, epi="id", M=None, add=None, add_scale=1.0, stream=None):
     """dX[M,K] = (dA[M,N] @ W[N,K] + add_scale*add) (* act'(below))."""
     N, K = W.shape

@@ -279,6 +279,14 @@ int gm_linear_bwd_dw_adam_head_ex(void* stream, const float* dA, int64_t lda, co
 int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
                           int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
                           int epi, const gm_head_bwd_args* head);
+/* gm_linear_fwd that also writes WGAN-GP's interpolate for its first `rows` output rows
+ * (w_gp_gan.py:197-201: x_hat = eps * x + (1 - eps) * G(z), computed where G(z) is produced):
+ *   x_hat[m][n] = eps[m] * x_real[m][n] + (1 - eps[m]) * Y[m][n],  m < rows
+ * eps: per-row uniforms (ring base + eps_slot).  Saves the separate gm_interp launch. */
+int gm_linear_fwd_interp(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                         const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                         const float* eps, gm_slot eps_slot, const float* x_real, int64_t ld_real,
+                         float* x_hat, int64_t ld_hat, int rows);
 /* gm_linear_fwd and gm_gather_rows as ONE launch: the gather workgroups ride in the GEMM's grid.  The
  * gather only reads the index ring and the resident dataset, so any forward launch that does not
  * touch `out` can carry it (the engine uses the generator's first layer, ns_gan.py:44 + :222-226). */

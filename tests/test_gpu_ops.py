@@ -626,3 +626,28 @@ def test_stage_in_gate_waits_for_the_host_and_times_out_without_hanging():
     assert int(gate[1]) == 1 and 0.04 < dt < 2.0, (int(gate[1]), dt)
     x = torch.ones(4, device="cuda") * 2
     assert float(x.sum()) == 8.0
+
+
+@pytest.mark.parametrize("M,K,N,rows", [(512, 400, 784, 256), (96, 48, 64, 40), (2048, 400, 784, 1024)])
+def test_linear_fwd_with_interp_epilogue_equals_separate_launches(M, K, N, rows):
+    """gm_linear_fwd_interp: the generator's last layer also writes WGAN-GP's x_hat for its first
+    `rows` rows -- bit-identical to gm_linear_fwd followed by gm_interp (w_gp_gan.py:197-201), for the
+    split-reduction kernel and the LDS macro-tile kernel (M >= 1024) alike."""
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(M + N)
+    dev = "cuda"
+    x = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev) * 0.1
+    real = torch.bernoulli(torch.full((rows, N), 0.3, device=dev))
+    eps = torch.rand(rows, device=dev)
+    y0, y1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    xh0, xh1 = torch.zeros(rows, N, device=dev), torch.full((rows, N), -3.0, device=dev)
+    ops.linear_fwd(x, W, b, y0, "sigmoid")
+    of.interp(eps, ops.NO_SLOT, real, y0[:rows], xh0)
+    ops.linear_fwd_interp(x, W, b, y1, "sigmoid", eps, ops.NO_SLOT, real, xh1, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(xh0, xh1)
+    e, r, g = eps.cpu()[:, None], real.cpu(), y0[:rows].cpu()
+    ref = e * r + (1 - e) * g                          # torch CPU: two rounded products, one add
+    assert torch.equal(xh1.cpu(), ref)
