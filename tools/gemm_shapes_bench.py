@@ -53,11 +53,34 @@ def time_shape(kind, M, K, N, reps=50):
     e1.record(s)
     e1.sync()
     us = e0.elapsed_ms(e1) * 1e3 / reps
-    return us, 2.0 * M * K * N / us / 1e6
+    # the vendor library on the same contraction (torch -> hipBLASLt / rocBLAS), same timing method;
+    # fwd: bias fused by the library, relu not included; dx: without the relu mask; dw: without db
+    if kind == "fwd":
+        vfn = lambda: torch.addmm(b, x, W.t(), out=y)
+    elif kind == "dx":
+        vfn = lambda: torch.mm(dA, W, out=dX)
+    else:
+        vfn = lambda: torch.mm(dA.t(), x, out=dW)
+    vfn()
+    torch.cuda.synchronize()
+    tg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(tg):
+        for _ in range(reps):
+            vfn()
+    for _ in range(3):
+        tg.replay()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    tg.replay()
+    t1.record()
+    t1.synchronize()
+    vus = t0.elapsed_time(t1) * 1e3 / reps
+    return us, 2.0 * M * K * N / us / 1e6, vus
 
 
 if __name__ == "__main__":
     for a in sys.argv[1:]:
         kind, M, K, N = a.split(":")
-        us, tf = time_shape(kind, int(M), int(K), int(N))
-        print("%-3s M=%5s K=%4s N=%4s : %8.2f us  %6.2f TFLOP/s" % (kind, M, K, N, us, tf), flush=True)
+        us, tf, vus = time_shape(kind, int(M), int(K), int(N))
+        print("%-3s M=%5s K=%4s N=%4s : %8.2f us  %6.2f TFLOP/s   | vendor GEMM (torch) %8.2f us  %6.2f TFLOP/s"
+              % (kind, M, K, N, us, tf, vus, 2.0 * int(M) * int(K) * int(N) / vus / 1e6), flush=True)
