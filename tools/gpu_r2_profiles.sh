@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace stats + the two PMC passes (each in its OWN run: --pmc with --kernel-trace only)
 # for the headline workload and the configs 3/4/5 legs; summaries land in gpurun_out/profiles_r02/.
+# usage: gpu_r2_profiles.sh [all | comma list of nsgan_b256,ns_b1024,wgp_b256,vae_b512]
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out/profiles_r02; export TMPDIR=/tmp
 OUT=$R/gpurun_out/profiles_r02
@@ -17,8 +18,10 @@ prof() {   # tag, description, bench args...
   python $R/profiles/make_pmc_summary.py $R/gpurun_out/pmc_${tag}_ $tag $OUT "$what" > /dev/null
   find $R/gpurun_out -name "*kernel_trace.csv" -delete; find $R/gpurun_out -name "*counter_collection.csv" -delete
 }
-prof r02_nsgan_b256 "NSGAN bs=256 (headline), bench.py --steps 400 --warmup 50" --steps 400 --warmup 50 --reps 1 --no-cpu-baseline --no-configs
-prof r02_ns_b1024 "NSGAN bs=1024 (configs[4] single-GPU leg), bench.py --only ns_b1024" --only ns_b1024 --steps 200 --warmup 20 --reps 1
-prof r02_wgp_b256 "WGAN-GP bs=256 D_steps=1 (configs[2]), bench.py --only wgp_b256" --only wgp_b256 --steps 200 --warmup 20 --reps 1
-prof r02_vae_b512 "VAE bs=512 full epochs (configs[3]), bench.py --only vae_b512" --only vae_b512 --steps 200 --warmup 20 --reps 1
+WHICH="${1:-all}"
+want() { [ "$WHICH" = "all" ] || [[ ",$WHICH," == *",$1,"* ]]; }
+want nsgan_b256 && prof r02_nsgan_b256 "NSGAN bs=256 (headline), bench.py --steps 400 --warmup 50" --steps 400 --warmup 50 --reps 1 --no-cpu-baseline --no-configs
+want ns_b1024 && prof r02_ns_b1024 "NSGAN bs=1024 (configs[4] single-GPU leg), bench.py --only ns_b1024" --only ns_b1024 --steps 200 --warmup 20 --reps 1
+want wgp_b256 && prof r02_wgp_b256 "WGAN-GP bs=256 D_steps=1 (configs[2]), bench.py --only wgp_b256" --only wgp_b256 --steps 200 --warmup 20 --reps 1
+want vae_b512 && prof r02_vae_b512 "VAE bs=512 full epochs (configs[3]), bench.py --only vae_b512" --only vae_b512 --steps 200 --warmup 20 --reps 1
 ls -la $OUT; du -sh $R/gpurun_out
