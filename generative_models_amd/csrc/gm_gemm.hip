@@ -280,9 +280,10 @@ template <int MODE, int BM, int BN, int WTM, int WTN, int WK, int KU>
 struct LdsCfg {
     static constexpr int WM = BM / WTM, WN = BN / WTN, NW = WM * WN * WK, NT = 64 * NW, BK = 8 * WK * KU;
     static constexpr int TI = WTM / 32, TJ = WTN / 32;
-    static constexpr bool B_KC = (MODE == MODE_FWD);       // B(k,n) = W[n][k] (fwd) / W[k][n] (dx)
-    static constexpr int LDK = BK + 4, LDXB = BN + 4;
-    static constexpr int A_SZ = BM * LDK;
+    static constexpr bool A_KC = (MODE != MODE_DW);        // A(m,k) = X[m][k] (fwd, dx) / dA[k][m] (dw)
+    static constexpr bool B_KC = (MODE == MODE_FWD);       // B(k,n) = W[n][k] (fwd) / W[k][n] (dx) / X[k][n] (dw)
+    static constexpr int LDK = BK + 4, LDXB = BN + 4, LDXA = BM + 4;
+    static constexpr int A_SZ = A_KC ? BM * LDK : BK * LDXA;
     static constexpr int B_SZ = B_KC ? BN * LDK : BK * LDXB;
     static constexpr int STAGE = A_SZ + B_SZ;
     static constexpr int NBUF = 3;                          // LDS stage buffers (see the pipeline below)
@@ -318,28 +319,40 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
     const float* B = p.B + gm_slot_offset(p.b_slot);
 
     constexpr int KQ = BK / 4;                                    // 16-byte units per k-contiguous row
-    constexpr int XQ = BN / 4;                                    // 16-byte units per x-contiguous row
-    constexpr int UA = BM * KQ, CA = (UA + NT - 1) / NT;
+    constexpr int XQ = BN / 4, XQA = BM / 4;                      // 16-byte units per x-contiguous row
+    constexpr int LDXA = C::LDXA;
+    constexpr int UA = C::A_KC ? BM * KQ : BK * XQA, CA = (UA + NT - 1) / NT;
     constexpr int UB = C::B_KC ? BN * KQ : BK * XQ, CB = (UB + NT - 1) / NT;
+    // dw: B's real columns end at n_real; column n_real is the virtual ones column (bias gradient),
+    // 1 for reduction rows >= ones_from.  Edge tiles (and only they) pay for the column masks.
+    const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;
+    const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
+    const bool edge_m = (MODE == MODE_DW) && (m0 + BM > p.M);
+    const bool edge_n = (MODE == MODE_DW) && (n0 + BN > b_cols);
     // per-thread base address of each 16-byte unit of the stage tiles (row clamps applied once)
     const float* baseA[CA];
     const float* baseB[CB];
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
         const int u = min(t + i * NT, UA - 1);
-        baseA[i] = A + (int64_t)min(m0 + u / KQ, p.M - 1) * p.lda + 4 * (u % KQ);
+        if (C::A_KC) baseA[i] = A + (int64_t)min(m0 + u / KQ, p.M - 1) * p.lda + 4 * (u % KQ);
+        else baseA[i] = A + min(m0 + 4 * (u % XQA), p.M - 4);    // + k * lda per stage
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
         const int u = min(t + i * NT, UB - 1);
         if (C::B_KC) baseB[i] = B + (int64_t)min(n0 + u / KQ, p.N - 1) * p.ldb + 4 * (u % KQ);
-        else baseB[i] = B + min(n0 + 4 * (u % XQ), p.N - 4);      // + k * ldb per stage
+        else baseB[i] = B + min(n0 + 4 * (u % XQ), b_cols - 4);   // + k * ldb per stage
     }
     // One 16-byte unit of stage q.  The lambdas RETURN the value (a lambda that writes a captured
     // register array makes hipcc keep the array in scratch memory, with a vmcnt(0) behind every
     // load -- measured: 1.4 us per stage).  Branch-free: `inside` (the whole stage lies below K) is
     // a compile-time constant in the unrolled kernels, otherwise the k index is clamped.
     auto load_a = [&](const float* base, int i, int q, bool inside) -> float4 {
+        if (!C::A_KC) {
+            const int kk = q * BK + min(t + i * NT, UA - 1) / XQA;
+            return *reinterpret_cast<const float4*>(base + (int64_t)(inside ? kk : min(kk, p.K - 1)) * p.lda);
+        }
         if (inside) return *reinterpret_cast<const float4*>(base + q * BK);
         const int kq4 = 4 * (min(t + i * NT, UA - 1) % KQ);
         return *reinterpret_cast<const float4*>(base - kq4 + min(q * BK + kq4, p.K - 4));
@@ -356,8 +369,15 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
     };
     // the K-tail zeroing select happens here, at the LDS write, never right behind the load
     auto store_a = [&](int buf, int i, int q, bool inside, float4 v) {
-        const int u = t + i * NT, row = u / KQ, kq = u % KQ;
+        const int u = t + i * NT;
         if (UA % NT != 0 && u >= UA) return;
+        if (!C::A_KC) {
+            const int kr = u / XQA, xq = u % XQA;
+            const bool ok = (inside || q * BK + kr < p.K) && (!edge_m || m0 + 4 * xq < p.M);
+            *reinterpret_cast<float4*>(&lds[buf * C::STAGE + kr * LDXA + 4 * xq]) = keep4(ok, v);
+            return;
+        }
+        const int row = u / KQ, kq = u % KQ;
         *reinterpret_cast<float4*>(&lds[buf * C::STAGE + row * LDK + 4 * kq]) = inside ? v : keep4(q * BK + 4 * kq < p.K, v);
     };
     auto store_b = [&](int buf, int i, int q, bool inside, float4 v) {
@@ -369,11 +389,26 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
             *reinterpret_cast<float4*>(&Bs[row * LDK + 4 * kq]) = inside ? v : keep4(q * BK + 4 * kq < p.K, v);
         } else {
             const int kr = u / XQ, xq = u % XQ;
+            if (MODE == MODE_DW && edge_n) {
+                const int k = q * BK + kr, c0 = n0 + 4 * xq;
+                const bool kin = inside || k < p.K;
+                const float one = (kin && k >= p.ones_from) ? 1.f : 0.f;
+                v.x = (c0 + 0 < b_cols) ? (kin ? v.x : 0.f) : ((c0 + 0 == ones_col) ? one : 0.f);
+                v.y = (c0 + 1 < b_cols) ? (kin ? v.y : 0.f) : ((c0 + 1 == ones_col) ? one : 0.f);
+                v.z = (c0 + 2 < b_cols) ? (kin ? v.z : 0.f) : ((c0 + 2 == ones_col) ? one : 0.f);
+                v.w = (c0 + 3 < b_cols) ? (kin ? v.w : 0.f) : ((c0 + 3 == ones_col) ? one : 0.f);
+                *reinterpret_cast<float4*>(&Bs[kr * LDXB + 4 * xq]) = v;
+                return;
+            }
             *reinterpret_cast<float4*>(&Bs[kr * LDXB + 4 * xq]) = inside ? v : keep4(q * BK + kr < p.K, v);
         }
     };
     // MFMA fragments of one 8-deep k group: lane (r, h) holds k = kb + 4h + j, j = 0..3
     auto frag_a = [&](int buf, int ku, int ti) -> float4 {
+        if (!C::A_KC) {
+            const float* q = &lds[buf * C::STAGE + ((wk * KU + ku) * 8 + 4 * h) * LDXA + wm * WTM + ti * 32 + r];
+            return make_float4(q[0], q[LDXA], q[2 * LDXA], q[3 * LDXA]);
+        }
         return *reinterpret_cast<const float4*>(
             &lds[buf * C::STAGE + (wm * WTM + ti * 32 + r) * LDK + (wk * KU + ku) * 8 + 4 * h]);
     };
@@ -385,7 +420,7 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
         return make_float4(q[0], q[LDXB], q[2 * LDXB], q[3 * LDXB]);
     };
 
-    constexpr int NDSR = KU * (TI + (C::B_KC ? TJ : 4 * TJ));     // LDS read instructions per stage
+    constexpr int NDSR = KU * ((C::A_KC ? TI : 4 * TI) + (C::B_KC ? TJ : 4 * TJ));   // LDS read instructions per stage
     // a 32x32 wave tile alternates two accumulators MFMA by MFMA (consecutive MFMAs must not depend
     // on each other); bigger wave tiles have 2 or 4 accumulators anyway
     constexpr int NA = (TI * TJ == 1) ? 2 : 1;
@@ -524,24 +559,32 @@ int launch_lds_cfg(hipStream_t s, GemmP p) {
     GM_LAUNCH_RET();
 }
 
-// Returns -1 when the launch is not for this kernel (caller continues with the split-reduction
-// kernels), else the launch's return code.
+// Tile configuration of the LDS kernel for this launch, or 0 when the launch is not for it (the caller
+// continues with the split-reduction kernels).  1: 64x64 tile = 2 x 1 waves of 32x64 (two accumulators
+// each) x 4 reduction groups, BK = 32; 2: 32x64 tile = 1 x 2 waves of 32x32 x 4 reduction groups.
 template <int MODE>
-int try_launch_lds(hipStream_t s, const GemmP& p, bool vec, bool xv) {
+int lds_cfg_for(const GemmP& p, bool vec, bool xv) {
     if constexpr (MODE == MODE_DW) {
-        return -1;
+        // weight gradient: both operands are k-major (dA[k][m], X[k][n]); staged through LDS once per
+        // workgroup instead of DPP-transposed in every wave.  CORRECT BUT SLOWER than the
+        // split-reduction kernel in this form (2048 rows: 43.0 vs 31.5 us, vendor 20.6; 512 rows: 13.9
+        // vs 10.6, vendor 8.1 -- profiles/r02_experiments.md 4c), so it is off unless asked for.
+        static int min_k = -1;
+        if (min_k < 0) { const char* e = getenv("GM_LDS_DW_MIN_K"); min_k = e ? atoi(e) : (1 << 30); }
+        if (p.K < min_k || !xv || p.M < 32 || p.n_real < 32 || p.M % 4 != 0 || p.n_real % 4 != 0) return 0;
     } else {
         static int min_m = -1;
         if (min_m < 0) { const char* e = getenv("GM_LDS_MIN_M"); min_m = e ? atoi(e) : 1024; }
-        if (p.M < min_m || p.K < 64 || !vec || (MODE == MODE_DX && !xv) || p.N < 32) return -1;
-        switch (lds_pick_cfg(p.M, p.N)) {
-            // 64x64 tile: 2 x 1 waves of 32x64 (two accumulators each) x 4 reduction groups, BK = 32
-            case 1: return launch_lds_cfg<MODE, 64, 64, 32, 64, 4, 1, 4>(s, p);
-            // 32x64 tile: 1 x 2 waves of 32x32 x 4 reduction groups, BK = 32
-            case 2: return launch_lds_cfg<MODE, 32, 64, 32, 32, 4, 1, 4>(s, p);
-            default: return -1;
-        }
+        if (p.M < min_m || p.K < 64 || !vec || (MODE == MODE_DX && !xv) || p.N < 32) return 0;
     }
+    const int cfg = lds_pick_cfg(p.M, p.N);
+    return (cfg == 1 || cfg == 2) ? cfg : 0;
+}
+
+template <int MODE>
+int launch_lds(hipStream_t s, const GemmP& p, int cfg) {
+    if (cfg == 1) return launch_lds_cfg<MODE, 64, 64, 32, 64, 4, 1, 4>(s, p);
+    return launch_lds_cfg<MODE, 32, 64, 32, 32, 4, 1, 4>(s, p);
 }
 
 template <int MODE, bool VEC, int WAVES, int G, bool XV>
@@ -915,16 +958,12 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if (xvq < 0) { const char* e = getenv("GM_XVEC"); xvq = e ? atoi(e) : 1; }
         const bool xv_l = xvec && xvq && MODE != MODE_FWD;
         if (!rider.pair && p.xr == 0 && p.cpw == 0) {
-            static int min_m = -1;
-            if (min_m < 0) { const char* e = getenv("GM_LDS_MIN_M"); min_m = e ? atoi(e) : 1024; }
-            const bool fits = MODE != MODE_DW && p.M >= min_m && p.K >= 64 && p.N >= 32 && vec &&
-                              (MODE != MODE_DX || xv_l);
-            if (fits) {
+            const int cfg = lds_cfg_for<MODE>(p, vec, xv_l);
+            if (cfg) {
                 if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
                 if (rider.gather)
                     hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(*rider.gather, 4)), dim3(256), 0, s, *rider.gather);
-                const int rc = try_launch_lds<MODE>(s, p, vec, xv_l);
-                if (rc != -1) return rc;
+                return launch_lds<MODE>(s, p, cfg);
             }
         }
     }

@@ -38,6 +38,10 @@ def time_shape(kind, M, K, N, reps=50):
         ref, got = dA.t() @ x, dW
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, (kind, M, K, N, err)
+    if kind == "dw":
+        rb = dA.sum(0)
+        errb = float((db - rb).abs().max() / rb.abs().max())
+        assert errb < 2e-5, (kind, M, K, N, "db", errb)
 
     def body(gst):
         st[0] = gst
