@@ -279,3 +279,30 @@ def test_dp_ranks_replay_the_global_draw_protocol(variant):
             assert torch.equal(s[key][:, r0:r1], full[key][:, r0:r1]), (key, rank)
             assert bool((s[key][:, :r0] == -9).all()) and bool((s[key][:, r1:] == -9).all())
         assert torch.equal(state, full_state)
+
+
+@pytest.mark.parametrize("R,graph_iters", [(128, 32), (25, 32), (7, 8), (128, 8), (16, 32)])
+def test_launch_planner_invariants(R, graph_iters):
+    """GANEngine._plan: pieces are powers of two <= min(graph_iters, R), cover the run exactly, never
+    cross the end of the ring (a stage-in copies contiguous slots); a cold run starts with a piece of
+    at most FIRST_PIECE iterations and no piece exceeds 4x what precedes it."""
+    class E:
+        pass
+    e = E()
+    e.graph_iters, e.R, e.FIRST_PIECE = graph_iters, R, 2
+    plan = lambda it, n, cold: engine.GANEngine._plan(e, it, n, cold)
+    cap = min(graph_iters, R)
+    for it in (0, 5, R - 1, R, 3 * R + 2):
+        for n in (0, 1, 2, 3, 20, 25, 64, 200, 2000):
+            for cold in (False, True):
+                p = plan(it, n, cold)
+                assert sum(p) == n and all(x >= 1 and x & (x - 1) == 0 and x <= cap for x in p), (it, n, cold, p)
+                pos, done = it, 0
+                for x in p:
+                    assert pos % R + x <= R, (it, n, cold, p)      # no ring wrap inside a piece
+                    if cold:
+                        assert x <= (e.FIRST_PIECE if done == 0 else max(1, 4 * done)), (it, n, p)
+                    pos += x
+                    done += x
+    if R >= 32 and graph_iters >= 16:
+        assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
