@@ -511,7 +511,7 @@ def _plain(v):
     return v
 
 
-def _save_checkpoint(trainer, savepath, history):
+def _save_checkpoint(trainer, savepath, history, numpy_rng=False):
     eng = getattr(trainer, "_engine", None)
     if eng is None or not hasattr(eng, "steps_planned"):
         raise GMError("save_checkpoint needs a finished train() call on the fused engine")
@@ -519,6 +519,14 @@ def _save_checkpoint(trainer, savepath, history):
              "model": {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()},
              "optim": eng.optim_state(), "rng": torch.get_rng_state(),
              "history": {n: _plain(getattr(trainer, n)) for n in history}}
+    if numpy_rng:
+        # bir_vae.py:92-94 draws its reparameterisation noise from NUMPY's global generator: its
+        # state is part of the protocol cursor (stored as plain tensors / numbers: weights_only load)
+        kind, keys, pos, has_gauss, cached = np.random.get_state()
+        if kind != "MT19937":
+            raise GMError("numpy's global generator is not the legacy MT19937 one")
+        state["numpy_rng"] = {"keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),
+                              "has_gauss": int(has_gauss), "cached": float(cached)}
     from . import dp
     if dp.current()[1] == 0:                     # data parallel: replicas are identical, rank 0 writes
         torch.save(state, savepath)
@@ -533,6 +541,10 @@ def _load_checkpoint(trainer, loadpath, strict=True):
     for n, v in ck["history"].items():
         setattr(trainer, n, list(v) if isinstance(v, list) else v)
     trainer._resume_optim = dict(ck["optim"], lenient=not strict)   # consumed by the next train()
+    if "numpy_rng" in ck:
+        n = ck["numpy_rng"]
+        np.random.set_state(("MT19937", n["keys"].numpy().astype(np.uint32), int(n["pos"]),
+                             int(n["has_gauss"]), float(n["cached"])))
     torch.set_rng_state(ck["rng"])               # LAST: construction / loading drew nothing after
 
 
@@ -936,8 +948,10 @@ class BIRVAETrainer(VAETrainer):
                   % (epoch, num_epochs, np.mean(tot), np.mean(recon), np.mean(mmd), val_loss))
 
     def save_checkpoint(self, savepath):
-        raise GMError("BIR-VAE checkpoints would also have to carry numpy's global RNG state; use "
-                      "save_model / load_model")
+        """See GANTrainer.save_checkpoint; also carries numpy's global generator state (the
+        reparameterisation noise of bir_vae.py:92-94 comes from it)."""
+        hist = tuple(n for n in ("recon_loss", "mmd_loss", "num_epochs", "best_val_loss") if hasattr(self, n))
+        _save_checkpoint(self, savepath, hist, numpy_rng=True)
 
 
 # ============================================================================================

@@ -444,6 +444,45 @@ def test_bir_vae_engine_vs_oracle_eager_and_graph():
             assert (a.cpu() - b).abs().max().item() <= 5e-5, k
 
 
+def test_bir_vae_checkpoint_resume_is_bitwise_uninterrupted(tmp_path):
+    """train(1) + save + load into a fresh trainer + train(1) == train(2), bit for bit: weights, Adam
+    moments and schedule position, torch's AND numpy's generator cursors all travel."""
+    import bir_vae
+    import contextlib, io
+    cfg = SMALL
+
+    def build(seed, np_seed):
+        loaders = port.synthetic_loaders(cfg["batch"], n_train=150, n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                         image_shape=tuple(cfg["image_shape"]))
+        torch.manual_seed(seed)
+        np.random.seed(np_seed)
+        model = bir_vae.BIRVAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+        return bir_vae.BIRVAETrainer(model, *loaders, viz=False), model
+
+    def train(tr, n):
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(num_epochs=n)
+        torch.cuda.synchronize()
+
+    full, full_model = build(1234, 9)
+    train(full, 2)
+    full_rng, full_np = torch.get_rng_state(), np.random.get_state()[1].copy()
+    tr1, _ = build(1234, 9)
+    train(tr1, 1)
+    path = str(tmp_path / "bir.pt")
+    tr1.save_checkpoint(path)
+    tr2, model2 = build(999, 31337)                    # different init and generators: all overwritten
+    torch.manual_seed(4242)
+    np.random.seed(4242)
+    tr2.load_checkpoint(path)
+    train(tr2, 1)
+    assert torch.equal(torch.get_rng_state(), full_rng)
+    assert np.array_equal(np.random.get_state()[1], full_np)
+    assert tr2.recon_loss == full.recon_loss and tr2.mmd_loss == full.mmd_loss
+    for (k, a), (_, b) in zip(model2.state_dict().items(), full_model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_bir_vae_user_hook_takes_general_path():
     import bir_vae
     cfg = SMALL
