@@ -751,6 +751,53 @@ class VAETrainer:
             print("Epoch[%d/%d], Total Loss: %.4f, Reconst Loss: %.4f, KL Div: %.7f, Val Loss: %.4f"
                   % (epoch, num_epochs, np.mean(tot), np.mean(recon), np.mean(kl), val_loss))
         self.num_epochs += 1
+        self._viz_epoch(epoch)
+
+    # ---- visualisation hooks (vae.py:189-191, 225-362) ------------------
+    viz_dir = None          # default: ../viz/<name>/ like the reference (scripts run from src/)
+
+    def _viz_epoch(self, epoch):
+        if self.viz:
+            self.sample_images(epoch)               # vae.py:190: one randn(36, z_dim) from the global generator
+
+    def sample_images(self, epoch=-100, num_images=36, save=True):
+        from . import viz
+        return viz.vae_sample_images(self, epoch, num_images, save, self.viz_dir)
+
+    def reconstruct_images(self, images, epoch, save=True):
+        from . import viz
+        return viz.vae_reconstruct_images(self, images, epoch, save, self.viz_dir)
+
+    def sample_interpolated_images(self):
+        from . import viz
+        return viz.vae_sample_interpolated_images(self)
+
+    def explore_latent_space(self, num_epochs=3):
+        """vae.py:295-334: train a 2-latent model of the same family on get_data(), return it (its
+        variational means / a 10 x 10 decoded grid are what the reference plots)."""
+        train_iter, val_iter, test_iter = get_data()
+        latent_model = type(self.model)(image_size=784, hidden_dim=400, z_dim=2)
+        latent_space = type(self)(latent_model, train_iter, val_iter, test_iter)
+        latent_space.train(num_epochs)
+        latent_model = latent_space.best_model
+        mu = torch.stack([torch.FloatTensor([m1, m2]) for m1 in np.linspace(-2, 2, 10)
+                          for m2 in np.linspace(-2, 2, 10)])
+        with torch.no_grad():
+            self.latent_grid = latent_model.decoder(to_cuda(mu)).detach().cpu()
+        return latent_model
+
+    def make_all(self):
+        """vae.py:336-346."""
+        print("Sampled images from latent space:")
+        self.sample_images(save=False)
+        print("Interpolating between two randomly sampled")
+        self.sample_interpolated_images()
+        print("Exploring latent representations")
+        _ = self.explore_latent_space()
+
+    def viz_loss(self):
+        from . import viz
+        viz.vae_viz_loss(self, "kl_loss")
 
     def save_model(self, savepath):
         torch.save(self.model.state_dict(), savepath)
@@ -946,6 +993,11 @@ class BIRVAETrainer(VAETrainer):
             tot = [float(np.float32(a) + np.float32(b)) for a, b in zip(recon, mmd)]
             print("Epoch[%d/%d], Total Loss: %.4f, MSE Loss: %.4f, MMD Loss: %.4f, Val Loss: %.4f"
                   % (epoch, num_epochs, np.mean(tot), np.mean(recon), np.mean(mmd), val_loss))
+        self._viz_epoch(epoch)                      # bir_vae.py:176-178
+
+    def viz_loss(self):
+        from . import viz
+        viz.vae_viz_loss(self, "mmd_loss")
 
     def save_checkpoint(self, savepath):
         """See GANTrainer.save_checkpoint; also carries numpy's global generator state (the
@@ -1080,6 +1132,15 @@ class AutoencoderTrainer(VAETrainer):
             print("Epoch[%d/%d], Train Loss: %.4f, Val Loss: %.4f"
                   % (epoch, num_epochs, np.mean(recon), val_loss))
         self.num_epochs += 1
+        self._viz_epoch(epoch)
+
+    def _viz_epoch(self, epoch):
+        if self.viz:
+            self.reconstruct_images(self.debugging_image, epoch)     # ae.py:143-144 (draws nothing)
+
+    def viz_loss(self):
+        from . import viz
+        viz.vae_viz_loss(self, "none")
 
 
 # ============================================================================================

@@ -83,3 +83,79 @@ def viz_loss(trainer):
     plt.legend(["Discriminator", "Generator"])
     plt.title(trainer.name)
     plt.show()
+
+
+# ---- VAE family (vae.py:225-362, ae.py:166-205, bir_vae.py:234-374) -----------------------------
+def _outdir(trainer, outdir):
+    d = os.path.join(outdir if outdir is not None else os.path.join("..", "viz"), trainer.name)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _to_host_images(t, shape):
+    return t.detach().float().cpu().reshape(t.shape[0], shape, shape).numpy()
+
+
+def vae_sample_images(trainer, epoch=-100, num_images=36, save=True, outdir=None):
+    """vae.py:254-276: z ~ N(0, I) from the global CPU generator (the reference's own draw, so the
+    stream position after an epoch with viz on matches), decoded, written as ../viz/<name>/sample_<epoch>.png."""
+    from .trainers import to_cuda
+    m = trainer.model
+    with torch.no_grad():
+        z = to_cuda(torch.randn(num_images, m.z_dim))
+        sample = m.decoder(z)
+    images = _to_host_images(sample, m.shape)
+    if save:
+        write_png_gray(os.path.join(_outdir(trainer, outdir), "sample_%d.png" % epoch),
+                       make_grid(images, int(num_images ** 0.5)))
+    return images
+
+
+def vae_reconstruct_images(trainer, images, epoch, save=True, outdir=None):
+    """vae.py:225-252 / ae.py:166-193: the debugging batch through the model (a VAE samples eps here,
+    as the reference does), real.png + reconst_<epoch>.png."""
+    from .trainers import to_cuda
+    m = trainer.model
+    with torch.no_grad():
+        batch = to_cuda(images.view(images.shape[0], -1))
+        out = m(batch)
+        out = out[0] if isinstance(out, tuple) else out
+    side = int(round(out.shape[1] ** 0.5))
+    rec = _to_host_images(out, side)
+    if save:
+        d = _outdir(trainer, outdir)
+        grid = int(rec.shape[0] ** 0.5)
+        write_png_gray(os.path.join(d, "real.png"), make_grid(_to_host_images(images.reshape(images.shape[0], -1), side), grid))
+        write_png_gray(os.path.join(d, "reconst_%d.png" % epoch), make_grid(rec, grid))
+    return rec
+
+
+def vae_sample_interpolated_images(trainer):
+    """vae.py:278-293: two latent vectors from p(z), decoded along the line between them (z_dim steps).
+    Returns the list of decoded images (the reference displays them)."""
+    from .trainers import to_cuda
+    m = trainer.model
+    z1 = torch.normal(torch.zeros(m.z_dim), 1)
+    z2 = torch.normal(torch.zeros(m.z_dim), 1)
+    out = []
+    with torch.no_grad():
+        for alpha in np.linspace(0, 1, m.z_dim):
+            z = to_cuda((alpha * z1 + (1 - alpha) * z2).float().view(1, -1))
+            out.append(_to_host_images(m.decoder(z), m.shape)[0])
+    return out
+
+
+def vae_viz_loss(trainer, second="kl_loss"):
+    """vae.py:348-362: reconstruction loss in red, the second term (KL / MMD) in green."""
+    import matplotlib.pyplot as plt
+    plt.style.use("ggplot")
+    plt.rcParams["figure.figsize"] = (8, 6)
+    plt.plot(np.linspace(1, max(1, trainer.num_epochs), len(trainer.recon_loss)), trainer.recon_loss, "r")
+    other = getattr(trainer, second, None)
+    if other:
+        plt.plot(np.linspace(1, max(1, trainer.num_epochs), len(other)), other, "g")
+        plt.legend(["Reconstruction", "KL Divergence" if second == "kl_loss" else "MMD"])
+    else:
+        plt.legend(["Reconstruction"])
+    plt.title(trainer.name)
+    plt.show()

@@ -257,8 +257,51 @@ def gen_round2():
                                               rng=rng_digest(), torch=torch.__version__))
 
 
+def gen_vae_viz():
+    """vae.py / bir_vae.py with viz=True (vae.py:189-191, bir_vae.py:176-178): sample_images(epoch)
+    draws torch.randn(36, z_dim) from the global generator at every epoch end.  The reference's own
+    rendering needs torchvision / PIL / IPython's display(); they are replaced by arithmetic-free
+    no-ops here (the draw itself is the reference's own line)."""
+    import tempfile
+
+    class _Img:
+        def save(self, *a, **k):
+            pass
+    for name, modname, cls, tcls, hist in (("vae_small_viz", "vae", "VAE", "VAETrainer", ("recon_loss", "kl_loss")),
+                                           ("bir_small_viz", "bir_vae", "BIRVAE", "BIRVAETrainer",
+                                            ("recon_loss", "mmd_loss"))):
+        mod = ref_harness.load(modname)
+        mod.ToPILImage = lambda *a, **k: (lambda *b, **kk: _Img())
+        mod.make_grid = lambda t, *a, **k: t
+        mod.display = lambda *a, **k: None
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "src"))
+            os.chdir(os.path.join(tmp, "src"))
+            try:
+                loaders = ref_harness.synthetic_loaders(SMALL["batch"], n_train=150, n_val=SMALL["n_val"],
+                                                        n_test=SMALL["n_test"], image_shape=SMALL["image_shape"])
+                torch.manual_seed(1234)
+                np.random.seed(77)
+                model = getattr(mod, cls)(image_size=SMALL["image_size"], hidden_dim=SMALL["hidden_dim"],
+                                          z_dim=SMALL["z_dim"])
+                tr = getattr(mod, tcls)(model, *loaders, viz=True)
+                with ref_harness.quiet():
+                    tr.train(num_epochs=3)
+            finally:
+                os.chdir(cwd)
+        arrays = {h: np.array(getattr(tr, h)) for h in hist}
+        arrays["best_val_loss"] = np.array(tr.best_val_loss)
+        for k, v in model.state_dict().items():
+            arrays["param:" + k] = v.numpy()
+        save(name, arrays, dict(variant=modname, cfg=SMALL, n_train=150, np_seed=77, viz=True,
+                                train_kw=dict(num_epochs=3), rng=rng_digest(), torch=torch.__version__))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["round2"]:
+    if sys.argv[1:] == ["vae_viz"]:
+        gen_vae_viz()
+    elif sys.argv[1:] == ["round2"]:
         gen_round2()
     elif sys.argv[1:] == ["ae"]:
         gen_ae()                 # only the ae.py fixtures (the others are unchanged)

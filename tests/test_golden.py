@@ -122,3 +122,32 @@ def test_bir_vae(name):
     for k, v in model.state_dict().items():
         if "param:" + k in z:
             np.testing.assert_allclose(v.numpy(), z["param:" + k], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["vae_small_viz", "bir_small_viz"])
+def test_vae_family_viz_fixtures(name):
+    """viz=True fixtures of the unmodified reference (vae.py:189-191, bir_vae.py:176-178): the oracle
+    reproduces them once the one extra draw per epoch -- sample_images' torch.randn(36, z_dim), right
+    after the validation pass -- is made."""
+    z, meta = load(name)
+    cfg = meta["cfg"]
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=meta["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    base, kind, second = (port.VAEPort, "vae", "kl_loss") if meta["variant"] == "vae" else \
+        (port.BIRVAEPort, "bir", "mmd_loss")
+
+    class WithSampleDraw(base):
+        def evaluate(self, iterator):
+            v = super().evaluate(iterator)
+            torch.randn(36, cfg["z_dim"])
+            return v
+    np.random.seed(meta["np_seed"])
+    model = port.build(kind, cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    tr = WithSampleDraw(model, *loaders)
+    tr.train(**meta["train_kw"])
+    import hashlib
+    assert hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest() == meta["rng"]
+    np.testing.assert_allclose(np.array(tr.recon_loss), z["recon_loss"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(getattr(tr, second)), z[second], rtol=10 * RTOL, atol=1e-3)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z["param:" + k], rtol=RTOL, atol=ATOL)

@@ -483,6 +483,51 @@ def test_bir_vae_checkpoint_resume_is_bitwise_uninterrupted(tmp_path):
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("name", ["vae_small_viz", "bir_small_viz"])
+def test_vae_family_viz_stream_position_vs_reference_golden(name, tmp_path):
+    """viz=True (vae.py:189-191, bir_vae.py:176-178): sample_images(epoch) draws torch.randn(36, z) at
+    every epoch end; losses, parameters and the final generator digest against the UNMODIFIED reference
+    run with viz on; the PNG grids are written without torchvision / PIL."""
+    import contextlib, hashlib, io
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=meta["n_train"], n_val=cfg["n_val"],
+                                     n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(1234)
+    np.random.seed(meta["np_seed"])
+    if meta["variant"] == "vae":
+        import vae
+        model = vae.VAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+        tr = vae.VAETrainer(model, *loaders, viz=True)
+        second = "kl_loss"
+    else:
+        import bir_vae
+        model = bir_vae.BIRVAE(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"])
+        tr = bir_vae.BIRVAETrainer(model, *loaders, viz=True)
+        second = "mmd_loss"
+    tr.viz_dir = str(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**meta["train_kw"])
+    torch.cuda.synchronize()
+    assert tr._engine is not None
+    assert hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest() == meta["rng"]
+    ref, got = z["recon_loss"], np.array(tr.recon_loss)
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5
+    ref, got = z[second], np.array(getattr(tr, second))
+    tol = 2e-5 if second == "kl_loss" else 1e-4
+    assert np.max(np.abs(got - ref) / np.maximum(10 if second == "mmd_loss" else 1, np.abs(ref))) <= tol
+    for k, v in model.state_dict().items():
+        assert np.abs(v.cpu().numpy() - z["param:" + k]).max() <= 5e-5, k
+    for e in (1, 2, 3):
+        p = os.path.join(str(tmp_path), tr.name, "sample_%d.png" % e)
+        assert os.path.getsize(p) > 100 and open(p, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    rec = tr.reconstruct_images(tr.debugging_image, 7)
+    assert rec.shape[0] == tr.debugging_image.shape[0]
+    assert os.path.isfile(os.path.join(str(tmp_path), tr.name, "reconst_7.png"))
+    assert len(tr.sample_interpolated_images()) == cfg["z_dim"]
+
+
 def test_bir_vae_user_hook_takes_general_path():
     import bir_vae
     cfg = SMALL
