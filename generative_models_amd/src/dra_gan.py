@@ -20,6 +20,10 @@ class DRAGANTrainer(_t.GANTrainer):
     """dra_gan.py:77-245"""
     variant = "dra"
 
+    def train_D(self, images, LAMBDA=10, K=1, C=1):
+        """dra_gan.py:180-225."""
+        return super().train_D(images, LAMBDA=LAMBDA, K=K, C=C)
+
     def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=5):
         """dra_gan.py:94."""
         self._train(num_epochs, G_lr, D_lr, D_steps)

@@ -20,6 +20,14 @@ class LSGANTrainer(_t.GANTrainer):
     """ls_gan.py:33-215"""
     variant = "ls"
 
+    def train_D(self, images, a=0, b=1):
+        """ls_gan.py:159-180."""
+        return super().train_D(images, a=a, b=b)
+
+    def train_G(self, images, c=1):
+        """ls_gan.py:182-201."""
+        return super().train_G(images, c=c)
+
     def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=1):
         """ls_gan.py:95 (labels a=0, b=1, c=1: :173,:197)."""
         self._train(num_epochs, G_lr, D_lr, D_steps, hyper=(0.0, 1.0, 1.0))

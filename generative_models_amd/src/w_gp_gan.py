@@ -21,6 +21,10 @@ class WGPGANTrainer(_t.GANTrainer):
     """w_gp_gan.py:34-239"""
     variant = "wgp"
 
+    def train_D(self, images, LAMBDA=10):
+        """w_gp_gan.py:177-220."""
+        return super().train_D(images, LAMBDA=LAMBDA)
+
     def train(self, num_epochs, G_lr=1e-4, D_lr=1e-4, D_steps=5):
         """w_gp_gan.py:96 (LAMBDA=10 is the train_D default, :177)."""
         self._train(num_epochs, G_lr, D_lr, D_steps)

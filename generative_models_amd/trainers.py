@@ -575,6 +575,9 @@ class Decoder(_TwoLayer):
         super().__init__()
         self._build(z_dim, hidden_dim, image_size)
 
+    def forward(self, z):
+        return super().forward(z)
+
 
 @stock_model
 class VAE(nn.Module):
@@ -842,6 +845,9 @@ class BIRDecoder(_TwoLayer):
     def __init__(self, z_dim, hidden_dim, image_size):
         super().__init__()
         self._build(z_dim, hidden_dim, image_size)
+
+    def forward(self, z):
+        return super().forward(z)
 
 
 @stock_model
@@ -1376,6 +1382,13 @@ class InfoGANTrainerBase(GANTrainer):
     def _noise(self, images):
         m = self.model
         return self.compute_noise(images.shape[0], m.z_dim, m.disc_dim, m.cont_dim)
+
+    def generate_images(self, epoch, num_outputs=36, save=True, c=None):
+        """info_gan.py:333-365: c fixes the categorical code of every sample (latent exploration)."""
+        from . import viz
+        m = self.model
+        noise = self.compute_noise(num_outputs, m.z_dim, m.disc_dim, m.cont_dim, c=c)
+        return viz.generate_images(self, epoch, num_outputs, save, self.viz_dir, noise=noise)
 
     def train_D(self, images):
         m = self.model

@@ -45,12 +45,14 @@ def write_png_gray(path, img01):
         f.write(png)
 
 
-def generate_images(trainer, epoch, num_outputs=36, save=True, outdir=None):
-    """ns_gan.py:228-262.  Returns the host array [num_outputs, shape, shape]."""
+def generate_images(trainer, epoch, num_outputs=36, save=True, outdir=None, noise=None):
+    """ns_gan.py:228-262.  Returns the host array [num_outputs, shape, shape].  noise: the generator
+    input when the trainer's compute_noise takes more than (n, z_dim) (InfoGAN)."""
     m = trainer.model
     m.eval()
     with torch.no_grad():
-        noise = trainer.compute_noise(num_outputs, m.z_dim)          # same CPU-generator draw as the reference
+        if noise is None:
+            noise = trainer.compute_noise(num_outputs, m.z_dim)      # same CPU-generator draw as the reference
         images = m.G(noise)
     images = images.view(images.shape[0], m.shape, m.shape, -1).squeeze(-1).detach().float().cpu().numpy()
     grid_size = int(num_outputs ** 0.5)

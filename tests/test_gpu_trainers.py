@@ -528,6 +528,32 @@ def test_vae_family_viz_stream_position_vs_reference_golden(name, tmp_path):
     assert len(tr.sample_interpolated_images()) == cfg["z_dim"]
 
 
+def test_infogan_viz_epoch_and_latent_exploration(tmp_path):
+    """info_gan.py:306-365: generate_images builds its noise with the 4-argument compute_noise; c fixes
+    the categorical code of every sample.  viz=True must run through an epoch."""
+    import contextlib, io
+    import info_gan
+    cfg = SMALL
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=64, n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                     image_shape=tuple(cfg["image_shape"]))
+    torch.manual_seed(5)
+    model = info_gan.InfoGAN(image_size=cfg["image_size"], hidden_dim=cfg["hidden_dim"], z_dim=cfg["z_dim"],
+                             disc_dim=10, cont_dim=10)
+    tr = info_gan.InfoGANTrainer(model, *loaders, viz=True)
+    tr.viz_dir = str(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=1)
+    assert os.path.isfile(os.path.join(str(tmp_path), tr.name, "reconst_1.png"))
+    s0 = torch.get_rng_state()
+    a = tr.generate_images(9, num_outputs=16, save=False, c=3)
+    torch.set_rng_state(s0)
+    b = tr.generate_images(9, num_outputs=16, save=False, c=3)
+    assert a.shape == (16, model.shape, model.shape) and np.array_equal(a, b)
+    torch.set_rng_state(s0)
+    c = tr.generate_images(9, num_outputs=16, save=False, c=7)         # same z / c2 draws, other category
+    assert not np.array_equal(a, c)
+
+
 def test_bir_vae_user_hook_takes_general_path():
     import bir_vae
     cfg = SMALL

@@ -156,3 +156,41 @@ def test_vae_port_bit_exact():
     for k in ref_sd:
         assert torch.equal(ref_sd[k], my_sd[k]), k
     assert torch.equal(ref_state, torch.get_rng_state())
+
+
+@needs_ref
+def test_dropin_modules_expose_the_reference_surface():
+    """Every class, function and public method of the reference's src/*.py exists in the drop-in
+    module of the same name with the same leading parameters and defaults (extra trailing keyword
+    parameters are allowed) -- what a script written against the reference relies on."""
+    import importlib
+    import inspect
+    import os
+    import sys
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "generative_models_amd", "src")
+    if src not in sys.path:
+        sys.path.insert(0, src)
+
+    def sig(f):
+        return [(p.name, p.default if p.default is not inspect._empty else "<required>")
+                for p in inspect.signature(f).parameters.values()]
+    problems = []
+    for m in ["ns_gan", "mm_gan", "w_gan", "w_gp_gan", "ls_gan", "dra_gan", "be_gan", "ra_gan", "f_gan",
+              "fisher_gan", "info_gan", "vae", "ae", "bir_vae"]:
+        ref, mine = ref_harness.load(m), importlib.import_module(m)
+        for name, obj in vars(ref).items():
+            if getattr(obj, "__module__", None) != ref.__name__:
+                continue
+            if not hasattr(mine, name):
+                problems.append("%s.%s missing" % (m, name))
+                continue
+            if inspect.isclass(obj):
+                for meth, v in vars(obj).items():
+                    if callable(v) and (meth in ("__init__", "train") or not meth.startswith("_")):
+                        if not hasattr(getattr(mine, name), meth):
+                            problems.append("%s.%s.%s missing" % (m, name, meth))
+                            continue
+                        a, b = sig(v), sig(getattr(getattr(mine, name), meth))
+                        if a != b[:len(a)]:
+                            problems.append("%s.%s.%s: %s vs %s" % (m, name, meth, a, b))
+    assert not problems, problems
