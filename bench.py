@@ -394,6 +394,23 @@ def bench_vae(B, dev, with_eval, warm_epochs=1, epochs=3, n_val=10000):
     return epochs * N_TRAIN / dt, dt / (epochs * steps) * 1e3, epochs * steps
 
 
+BYTES_PER_IMAGE_B256 = 82944
+
+
+def mfma_busy_frac(kernel, launch_us, mhz):
+    """MFMA-pipe busy fraction of the dominant kernel from the COMMITTED SQ PMC pass
+    (profiles/r02_nsgan_b256_sq_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES per dispatch, summed over the 1024
+    SIMDs) over this run's launch duration; None when the pass does not list the kernel."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_nsgan_b256_sq_pmc.json")))
+        rows = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for k, v in pmc.items() if k.split("|")[0] == kernel]
+        if not rows:
+            return None
+        return (sum(rows) / len(rows) / 1024.0) / (launch_us * mhz)
+    except Exception:                                # noqa: BLE001
+        return None
+
+
 def dominant_gemm_roofline(M, K, N, reps=50):
     """Isolated HIP-event timing of the forward GEMM [M,K]x[K,N] (the largest contraction of the
     config) -> roofline entry."""
@@ -408,7 +425,7 @@ def dominant_gemm_roofline(M, K, N, reps=50):
 def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
     """BASELINE.json configs 3/4/5 on one MI355X, >= 200 timed steps each (+ DRAGAN,
     the variant whose per-step host draw is the largest: B x 784 uniforms).  only: one of
-    wgp_b256 / ns_b1024 / ls_b1024 / dra_b256 / vae_b512 (profiling runs)."""
+    wgp_b256 / wgp_b256_d5 / ns_b1024 / ls_b1024 / dra_b256 / vae_b512 (profiling runs)."""
     K, W = max(steps, 200), max(warmup, 20)
     out = []
     want = lambda tag: only is None or only == tag
@@ -429,6 +446,16 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
     if want("wgp_b256"):
         gan("WGAN-GP MNIST bs=256 D_steps=1 (BASELINE.json configs[2]; w_gp_gan.py __main__)", "wgp", 256,
             (1e-4, 1e-4), 8_836_000, "wgp")
+    if want("wgp_b256_d5"):
+        # SURVEY.md 8d config 3 also asks for the reference's D_steps=5 default (w_gp_gan.py:96): images =
+        # real images consumed by the critic steps = 5 B per D+G iteration
+        eng, secs = bench_gan("wgp", 256, W, K, reps, dev, lrs=(1e-4, 1e-4), D_steps=5)
+        dt = float(np.median(secs))
+        out.append({"workload": "WGAN-GP MNIST bs=256 D_steps=5 (train() default, w_gp_gan.py:96); images = critic-step images",
+                    "img_s": K * 5 * 256 / dt, "ms_per_step": dt / K * 1e3, "steps": K,
+                    "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs]})
+        log("WGAN-GP bs=256 D_steps=5: %.0f img/s" % (K * 5 * 256 / dt))
+        del eng
     if want("ns_b1024"):
         gan("NSGAN MNIST bs=1024, 1 GPU (BASELINE.json configs[4], single-GPU leg)", "ns", 1024,
             (2e-4, 2e-4), FLOP_PER_IMAGE, "ns")
@@ -563,11 +590,15 @@ def main():
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
                        "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw"},
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            # compulsory HBM bytes of a step (Adam 7 x 4 B/param + gradient write + image rows +
+            # noise = 82 944 B/image at B=256) against 8 TB/s: the path is nowhere near the HBM roof
+            "step_hbm_frac": img_s / world * BYTES_PER_IMAGE_B256 / 8.0e12,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "shader_clock_mhz": round(mhz),
+                         "mfma_busy_frac": mfma_busy_frac(dom, t_us / n, mhz),
                          "launches_per_step": n, "avg_launch_us": t_us / n,
                          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
         }
