@@ -1704,6 +1704,7 @@ class VAEEngine:
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))   # batches per graph
+        self.prefetch_gather = os.environ.get("GM_VAE_PREFETCH_GATHER", "1") != "0"
 
     def _alloc(self, B):
         if self._bufB == B:
@@ -1711,6 +1712,7 @@ class VAEEngine:
         dev, I, H, Z = self.device, self.I, self.H, self.Z
         z = lambda *s: torch.zeros(*s, device=dev)
         self.X, self.He, self.ml, self.Zs = z(B, I), z(B, H), z(B, 2 * Z), z(B, Z)
+        self.Xb = (self.X, z(B, I))                 # batch i of a multi-batch graph reads Xb[i % 2]
         self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
         self.dHdec, self.dZ, self.dml, self.dHe = z(B, H), z(B, Z), z(B, 2 * Z), z(B, H)
         self.part = z(B)
@@ -1725,9 +1727,27 @@ class VAEEngine:
             i %= ring
         return ops.slot(0, 0, i, 0, stride)
 
-    def _issue(self, st, t, b, train):
+    def _gather_plan(self, pos, of):
+        """Batch `pos` of a graph of `of` equal-size batches: (its image buffer, whether it gathers its
+        own rows, the buffer the NEXT batch's rows are prefetched into or None).  Inside a multi-batch
+        graph the gather of batch i+1 rides in a small forward GEMM of batch i (gm_linear_fwd_gather:
+        extra workgroups of that launch), so only the graph's first batch pays a gather launch."""
+        X = self.Xb[pos % 2]
+        nxt = self.Xb[(pos + 1) % 2] if (self.prefetch_gather and pos + 1 < of) else None
+        return X, (pos == 0 or not self.prefetch_gather), nxt
+
+    def _fwd_with_prefetch(self, st, t, lo, b, x, lin, y, act, nxt):
+        """linear_fwd, carrying the gather of the next batch's rows (ring slot t + 1) when asked to."""
+        if nxt is None:
+            ops.linear_fwd(x, lin.W, lin.b, y, act, M=b, stream=st)
+        else:
+            ops.linear_fwd_gather(x, lin.W, lin.b, y, act, self.data, self.idx_ring.view(-1)[lo:], nxt, M=b,
+                                  B=b, idx_slot=self._slot(t, 1, 1, self.R, self.B), stream=st)
+
+    def _issue(self, st, t, b, train, pos=0, of=1):
         """One batch of size b: forward + losses (+ backward + Adam when train)."""
-        from . import ops_fused as of
+        from . import ops_fused as of_
+        of = max(1, of)
         R, B, Z = self.R, self.B, self.Z
         E1, ML, D1, D2 = self.E1, self.ML, self.D1, self.D2
         idx_slot = self._slot(t, 1, 0, R, B)
@@ -1736,15 +1756,17 @@ class VAEEngine:
         recon_out, kl_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
         lo, hi = self._rows(b)                       # this rank's rows of the batch
         b = hi - lo
-        ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], self.X, B=b, idx_slot=idx_slot, stream=st)
-        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
-        ops.linear_fwd(self.He, ML.W, ML.b, self.ml, "id", M=b, stream=st)
+        X, own, nxt = self._gather_plan(pos, of)
+        if own:
+            ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], X, B=b, idx_slot=idx_slot, stream=st)
+        ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        self._fwd_with_prefetch(st, t, lo, b, self.He, ML, self.ml, "id", nxt)
         eps_base = self.eps_ring.view(-1)[lo * Z:]
-        of.vae_reparam(self.ml, eps_base, self.Zs, kl_out, b, Z, eps_slot=eps_slot,
+        of_.vae_reparam(self.ml, eps_base, self.Zs, kl_out, b, Z, eps_slot=eps_slot,
                        kl_slot=loss_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
+        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             if self.fuse_adam and not self._dp():
@@ -1768,13 +1790,13 @@ class VAEEngine:
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
             ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
             dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
-            of.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
+            of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
                                eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            dw2((self.dml, self.He, ML), (self.dHe, self.X, E1))
+            dw2((self.dml, self.He, ML), (self.dHe, X, E1))
             self._optimizer_step(st, sched_slot)
         # the reconstruction sum is the step's LAST launch and carries the counter tick
-        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
+        of_.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
                         tick=self.ctr if self.use_graph else None, stream=st)
 
     def _optimizer_step(self, st, sched_slot):
@@ -1833,7 +1855,7 @@ class VAEEngine:
         if key not in self.graphs:
             torch.cuda.synchronize()
             self.graphs[key] = ops.Graph().capture(
-                lambda st: [self._issue(st, 0, b, train) for _ in range(k)])
+                lambda st: [self._issue(st, 0, b, train, pos=i, of=k) for i in range(k)])
         return self.graphs[key]
 
     def run_pass(self, data, perm, train, t0):
@@ -1938,32 +1960,35 @@ class AEEngine(VAEEngine):
             return
         z = lambda *s: torch.zeros(*s, device=self.device)
         self.X, self.He, self.Xr, self.dA = z(B, self.I), z(B, self.H), z(B, self.I), z(B, self.I)
+        self.Xb = (self.X, z(B, self.I))
         self.dHe, self.part = z(B, self.H), z(B)
         self._bufB = B
         self.graphs = {}
 
-    def _issue(self, st, t, b, train):
+    def _issue(self, st, t, b, train, pos=0, of=1):
         """One batch of size b: ae.py:147-160 (+ backward and Adam when train)."""
-        from . import ops_fused as of
+        from . import ops_fused as of_
         E1, D2 = self.E1, self.D2
         idx_slot = self._slot(t, 1, 0, self.R, self.B)
         loss_slot = self._slot(t, 1, 0, 0, 1)
         lo, hi = self._rows(b)                       # this rank's rows of the batch
         b = hi - lo
-        ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], self.X, B=b, idx_slot=idx_slot, stream=st)
-        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        X, own, nxt = self._gather_plan(pos, of)
+        if own:
+            ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], X, B=b, idx_slot=idx_slot, stream=st)
+        self._fwd_with_prefetch(st, t, lo, b, X, E1, self.He, "relu", nxt)
         ops.linear_fwd(self.He, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
+        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             adam = dict(sched=self.sched, sched_slot=sched_slot) if (self.fuse_adam and not self._dp()) else None
             # dH reads the decoder weights before the paired dW launch updates them
             ops.linear_bwd_dx(self.dA, D2.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             ops.linear_bwd_dw_adam_pair(dict(dA=self.dA, X=self.He, lin=D2, adam=adam, M=b),
-                                        dict(dA=self.dHe, X=self.X, lin=E1, adam=adam, M=b),
+                                        dict(dA=self.dHe, X=X, lin=E1, adam=adam, M=b),
                                         weight_decay=self.wd if adam is not None else 0.0, stream=st)
             self._optimizer_step(st, sched_slot)
-        of.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
+        of_.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
                         tick=self.ctr if self.use_graph else None, stream=st)
 
 
@@ -2001,6 +2026,7 @@ class BIRVAEEngine(VAEEngine):
         dev, I, H, Z = self.device, self.I, self.H, self.Z
         z = lambda *s: torch.zeros(*s, device=dev)
         self.X, self.He, self.Mu, self.Zs = z(B, I), z(B, H), z(B, Z), z(B, Z)
+        self.Xb = (self.X, z(B, I))
         self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
         self.dHdec, self.dZ, self.dZm, self.dHe = z(B, H), z(B, Z), z(B, Z), z(B, H)
         self.part, self.partm = z(B), z(B)
@@ -2027,24 +2053,26 @@ class BIRVAEEngine(VAEEngine):
         self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
         self.prior_ring[r:r + cnt].copy_(s["prior"][:cnt], non_blocking=True)
 
-    def _issue(self, st, t, b, train):
-        from . import ops_fused as of
+    def _issue(self, st, t, b, train, pos=0, of=1):
+        from . import ops_fused as of_
         R, B, Z = self.R, self.B, self.Z
         E1, MU, D1, D2 = self.E1, self.MU, self.D1, self.D2
         idx_slot = self._slot(t, 1, 0, R, B)
         eps_slot = self._slot(t, 1, 0, R, B * Z)
         loss_slot = self._slot(t, 1, 0, 0, 1)
         recon_out, mmd_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
-        ops.gather_rows(self.data, self.idx_ring.view(-1), self.X, B=b, idx_slot=idx_slot, stream=st)
-        ops.linear_fwd(self.X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
-        ops.linear_fwd(self.He, MU.W, MU.b, self.Mu, "id", M=b, stream=st)
-        of.bir_reparam(self.Mu, self.eps_ring.view(-1), self.Zs, b, Z, eps_slot=eps_slot, stream=st)
+        X, own, nxt = self._gather_plan(pos, of)
+        if own:
+            ops.gather_rows(self.data, self.idx_ring.view(-1), X, B=b, idx_slot=idx_slot, stream=st)
+        ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
+        self._fwd_with_prefetch(st, t, 0, b, self.He, MU, self.Mu, "id", nxt)
+        of_.bir_reparam(self.Mu, self.eps_ring.view(-1), self.Zs, b, Z, eps_slot=eps_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of.sqerr_sigmoid_bwd(self.X, self.Xr, self.dA, self.part, b, stream=st)
-        of.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
+        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
+        of_.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
                    self.LAMBDA, prior_slot=eps_slot, stream=st)
-        of.sum_finalize(self.partm, b, mmd_out, scale=self.LAMBDA, out_slot=loss_slot, stream=st)
+        of_.sum_finalize(self.partm, b, mmd_out, scale=self.LAMBDA, out_slot=loss_slot, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
@@ -2058,9 +2086,9 @@ class BIRVAEEngine(VAEEngine):
             ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, add=self.dZm, add_scale=1.0, stream=st)
             dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
             ops.linear_bwd_dx(self.dZ, MU.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            dw2((self.dZ, self.He, MU), (self.dHe, self.X, E1))
+            dw2((self.dZ, self.He, MU), (self.dHe, X, E1))
             self._optimizer_step(st, sched_slot)
-        of.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
+        of_.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
                         tick=self.ctr if self.use_graph else None, stream=st)
 
 
