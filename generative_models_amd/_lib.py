@@ -105,6 +105,8 @@ _SIGNATURES = {
     "gm_sqerr_sigmoid_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int]),
     "gm_sum_finalize": (c_int, [_P, _P, c_int, c_float, _P, Slot]),
     "gm_sum_finalize_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P]),
+    "gm_sum_finalize2_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P, c_int, c_float, _P, Slot, _P]),
+    "gm_vae_reparam_wide": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int, c_int, c_int]),
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),

@@ -357,6 +357,40 @@ extern "C" int gm_vae_reparam(void* stream, const float* ml, int64_t ldml, const
     GM_LAUNCH_RET();
 }
 
+// Wide form: 256-thread workgroups over the B*Z elements, per-WORKGROUP KL partials (fp64 inside, one
+// float each, fixed order) -- the step's last launch (gm_sum_finalize2_tick) adds them up.  The
+// one-workgroup form above costs 8.4 us at B*Z = 10 240; this one is a ~3 us launch.
+__global__ __launch_bounds__(256) void vae_reparam_wide_kernel(const float* __restrict__ ml, int64_t ldml,
+                                                              const float* __restrict__ eps, gm_slot eps_slot,
+                                                              float* __restrict__ z, int64_t ldz,
+                                                              float* __restrict__ kl_part, int B, int Z) {
+    __shared__ double sh[4];
+    const float* e = eps + gm_slot_offset(eps_slot);
+    const int n = B * Z, i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (i < n) {
+        const int b = i / Z, c = i % Z;
+        const float mu = ml[(int64_t)b * ldml + c], lv = ml[(int64_t)b * ldml + Z + c];
+        z[(int64_t)b * ldz + c] = mu + e[i] * expf(lv / 2.f);
+        acc = (double)(0.5f * (((mu * mu) + expf(lv)) - lv - 1.f));
+    }
+    acc = gm_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) kl_part[blockIdx.x] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+extern "C" int gm_vae_reparam_wide(void* stream, const float* ml, int64_t ldml, const float* eps,
+                                   gm_slot eps_slot, float* z, int64_t ldz, float* kl_part, int n_part,
+                                   int B, int Z) {
+    GM_CHECK_ARG(ml && eps && z && kl_part && B > 0 && Z > 0 && ldml >= 2 * Z);
+    const int blocks = (B * Z + 255) / 256;
+    GM_CHECK_ARG(n_part >= blocks);
+    hipLaunchKernelGGL(vae_reparam_wide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ml, ldml, eps,
+                       eps_slot, z, ldz, kl_part, B, Z);
+    GM_LAUNCH_RET();
+}
+
 // K14c reparameterisation backward: dml = [dz + mu | dz*eps*0.5*exp(lv/2) + 0.5*(exp(lv)-1)]
 __global__ __launch_bounds__(256) void vae_reparam_bwd_kernel(const float* __restrict__ ml,
                                                              int64_t ldml,
@@ -450,6 +484,35 @@ extern "C" int gm_sum_finalize_tick(void* stream, const float* partial, int n, f
     GM_CHECK_ARG(partial && out && n > 0 && tick);
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n,
                        scale, out, out_slot, tick);
+    GM_LAUNCH_RET();
+}
+
+// Two sums in one launch (the VAE step's reconstruction rows and KL partials), optional tick.
+__global__ __launch_bounds__(256) void sum_finalize2_kernel(const float* __restrict__ pa, int na, float sa,
+                                                           float* __restrict__ oa, gm_slot slot_a,
+                                                           const float* __restrict__ pb, int nb, float sb,
+                                                           float* __restrict__ ob, gm_slot slot_b,
+                                                           int64_t* tick) {
+    __shared__ double sh[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < na; i += 256) a += (double)pa[i];
+    for (int i = threadIdx.x; i < nb; i += 256) b += (double)pb[i];
+    a = gm_wave_sum_d(a); b = gm_wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        oa[gm_slot_index(slot_a)] = (float)(((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])) * (double)sa);
+        ob[gm_slot_index(slot_b)] = (float)(((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])) * (double)sb);
+        if (tick) *tick += 1;
+    }
+}
+
+extern "C" int gm_sum_finalize2_tick(void* stream, const float* pa, int na, float scale_a, float* out_a,
+                                     gm_slot slot_a, const float* pb, int nb, float scale_b, float* out_b,
+                                     gm_slot slot_b, int64_t* tick) {
+    GM_CHECK_ARG(pa && pb && out_a && out_b && na > 0 && nb > 0);
+    hipLaunchKernelGGL(sum_finalize2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pa, na, scale_a,
+                       out_a, slot_a, pb, nb, scale_b, out_b, slot_b, tick);
     GM_LAUNCH_RET();
 }
 

@@ -1716,6 +1716,7 @@ class VAEEngine:
         self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
         self.dHdec, self.dZ, self.dml, self.dHe = z(B, H), z(B, Z), z(B, 2 * Z), z(B, H)
         self.part = z(B)
+        self.part_kl = z((B * Z + 255) // 256)
         self._bufB = B
         self.graphs = {}
 
@@ -1762,8 +1763,7 @@ class VAEEngine:
         ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
         self._fwd_with_prefetch(st, t, lo, b, self.He, ML, self.ml, "id", nxt)
         eps_base = self.eps_ring.view(-1)[lo * Z:]
-        of_.vae_reparam(self.ml, eps_base, self.Zs, kl_out, b, Z, eps_slot=eps_slot,
-                       kl_slot=loss_slot, stream=st)
+        n_kl = of_.vae_reparam_wide(self.ml, eps_base, self.Zs, self.part_kl, b, Z, eps_slot=eps_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
         of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
@@ -1793,11 +1793,11 @@ class VAEEngine:
             of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
                                eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            dw2((self.dml, self.He, ML), (self.dHe, X, E1))
+            dw2((self.dHe, X, E1), (self.dml, self.He, ML))    # (the big GEMM first: its tile shape serves both)
             self._optimizer_step(st, sched_slot)
-        # the reconstruction sum is the step's LAST launch and carries the counter tick
-        of_.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
-                        tick=self.ctr if self.use_graph else None, stream=st)
+        # both loss sums (vae.py:203, :212) are the step's LAST launch, which also carries the counter tick
+        of_.sum_finalize2(self.part, b, recon_out, loss_slot, self.part_kl, n_kl, kl_out, loss_slot,
+                          tick=self.ctr if self.use_graph else None, stream=st)
 
     def _optimizer_step(self, st, sched_slot):
         """optimizer.step() (vae.py:162) when it is not fused into the dW epilogues: data parallel ->
@@ -2072,7 +2072,6 @@ class BIRVAEEngine(VAEEngine):
         of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
         of_.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
                    self.LAMBDA, prior_slot=eps_slot, stream=st)
-        of_.sum_finalize(self.partm, b, mmd_out, scale=self.LAMBDA, out_slot=loss_slot, stream=st)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
@@ -2088,8 +2087,9 @@ class BIRVAEEngine(VAEEngine):
             ops.linear_bwd_dx(self.dZ, MU.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             dw2((self.dZ, self.He, MU), (self.dHe, X, E1))
             self._optimizer_step(st, sched_slot)
-        of_.sum_finalize(self.part, b, recon_out, out_slot=loss_slot,
-                        tick=self.ctr if self.use_graph else None, stream=st)
+        # reconstruction sum and 1000 * MMD in the step's last launch, which also carries the tick
+        of_.sum_finalize2(self.part, b, recon_out, loss_slot, self.partm, b, mmd_out, loss_slot,
+                          scale_b=self.LAMBDA, tick=self.ctr if self.use_graph else None, stream=st)
 
 
 class BEGANEngine(GANEngine):

@@ -63,6 +63,20 @@ def vae_reparam(ml, eps, z, kl_out, B, Z, eps_slot=NO_SLOT, kl_slot=NO_SLOT, str
               eps_slot, z.data_ptr(), _ld(z), kl_out.data_ptr(), kl_slot, B, Z)
 
 
+def vae_reparam_wide(ml, eps, z, kl_part, B, Z, eps_slot=NO_SLOT, stream=None):
+    """z = mu + eps*exp(lv/2); KL left as per-workgroup partial sums in kl_part (see sum_finalize2)."""
+    _lib.call("gm_vae_reparam_wide", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
+              eps_slot, z.data_ptr(), _ld(z), kl_part.data_ptr(), kl_part.numel(), B, Z)
+    return (B * Z + 255) // 256
+
+
+def sum_finalize2(pa, na, out_a, slot_a, pb, nb, out_b, slot_b, scale_a=1.0, scale_b=1.0, tick=None, stream=None):
+    """Two fixed-order fp64 sums in one launch; tick: device step counter to advance (last launch of a step)."""
+    _lib.call("gm_sum_finalize2_tick", stream or stream_ptr(), pa.data_ptr(), na, scale_a, out_a.data_ptr(),
+              slot_a, pb.data_ptr(), nb, scale_b, out_b.data_ptr(), slot_b,
+              tick.data_ptr() if tick is not None else None)
+
+
 def vae_reparam_bwd(ml, eps, dz, dml, B, Z, eps_slot=NO_SLOT, stream=None):
     _lib.call("gm_vae_reparam_bwd", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(),
               eps_slot, dz.data_ptr(), _ld(dz), dml.data_ptr(), _ld(dml), B, Z)

@@ -173,6 +173,10 @@ int gm_bir_mmd(void* stream, const float* z, int64_t ldz, const float* prior, gm
  * (x-xr)^2 (vae.py:203) + gradient w.r.t. the decoder's pre-sigmoid output. */
 int gm_vae_reparam(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
                    float* z, int64_t ldz, float* kl_out, gm_slot kl_slot, int B, int Z);
+/* Wide form of gm_vae_reparam: many workgroups, the KL term left as ceil(B*Z/256) per-workgroup partial
+ * sums in kl_part[0..n_part) for gm_sum_finalize2_tick to add up. */
+int gm_vae_reparam_wide(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
+                        float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z);
 int gm_vae_reparam_bwd(void* stream, const float* ml, int64_t ldml, const float* eps,
                        gm_slot eps_slot, const float* dz, int64_t lddz, float* dml, int64_t ldd,
                        int B, int Z);
@@ -185,6 +189,10 @@ int gm_sum_finalize(void* stream, const float* partial, int n, float scale, floa
  * slot of the step has been resolved by then), saving the separate gm_tick launch. */
 int gm_sum_finalize_tick(void* stream, const float* partial, int n, float scale, float* out,
                          gm_slot out_slot, int64_t* tick);
+/* Two such sums in one launch (vae.py:203 and :212 of one batch), tick optional (may be NULL). */
+int gm_sum_finalize2_tick(void* stream, const float* pa, int na, float scale_a, float* out_a, gm_slot slot_a,
+                          const float* pb, int nb, float scale_b, float* out_b, gm_slot slot_b,
+                          int64_t* tick);
 
 /* ---- fused critic head (output_dim == 1, separable loss variants): replaces the N=1 GEMV
  * (`self.discriminate`, ns_gan.py:59), the loss lines of train_D / train_G (appendix A.2) and, in

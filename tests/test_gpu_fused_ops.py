@@ -272,3 +272,27 @@ def test_bir_mmd_matches_fp64_autograd(B, Z):
     of.bir_mmd(z, x.view(-1), part, None, B, Z, lam)
     torch.cuda.synchronize()
     assert bool((dz == 7.0).all())
+
+
+@pytest.mark.parametrize("B,Z", [(512, 20), (336, 20), (37, 6)])
+def test_vae_reparam_wide_and_dual_finalize(B, Z):
+    """gm_vae_reparam_wide + gm_sum_finalize2_tick == gm_vae_reparam + gm_sum_finalize: same z bit for
+    bit, KL and reconstruction sums to fp64-summation order, counter advanced by the last launch."""
+    torch.manual_seed(B)
+    ml = (torch.randn(B, 2 * Z) * 0.5).cuda()
+    eps = torch.randn(B * Z).cuda()
+    z0, z1 = torch.empty(B, Z, device="cuda"), torch.empty(B, Z, device="cuda")
+    kl0 = torch.zeros(1, device="cuda")
+    of.vae_reparam(ml, eps, z0, kl0, B, Z)
+    part_kl = torch.full(((B * Z + 255) // 256 + 3,), 7.0, device="cuda")
+    n_kl = of.vae_reparam_wide(ml, eps, z1, part_kl, B, Z)
+    rows = torch.rand(B, device="cuda") * 50
+    out_a, out_b = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    of.sum_finalize2(rows, B, out_a, ops.slot(0, 0, 1, 0, 1), part_kl, n_kl, out_b, ops.slot(0, 0, 1, 0, 1), tick=ctr)
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    assert abs(out_b[1].item() - kl0.item()) <= 1e-6 * max(1.0, abs(kl0.item()))
+    assert abs(out_a[1].item() - rows.double().sum().item()) <= 1e-6 * rows.double().sum().item()
+    assert out_a[0].item() == 0.0 and out_b[0].item() == 0.0 and int(ctr) == 1
+    assert bool((part_kl[n_kl:] == 7.0).all())
