@@ -1854,8 +1854,21 @@ class VAEEngine:
         key = (b, train, self.data.data_ptr(), k)
         if key not in self.graphs:
             torch.cuda.synchronize()
-            self.graphs[key] = ops.Graph().capture(
-                lambda st: [self._issue(st, 0, b, train, pos=i, of=k) for i in range(k)])
+            # full batches: every power-of-two size at once (an epoch's chunking asks for different
+            # sizes from pass to pass; capturing them one by one would land inside later passes)
+            sizes = [k]
+            if b == self.B and self.use_graph:
+                sizes, n = [], 1
+                while n <= self.graph_iters:
+                    sizes.append(n)
+                    n *= 2
+                if k not in sizes:
+                    sizes.append(k)
+            for n in sizes:
+                kk = (b, train, self.data.data_ptr(), n)
+                if kk not in self.graphs:
+                    self.graphs[kk] = ops.Graph().capture(
+                        lambda st, n=n: [self._issue(st, 0, b, train, pos=i, of=n) for i in range(n)])
         return self.graphs[key]
 
     def run_pass(self, data, perm, train, t0):
@@ -1894,14 +1907,15 @@ class VAEEngine:
                     k += 1
                     continue
                 run = 1
-                while k + run < len(sizes) and sizes[k + run] == b and run < self.graph_iters:
+                while k + run < len(sizes) and sizes[k + run] == b:
                     run += 1
-                if run == self.graph_iters and run > 1:
-                    self._graph(b, train, run).launch()
-                    k += run
-                else:
-                    self._graph(b, train).launch()
-                    k += 1
+                # the run of equal-size batches as power-of-two graphs, largest first (each size is
+                # captured once, on first use): only a graph's FIRST batch pays its own gather launch
+                piece = 1
+                while piece * 2 <= min(run, self.graph_iters):
+                    piece *= 2
+                self._graph(b, train, piece).launch()
+                k += piece
             done += cnt
         return nb
 
