@@ -316,7 +316,8 @@ def timed_reps(run_rep, reps, K, world, dev):
         fence(world)
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            gloo = torch.distributed.get_backend() == "gloo"
+            t = torch.tensor([dt], device="cpu" if gloo else dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
         out.append(dt)
@@ -519,6 +520,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry run of the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo as control
+    # plane -- what tests/test_gpu_dp.py does): GM_BENCH_ONE_DEVICE=1.  Not a measurement.
+    one_device = os.environ.get("GM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world != args.gpus:
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
@@ -530,8 +536,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
         ranks_seen = dist.get_world_size()
 
     dev = torch.device("cuda", local_rank)
