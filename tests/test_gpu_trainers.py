@@ -201,6 +201,40 @@ def test_run_to_run_determinism():
     assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses
 
 
+def test_failed_host_draws_raise_and_never_leave_the_gpu_waiting():
+    """A draw job that fails on the fill worker (here: an op outside the restated paths injected into
+    the programme of a later ring slot) must surface as GMError from run() within moments -- the fill
+    gate of every already-enqueued graph is opened by the error path, nothing waits for its 20 s
+    time-out -- and the engine must train normally again afterwards."""
+    import time
+    from generative_models_amd import _lib, engine
+    tr, model = build_product("ns", SMALL, SMALL["batch"])
+    eng = tr._get_engine()
+    eng.configure(40, 2e-4, 2e-4, 1)
+    eng.run(8, it_start=0)
+    torch.cuda.synchronize()
+    if not eng._native_fill:
+        pytest.skip("native fill worker not in use")
+    # corrupt the draw programme of ring slot 12: normal_ on 8 elements is unsupported by the replay
+    bad_dst = torch.empty(8)
+    v = eng._host_views(12 % eng.R)
+    good = v["program"]
+    ops_list = [engine.HostReplay.op(_lib.DRAW_NORMAL, 8, bad_dst, 0)]
+    v["program"] = (_lib.DrawOp * 1)(*ops_list)
+    # (a cold run's sub-chunks are 1, 1, 2, 4, ... iterations: the fourth one starts at iteration 12)
+    t0 = time.perf_counter()
+    with pytest.raises(_lib.GMError):
+        eng.run(32, it_start=8)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0, "the error path waited for a gate time-out"
+    v["program"] = good
+    assert torch.equal(torch.ones(3, device="cuda") * 2, torch.full((3,), 2.0, device="cuda"))
+    # a fresh configure() + train on the same engine works and matches the oracle again
+    p, p_model, _ = run_product("ns", SMALL, SMALL["batch"], dict(num_epochs=1))
+    o, _, _ = run_oracle("ns", SMALL, SMALL["batch"], dict(num_epochs=1))
+    lclose(p.Glosses, o.Glosses, "G after a failed run")
+
+
 def test_two_train_calls_reset_adam():
     """Optimizers are locals of the reference's train(): Adam state resets per call."""
     cfg = SMALL
