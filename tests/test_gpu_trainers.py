@@ -235,6 +235,20 @@ def test_failed_host_draws_raise_and_never_leave_the_gpu_waiting():
     lclose(p.Glosses, o.Glosses, "G after a failed run")
 
 
+@pytest.mark.parametrize("ring", ["8", "5"])
+def test_small_ring_wraps_many_times_and_changes_nothing(ring, monkeypatch):
+    """GM_RING=8 / 5: the host / device rings wrap every few iterations (slot reuse gated on the launches
+    that last staged them in, pieces never crossing the ring end) -- losses and parameters identical
+    to the default 128-slot ring, bit for bit."""
+    ref, ref_model, ref_rng = run_product("ns", SMALL, SMALL["batch"], dict(num_epochs=3))
+    monkeypatch.setenv("GM_RING", ring)
+    got, got_model, got_rng = run_product("ns", SMALL, SMALL["batch"], dict(num_epochs=3))
+    assert got._engine.R == int(ring)
+    assert got.Glosses == ref.Glosses and got.Dlosses == ref.Dlosses and torch.equal(ref_rng, got_rng)
+    for (k, a), (_, b) in zip(got_model.state_dict().items(), ref_model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_two_train_calls_reset_adam():
     """Optimizers are locals of the reference's train(): Adam state resets per call."""
     cfg = SMALL
