@@ -1238,11 +1238,13 @@ class GANEngine:
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
         self._event_pool = []
-        # DRAGAN prefetches a B x 784 uniform tensor per critic step: keep its ring small
         import os
         ring = int(os.environ.get("GM_RING", GAN_RING))
         # (not shrunk to short runs: a later, longer train() on this engine then keeps rings AND graphs)
-        R = max(1, 16 if self.variant == "dra" else ring)
+        # DRAGAN stages a B x 784 uniform tensor per critic step (0.8 MB at B = 256): 64 slots = 51 MB of
+        # pinned + device ring.  (16 slots, round 1's choice, serialised host fills and GPU graphs: a
+        # 16-iteration graph had to FINISH before its slots could be refilled -- 236 us per iteration.)
+        R = max(1, min(ring, 64) if self.variant == "dra" else ring)
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
                self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated)
         self.D_steps = D_steps
