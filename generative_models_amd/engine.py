@@ -1508,7 +1508,7 @@ class GANEngine:
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
         if self.use_graph and self._one_graph():
-            for size, g in self.graphs_by_size:           # largest first: 8, 4, 2, 1 iterations
+            for size, g in self.graphs_by_size:           # largest first: 32, 16, ..., 1 iterations
                 while k >= size:
                     g.launch()
                     k -= size
@@ -1525,9 +1525,11 @@ class GANEngine:
                 self._issue_iteration(st, it + i)
 
     def run(self, n_iters, it_start=0, horizon=None):
-        """Run iterations [it_start, it_start+n_iters): host draws in sub-chunks of `SUB`
-        iterations on the prefetch thread, one H2D upload per sub-chunk, graph replays.  The GPU
-        starts after the FIRST sub-chunk is drawn, not after a whole ring.
+        """Run iterations [it_start, it_start+n_iters): the run is cut into power-of-two graph launches
+        (_plan); the host draws of every piece are SUBMITTED (native fill worker, or the prefetch
+        thread) before its graph is enqueued and the graph's stage-in kernel waits for them on the fill
+        gate, so launches run ahead of the draws.  The GPU starts after the first one or two
+        iterations' worth of draws, not after a whole ring.
         horizon: the host may draw ahead up to this iteration (exclusive) while the caller does
         something else after run() returns (train(): the epoch-end loss read-back); never past
         what configure() planned.  Without it the host draws exactly what this call consumes, so a
