@@ -4,14 +4,15 @@ vae.py:144-167) re-designed for MI355X.
 Reference per step: DataLoader reshuffle on the host, 3 H2D copies, ~60 tiny autograd ops,
 two `.item()` syncs.  Here, per iteration:
 
-  host   : replays the reference's global-CPU-generator draw order ahead
-           of time into pinned staging buffers -- sampler seed -> O(B) randperm prefix
-           (gm_randperm_prefix), noise/eps via the same torch CPU generator calls -- one H2D copy
-           per CHUNK of iterations;
-  device : one hipGraph replay per iteration (D_steps critic steps + 1 generator step): gather,
-           MFMA GEMMs with fused bias/activation/activation-gradient epilogues, loss + score
-           gradient, flat Adam.  A device counter advanced by the graph itself selects the ring
-           slot / Adam-schedule row / loss slot, so replays need no host-side arguments;
+  host   : replays the reference's global-CPU-generator draw order in C
+           (csrc/gm_hostrng.cpp: mt19937 + ATen's normal_/uniform_/random_/randint restated bit
+           for bit, O(B) randperm prefix for the sampler) on a native worker thread, straight into
+           PINNED host rings that mirror the device rings; graphs are enqueued ahead of their draws;
+  device : hipGraphs of 1..32 iterations (each: D_steps critic steps + 1 generator step): a stage-in
+           kernel that waits on the fill gate and pulls its iterations' ring slots over PCIe, then
+           MFMA GEMMs with fused bias/activation/activation-gradient epilogues (gather, critic head,
+           Adam riding in their launches).  A device counter advanced by the graph itself selects
+           the ring slot / Adam-schedule row / loss slot, so replays need no host-side arguments;
   sync   : none until the epoch ends (losses are read back in one copy).
 
 Only the wasted work of the reference is skipped (G gradients during the D
