@@ -306,3 +306,30 @@ def test_launch_planner_invariants(R, graph_iters):
                     done += x
     if R >= 32 and graph_iters >= 16:
         assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
+
+
+@pytest.mark.parametrize("record", ["r02_bench_default.json", "r02_bench_steps20_warmup5.json"])
+def test_committed_bench_records_follow_the_contract(record):
+    """The bench lines committed under profiles/ carry every key of the driver's contract with the
+    right types, the roofline / cpu_baseline objects, and the configs 3/4/5 section."""
+    import json
+    root = os.path.dirname(HERE)
+    line = json.loads(open(os.path.join(root, "profiles", record)).read().strip().splitlines()[-1])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int),
+                     ("warmup", int), ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str),
+                     ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), (key, type(line[key]))
+    assert "vs_baseline" in line and line["vs_baseline"] is None        # BASELINE.md holds no number for this metric
+    assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 256 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if record == "r02_bench_steps20_warmup5.json":
+        assert line["steps"] == 20 and line["warmup"] == 5          # the driver's command
+    names = " | ".join(e["workload"] for e in line.get("configs", []))
+    for needle in ("WGAN-GP", "NSGAN MNIST bs=1024", "LSGAN MNIST bs=1024", "VAE MNIST bs=512"):
+        assert needle in names, (needle, names)

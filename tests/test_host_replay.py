@@ -225,3 +225,77 @@ def test_fill_worker_matches_inline_replay_and_opens_gate():
     assert lib.gm_fill_reset() == 0
     j3 = lib.gm_fill_submit(st.data_ptr(), st.numel(), (_lib.DrawOp * 2)(*p), 2, 1, gate.data_ptr(), 7)
     assert lib.gm_fill_wait(j3) == 0 and int(gate[0]) == 7
+
+
+def _torch_sequence(gen_state, seq, B_info=None):
+    """The draws of `seq` made by torch itself on a private generator positioned at gen_state."""
+    g = torch.Generator()
+    g.set_state(gen_state.clone())
+    out = []
+    for kind, a, b in seq:
+        if kind == "normal":
+            out.append(torch.empty(a).normal_(generator=g))
+        elif kind == "uniform":
+            out.append(torch.empty(a).uniform_(generator=g))
+        elif kind == "sampler":                       # DataLoader(shuffle=True): base seed, sampler seed, randperm
+            torch.empty((), dtype=torch.int64).random_(generator=g)
+            seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item())
+            out.append(torch.randperm(a, generator=torch.Generator().manual_seed(seed))[:b])
+        else:                                         # info: randn(B, zd) | one_hot(randint(0, nd)) | randn(B, nc)
+            zd, nd, nc = b
+            zz = torch.empty(a, zd).normal_(generator=g)
+            cat = torch.randint(0, nd, (a,), dtype=torch.long, generator=g)
+            cc = torch.empty(a, nc).normal_(generator=g)
+            t = torch.zeros(a, zd + nd + nc)
+            t[:, :zd] = zz
+            t[torch.arange(a), zd + cat] = 1
+            t[:, zd + nd:] = cc
+            out.append(t)
+    return out, g.get_state()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_draw_programmes_match_torch_bit_for_bit(seed):
+    """Randomly composed programmes (normal_ on 16..6000 elements incl. lengths that are not multiples
+    of 16, uniform_ on 1..5000, sampler prefixes, InfoGAN's composite noise), started from a generator
+    left mid-block with a pending state twist at a random distance: every value and the final
+    generator state must equal torch's own."""
+    import random
+    rnd = random.Random(1000 + seed)
+    g0 = torch.Generator().manual_seed(seed * 7919 + 1)
+    torch.empty(rnd.randint(0, 700)).uniform_(generator=g0)          # random position inside the 624-word block
+    s0 = g0.get_state()
+    seq = []
+    for _ in range(rnd.randint(3, 9)):
+        k = rnd.choice(["normal", "normal", "uniform", "sampler", "info"])
+        if k == "normal":
+            seq.append((k, rnd.choice([16, 17, 31, 32, 100, 640, 5120, rnd.randint(16, 6000)]), None))
+        elif k == "uniform":
+            seq.append((k, rnd.choice([1, 7, 256, 1003, rnd.randint(1, 5000)]), None))
+        elif k == "sampler":
+            n = rnd.choice([64, 1000, 50000])
+            seq.append((k, n, rnd.randint(1, min(n, 300))))
+        else:
+            zd, nd, nc = rnd.choice([(4, 10, 6), (20, 10, 10), (8, 3, 5)])
+            # (the composite path is restated for 16-multiples of B*zd and B*nc; other shapes return
+            # GM_EUNSUPPORTED and the engine draws them through torch)
+            bsz = rnd.choice([b for b in (4, 16, 24, 48, 256) if (b * zd) % 16 == 0 and (b * nc) % 16 == 0])
+            seq.append((k, bsz, (zd, nd, nc)))
+    ref, s1 = _torch_sequence(s0, seq)
+    outs, ops = [], []
+    for kind, a, b in seq:
+        if kind == "normal":
+            t = torch.empty(a); ops.append(HostReplay.op(DRAW_NORMAL, a, t, 0))
+        elif kind == "uniform":
+            t = torch.empty(a); ops.append(HostReplay.op(DRAW_UNIFORM, a, t, 0))
+        elif kind == "sampler":
+            t = torch.empty(b, dtype=torch.int64); ops.append(HostReplay.op(DRAW_SAMPLER, b, t, 0, a=a))
+        else:
+            zd, nd, nc = b
+            t = torch.empty(a, zd + nd + nc); ops.append(HostReplay.op(DRAW_INFO, a, t, 0, a=zd, b=nd, c=nc))
+        outs.append(t)
+    st = s0.clone()
+    assert HostReplay.call(st, ops, 1) == 0
+    for i, (r, o) in enumerate(zip(ref, outs)):
+        assert torch.equal(r, o), (seed, i, seq[i])
+    assert torch.equal(st, s1), (seed, seq)
