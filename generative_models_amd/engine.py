@@ -968,7 +968,15 @@ class GANEngine:
         import ctypes
         from . import _lib
         segs = []
+        # DRAGAN's uniforms (B x 784 per critic step, 0.8 MB at B = 256) do not go through the in-graph
+        # stage-in -- 36 us of serial GPU-initiated PCIe reads per iteration -- but through the copy
+        # engine on a side stream, overlapping the previous piece's kernels (_copy_U)
+        import os
+        self._u_copy = ("U" in shapes) and os.environ.get("GM_DRA_UCOPY", "1") != "0"
+        self._u_copied, self._u_stream = 0, None
         for k in shapes:
+            if k == "U" and self._u_copy:
+                continue
             h, dv = self.hring[k], self.dring[k]
             devp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", h.data_ptr(), ctypes.byref(devp))
@@ -1232,6 +1240,7 @@ class GANEngine:
         from collections import deque
         self.n_planned = n_iters
         self._fills, self._cursor, self._next_it = deque(), 0, 0
+        self._u_copied = 0
         self._launched, self._ramp = deque(), []
         if self._gate is not None:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
@@ -1501,6 +1510,24 @@ class GANEngine:
             n -= seg
         return out
 
+    def _copy_U(self, upto):
+        """DRAGAN: host ring -> device ring for the uniforms of iterations [_u_copied, upto) on the copy
+        engine (side stream); the launch stream waits for it.  Their draws are complete (the caller
+        waited), and their device slots are free: a slot's draws are only made after the launch that
+        last read it has completed (_slots_free_now)."""
+        if self._u_stream is None:
+            self._u_stream = torch.cuda.Stream(device=self.device)
+        d, R = self.D_steps, self.R
+        with torch.cuda.stream(self._u_stream):
+            while self._u_copied < upto:
+                r = self._u_copied % R
+                m = min(upto - self._u_copied, R - r)
+                self.dring["U"][r * d:(r + m) * d].copy_(self.hring["U"][r * d:(r + m) * d], non_blocking=True)
+                self._u_copied += m
+        ev = torch.cuda.Event()
+        ev.record(self._u_stream)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+
     def _check_gate(self):
         if self._gate is not None and self._gate_np[1] != 0:
             raise GMError("a stage-in kernel gave up waiting for the host draws of its iterations "
@@ -1570,6 +1597,9 @@ class GANEngine:
                 if not gated:
                     self._reap(upto=it + k)
                     self._pump(limit)                 # further draws overlap the launch below
+                if self._u_copy:
+                    self._reap(upto=it + k)           # the uniforms must exist before the copy engine moves them
+                    self._copy_U(it + k)
                 if trace is not None:
                     trace.append(("got", it, time.perf_counter()))
                 self._launch(it, k)
