@@ -157,3 +157,24 @@ def test_two_ranks_assemble_the_single_process_noise_from_their_own_rows():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, True)], res
+
+
+def test_ragged_batch_row_split_covers_every_row_once():
+    """VAEEngine._rows: a batch of b rows (incl. the ragged last one, 50 000 mod 512 = 336) is split over
+    the ranks without gaps or overlaps, sizes differing by at most one."""
+    from generative_models_amd.engine import VAEEngine
+
+    class E:
+        pass
+    for world in (1, 2, 3, 4, 8):
+        for b in (1, 6, 7, 16, 336, 512, 1000):
+            seen, sizes = [], []
+            for rank in range(world):
+                e = E()
+                e.world, e.rank = world, rank
+                lo, hi = VAEEngine._rows(e, b)
+                assert 0 <= lo <= hi <= b
+                seen += list(range(lo, hi))
+                sizes.append(hi - lo)
+            assert seen == list(range(b)), (world, b)
+            assert max(sizes) - min(sizes) <= 1, (world, b, sizes)
