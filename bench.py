@@ -40,11 +40,19 @@ LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip tr
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
 
 
+_DATASET = None
+
+
 def synthetic_dataset():
-    torch.manual_seed(3435)
-    img = torch.bernoulli(torch.full((N_TRAIN, 1, 28, 28), 0.1307))
-    ds = torch.utils.data.TensorDataset(img, torch.zeros(N_TRAIN, dtype=torch.int64))
-    return ds
+    """seed 3435, Bernoulli(0.1307) 50 000 x 1 x 28 x 28 (built once per process)."""
+    global _DATASET
+    if _DATASET is None:
+        st = torch.get_rng_state()
+        torch.manual_seed(3435)
+        img = torch.bernoulli(torch.full((N_TRAIN, 1, 28, 28), 0.1307))
+        _DATASET = torch.utils.data.TensorDataset(img, torch.zeros(N_TRAIN, dtype=torch.int64))
+        torch.set_rng_state(st)
+    return _DATASET
 
 
 def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather=True, pair_dw=True,
@@ -325,8 +333,9 @@ def timed_reps(run_rep, reps, K, world, dev):
 
 
 def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=True, force_dp=False,
-              lrs=(2e-4, 2e-4), D_steps=1):
-    """W warm-up + reps x K timed iterations of the fused engine.  Returns (engine, [seconds])."""
+              lrs=(2e-4, 2e-4), D_steps=1, solo=False, long_steps=0):
+    """W warm-up + reps x K timed iterations of the fused engine.  Returns (engine, [seconds]).
+    solo: a 1-rank engine timed on this rank alone inside a multi-rank job (no barrier / max)."""
     import importlib
     from generative_models_amd import engine as gm_engine
     mod, cls = {"ns": ("ns_gan", "NSGAN"), "ls": ("ls_gan", "LSGAN"), "wgp": ("w_gp_gan", "WGPGAN"),
@@ -340,7 +349,7 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
     eng = gm_engine.GANEngine(variant, trainer.model, data, B_global, dev, use_graph=use_graph,
                               world_size=world, rank=rank, force_dp=force_dp)
-    eng.configure(W + reps * K, lrs[0], lrs[1], D_steps)
+    eng.configure(W + reps * K + long_steps, lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
     marks = []
 
@@ -348,14 +357,21 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
         marks.append(time.perf_counter())
         eng.run(K, it_start=W + r * K)
         marks.append(time.perf_counter())
-    secs = timed_reps(rep, reps, K, world, dev)
+    secs = timed_reps(rep, reps, K, 1 if solo else world, dev)
     if eng._trace:                                   # GM_TRACE_RUN=1: host timeline of each repetition
         for r in range(reps):
             t0, t1 = marks[2 * r], marks[2 * r + 1]
             ev = [(k, a, round((t - t0) * 1e6)) for k, a, t in eng._trace if t0 <= t <= t1 + 1e-3]
             print("[trace rep %d] run() returned at %d us, total %d us: %s"
                   % (r, (t1 - t0) * 1e6, secs[r] * 1e6, ev), file=sys.stderr, flush=True)
-    G, D = eng.losses(W, W + reps * K)
+    eng.steady_us_per_step = None
+    if long_steps:
+        # one long region right behind the timed ones: the steady-state step, so that the fixed cost
+        # of a K-step run() (cold start of the host draws, graph boundaries, final sync) can be reported
+        ls = timed_reps(lambda r: eng.run(long_steps, it_start=W + reps * K), 1, long_steps,
+                        1 if solo else world, dev)
+        eng.steady_us_per_step = ls[0] / long_steps * 1e6
+    G, D = eng.losses(W, W + reps * K + long_steps)
     assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
     return eng, secs
 
@@ -492,6 +508,80 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
     return out
 
 
+def comm_mode_of(eng):
+    """How this engine exchanges gradients (config.launch / the DP series entries)."""
+    if eng.world == 1 and not eng.force_segments:
+        return "none (1 rank)"
+    if eng._peer():
+        return "in-graph peer kernels over hipIpc/xGMI mappings, %s exchange regions" % eng.comm_memory
+    why = (" (peer exchange refused: %s)" % eng.comm_fallback) if getattr(eng, "comm_fallback", None) else ""
+    return "host-launched RCCL all-reduce between segment graphs" + why
+
+
+def dp_series(dev, world, rank, ranks_seen, K, W, reps):
+    """BASELINE.json configs[4] / SURVEY.md 8(d)(5): NSGAN and LSGAN at batch 1024 across the `world`
+    ranks of this run (loops being sharded: ns_gan.py:122-156, ls_gan.py:95-171), two series each:
+      weak   -- 1024 rows PER RANK (global batch 1024 x N); eff = img/s(N) / (N x img/s(1))  [the >= 70 % target]
+      strong -- GLOBAL batch 1024 (1024 / N rows per rank); speed-up = img/s(N) / img/s(1)
+    img/s(1) is measured IN THIS RUN: rank 0 runs the 1-rank fused engine on its own GPU while the
+    other ranks wait at the barrier.  Every timed region: barrier + synchronize on both sides, max
+    over ranks, median of `reps` repetitions of K iterations."""
+    out = []
+    lrs = {"ns": (2e-4, 2e-4), "ls": (1e-4, 1e-4)}
+    for variant in ("ns", "ls"):
+        one = None
+        if rank == 0:
+            eng, secs = bench_gan(variant, 1024, W, K, reps, dev, world=1, rank=0, lrs=lrs[variant], solo=True)
+            one = K * 1024 / float(np.median(secs))
+            del eng
+        fence(world)
+        entry = {"workload": "%s MNIST batch 1024 data-parallel (BASELINE.json configs[4])"
+                             % {"ns": "NSGAN", "ls": "LSGAN"}[variant],
+                 "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "reps": reps,
+                 "n1_img_s_same_run": one}
+        for kind, Bg in (("weak", 1024 * world), ("strong", 1024)):
+            eng, secs = bench_gan(variant, Bg, W, K, reps, dev, world=world, rank=rank, lrs=lrs[variant])
+            dt = float(np.median(secs))
+            e = {"global_batch": Bg, "rows_per_rank": Bg // world, "img_s": K * Bg / dt,
+                 "ms_per_step": dt / K * 1e3, "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
+                 "comm": comm_mode_of(eng)}
+            if one:
+                e["speedup_vs_n1"] = e["img_s"] / one
+                e["efficiency"] = e["img_s"] / one / world
+            entry[kind] = e
+            log("%s %s N=%d: %.0f img/s" % (variant, kind, world, e["img_s"]))
+            del eng
+            fence(world)
+        out.append(entry)
+    return out
+
+
+def bench_trainer(epochs=3):
+    """What a user of the reference's API gets (north_star: the path IS Trainer.train, ns_gan.py:94-170):
+    `NSGANTrainer.train(epochs)` through the drop-in module -- per-epoch loss read-back, the reference's
+    list extends (:159-160) and the epoch-end print included -- after one warm-up epoch on the same
+    trainer (graph capture, clocks).  images = real images consumed by the critic steps."""
+    import ns_gan
+    ds = synthetic_dataset()
+    mk = lambda: torch.utils.data.DataLoader(ds, batch_size=B_PER_GPU, shuffle=True)
+    torch.manual_seed(1234)
+    model = ns_gan.NSGAN(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    tr = ns_gan.NSGANTrainer(model, mk(), None, None, viz=False)
+    steps = len(tr.train_iter)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train(epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert len(tr.Glosses) == (1 + epochs) * steps and np.isfinite(tr.Glosses).all()
+    return {"what": "ns_gan.NSGANTrainer(model, train_iter, ...).train(%d) through the drop-in module, warm "
+                    "(bs=256, %d iterations per epoch)" % (epochs, steps),
+            "img_s": epochs * steps * B_PER_GPU / dt, "ms_per_step": dt / (epochs * steps) * 1e3,
+            "steps": epochs * steps}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-run under torch.distributed.run."""
     import socket
@@ -554,10 +644,21 @@ def main():
         return
     B_global = B_PER_GPU * world
     eng, secs = bench_gan("ns", B_global, W, K, reps, dev, world=world, rank=rank,
-                          use_graph=not args.no_graph, force_dp=force_dp)
+                          use_graph=not args.no_graph, force_dp=force_dp, long_steps=512)
     dt = float(np.median(secs))
     log('timed regions done: %s' % ["%.4f" % x for x in secs])
     img_s = K * B_global / dt
+    n1_img_s, series = None, None
+    if world > 1:
+        # N = 1 figure of THIS run (rank 0 alone, same K / W / reps), then the batch-1024 series
+        if rank == 0:
+            e1, s1 = bench_gan("ns", B_PER_GPU, W, K, reps, dev, world=1, rank=0,
+                               use_graph=not args.no_graph, solo=True)
+            n1_img_s = K * B_PER_GPU / float(np.median(s1))
+            del e1
+        fence(world)
+        if not args.no_configs:
+            series = dp_series(dev, world, rank, ranks_seen, max(K, 100), max(W, 10), min(reps, 3))
 
     if rank == 0:
         kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
@@ -599,9 +700,14 @@ def main():
                                    if eng._peer() else "hipGraph per segment + 2 RCCL all-reduces/iteration"))
                        if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
+                       "gradient_exchange": comm_mode_of(eng),
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
                        "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw"},
+            # steady-state step of the same engine (one 512-step region behind the timed ones) and what a
+            # K-step run() costs on top of K of those: cold start of the host draws, graph boundaries, final sync
+            "steady_us_per_step": eng.steady_us_per_step,
+            "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if eng.steady_us_per_step else None,
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             # compulsory HBM bytes of a step (Adam 7 x 4 B/param + gradient write + image rows +
             # noise = 82 944 B/image at B=256) against 8 TB/s: the path is nowhere near the HBM roof
@@ -616,7 +722,14 @@ def main():
                          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
         }
         del eng
+        if world > 1:
+            line["config"]["n1_img_s_same_run"] = n1_img_s
+            line["config"]["efficiency_vs_n1_same_run"] = img_s / (world * n1_img_s) if n1_img_s else None
+            if series is not None:
+                line["dp_series"] = series
         if world == 1 and not force_dp:
+            if not args.no_configs:
+                line["trainer"] = bench_trainer()
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline_gan("ns", B_PER_GPU)
                 line["cpu_baseline_compute_only"] = cpu_baseline_gan(

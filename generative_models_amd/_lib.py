@@ -62,7 +62,9 @@ class DrawOp(ctypes.Structure):
 
 class StageSeg(ctypes.Structure):
     """gm_stage_seg (include/gm_hip.h)."""
-    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("bytes_per_iter", c_int64)]
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("bytes_per_iter", c_int64),
+                ("blocks", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("src_block_stride", c_int64), ("dst_block_stride", c_int64)]
 
 
 DRAW_SAMPLER, DRAW_NORMAL, DRAW_UNIFORM, DRAW_INFO = 0, 1, 2, 3
@@ -170,6 +172,7 @@ _SIGNATURES = {
     "gm_comm_connect": (c_int, [_P, _P]),
     "gm_comm_destroy": (c_int, [_P]),
     "gm_comm_error": (c_int, [_P, POINTER(c_int)]),
+    "gm_comm_info": (c_int, [_P, POINTER(c_int)]),
     "gm_comm_buffer": (c_int, [_P, POINTER(c_void_p), POINTER(c_int64)]),
     "gm_allreduce_f32": (c_int, [_P, _P, _P, c_int64]),
     "gm_allreduce_adam_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, Slot, ctypes.c_double,

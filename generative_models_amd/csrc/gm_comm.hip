@@ -58,6 +58,7 @@ struct Comm {
     unsigned long long* seq;   // device: number of completed all-reduces; [1]: copy for the gather phase
     unsigned long long* sseq;  // device: number of completed scalar exchanges
     int* err;                  // device: set when a bounded wait expired
+    int coarse;                // 1: the region is plain hipMalloc memory (fine-grained allocation refused)
 };
 
 struct CommP {
@@ -232,32 +233,59 @@ CommP params_of(const Comm* cm) {
 
 }  // namespace
 
-extern "C" int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void* handle_out64) {
-    GM_CHECK_ARG(comm_out && handle_out64 && world >= 1 && world <= MAXW && rank >= 0 && rank < world && n_floats > 0);
-    Comm* cm = new Comm();
-    cm->rank = rank; cm->world = world; cm->n_floats = n_floats; cm->lay = layout(n_floats);
-    for (int i = 0; i < MAXW; ++i) { cm->base[i] = nullptr; cm->opened[i] = false; }
+extern "C" int gm_comm_destroy(void* comm);
+
+// The exchange region must be FINE-GRAINED device memory when peers on other GPUs store into it and
+// a running kernel polls it (no kernel boundary between a peer's store and my load).  If the runtime
+// refuses that allocation the region falls back to plain hipMalloc and the communicator is marked
+// coarse (gm_comm_info): correct when every rank shares ONE device (the single-GPU multi-process
+// tests), NOT across GPUs -- dp.PeerComm refuses a coarse region there and the engine drops to RCCL.
+static int comm_create_impl(Comm* cm, void* handle_out64) {
     void* p = nullptr;
-    // fine-grained device memory: stores by a peer over xGMI are visible to this GPU's loads without
-    // a kernel boundary; plain hipMalloc as a fallback (single-GPU multi-process tests)
     hipError_t e = hipExtMallocWithFlags(&p, (size_t)cm->lay.total, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); GM_HIPC(hipMalloc(&p, (size_t)cm->lay.total)); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cm->coarse = 1;
+        GM_HIPC(hipMalloc(&p, (size_t)cm->lay.total));
+    }
+    cm->base[cm->rank] = static_cast<char*>(p);           // owned from here on: gm_comm_destroy frees it
     GM_HIPC(hipMemset(p, 0, (size_t)cm->lay.total));
-    cm->base[rank] = static_cast<char*>(p);
     void* ctr = nullptr;
     GM_HIPC(hipMalloc(&ctr, 64));
-    GM_HIPC(hipMemset(ctr, 0, 64));
     cm->seq = static_cast<unsigned long long*>(ctr);
+    GM_HIPC(hipMemset(ctr, 0, 64));
     cm->sseq = cm->seq + 2;
     cm->err = reinterpret_cast<int*>(cm->seq + 4);
     hipIpcMemHandle_t h;
     std::memset(&h, 0, sizeof(h));
-    if (world > 1) GM_HIPC(hipIpcGetMemHandle(&h, p));
+    if (cm->world > 1) GM_HIPC(hipIpcGetMemHandle(&h, p));
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle travels as 64 bytes");
     std::memset(handle_out64, 0, 64);
     std::memcpy(handle_out64, &h, sizeof(h));
     GM_HIPC(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void* handle_out64) {
+    GM_CHECK_ARG(comm_out && handle_out64 && world >= 1 && world <= MAXW && rank >= 0 && rank < world && n_floats > 0);
+    Comm* cm = new Comm();
+    cm->rank = rank; cm->world = world; cm->n_floats = n_floats; cm->lay = layout(n_floats);
+    cm->seq = nullptr; cm->sseq = nullptr; cm->err = nullptr; cm->coarse = 0;
+    for (int i = 0; i < MAXW; ++i) { cm->base[i] = nullptr; cm->opened[i] = false; }
+    const int rc = comm_create_impl(cm, handle_out64);
+    if (rc) {                                             // nothing leaks on a failed construction
+        (void)gm_comm_destroy(cm);
+        *comm_out = nullptr;
+        return rc;
+    }
     *comm_out = cm;
+    return 0;
+}
+
+extern "C" int gm_comm_info(void* comm, int* fine_grained_out) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && fine_grained_out);
+    *fine_grained_out = cm->coarse ? 0 : 1;
     return 0;
 }
 

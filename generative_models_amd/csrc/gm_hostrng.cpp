@@ -31,7 +31,7 @@
 #include <vector>
 
 extern "C" void gm_set_error(const char* msg);     // gm_ops.hip
-extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out);
+extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out);   // below
 
 namespace {
 
@@ -543,6 +543,60 @@ void run_spans(const std::vector<Span>& spans) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------
+// O(B) prefix of torch.randperm(n) for a freshly seeded CPU generator (see gm_hip.h):
+// at::native::randperm_cpu is a forward Fisher-Yates, r[i] <-> r[i + random() % (n - i)], so the
+// first B outputs need B draws.  The permutation array is a thread-local dense int32 identity that
+// survives between calls: the 2B entries a call touches are put back afterwards (an undo walk
+// instead of a hash table: a data-parallel run draws the GLOBAL batch's indices on every rank, 8192
+// per step at 8 x 1024 rows -- the table cost 20 ns per index, this costs ~3).  The draws come from
+// the vectorised twist / temper above, one block of 624 at a time; random() % range is a 32-bit
+// unsigned remainder (both operands < 2^32; torch computes it in 64 bits, same value).
+// ------------------------------------------------------------------------------------------
+extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out) {
+    if (!(out && n > 0 && B > 0 && B <= n && n < (int64_t)(0xffffffffu / 20))) {
+        gm_set_error("bad argument: gm_randperm_prefix(seed, n, B, out)");
+        return GM_EINVAL;
+    }
+    static thread_local std::vector<int32_t> perm;       // identity between calls
+    if ((int64_t)perm.size() < n) {
+        const size_t old = perm.size();
+        perm.resize((size_t)n);
+        for (size_t i = old; i < (size_t)n; ++i) perm[i] = (int32_t)i;
+    }
+    static thread_local std::vector<int32_t> touched;
+    touched.clear();
+    touched.reserve((size_t)B);
+    // mt19937 seeded like at::mt19937(seed) (init_with_uint32), first use twists
+    Mt m;
+    m.s[0] = (uint32_t)(seed & 0xffffffffu);
+    for (int j = 1; j < 624; ++j) m.s[j] = 1812433253u * (m.s[j - 1] ^ (m.s[j - 1] >> 30)) + (uint32_t)j;
+    m.next = 624; m.remain = 0;
+    uint32_t block[624];
+    int have = 0, at = 0;
+    int32_t* r = perm.data();
+    const int64_t draws = (B < n) ? B : n - 1;            // the last element of a full permutation: no draw
+    for (int64_t i = 0; i < draws; ++i) {
+        if (at == have) {
+            const int64_t left = draws - i;
+            have = (int)(left < 624 ? left : 624);
+            mt_raw(m, block, have);
+            at = 0;
+        }
+        const uint32_t z = block[at++] % (uint32_t)(n - i);
+        const int64_t j = i + (int64_t)z;
+        const int32_t vi = r[i], vj = r[j];
+        r[i] = vj; r[j] = vi;
+        touched.push_back((int32_t)j);
+        out[i] = (int64_t)vj;
+    }
+    if (draws < B) out[B - 1] = (int64_t)r[B - 1];
+    // undo: every touched slot back to identity (positions i < draws and the recorded partners)
+    for (int64_t i = 0; i < draws; ++i) r[i] = (int32_t)i;
+    for (int32_t j : touched) r[j] = j;
+    return 0;
+}
 
 // Replay `n_iters` iterations of the per-iteration draw program `ops[0..n_ops)` from the
 // serialized torch CPU generator state (torch.get_rng_state(): 5056 bytes), advancing it exactly as

@@ -74,19 +74,42 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     }
     const gm_stage_seg sg = p.seg[blockIdx.y];
     const int64_t first = gm_slot_index(p.slot);
-    const int64_t bytes = sg.bytes_per_iter * (int64_t)p.n_iters;
-    const char* src = reinterpret_cast<const char*>(sg.src) + first * sg.bytes_per_iter;
-    char* dst = reinterpret_cast<char*>(sg.dst) + first * sg.bytes_per_iter;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 15) == 0) {
-        const uint4* s4 = reinterpret_cast<const uint4*>(src);
-        uint4* d4 = reinterpret_cast<uint4*>(dst);
-        for (int64_t i = t; i < bytes / 16; i += stride) d4[i] = s4[i];
-    } else {                                          // odd test shapes: 4-byte granularity
-        const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
-        uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
-        for (int64_t i = t; i < bytes / 4; i += stride) d1[i] = s1[i];
+    const int m = sg.blocks > 1 ? sg.blocks : 1;
+    const int64_t bb = sg.bytes_per_iter / m;                     // bytes per piece
+    const int64_t ss = sg.src_block_stride ? sg.src_block_stride : bb;
+    const int64_t ds = sg.dst_block_stride ? sg.dst_block_stride : bb;
+    const int64_t nblk = (int64_t)p.n_iters * m;
+    const char* src = reinterpret_cast<const char*>(sg.src) + first * m * ss;
+    char* dst = reinterpret_cast<char*>(sg.dst) + first * m * ds;
+    if (ss == bb && ds == bb) {                                   // dense: one flat range
+        const int64_t bytes = bb * nblk;
+        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 15) == 0) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src);
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (int64_t i = t; i < bytes / 16; i += stride) d4[i] = s4[i];
+        } else {                                      // odd test shapes: 4-byte granularity
+            const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+            uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+            for (int64_t i = t; i < bytes / 4; i += stride) d1[i] = s1[i];
+        }
+        return;
+    }
+    // strided pieces (a data-parallel rank's rows of every draw of the global batch)
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bb | (uintptr_t)ss |
+          (uintptr_t)ds) & 15) == 0) {
+        const int64_t upb = bb / 16;
+        for (int64_t u = t; u < nblk * upb; u += stride) {
+            const int64_t q = u / upb, o = u - q * upb;
+            reinterpret_cast<uint4*>(dst + q * ds)[o] = reinterpret_cast<const uint4*>(src + q * ss)[o];
+        }
+    } else {
+        const int64_t upb = bb / 4;
+        for (int64_t u = t; u < nblk * upb; u += stride) {
+            const int64_t q = u / upb, o = u - q * upb;
+            reinterpret_cast<uint32_t*>(dst + q * ds)[o] = reinterpret_cast<const uint32_t*>(src + q * ss)[o];
+        }
     }
 }
 
@@ -98,6 +121,12 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
     int64_t most = 0;
     for (int i = 0; i < n_segs; ++i) {
         GM_CHECK_ARG(segs[i].src && segs[i].dst && segs[i].bytes_per_iter > 0 && segs[i].bytes_per_iter % 4 == 0);
+        const int m = segs[i].blocks > 1 ? segs[i].blocks : 1;
+        GM_CHECK_ARG(segs[i].blocks >= 0 && segs[i].bytes_per_iter % (4 * m) == 0);
+        GM_CHECK_ARG(segs[i].src_block_stride >= 0 && segs[i].dst_block_stride >= 0 &&
+                     segs[i].src_block_stride % 4 == 0 && segs[i].dst_block_stride % 4 == 0);
+        GM_CHECK_ARG(!segs[i].src_block_stride || segs[i].src_block_stride >= segs[i].bytes_per_iter / m);
+        GM_CHECK_ARG(!segs[i].dst_block_stride || segs[i].dst_block_stride >= segs[i].bytes_per_iter / m);
         p.seg[i] = segs[i];
         if (segs[i].bytes_per_iter > most) most = segs[i].bytes_per_iter;
     }
@@ -462,69 +491,7 @@ extern "C" int gm_act_bwd(void* stream, const float* dY, const float* Y, float* 
     GM_LAUNCH_RET();
 }
 
-// ------------------------------------------------------------------------------------------
-// HOST: O(B) prefix of torch.randperm(n) for a freshly seeded CPU generator (see gm_hip.h)
-// ------------------------------------------------------------------------------------------
-namespace {
-struct Mt19937 {
-    uint32_t s[624];
-    int pos;
-    explicit Mt19937(uint32_t seed) {
-        s[0] = seed;
-        for (int j = 1; j < 624; ++j) s[j] = 1812433253u * (s[j - 1] ^ (s[j - 1] >> 30)) + j;
-        pos = 624;
-    }
-    void twist() {
-        for (int k = 0; k < 624; ++k) {
-            const uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
-            s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        pos = 0;
-    }
-    uint32_t next() {
-        if (pos >= 624) twist();
-        uint32_t y = s[pos++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
-    }
-};
-}  // namespace
-
-extern "C" int gm_randperm_prefix(uint64_t seed, int64_t n, int B, int64_t* out) {
-    GM_CHECK_ARG(out && n > 0 && B > 0 && B <= n && n < (int64_t)(0xffffffffu / 20));
-    Mt19937 rng((uint32_t)(seed & 0xffffffffu));
-    // sparse view of the permutation array r[] (identity except for touched entries):
-    // open-addressing table of (key, value), capacity >= 4B, power of two.
-    size_t cap = 16;
-    while (cap < (size_t)B * 4) cap <<= 1;
-    std::string storage(cap * 2 * sizeof(int64_t), '\0');
-    int64_t* keys = reinterpret_cast<int64_t*>(&storage[0]);
-    int64_t* vals = keys + cap;
-    for (size_t i = 0; i < cap; ++i) keys[i] = -1;
-    auto find = [&](int64_t k) -> size_t {
-        size_t h = (size_t)((uint64_t)k * 0x9E3779B97F4A7C15ull) & (cap - 1);
-        while (keys[h] != -1 && keys[h] != k) h = (h + 1) & (cap - 1);
-        return h;
-    };
-    auto get = [&](int64_t k) -> int64_t { size_t h = find(k); return keys[h] == k ? vals[h] : k; };
-    auto put = [&](int64_t k, int64_t v) { size_t h = find(k); keys[h] = k; vals[h] = v; };
-    for (int64_t i = 0; i < B; ++i) {
-        if (i < n - 1) {
-            const int64_t z = (int64_t)(rng.next() % (uint64_t)(n - i));
-            const int64_t j = i + z;
-            const int64_t vi = get(i), vj = get(j);
-            put(i, vj);
-            put(j, vi);
-            out[i] = vj;
-        } else {
-            out[i] = get(i);          // last element of a full permutation: no draw
-        }
-    }
-    return 0;
-}
+// (gm_randperm_prefix, the O(B) prefix of torch.randperm(n), lives in gm_hostrng.cpp)
 
 // ------------------------------------------------------------------------------------------
 // HOST: advance a serialized torch CPU generator (mt19937) by n 32-bit outputs WITHOUT producing

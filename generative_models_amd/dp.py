@@ -59,6 +59,21 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+def _device_identity():
+    """Something that tells two ranks whether they drive the SAME physical GPU (uuid where the
+    torch build exposes it, else PCI address, else the visible-device string + index)."""
+    d = torch.cuda.current_device()
+    pr = torch.cuda.get_device_properties(d)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(pr, attr, None)
+        if v is not None:
+            if attr == "pci_bus_id":
+                v = (getattr(pr, "pci_domain_id", 0), v, getattr(pr, "pci_device_id", 0))
+            return "%s:%s" % (attr, v)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+    return "idx:%s:%d" % (vis, d)
+
+
 class PeerComm:
     """Gradient exchange as kernels inside the iteration graph (csrc/gm_comm.hip): every rank maps
     the other ranks' exchange buffers over hipIpc / xGMI peer mappings; all-reduce = stage ->
@@ -81,17 +96,31 @@ class PeerComm:
             _lib.call("gm_comm_create", rank, world, self.n, ctypes.byref(self.h), handle)
         except Exception as e:                       # noqa: BLE001
             err = e
+        self.fine_grained = True
+        if err is None:
+            fg = ctypes.c_int(1)
+            _lib.call("gm_comm_info", self.h, ctypes.byref(fg))
+            self.fine_grained = bool(fg.value)
         if world > 1:
             import torch.distributed as dist
             got = [None] * world
-            dist.all_gather_object(got, None if err is not None else bytes(handle.raw), group=group)
+            mine = None if err is not None else (bytes(handle.raw), self.fine_grained, _device_identity())
+            dist.all_gather_object(got, mine, group=group)
             if any(g is None for g in got):
                 self.close()
                 raise _lib.GMError("peer communicator: exchange region could not be created / exported on "
                                    "rank(s) %s%s" % ([i for i, g in enumerate(got) if g is None],
                                                      (": %s" % err) if err is not None else ""))
+            # A coarse-grained region (the runtime refused hipDeviceMallocFinegrained) is only coherent
+            # for peers on the SAME device (the single-GPU multi-process tests).  Across GPUs a kernel
+            # polling it for peer stores may read stale lines: refuse, every rank alike.
+            coarse = [i for i, g in enumerate(got) if not g[1]]
+            if coarse and len({g[2] for g in got}) > 1:
+                self.close()
+                raise _lib.GMError("peer communicator: rank(s) %s could only allocate COARSE-grained exchange "
+                                   "regions and the ranks are on different GPUs -- not coherent" % coarse)
             try:
-                blob = ctypes.create_string_buffer(b"".join(got), 64 * world)
+                blob = ctypes.create_string_buffer(b"".join(g[0] for g in got), 64 * world)
                 _lib.call("gm_comm_connect", self.h, blob)
             except Exception as e:                   # noqa: BLE001
                 err = e

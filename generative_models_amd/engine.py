@@ -296,6 +296,8 @@ class GANEngine:
                  world_size=1, rank=0, process_group=None, force_dp=False):
         """force_dp: run the data-parallel launch structure on one rank (diagnostics / tests)."""
         assert variant in self.SUPPORTED, variant
+        from . import _respect_cpu_quota
+        _respect_cpu_quota(force=False)             # once per process, when the first engine is built
         self.variant, self.model, self.device = variant, model, device
         self.method = method
         self.loss_key = ("f_" + method) if variant == "f" else \
@@ -321,6 +323,7 @@ class GANEngine:
         self.comm_mode = os.environ.get("GM_DP_COMM", "peer")
         self.force_segments = bool(force_dp)
         self._comms = None
+        self.comm_memory, self.comm_fallback = "none", None
         if (world_size > 1 or force_dp) and self.comm_mode == "peer":
             sizes = {"D": sum(_align4(p.numel()) for p in D.parameters()),
                      "G": sum(_align4(p.numel()) for p in G.parameters())}
@@ -554,9 +557,9 @@ class GANEngine:
 
     def _gather_args(self, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
-        r0 = self.rank * Bl                       # this rank's rows of the global batch
+        r0 = self.ring_r0                         # this rank's rows of the (device) index ring
         return dict(data=self.data, idx=self.idx_ring.view(-1)[r0:], out=self.X2, B=Bl,
-                    idx_slot=self._slot(it, d, j, R * d, self.B))
+                    idx_slot=self._slot(it, d, j, R * d, self.ring_B))
 
     def _D_gather(self, st, it, j):
         if self._gather_rides():
@@ -573,7 +576,7 @@ class GANEngine:
         Bl, d, R = self.Bl, self.D_steps, self.R
         G1, G2 = self.G1, self.G2
         zD_slot = self._slot(it, d, j, R * d, self.zD_stride)
-        zbase = self.zD_base[self.rank * Bl * self.Z:].view(-1, self.Z)
+        zbase = self.zD_base[self.ring_r0 * self.Z:].view(-1, self.Z)
         rows = 2 * Bl if (self._batch_gen() and not self._standalone_G) else Bl
         if self._gather_rides():
             ops.linear_fwd_gather(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot,
@@ -583,9 +586,9 @@ class GANEngine:
         if self._interp_in_gen():
             # WGAN-GP: x_hat = eps*x + (1-eps)*G(zD) written by this launch's epilogue for its first
             # Bl rows (the real rows were gathered by the previous launch's rider)
-            r0 = self.rank * Bl
+            r0 = self.ring_r0
             ops.linear_fwd_interp(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", self.eps_ring.view(-1)[r0:],
-                                  self._slot(it, d, j, R * d, self.B), self.XX[:Bl], self.Xh, Bl, M=rows,
+                                  self._slot(it, d, j, R * d, self.ring_B), self.XX[:Bl], self.Xh, Bl, M=rows,
                                   stream=st)
         else:
             ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
@@ -683,8 +686,8 @@ class GANEngine:
         Bl, R = self.Bl, self.R
         G1, G2, Q1, Q2 = self.G1, self.G2, self.Q1, self.Q2
         Hg, Xg = self.Hg2, self.Xg2                   # free again: the generator step is done
-        zbase = self.zQ_ring.view(-1)[self.rank * Bl * self.Z:].view(-1, self.Z)
-        z_slot = self._slot(it, 1, 0, R, self.B * self.Z, post=True)
+        zbase = self.zQ_ring.view(-1)[self.ring_r0 * self.Z:].view(-1, self.Z)
+        z_slot = self._slot(it, 1, 0, R, self.ring_B * self.Z, post=True)
         s_slot = self._slot(it, 1, 0, 0, 1, post=True)
         ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=z_slot, stream=st)
         ops.linear_fwd(Hg, G2.W, G2.b, Xg, "sigmoid", M=Bl, stream=st)
@@ -728,7 +731,7 @@ class GANEngine:
     # ---- pieces of the generator step (own Hg2/Xg2 buffers: its generator forward only needs G's
     # parameters, so it can run as a parallel branch of the critic step) ----------------------
     def _G_zslot(self, it):
-        zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
         return zbase, self._slot(it, 1, 0, self.R, self.zG_stride)
 
     def _G_gen(self, st, it):
@@ -791,7 +794,7 @@ class GANEngine:
             ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
 
     def _G_dw1(self, st, it):
-        zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+        zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
         zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
         if self._adam_in_epilogue("G"):
             ops.linear_bwd_dw_adam(self.dHg, zbase, self.G1,
@@ -812,7 +815,7 @@ class GANEngine:
         if self.pair_dw and not self.dag:
             # both weight gradients of the generator (+ their Adam steps on one GPU): ONE launch
             adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
-            zbase = self.zG_base[self.rank * self.Bl * self.Z:].view(-1, self.Z)
+            zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
             zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
             ops.linear_bwd_dw_adam_pair(
                 dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
@@ -860,8 +863,8 @@ class GANEngine:
         from . import ops_fused as ops_gp
         Bl, d, R = self.Bl, self.D_steps, self.R
         D1, D2 = self.D1, self.D2
-        r0 = self.rank * Bl
-        eps_slot = self._slot(it, d, j, R * d, self.B)
+        r0 = self.ring_r0
+        eps_slot = self._slot(it, d, j, R * d, self.ring_B)
         if not self._interp_in_gen():
             ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
                           stream=st)
@@ -893,9 +896,9 @@ class GANEngine:
             of.std_from_sums(self.pre[8:], self.B * self.I, self.stdv, stream=st)
         else:
             of.std_all(x, Bl, self.stdv, stream=st)                               # images.data.std()
-        r0 = self.rank * Bl                                                        # my rows of the draws
-        of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.B),
-                       self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.B * self.I),
+        r0 = self.ring_r0                                                          # my rows of the draws
+        of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.ring_B),
+                       self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.ring_B * self.I),
                        self.stdv, self.Xh, Bl, stream=st)
         ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
         ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "sigmoid", M=Bl, stream=st)
@@ -936,32 +939,48 @@ class GANEngine:
         self.R = R
         self.SUB = max(1, min(self.graph_iters, R))
         self.z_joint = self._batch_gen()
-        shapes = {"idx": ((R * d, B), torch.int64)}
+        # (leading dims per ring, pieces per iteration, trailing dims): every ring is a sequence of
+        # [B, *tail] draws, `pieces` of them per iteration
+        layout = {"idx": ((R * d,), d, (), torch.int64)}
         if self.z_joint:          # one ring of [zD; zG] pairs: slot stride 2*B*Z
-            shapes["z"] = ((R, 2, B, Z), torch.float32)
+            layout["z"] = ((R, 2), 2, (Z,), torch.float32)
         else:
-            shapes["zD"] = ((R * d, B, Z), torch.float32)
-            shapes["zG"] = ((R, B, Z), torch.float32)
+            layout["zD"] = ((R * d,), d, (Z,), torch.float32)
+            layout["zG"] = ((R,), 1, (Z,), torch.float32)
         if self.variant == "wgp":
-            shapes["eps"] = ((R * d, B), torch.float32)
+            layout["eps"] = ((R * d,), d, (), torch.float32)
         if self.variant == "info":
-            shapes["zQ"] = ((R, B, Z), torch.float32)
+            layout["zQ"] = ((R,), 1, (Z,), torch.float32)
         if self.variant == "dra":
-            shapes["delta"] = ((R * d, B), torch.float32)
-            shapes["U"] = ((R * d, B, self.I), torch.float32)
-        self.dring = {k: torch.zeros(*sh, dtype=dt, device=dev) for k, (sh, dt) in shapes.items()}
+            layout["delta"] = ((R * d,), d, (), torch.float32)
+            layout["U"] = ((R * d,), d, (self.I,), torch.float32)
+        # Data parallel: the HOST rings hold every draw of the GLOBAL batch (the replay advances the one
+        # global generator; it materialises this rank's rows at their global offsets), the DEVICE rings
+        # only this rank's rows -- the stage-in pulls Bl of every B rows over PCIe, so its cost per
+        # iteration does not grow with the number of ranks (at 8 x 256 rows the global slot is 344 KB =
+        # 15.6 us of a ~85 us step; the rank's share is 43 KB).  DRAGAN's uniforms go through the copy
+        # engine (_copy_U) in whole slots and keep the global layout.
+        import os
+        self.local_rings = self.world > 1 and self.variant != "dra" and \
+            os.environ.get("GM_LOCAL_RINGS", "1") != "0"
+        self.ring_B = self.Bl if self.local_rings else B          # rows per draw in the device rings
+        self.ring_r0 = 0 if self.local_rings else self.rank * self.Bl   # my first row inside them
+        shapes = {k: (lead + (B,) + tail, dt) for k, (lead, m, tail, dt) in layout.items()}
+        dshapes = {k: (lead + (self.ring_B,) + tail, dt) for k, (lead, m, tail, dt) in layout.items()}
+        self.dring = {k: torch.zeros(*sh, dtype=dt, device=dev) for k, (sh, dt) in dshapes.items()}
         self.hring = {k: torch.zeros(*sh, dtype=dt).pin_memory() for k, (sh, dt) in shapes.items()}
         self.idx_ring = self.dring["idx"]
+        rB = self.ring_B
         if self.z_joint:
             self.z_ring = self.dring["z"]
             self.zD_ring, self.zG_ring = self.z_ring[:, 0], self.z_ring[:, 1]
             flat = self.z_ring.view(-1)
-            self.zD_base, self.zG_base = flat, flat[B * Z:]
-            self.zD_stride = self.zG_stride = 2 * B * Z
+            self.zD_base, self.zG_base = flat, flat[rB * Z:]
+            self.zD_stride = self.zG_stride = 2 * rB * Z
         else:
             self.zD_ring, self.zG_ring = self.dring["zD"], self.dring["zG"]
             self.zD_base, self.zG_base = self.zD_ring.view(-1), self.zG_ring.view(-1)
-            self.zD_stride = self.zG_stride = B * Z
+            self.zD_stride = self.zG_stride = rB * Z
         self.eps_ring, self.zQ_ring = self.dring.get("eps"), self.dring.get("zQ")
         self.delta_ring, self.U_ring = self.dring.get("delta"), self.dring.get("U")
         # stage-in segments: (device-visible address of the host ring, device ring, bytes / iteration)
@@ -980,7 +999,13 @@ class GANEngine:
             h, dv = self.hring[k], self.dring[k]
             devp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", h.data_ptr(), ctypes.byref(devp))
-            segs.append(_lib.StageSeg(devp.value, dv.data_ptr(), h.numel() * h.element_size() // R))
+            if not self.local_rings:
+                segs.append(_lib.StageSeg(devp.value, dv.data_ptr(), h.numel() * h.element_size() // R))
+                continue
+            _, m, tail, _dt = layout[k]
+            wb = int(np.prod(tail, dtype=np.int64)) * h.element_size()     # bytes per row of a draw
+            segs.append(_lib.StageSeg(devp.value + self.rank * self.Bl * wb, dv.data_ptr(), m * self.Bl * wb,
+                                      m, 0, B * wb, self.Bl * wb))
         self._segs = (_lib.StageSeg * len(segs))(*segs)
         if getattr(self, "_gate", None) is None:
             # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
@@ -1129,35 +1154,12 @@ class GANEngine:
             r0 = self.rank * self.Bl
             draw_rows(dst, r0, r0 + self.Bl, kind)
 
-    def _wait_slots_free(self, c0, n):
-        """The host ring slots of iterations [c0, c0+n) were last used by iterations c0-R ...: wait
-        until the graphs that staged those in have run (events recorded after every launch group)."""
-        need = c0 + n - self.R
-        if need <= 0:
-            return
-        import time
-        t_end = time.monotonic() + 60.0
-        while True:
-            ev = None
-            for it_end, e in list(self._launched):
-                if it_end >= need:
-                    ev = e
-                    break
-            if ev is not None:
-                ev.synchronize()
-                while self._launched and self._launched[0][0] < need:
-                    self._launched.popleft()
-                return
-            if time.monotonic() > t_end:              # cannot happen: iterations < c0 are launched
-                raise GMError("host ring: the launch of iteration %d never happened" % (need - 1))
-            time.sleep(20e-6)                         # the main thread is still launching them
-
     def _fill(self, c0, n_it):
         """HOST: replay the reference's draw order for iterations [c0, c0+n_it) into the pinned host
         ring.  Runs on the prefetch thread while the main thread launches earlier sub-chunks (the C
         replay and torch's RNG kernels release the GIL; the draws stay strictly in order: single
-        worker, sub-chunks submitted in order)."""
-        self._wait_slots_free(c0, n_it)
+        worker, sub-chunks submitted in order).  The ring slots are free: _pump only submits a fill
+        once the launch that last staged them in has completed (_slots_free_now)."""
         s = self._host_views(c0 % self.R)
         if self._replay_ok:
             if HostReplay.run(s["program"], n_it):
@@ -1177,7 +1179,7 @@ class GANEngine:
 
     # -- public: run `n_iters` iterations starting a fresh train() ----------------------------
     def configure(self, n_iters, G_lr, D_lr, D_steps, clip=0.0, hyper=(), g_init=0,
-                  gp_lambda=10.0, resume=None):
+                  gp_lambda=10.0, resume=None, extra_config=None):
         """Called once per train(): fresh Adam state (optimizers are locals of the reference's
         train()), schedules, loss buffers, rings, graph.
         resume: optimizer state of a checkpoint (optim_state()) -- the Adam moments are restored
@@ -1193,7 +1195,11 @@ class GANEngine:
         self.fG.grad.zero_(); self.fD.grad.zero_()
         self.step0 = {"G": 0, "D": 0, "MI": 0}
         self.run_config = {"variant": self.variant, "B": int(self.B), "D_steps": int(D_steps),
-                           "G_lr": float(G_lr), "D_lr": float(D_lr)}
+                           "G_lr": float(G_lr), "D_lr": float(D_lr), "clip": float(clip),
+                           "hyper": [float(h) for h in hyper]}
+        # settings of a subclass that the restored state depends on (BEGAN: GAMMA, LAMBDA, patience):
+        # part of the strict comparison below, not added after it
+        self.run_config.update(extra_config or {})
         if resume is not None:
             saved = resume.get("config")
             if saved is not None and not resume.get("lenient", False):
@@ -1292,22 +1298,43 @@ class GANEngine:
         buffers are placed inside them.  Every rank runs the self-check; unless ALL ranks pass,
         every rank falls back to RCCL."""
         from . import dp
+        comms, why = {}, None
         try:
-            comms = {k: dp.PeerComm(n, self.world, self.rank, self.pg) for k, n in sizes.items()}
-            ok = all(c.selfcheck(self.device) for c in comms.values())
-        except Exception:                            # noqa: BLE001  (no IPC / no peer access here)
-            comms, ok = None, False
+            for k, n in sizes.items():
+                comms[k] = dp.PeerComm(n, self.world, self.rank, self.pg)
+            # EVERY communicator's self-check runs on EVERY rank (they are collective kernels: a rank
+            # that skipped one would leave its peers in a 10 s bounded wait)
+            checks = [c.selfcheck(self.device) for c in comms.values()]
+            ok = all(checks)
+            if not ok:
+                why = "self-check failed for %s" % [k for k, c in zip(comms, checks) if not c]
+        except Exception as e:                       # noqa: BLE001  (no IPC / no peer access here)
+            ok, why = False, "%s: %s" % (type(e).__name__, e)
         if self.world > 1:
             import torch.distributed as dist
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
             if dist.get_backend(self.pg) == "nccl":
                 flag = flag.to(self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            if ok and not bool(flag.item()):
+                why = "another rank could not use the peer exchange"
             ok = bool(flag.item())
+        # what the exchange regions are made of (bench.py reports it in config.launch)
+        self.comm_memory = "fine-grained" if comms and all(c.fine_grained for c in comms.values()) else \
+            ("coarse-grained (one shared device)" if comms else "none")
         if ok:
             self._comms = comms
         else:
+            import warnings
+            for c in comms.values():                 # nothing stays mapped on the fallback path
+                try:
+                    c.close()
+                except Exception:                    # noqa: BLE001
+                    pass
             self.comm_mode = "rccl"
+            self.comm_fallback = why or "unknown"
+            warnings.warn("generative_models_amd: in-graph peer gradient exchange unavailable (%s); "
+                          "falling back to host-launched RCCL all-reduces" % self.comm_fallback)
 
     def optim_state(self):
         """Everything the optimizers and controllers carry across steps, after the train() call that
@@ -1419,9 +1446,12 @@ class GANEngine:
             it = self._cursor
             want = self._ramp[0] if self._ramp else self.SUB
             n = min(want, self.SUB, self.R - it % self.R, limit - it)
+            # never submit a fill whose ring slots belong to iterations that are not launched /
+            # finished yet (a draw-ahead past `end` would otherwise sit in the worker until the next
+            # run() -- however long the caller takes between epochs)
+            if not self._slots_free_now(it, n, wait=upto is not None):
+                break
             if self._native_fill:
-                if not self._slots_free_now(it, n, wait=upto is not None):
-                    break
                 fut = self._submit_native(it, n)
             else:
                 fut = _prefetch_pool().submit(self._fill, it, n)
@@ -1432,8 +1462,7 @@ class GANEngine:
             unfinished += n
 
     def _slots_free_now(self, c0, n, wait):
-        """Main-thread form of _wait_slots_free: True when the ring slots of [c0, c0+n) can be
-        rewritten (the launch that last staged them in has completed); wait=True blocks for it."""
+        """True when the ring slots of [c0, c0+n) can be rewritten (the launch that last staged them in has completed); wait=True blocks for it."""
         need = c0 + n - self.R
         if need <= 0:
             return True
@@ -1634,7 +1663,10 @@ class GANEngine:
         for k in range(n):
             draw_sampler_indices(self.N, self.B, s["idx_np"][0])    # images are unused by train_G
             s["zG"][0].normal_()
-            self.zG_ring[0].copy_(s["zG"][0])
+            src = s["zG"][0]
+            if self.local_rings:                       # the device ring holds this rank's rows only
+                src = src[self.rank * self.Bl:(self.rank + 1) * self.Bl]
+            self.zG_ring[0].copy_(src)
             self.g_off = k
             self._issue_G(st, 0)
             torch.cuda.synchronize()                 # the host slot is rewritten by the next pre-step
@@ -1650,7 +1682,8 @@ class GANEngine:
             import torch.distributed as dist
             from . import dp
             if self._comms is not None:
-                self._comms["D"].check(); self._comms["G"].check()
+                for c in self._comms.values():        # D, G and InfoGAN's Q bucket
+                    c.check()
             cpu = dist.get_backend(self.pg) != "nccl"           # gloo control plane: host tensors
             lg_t, ld_t = (lg_t.cpu() if cpu else lg_t.clone()), (ld_t.cpu() if cpu else ld_t.clone())
             dp.allreduce_sum_(lg_t, self.pg)
@@ -1760,6 +1793,8 @@ class VAEEngine:
         return t.cpu().numpy()
 
     def _common_init(self, device):
+        from . import _respect_cpu_quota
+        _respect_cpu_quota(force=False)             # once per process, when the first engine is built
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
         self.graphs = {}
         self._bufB = None
@@ -2206,9 +2241,9 @@ class BEGANEngine(GANEngine):
     def configure(self, n_iters, G_lr, D_lr, D_steps, GAMMA=0.5, LAMBDA=1e-3, K=0.0, patience=0,
                   **kw):
         resume = kw.get("resume")
-        super().configure(n_iters, G_lr, D_lr, D_steps, resume=resume)
         self.gamma, self.lam, self.patience = float(GAMMA), float(LAMBDA), int(patience)
-        self.run_config.update(GAMMA=self.gamma, LAMBDA=self.lam, patience=self.patience)
+        super().configure(n_iters, G_lr, D_lr, D_steps, resume=resume,
+                          extra_config=dict(GAMMA=self.gamma, LAMBDA=self.lam, patience=self.patience))
         self.st.zero_()
         self.st[0] = float(K)
         self.st[4] = 1.0

@@ -528,15 +528,25 @@ def _save_checkpoint(trainer, savepath, history, numpy_rng=False):
         state["numpy_rng"] = {"keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),
                               "has_gauss": int(has_gauss), "cached": float(cached)}
     from . import dp
-    if dp.current()[1] == 0:                     # data parallel: replicas are identical, rank 0 writes
+    world, rank, _ = dp.current()
+    if rank == 0:                                # data parallel: replicas are identical, rank 0 writes
         torch.save(state, savepath)
+    if world > 1:                                # nobody loads a half-written file
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def _load_checkpoint(trainer, loadpath, strict=True):
     # plain tensors / numbers / containers only: no pickled code is executed
     ck = torch.load(loadpath, weights_only=True)
-    if ck.get("version") != CHECKPOINT_VERSION or ck.get("name") != trainer.name:
-        raise GMError("not a checkpoint of a %s trainer" % trainer.name)
+    if not isinstance(ck, dict) or "name" not in ck or "optim" not in ck:
+        raise GMError("%s is not a checkpoint written by save_checkpoint()" % loadpath)
+    if ck.get("version") != CHECKPOINT_VERSION:
+        raise GMError("checkpoint format version %r, this build reads version %d -- re-save it with the "
+                      "build that wrote it, or keep only the weights (ck['model'])"
+                      % (ck.get("version"), CHECKPOINT_VERSION))
+    if ck.get("name") != trainer.name:
+        raise GMError("checkpoint of a %s trainer, not of a %s trainer" % (ck.get("name"), trainer.name))
     trainer.model.load_state_dict(ck["model"])
     for n, v in ck["history"].items():
         setattr(trainer, n, list(v) if isinstance(v, list) else v)

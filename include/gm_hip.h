@@ -374,7 +374,16 @@ int gm_act_bwd(void* stream, const float* dY, const float* Y, float* dA, int64_t
 typedef struct gm_stage_seg {
     const void* src;
     void* dst;
-    int64_t bytes_per_iter;
+    int64_t bytes_per_iter;     /* bytes copied per iteration (all of its blocks) */
+    /* An iteration's slot may consist of `blocks` equal pieces that are not adjacent in the source or
+     * the destination: a data-parallel rank stages only ITS rows of every [B, w] draw of the global
+     * batch (host ring: global batch; device ring: the rank's rows).  Piece q of iteration i is
+     * bytes_per_iter / blocks bytes at src + (i * blocks + q) * src_block_stride, written to
+     * dst + (i * blocks + q) * dst_block_stride.  blocks <= 1 and strides 0: one dense piece per
+     * iteration (stride = bytes_per_iter), the single-rank layout. */
+    int32_t blocks;
+    int32_t reserved;
+    int64_t src_block_stride, dst_block_stride;
 } gm_stage_seg;
 int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters);
 /* The same with a FILL GATE: the launch may be enqueued before the host has finished writing the
@@ -408,6 +417,10 @@ int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void*
 int gm_comm_connect(void* comm, const void* all_handles /* world x 64 bytes, rank order */);
 int gm_comm_destroy(void* comm);
 int gm_comm_error(void* comm, int* flag_out);
+/* *fine_grained_out = 1 when the exchange region is fine-grained device memory (peers on OTHER GPUs
+ * may store into it while a kernel polls it), 0 when the runtime refused that allocation and the
+ * region is plain device memory: valid only when every rank shares one device. */
+int gm_comm_info(void* comm, int* fine_grained_out);
 /* The region's own bucket (n_floats fp32, 256-byte aligned): a gradient buffer placed here is
  * all-reduced without a staging copy. */
 int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out);

@@ -130,7 +130,7 @@ MODS = {"ns": ("ns_gan", "NSGAN", "NSGANTrainer"), "ls": ("ls_gan", "LSGAN", "LS
         "info": ("info_gan", "InfoGAN", "InfoGANTrainer")}
 
 
-def _train_worker(rank, world, port, variant, kw, q, real=False):
+def _train_worker(rank, world, port, variant, kw, q, real=False, cfg=None):
     dist = _init(rank, world, port, real) if world > 1 else None
     if world == 1:
         sys.path.insert(0, os.path.dirname(HERE))
@@ -142,7 +142,7 @@ def _train_worker(rank, world, port, variant, kw, q, real=False):
     from oracle import port as oport
     mod_name, model_name, trainer_name = MODS[variant]
     mod = importlib.import_module(mod_name)
-    cfg = SMALL
+    cfg = cfg or SMALL
     loaders = oport.synthetic_loaders(cfg["batch"], n_train=cfg["n_train"], n_val=cfg["n_val"],
                                       n_test=cfg["n_test"], image_shape=tuple(cfg["image_shape"]))
     torch.manual_seed(1234)
@@ -165,11 +165,12 @@ def _train_worker(rank, world, port, variant, kw, q, real=False):
         dist.destroy_process_group()
 
 
-def _run_world(world, variant, kw, real=False):
+def _run_world(world, variant, kw, real=False, cfg=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q, real)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q, real, cfg))
+             for r in range(world)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
@@ -232,7 +233,7 @@ def test_two_gpu_engine_equals_one_rank(variant, kw):
         assert np.array_equal(v, two[1]["params"][k]), k
 
 
-def _vae_worker(rank, world, port, kind, q):
+def _vae_worker(rank, world, port, kind, q, cfg=None, n_train=150):
     dist = _init(rank, world, port) if world > 1 else None
     if world == 1:
         sys.path.insert(0, os.path.dirname(HERE))
@@ -241,8 +242,8 @@ def _vae_worker(rank, world, port, kind, q):
     import contextlib
     import io
     from oracle import port as oport
-    cfg = SMALL
-    loaders = oport.synthetic_loaders(cfg["batch"], n_train=150, n_val=cfg["n_val"], n_test=cfg["n_test"],
+    cfg = cfg or SMALL
+    loaders = oport.synthetic_loaders(cfg["batch"], n_train=n_train, n_val=cfg["n_val"], n_test=cfg["n_test"],
                                       image_shape=tuple(cfg["image_shape"]))      # 150: ragged last batch of 6
     torch.manual_seed(1234)
     if kind == "vae":
@@ -265,27 +266,23 @@ def _vae_worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["vae", "ae"])
-def test_two_rank_vae_equals_one_rank(kind):
-    """vae.py / ae.py under data parallelism: every batch's rows (incl. the ragged last one) split
-    over two ranks, gradient SUM without 1/N (the losses are sums, vae.py:203,212), per-rank loss
-    slots add up to the single-rank values."""
-    def run(world):
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_vae_worker, args=(r, world, port, kind, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
-        return out
-    one = run(1)[0]
-    two = run(2)
-    for o in two:
-        assert o["world"] == 2 and o["rng"] == one["rng"]
+def _run_vae_world(world, kind, cfg=None, n_train=150):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vae_worker, args=(r, world, port, kind, q, cfg, n_train)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def _assert_vae_equal(one, many):
+    for o in many:
+        assert o["world"] == len(many) and o["rng"] == one["rng"]
         for key in ("recon", "kl"):
             a, b = np.array(o[key]), np.array(one[key])
             assert a.shape == b.shape
@@ -294,5 +291,76 @@ def test_two_rank_vae_equals_one_rank(kind):
         assert abs(o["best"] - one["best"]) <= 2e-5 * abs(one["best"])
         for k, v in o["params"].items():
             assert np.max(np.abs(v - one["params"][k])) <= 2e-5, k
-    for k, v in two[0]["params"].items():
-        assert np.array_equal(v, two[1]["params"][k]), k
+    for o in many[1:]:
+        for k, v in many[0]["params"].items():
+            assert np.array_equal(v, o["params"][k]), k
+
+
+@pytest.mark.parametrize("kind", ["vae", "ae"])
+def test_two_rank_vae_equals_one_rank(kind):
+    """vae.py / ae.py under data parallelism: every batch's rows (incl. the ragged last one) split
+    over two ranks, gradient SUM without 1/N (the losses are sums, vae.py:203,212), per-rank loss
+    slots add up to the single-rank values."""
+    one = _run_vae_world(1, kind)[0]
+    _assert_vae_equal(one, _run_vae_world(2, kind))
+
+
+# ---------------------------------------------------------------------------------------------
+# The same comparisons at the REAL layer widths and batch sizes of BASELINE.json configs[2..4]
+# (784-400-20; NSGAN / LSGAN global B = 1024 on 2 / 4 / 8 ranks = 512 / 256 / 128 rows per rank: other
+# tile shapes than the 1-rank run, the LDS macro-tile kernel on one side of its M >= 1024 threshold
+# and the split-reduction kernel on the other; WGAN-GP B = 256; VAE B = 512 incl. the ragged 336
+# batch = 168 rows per rank).  Loops being sharded: ns_gan.py:122-156, ls_gan.py:95-171,
+# w_gp_gan.py:96-175, vae.py:144-167.
+# ---------------------------------------------------------------------------------------------
+FULL = dict(image_size=784, hidden_dim=400, z_dim=20, n_val=64, n_test=64, image_shape=(1, 28, 28))
+_ONE_RANK = {}
+
+
+def _full_cfg(batch, steps_per_epoch=4):
+    return dict(FULL, batch=batch, n_train=batch * steps_per_epoch)
+
+
+def _one_rank_full(variant, batch, kw):
+    key = (variant, batch)
+    if key not in _ONE_RANK:
+        _ONE_RANK[key] = _run_world(1, variant, kw, cfg=_full_cfg(batch))[0]
+    return _ONE_RANK[key]
+
+
+@pytest.mark.parametrize("variant,batch,world,kw",
+                         [("ns", 1024, 2, dict(num_epochs=2)), ("ns", 1024, 4, dict(num_epochs=2)),
+                          ("ns", 1024, 8, dict(num_epochs=2)),
+                          ("ls", 1024, 2, dict(num_epochs=2)), ("ls", 1024, 4, dict(num_epochs=2)),
+                          ("ls", 1024, 8, dict(num_epochs=2)),
+                          ("wgp", 256, 2, dict(num_epochs=2, D_steps=1))],
+                         ids=["ns1024-w2", "ns1024-w4", "ns1024-w8", "ls1024-w2", "ls1024-w4", "ls1024-w8",
+                              "wgp256-w2"])
+def test_n_rank_engine_equals_one_rank_full_size(variant, batch, world, kw):
+    """BASELINE.json configs[4] in its multi-GPU form (and configs[2] on two ranks): 8 free-running
+    D+G iterations at 784-400-20, global batch split over `world` ranks sharing GPU 0, against the
+    1-rank fused engine: losses 1e-5, parameters 2e-5, replicas bit-identical, RNG position equal."""
+    one = _one_rank_full(variant, batch, kw)
+    many = _run_world(world, variant, kw, cfg=_full_cfg(batch))
+    assert all(o["world"] == world and o["mode"] == "peer" for o in many), [o["mode"] for o in many]
+    assert len(one["G"]) == 8
+    for o in many:
+        assert o["rng"] == one["rng"]
+        for key in ("G", "D"):
+            a, b = np.array(o[key]), np.array(one[key])
+            assert a.shape == b.shape
+            assert np.max(np.abs(a - b) / np.maximum(1, np.abs(b))) <= 1e-5, key
+        for k, v in o["params"].items():
+            assert np.max(np.abs(v - one["params"][k])) <= 2e-5, k
+    for o in many[1:]:
+        for k, v in many[0]["params"].items():
+            assert np.array_equal(v, o["params"][k]), k
+
+
+def test_two_rank_vae_equals_one_rank_full_size():
+    """BASELINE.json configs[3] on two ranks: VAE 784-400-20, B = 512, n = 1360 so that every epoch
+    ends with the ragged 336 batch of the real 50 000-image run (168 rows per rank)."""
+    cfg = dict(FULL, batch=512)
+    one = _run_vae_world(1, "vae", cfg, 1360)[0]
+    assert len(one["recon"]) == 6                     # 2 epochs x (512, 512, 336)
+    _assert_vae_equal(one, _run_vae_world(2, "vae", cfg, 1360))

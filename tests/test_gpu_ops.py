@@ -628,6 +628,30 @@ def test_stage_in_gate_waits_for_the_host_and_times_out_without_hanging():
     assert float(x.sum()) == 8.0
 
 
+@pytest.mark.parametrize("B,Bl,w,dtype", [(64, 16, 20, torch.float32), (24, 8, 1, torch.int64), (12, 3, 5, torch.float32)])
+def test_stage_in_strided_pieces_copy_only_the_ranks_rows(B, Bl, w, dtype):
+    """gm_stage_seg with blocks / block strides: a data-parallel rank stages ITS rows of every [B, w] draw
+    of the global batch (host ring: global rows; device ring: the rank's rows) -- pieces of an iteration
+    that are adjacent neither in the source nor in the destination; 16-byte and 4-byte paths."""
+    import ctypes
+    from generative_models_amd import _lib
+    R, m, rank = 8, 3, 2                                 # ring of 8 iterations, 3 draws per iteration
+    host = (torch.arange(R * m * B * w, dtype=torch.float32).view(R * m, B, w) + 1).to(dtype).pin_memory()
+    dev = torch.full((R * m, Bl, w), -1, dtype=dtype, device="cuda")
+    hp = ctypes.c_void_p()
+    _lib.call("gm_host_device_ptr", host.data_ptr(), ctypes.byref(hp))
+    es = host.element_size()
+    wb = w * es
+    seg = _lib.StageSeg(hp.value + rank * Bl * wb, dev.data_ptr(), m * Bl * wb, m, 0, B * wb, Bl * wb)
+    segs = (_lib.StageSeg * 1)(seg)
+    it, k = 5, 2                                          # iterations [5, 7) -> ring slots 5, 6
+    _lib.call("gm_stage_in", ops.stream_ptr(), segs, 1, ops.slot(0, 0, it, R, 1), k)
+    torch.cuda.synchronize()
+    want = torch.full_like(dev, -1).cpu()
+    want[it * m:(it + k) * m] = host[it * m:(it + k) * m, rank * Bl:(rank + 1) * Bl]
+    assert torch.equal(dev.cpu(), want)
+
+
 @pytest.mark.parametrize("M,K,N,rows", [(512, 400, 784, 256), (96, 48, 64, 40), (2048, 400, 784, 1024)])
 def test_linear_fwd_with_interp_epilogue_equals_separate_launches(M, K, N, rows):
     """gm_linear_fwd_interp: the generator's last layer also writes WGAN-GP's x_hat for its first

@@ -158,7 +158,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         pytest.skip("no host C compiler")
     root = os.path.dirname(HERE)
     structs = {"gm_slot": _lib.Slot, "gm_head_bwd_args": _lib.HeadBwdArgs,
-               "gm_dw_adam_args": _lib.DwAdamArgs}
+               "gm_dw_adam_args": _lib.DwAdamArgs, "gm_stage_seg": _lib.StageSeg,
+               "gm_draw_op": _lib.DrawOp}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gm_hip.h"', 'int main(void) {']
     for cname, ct in structs.items():
         lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -35,13 +35,25 @@ def test_cap_applies(monkeypatch):
     import generative_models_amd as gm
     before = torch.get_num_threads()
     try:
-        torch.set_num_threads(max(2, before))
+        torch.set_num_threads(max(4, before))
         monkeypatch.setattr(gm, "_cpu_quota_cores", lambda: 1.5)
         gm._respect_cpu_quota()
+        assert torch.get_num_threads() == 2           # rounded up, never truncated
+        monkeypatch.setattr(gm, "_cpu_quota_cores", lambda: 1.0)
+        gm._respect_cpu_quota()
         assert torch.get_num_threads() == 1
-        torch.set_num_threads(max(2, before))
+        torch.set_num_threads(max(4, before))
         monkeypatch.setenv("GM_KEEP_THREADS", "1")
         gm._respect_cpu_quota()
-        assert torch.get_num_threads() == max(2, before)
+        assert torch.get_num_threads() == max(4, before)
     finally:
         torch.set_num_threads(before)
+
+
+def test_import_has_no_side_effect():
+    """Importing the package must not touch torch's global thread pool (applied when the first
+    fused engine is built)."""
+    import subprocess
+    code = ("import torch; torch.set_num_threads(7); import sys; sys.path.insert(0, %r); "
+            "import generative_models_amd; assert torch.get_num_threads() == 7" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=300)
