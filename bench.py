@@ -38,6 +38,8 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
 LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip try_launch_lds
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
+PROFILE_ROUND = "r03"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
+FOLD_HEAD_DEFAULT = os.environ.get("GM_FOLD_HEAD", "1") != "0"   # engine default (folded critic head)
 
 
 _DATASET = None
@@ -56,7 +58,7 @@ def synthetic_dataset():
 
 
 def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather=True, pair_dw=True,
-                ride_head_dx=True):
+                ride_head_dx=True, fold_head=False):
     """Every GEMM launch of one NSGAN iteration: (kind, M, K, N) in layer terms.  With the fused
     critic-head kernels (default) the N=1 layer is not a GEMM launch any more; with the batched
     generator forward (default at D_steps=1) G(zD) and G(zG) are one 2B-row launch pair."""
@@ -70,6 +72,11 @@ def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather
         gen[0] = ("fwdg",) + gen[0][1:]
     # "dwp": both generator weight gradients as one launch (second GEMM: dW1, [HID, Z])
     g_dw = [("dwp", B, HID, IMG)] if pair_dw else [("dw", B, HID, IMG), ("dw", B, Z, HID)]
+    if fold_head:
+        # folded critic head: "fwdp" = hidden-layer forward that also leaves the head's partial dots,
+        # "dwhf" / "dxhf" = the riding launches that rebuild dS and form dH in registers
+        return (gen + [("fwdp", 2 * B, IMG, HID), ("dwhf", 2 * B, IMG, HID), ("fwdp", B, IMG, HID),
+                       ("dxhf", B, IMG, HID), ("dx", B, HID, IMG)] + g_dw)
     return (gen + [("fwd", 2 * B, IMG, HID)] + d_head + [(dw1, 2 * B, IMG, HID)] +
             [("fwd", B, IMG, HID)] + g_head +
             # "dxh": the generator-mode head's scalar workgroup (loss + tick) rides in this launch
@@ -80,9 +87,9 @@ def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
     load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
-    if kind in ("fwd", "fwdg"):
+    if kind in ("fwd", "fwdg", "fwdp"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
-    elif kind in ("dx", "dxh"):
+    elif kind in ("dx", "dxh", "dxhf"):
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
     else:
         mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
@@ -104,12 +111,12 @@ def gemm_variant(kind, M, K, N):
     elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
         mi, ni = 1, 2
     b = lambda v: "true" if v else "false"
-    if kind == "dwh":
-        # last argument: ones column with a row offset (WGAN-GP's stacked weight gradient only)
-        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, false>" % (g, b(xv), mi, ni)
-    if kind == "dxh":
+    if kind in ("dwh", "dwhf"):
+        # last two arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded head
+        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, false, %s>" % (g, b(xv), mi, ni, b(kind == "dwhf"))
+    if kind in ("dxh", "dxhf"):
         assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
-        return "gemm16_dx_head_kernel<%d, %d, %d>" % (g, mi, ni)
+        return "gemm16_dx_head_kernel<%d, %d, %d, %s>" % (g, mi, ni, b(kind == "dxhf"))
     if kind == "fwdg":
         assert vec and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
@@ -140,7 +147,8 @@ def _holder(N, K, dev):
 
 
 def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_head=True,
-                          ride_gather=True, pair_dw=True, ride_head_dx=True, fused_adam=True, shapes=None):
+                          ride_gather=True, pair_dw=True, ride_head_dx=True, fused_adam=True, shapes=None,
+                          fold_head=False):
     """HIP-event timing (on the launch stream) of each GEMM launch shape of the step, run back to
     back `reps` times.  Returns {kernel instantiation name: (total_us_per_step,
     total_flop_per_step, n_launches_per_step)}."""
@@ -150,7 +158,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
     st = ops.stream_ptr()
     data = idx = xr = None
     for kind, M, K, N in (shapes or gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather,
-                                                pair_dw, ride_head_dx)):
+                                                pair_dw, ride_head_dx, fold_head)):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -162,6 +170,25 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
         flop = 2.0 * M * K * N
         if kind == "fwd":
             fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st)
+        elif kind in ("fwdp", "dwhf", "dxhf"):
+            # the folded head's launches on a consistent state: forward first (partial dots, snapshot)
+            L1, L2 = _holder(N, K, dev), _holder(1, N, dev)
+            fold = ops.HeadFold(M, N, dev)
+            Hh, lo = torch.empty(M, N, device=dev), torch.zeros(1, device=dev)
+            ops.linear_fwd_headpart(x, L1.W, L1.b, Hh, "relu", L2, fold, stream=st)
+            sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
+            ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
+            if kind == "fwdp":
+                fn = lambda: ops.linear_fwd_headpart(x, L1.W, L1.b, Hh, "relu", L2, fold, stream=st)
+            elif kind == "dwhf":
+                fa = fold.args("ns", "sigmoid")
+                head = dict(H=Hh, lin=L2, loss_out=lo, loss_slot=ops.NO_SLOT, inv_b=2.0 / M, B=M // 2, adam=ad)
+                # (Adam steps L1 / L2 between timed launches; the partial dots stay those of the first forward)
+                fn = lambda: ops.linear_bwd_dw_adam_head_fold(Hh, x, L1, ad, head, fa, stream=st)
+            else:
+                fa = fold.args("ns", "sigmoid")
+                head = dict(H=Hh, lin=L2, loss_out=lo, loss_slot=ops.NO_SLOT, inv_b=1.0 / M, B=M, gen_mode=True)
+                fn = lambda: ops.linear_bwd_dx_head_fold(Hh, L1.W, dX, head, fa, below=x, epi="sigmoid", stream=st)
         elif kind == "fwdg":
             if data is None:
                 data = (torch.rand(N_TRAIN, IMG, device=dev) > 0.5).float()
@@ -423,7 +450,7 @@ def mfma_busy_frac(kernel, launch_us, mhz):
     (profiles/r02_nsgan_b256_sq_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES per dispatch, summed over the 1024
     SIMDs) over this run's launch duration; None when the pass does not list the kernel."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_nsgan_b256_sq_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_nsgan_b256_sq_pmc.json")))
         rows = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for k, v in pmc.items() if k.split("|")[0] == kernel]
         if not rows:
             return None
@@ -662,7 +689,7 @@ def main():
 
     if rank == 0:
         kt = time_kernels_isolated(B_PER_GPU, fused_head=eng.fuse_head, batch_gen=eng._batch_gen(),
-                                   group_head=eng.group_head,
+                                   group_head=eng.group_head, fold_head=eng._fold_head(),
                                    ride_gather=eng._gather_rides(),
                                    pair_dw=eng.pair_dw, fused_adam=eng._adam_in_epilogue("G"),
                                    ride_head_dx=eng.ride_head_dx and not eng.head_final)
@@ -674,7 +701,7 @@ def main():
         # x2 gfx950 correction + WRITE_SIZE per dispatch; PMC counters cannot be read from inside this
         # process) -- the source file is named next to the number
         traffic, traffic_src = None, None
-        for cand in ("r02_nsgan_b256_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in (PROFILE_ROUND + "_nsgan_b256_pmc_traffic.json",):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]

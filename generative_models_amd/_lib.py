@@ -44,6 +44,13 @@ class HeadBwdArgs(ctypes.Structure):
 
 
 
+class HeadFoldArgs(ctypes.Structure):
+    """gm_head_fold_args (include/gm_hip.h): the folded critic head's partial dots + loss settings."""
+    _fields_ = [("part", c_void_p), ("ldp", c_int64), ("nparts", c_int), ("snap", c_void_p),
+                ("variant", c_int), ("out_act", c_int), ("hyper", c_float * 8), ("n_hyper", c_int),
+                ("pen", c_void_p), ("S", c_void_p), ("dS", c_void_p), ("rowloss", c_void_p)]
+
+
 class DwAdamArgs(ctypes.Structure):
     """gm_dw_adam_args (include/gm_hip.h): gm_linear_bwd_dw_adam's arguments as one block."""
     _fields_ = [("dA", c_void_p), ("lda", c_int64), ("X", c_void_p), ("ldx", c_int64),
@@ -121,6 +128,18 @@ _SIGNATURES = {
     "gm_gather_rows_bits": (c_int, [_P, _P, c_int, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
     "gm_linear_bwd_dx_head": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                       c_int, c_int, POINTER(HeadBwdArgs)]),
+    "gm_linear_bwd_dx_head_fold": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
+                                           c_int, c_int, POINTER(HeadBwdArgs), POINTER(HeadFoldArgs)]),
+    "gm_linear_fwd_sqerr": (c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64,
+                                    _P, c_int64, _P, c_int64]),
+    "gm_linear_bwd_dx_reparam": (c_int, [_P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64,
+                                         _P, Slot, _P, c_int64]),
+    "gm_linear_fwd_headpart": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int,
+                                       _P, _P, _P, c_int64, _P]),
+    "gm_linear_bwd_dw_adam_head_fold": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
+                                                c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                                ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
+                                                POINTER(HeadBwdArgs), POINTER(HeadFoldArgs)]),
     "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),
     "gm_linear_bwd_dw_adam_head": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
                                            c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,

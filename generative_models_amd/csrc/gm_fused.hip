@@ -455,18 +455,34 @@ extern "C" int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, c
     GM_LAUNCH_RET();
 }
 
-// out[slot] = scale * sum_{i<n} partial[i]   (single workgroup, fp64 accumulate, fixed order)
-__global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restrict__ partial, int n,
-                                                          float scale, float* __restrict__ out,
-                                                          gm_slot out_slot, int64_t* tick) {
-    __shared__ double sh[4];
+// Strided fp64 sum of partial[0..n) by one 1024-thread workgroup: thread t takes elements t, t + 1024, ...
+// in batches of 8 INDEPENDENT loads (a row-tile partial array of the fused reconstruction loss has
+// 14 336 entries at B = 512: 14 per thread, two memory round trips instead of 14 dependent ones).
+static __device__ __forceinline__ double strided_sum_1024(const float* __restrict__ p, int n) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += (double)partial[i];
-    acc = gm_wave_sum_d(acc);
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + u * 1024, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < n) acc += (double)v[u];
+    }
+    return acc;
+}
+
+// out[slot] = scale * sum_{i<n} partial[i]   (single workgroup, fp64 accumulate, fixed order)
+__global__ __launch_bounds__(1024) void sum_finalize_kernel(const float* __restrict__ partial, int n,
+                                                           float scale, float* __restrict__ out,
+                                                           gm_slot out_slot, int64_t* tick) {
+    __shared__ double sh[16];
+    double acc = gm_wave_sum_d(strided_sum_1024(partial, n));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[gm_slot_index(out_slot)] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * (double)scale);
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];                 // fixed order
+        out[gm_slot_index(out_slot)] = (float)(t * (double)scale);
         if (tick) *tick += 1;                       // after the slot is resolved: last launch of a step
     }
 }
@@ -474,7 +490,7 @@ __global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restri
 extern "C" int gm_sum_finalize(void* stream, const float* partial, int n, float scale, float* out,
                                gm_slot out_slot) {
     GM_CHECK_ARG(partial && out && n > 0);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n,
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, n,
                        scale, out, out_slot, (int64_t*)nullptr);
     GM_LAUNCH_RET();
 }
@@ -482,27 +498,27 @@ extern "C" int gm_sum_finalize(void* stream, const float* partial, int n, float 
 extern "C" int gm_sum_finalize_tick(void* stream, const float* partial, int n, float scale, float* out,
                                     gm_slot out_slot, int64_t* tick) {
     GM_CHECK_ARG(partial && out && n > 0 && tick);
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n,
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, n,
                        scale, out, out_slot, tick);
     GM_LAUNCH_RET();
 }
 
-// Two sums in one launch (the VAE step's reconstruction rows and KL partials), optional tick.
-__global__ __launch_bounds__(256) void sum_finalize2_kernel(const float* __restrict__ pa, int na, float sa,
-                                                           float* __restrict__ oa, gm_slot slot_a,
-                                                           const float* __restrict__ pb, int nb, float sb,
-                                                           float* __restrict__ ob, gm_slot slot_b,
-                                                           int64_t* tick) {
-    __shared__ double sh[2][4];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < na; i += 256) a += (double)pa[i];
-    for (int i = threadIdx.x; i < nb; i += 256) b += (double)pb[i];
+// Two sums in one launch (the VAE step's reconstruction partials and KL partials), optional tick.
+__global__ __launch_bounds__(1024) void sum_finalize2_kernel(const float* __restrict__ pa, int na, float sa,
+                                                            float* __restrict__ oa, gm_slot slot_a,
+                                                            const float* __restrict__ pb, int nb, float sb,
+                                                            float* __restrict__ ob, gm_slot slot_b,
+                                                            int64_t* tick) {
+    __shared__ double sh[2][16];
+    double a = strided_sum_1024(pa, na), b = strided_sum_1024(pb, nb);
     a = gm_wave_sum_d(a); b = gm_wave_sum_d(b);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        oa[gm_slot_index(slot_a)] = (float)(((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])) * (double)sa);
-        ob[gm_slot_index(slot_b)] = (float)(((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])) * (double)sb);
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 16; ++w) { ta += sh[0][w]; tb += sh[1][w]; }
+        oa[gm_slot_index(slot_a)] = (float)(ta * (double)sa);
+        ob[gm_slot_index(slot_b)] = (float)(tb * (double)sb);
         if (tick) *tick += 1;
     }
 }
@@ -511,7 +527,7 @@ extern "C" int gm_sum_finalize2_tick(void* stream, const float* pa, int na, floa
                                      gm_slot slot_a, const float* pb, int nb, float scale_b, float* out_b,
                                      gm_slot slot_b, int64_t* tick) {
     GM_CHECK_ARG(pa && pb && out_a && out_b && na > 0 && nb > 0);
-    hipLaunchKernelGGL(sum_finalize2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pa, na, scale_a,
+    hipLaunchKernelGGL(sum_finalize2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pa, na, scale_a,
                        out_a, slot_a, pb, nb, scale_b, out_b, slot_b, tick);
     GM_LAUNCH_RET();
 }

@@ -72,6 +72,7 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
+    int batch_loads;          // gemm16 kernels: all of a wave's chunk loads up front (GM_BATCH_LOADS, experiment)
     // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
     // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
     const float* ip_eps; gm_slot ip_slot;
@@ -79,6 +80,20 @@ struct GemmP {
     float* ip_out; int64_t ip_ldo;
     int ip_rows;
     gm_adam_epi adam;         // dw: apply Adam to the parameter right where its gradient is produced
+    // fwd, folded critic head (gm_head.h): partial dots of the N = 1 layer over this launch's output,
+    // one per 32-column tile and row, + a snapshot of the head parameters used
+    const float* hd_w2; const float* hd_b2; float* hd_part; int64_t hd_ldp; float* hd_snap;
+    // fwd, reconstruction loss in the epilogue (vae.py:203, ae.py:152: sum (x - x_hat)^2 over a sigmoid
+    // output layer): sq_dA[m][n] = d loss / d (pre-sigmoid output), sq_part[m * sq_ldp + n0/32] = the
+    // row's squared error inside this 32-column tile (summed later in a fixed order, gm_sum_finalize*)
+    const float* sq_x; int64_t sq_ldx; float* sq_dA; int64_t sq_lda; float* sq_part; int64_t sq_ldp;
+    // dx, reparameterisation backward in the epilogue (vae.py:100-106,210-212): the output IS dz; the
+    // epilogue writes d loss / d [mu | log_var] = [dz + mu | dz*eps*exp(lv/2)/2 + (exp(lv) - 1)/2]
+    const float* rp_ml; int64_t rp_ldml; const float* rp_eps; gm_slot rp_slot; float* rp_dml; int64_t rp_ldd;
+    int rp_Z;
+    // dw / dx, folded head: A is the hidden layer h; dH = dS[row] * fold_w2[col] * [h > 0] is formed
+    // in registers (dS: the workgroup's LDS copy, filled by the kernel's prologue)
+    const float* fold_w2;
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
     float add_scale;
@@ -160,12 +175,18 @@ __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, 
 }
 
 // Epilogue of one finished output element C(m, n) = v (m < M, n < N checked by the caller).
+// forward epilogue value: bias + activation
+__device__ __forceinline__ float fwd_value(const GemmP& p, float v, int n) {
+    if (p.bias) v += p.bias[n];
+    if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
+    return v;
+}
+
 template <int MODE>
 __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, int n) {
     if (MODE == MODE_FWD) {
-        if (p.bias) v += p.bias[n];
-        if (p.epi == GM_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.epi == GM_ACT_SIGMOID) v = gm_sigmoid(v);
+        v = fwd_value(p, v, n);
         p.C[(int64_t)m * p.ldc + n] = v;
         if (p.ip_out && m < p.ip_rows) {
             // two roundings and an add, never contracted: torch's eps * x + (1 - eps) * g
@@ -183,6 +204,14 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
         }
         float* cp = p.C + (int64_t)m * p.ldc + n;
         *cp = p.accumulate ? (*cp + v) : v;
+        if (p.rp_dml) {                                       // kernel-argument uniform
+            // same expressions, same order as gm_vae_reparam_bwd (bit-identical to the separate launch)
+            const int Z = p.rp_Z;
+            const float mu = p.rp_ml[(int64_t)m * p.rp_ldml + n], lv = p.rp_ml[(int64_t)m * p.rp_ldml + Z + n];
+            const float e = (p.rp_eps + gm_slot_offset(p.rp_slot))[(int64_t)m * Z + n];
+            p.rp_dml[(int64_t)m * p.rp_ldd + n] = v + 0.5f * (2.f * mu);
+            p.rp_dml[(int64_t)m * p.rp_ldd + Z + n] = ((v * e) * expf(lv / 2.f)) / 2.f + 0.5f * (expf(lv) - 1.f);
+        }
     } else {
         const bool is_b = (n == p.n_real);
         float* cp = is_b ? (p.db + m) : (p.C + (int64_t)m * p.ldc + n);
@@ -198,6 +227,9 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
             // (prefetching p/m/v or the schedule scalars at kernel start was measured SLOWER: vmcnt
             // and lgkmcnt retire in order, so the early requests hold back the operand loads --
             // profiles/r01_experiments.md)
+            // (loading p / m / v EARLY was measured slower twice: at kernel start, ahead of the operand loads
+            // (round 1, +1.4 us on the paired launch), and right behind the last chunk's operand loads
+            // (round 3: dW+head 13.8 -> 15.2 us, pair 10.9 -> 12.5 us, profiles/r03_experiments.md))
             const int64_t si = gm_slot_index(p.adam.sched_slot);
             const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
             float P = *pp, M = *mm, V = *vv;
@@ -212,6 +244,68 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
 template <int MODE, int WAVES, int ROWS = 32>
 __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
                                                  int n0) {
+    if (MODE == MODE_FWD && p.hd_part) {                     // kernel-argument uniform
+        // Folded critic head: every row of this 32-column block also leaves its partial dot with w2.
+        // The 32 lanes that hold a row (one half of a wave) sum their products in a fixed butterfly;
+        // no lane leaves the loop early, out-of-range elements contribute 0.
+#pragma unroll
+        for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
+            const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
+            const bool live = !(ROWS < 32 && row >= ROWS);
+            float v = 0.f;
+            if (live) {
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+            }
+            const int m = m0 + row, n = n0 + col;
+            const bool ok = live && m < p.M && n < p.N;
+            float pv = 0.f;
+            if (ok) {
+                const float w = p.hd_w2[n];
+                const float y = fwd_value(p, v, n);
+                p.C[(int64_t)m * p.ldc + n] = y;
+                pv = y * w;
+                if (m == 0 && p.hd_snap) {                   // the head parameters this forward used
+                    p.hd_snap[n] = w;
+                    if (n == 0) p.hd_snap[p.N] = p.hd_b2[0];
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
+            if (col == 0 && live && m < p.M) p.hd_part[(int64_t)m * p.hd_ldp + (n0 >> 5)] = pv;
+        }
+        return;
+    }
+    if (MODE == MODE_FWD && p.sq_part) {                     // kernel-argument uniform
+        // Reconstruction loss where x_hat is produced: x and x_hat meet in this thread.  dA exactly as
+        // gm_sqerr_sigmoid_bwd writes it; the row's squared error inside this tile by the same 32-lane
+        // butterfly as the folded head's partial dots.
+#pragma unroll
+        for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
+            const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
+            const bool live = !(ROWS < 32 && row >= ROWS);
+            float v = 0.f;
+            if (live) {
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+            }
+            const int m = m0 + row, n = n0 + col;
+            const bool ok = live && m < p.M && n < p.N;
+            float pv = 0.f;
+            if (ok) {
+                const float r = fwd_value(p, v, n);
+                p.C[(int64_t)m * p.ldc + n] = r;
+                const float d = p.sq_x[(int64_t)m * p.sq_ldx + n] - r;
+                pv = d * d;
+                const float go = -(2.f * d);                  // PowBackward * SubBackward
+                p.sq_dA[(int64_t)m * p.sq_lda + n] = (go * (1.f - r)) * r;   // SigmoidBackward
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
+            if (col == 0 && live && m < p.M) p.sq_part[(int64_t)m * p.sq_ldp + (n0 >> 5)] = pv;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
         const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
@@ -721,8 +815,14 @@ __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_
 // OF: the ones column starts at reduction row p.ones_from (WGAN-GP's stacked dW only); compiled out
 // otherwise -- the four extra compares per fragment cost the generator's dW pair 1.2 us when they ran
 // unconditionally.
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false>
-__device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by) {
+// FOLD (folded critic head, gm_head.h): 1 = weight gradient whose A operand dH[k][x] is formed from
+// h[k][x], sds[k] (dS of reduction row k) and w2[x]; 2 = input gradient whose A operand dH[m][k] is
+// formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0>
+__device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
+                                            float* sds = nullptr, const FoldP* fold = nullptr) {
+    static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
+                  "folded head: 16-byte operand paths only");
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -734,6 +834,15 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
     const int nchunks = (p.K + 15) >> 4;
 
+    // folded head: what stays fixed per lane across the reduction
+    float4 fw[FOLD == 1 ? MI : 1];
+    float fds[FOLD == 2 ? MI : 1];
+    if constexpr (FOLD == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)                       // w2 of this lane's four A columns
+            fw[mi] = *reinterpret_cast<const float4*>(
+                p.fold_w2 + min(m0 + 16 * mi + 4 * ((lane >> 2) & 3), p.M - 4));
+    }
     auto load_a = [&](int c, int mi) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = m0 + 16 * mi;
         if (MODE == MODE_DW) {
@@ -748,8 +857,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
         return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
     };
-    auto fix_a = [&](float4 v, int c, int mi) -> float4 {
+    auto fix_a = [&](float4 v, int c, int mi, float4 wk) -> float4 {
         const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + i16;
+        if constexpr (FOLD == 1)                              // the loaded row is k = 16c + 4g + e (clamped)
+            v = fold_dh4(v, sds[min(16 * c + 4 * g4 + (lane & 3), p.K - 1)], fw[mi]);
+        if constexpr (FOLD == 2) v = fold_dh4(v, fds[mi], wk);
         if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
         return fix_kc(v, x, p.M, kb, p.K);
     };
@@ -772,11 +884,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // -- and measured slower here (fwd 512x784x400: G=4 8.8 us, G=2 7.7, G=1 7.4-7.6); a rolling
     // prefetch of the next chunk was slower still (iteration 71.7 -> 76.3 us).  G stays a template
     // parameter (= 1) so that kernel names keep their shape across rounds.
-    auto consume = [&](const float4 (&ra)[MI], const float4 (&rb)[NI], int q) {
+    auto consume = [&](const float4 (&ra)[MI], const float4 (&rb)[NI], float4 wk, int q) {
         const int cq = w + q * WAVES;
         float4 fa[MI], fb[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[mi], cq, mi);
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[mi], cq, mi, wk);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ni] = fix_b(rb[ni], cq, ni);
 #pragma unroll
@@ -792,14 +904,72 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             }
     };
     static_assert(G == 1, "the 16x16x4 kernel runs the per-chunk schedule only");
-    for (int q = 0; q < nq; ++q) {
+    auto load_wk = [&](int cc) -> float4 {                    // FOLD == 2: w2 of the chunk's four reduction columns
+        if constexpr (FOLD == 2) return *reinterpret_cast<const float4*>(p.fold_w2 + min(16 * cc + 4 * g4, p.K - 4));
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int q_first = 0;
+    if constexpr (FOLD != 0) {
+        // Folded head: the workgroup's dS rows are rebuilt from the forward's partial dots BEHIND the
+        // first chunk's operand loads -- both trips to the fabric are in flight together (the prologue
+        // in front of the loop cost a second, serial round trip per launch: in the real step, where
+        // every kernel's inputs are fresh from other XCDs, the folded step was only 1.2 us faster than
+        // the unfolded one although two launches were gone).  Waves without a chunk still take the barrier.
         float4 ra[MI], rb[NI];
-        const int cc = w + q * WAVES;
+        float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool have = nq > 0;
+        if (have) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
-        consume(ra, rb, q);
+            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
+            wk = load_wk(w);
+        }
+        if constexpr (FOLD == 1) {
+            fold_fill_lds(*fold, sds, fold->R);               // every reduction row (ends with the barrier)
+        } else {
+            if (t < 16 * MI) {                                // the tile's own rows
+                float s_, ds_, l_;
+                fold_row(*fold, min(m0 + t, fold->R - 1), s_, ds_, l_);
+                sds[t] = ds_;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fds[mi] = sds[16 * mi + i16];     // dS of this lane's A rows
+        }
+        if (have) consume(ra, rb, wk, 0);
+        q_first = 1;
+    }
+    // GM_BATCH_LOADS (experiment, off): a wave with at most BMAX chunks issues ALL its operand loads back to
+    // back (unconditional, clamped chunk index) and then consumes them in order -- one exposed trip to
+    // L2 / MALL instead of one per chunk.  Round 1 measured batching slower on back-to-back launches of
+    // one kernel; this switch exists to measure it inside the real step, where every launch starts
+    // with invalidated L2s.
+    constexpr int BMAX = (MI * NI <= 4) ? 4 : 2;
+    if (FOLD == 0 && p.batch_loads && nq <= BMAX) {           // kernel-argument / wave uniform
+        float4 ra[BMAX][MI], rb[BMAX][NI];
+#pragma unroll
+        for (int q = 0; q < BMAX; ++q) {
+            const int cc = w + min(q, max(nq - 1, 0)) * WAVES;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[q][mi] = load_a(min(cc, nchunks - 1), mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[q][ni] = load_b(min(cc, nchunks - 1), ni);
+        }
+#pragma unroll
+        for (int q = 0; q < BMAX; ++q)
+            if (q < nq) consume(ra[q], rb[q], make_float4(0.f, 0.f, 0.f, 0.f), q);
+    } else {
+        for (int q = q_first; q < nq; ++q) {
+            float4 ra[MI], rb[NI];
+            const int cc = w + q * WAVES;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+            const float4 wk = load_wk(cc);
+            consume(ra, rb, wk, q);
+        }
     }
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
@@ -845,30 +1015,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false>
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
     __shared__ float red[16 * 32 * 32];
+    __shared__ float sds[FOLDED ? FOLD_MAX_ROWS : 1];
+    constexpr int FOLD = FOLDED ? (MODE == MODE_DW ? 1 : 2) : 0;
+    // (folded head: the dS prologue runs inside the bodies, behind their first operand loads)
     if ((int)blockIdx.y < hrows) {                           // workgroup-uniform
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (bid < hblocks) head_bwd_body(hp, bid);
+        if (bid < hblocks) head_bwd_body(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF>(p, red, blockIdx.x, blockIdx.y - hrows);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
-template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false>
+template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
-    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF>(p, hp, hrows, hblocks);
+    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED>(p, hp, hrows, hblocks);
 }
 
 // The generator step's dX GEMM carrying the one scalar workgroup of the head (loss + tick): the
 // generator-mode head_bwd has nothing else to do once head_fwd_loss wrote dH.
-template <int G, int MI, int NI>
+template <int G, int MI, int NI, bool FOLDED = false>
 __global__ __launch_bounds__(1024) void gemm16_dx_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
-    gemm16_with_head<MODE_DX, true, G, true, MI, NI>(p, hp, hrows, hblocks);
+    gemm16_with_head<MODE_DX, true, G, true, MI, NI, false, FOLDED>(p, hp, hrows, hblocks);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -920,7 +1093,16 @@ struct Rider {
 template <int MODE>
 int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const Rider& rider = Rider()) {
     const HeadBwdP* head = rider.head;
+    // folded critic head: the head workgroups AND the GEMM's A operand depend on the fold -- only the
+    // riding 16x16x4 launches below implement it; every other configuration is refused, never
+    // silently run without it
+    const bool folded = head && head->fold.enabled;
     GemmP p = p_in;
+    {
+        static int bl = -1;
+        if (bl < 0) { const char* e = getenv("GM_BATCH_LOADS"); bl = e ? atoi(e) : 0; }
+        p.batch_loads = bl;
+    }
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
@@ -957,7 +1139,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         static int xvq = -1;
         if (xvq < 0) { const char* e = getenv("GM_XVEC"); xvq = e ? atoi(e) : 1; }
         const bool xv_l = xvec && xvq && MODE != MODE_FWD;
-        if (!rider.pair && p.xr == 0 && p.cpw == 0) {
+        if (!rider.pair && p.xr == 0 && p.cpw == 0 && !folded && !p.hd_part && !p.sq_part) {
             const int cfg = lds_cfg_for<MODE>(p, vec, xv_l);
             if (cfg) {
                 if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
@@ -1004,13 +1186,19 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int hblocks = gm_head_bwd_blocks(*head);
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
-#define GM_LH(V, GG, X, OFV) do {                                                                  \
-        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2, OFV>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
-#define GM_LH_G(V, X) do { if (p.ones_from > 0) GM_LH(V, 1, X, true); else GM_LH(V, 1, X, false); } while (0)
-                if (xv) GM_LH_G(false, true); else GM_LH_G(false, false);   // VEC is a k-contiguous notion
+#define GM_LH(V, GG, X, OFV, FD) do {                                                              \
+        if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
+#define GM_LH_G(V, X) do { if (p.ones_from > 0) GM_LH(V, 1, X, true, false); else GM_LH(V, 1, X, false, false); } while (0)
+                if (folded) {
+                    if (!xv || p.ones_from > 0) {
+                        gm_set_error("folded head: the weight gradient needs 16-byte aligned operands and no stacked rows");
+                        return GM_EINVAL;
+                    }
+                    GM_LH(false, 1, true, false, true);
+                } else if (xv) GM_LH_G(false, true); else GM_LH_G(false, false);   // VEC is a k-contiguous notion
 #undef GM_LH_G
 #undef GM_LH
                 GM_LAUNCH_RET();
@@ -1021,13 +1209,18 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int hblocks = gm_head_bwd_blocks(*head);
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
-#define GM_LXH(GG) do {                                                                            \
-        if (wide == 3) hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 1, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 2, 2>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
-                GM_LXH(1);
+#define GM_LXH(GG, FD) do {                                                                        \
+        if (wide == 3) hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 1, 2, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else hipLaunchKernelGGL((gemm16_dx_head_kernel<GG, 2, 2, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
+                if (folded) GM_LXH(1, true); else GM_LXH(1, false);
 #undef GM_LXH
                 GM_LAUNCH_RET();
             }
+        }
+        if (folded) {
+            gm_set_error("folded head: this launch configuration cannot carry it (needs the riding 16x16x4 "
+                         "kernels: 16-byte aligned operands, default tile maps)");
+            return GM_EINVAL;
         }
         if (head) {      // this configuration cannot carry the head workgroups: separate launch
             hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
@@ -1051,7 +1244,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
-                const GemmP& pb = *rider.pair;
+                GemmP pb = *rider.pair;
+                pb.batch_loads = p.batch_loads;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
@@ -1105,6 +1299,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
 #undef GM_L16_G
 #undef GM_L16
         GM_LAUNCH_RET();
+    }
+    if (folded) {
+        gm_set_error("folded head: not available with GM_MFMA16=0 / XCD tile maps / blocked chunks");
+        return GM_EINVAL;
     }
     if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
     if (rider.gather)
@@ -1164,6 +1362,41 @@ extern "C" int gm_linear_fwd_interp(void* stream, const float* X, int64_t ldx, g
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);
 }
 
+extern "C" int gm_linear_fwd_headpart(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                      const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                      int K, int N, int act, const float* w2, const float* b2,
+                                      float* part, int64_t ldp, float* snap) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
+    GM_CHECK_ARG(w2 && b2 && part && snap && ldp >= (N + 31) / 32 && ldp % 4 == 0);
+    GM_CHECK_ARG(part != Y && snap != Y && (const float*)part != X && (const float*)snap != X);
+    GemmP p{};
+    p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
+    p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = act;
+    p.a_slot = x_slot; p.b_slot = no_slot();
+    p.hd_w2 = w2; p.hd_b2 = b2; p.hd_part = part; p.hd_ldp = ldp; p.hd_snap = snap;
+    const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
+                     (x_slot.stride % 4 == 0);
+    return launch<MODE_FWD>((hipStream_t)stream, p, vec);
+}
+
+extern "C" int gm_linear_fwd_sqerr(void* stream, const float* X, int64_t ldx, const float* W,
+                                  const float* bias, float* Y, int64_t ldy, int M, int K, int N,
+                                  const float* target, int64_t ld_target, float* dA, int64_t lda,
+                                  float* part, int64_t ldp) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(target && dA && part && ld_target >= N && lda >= N && ldp >= (N + 31) / 32);
+    GM_CHECK_ARG(dA != Y && part != Y && part != dA && (const float*)dA != X && (const float*)part != X &&
+                 (const float*)Y != target && (const float*)dA != target);
+    GemmP p{};
+    p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
+    p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = GM_ACT_SIGMOID;
+    p.a_slot = no_slot(); p.b_slot = no_slot();
+    p.sq_x = target; p.sq_ldx = ld_target; p.sq_dA = dA; p.sq_lda = lda; p.sq_part = part; p.sq_ldp = ldp;
+    const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0);
+    return launch<MODE_FWD>((hipStream_t)stream, p, vec);
+}
+
 static int fwd_gather_impl(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
                            const float* W, const float* bias, float* Y, int64_t ldy, int M,
                            int K, int N, int act, const GatherP& g, float* out);
@@ -1210,7 +1443,8 @@ static int fwd_gather_impl(void* stream, const float* X, int64_t ldx, gm_slot x_
 
 static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
                    const float* below, int64_t ld_below, int M, int K, int N, int epi,
-                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head = nullptr);
+                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head = nullptr,
+                   const float* fold_w2 = nullptr);
 
 extern "C" int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W,
                                      float* dX, int64_t ldx, const float* below, int64_t ld_below,
@@ -1223,6 +1457,36 @@ extern "C" int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda,
     const int rc = gm_head_from_args(*head, &hp);
     if (rc) return rc;
     return dx_impl(stream, dA, lda, W, dX, ldx, below, ld_below, M, K, N, epi, nullptr, 0, 0.f, &hp);
+}
+
+extern "C" int gm_linear_bwd_dx_reparam(void* stream, const float* dA, int64_t lda, const float* W,
+                                        float* dZ, int64_t ldz, int M, int Z, int N, const float* ml,
+                                        int64_t ldml, const float* eps, gm_slot eps_slot, float* dml,
+                                        int64_t ldd) {
+    GM_CHECK_ARG(dA && W && dZ && M > 0 && Z > 0 && N > 0 && lda >= N && ldz >= Z);
+    GM_CHECK_ARG(ml && eps && dml && ldml >= 2 * Z && ldd >= 2 * Z && dml != dZ && (const float*)dml != ml &&
+                 (const float*)dml != dA);
+    GemmP p{};
+    p.A = dA; p.B = W; p.C = dZ; p.M = M; p.N = Z; p.K = N;
+    p.lda = lda; p.ldb = Z; p.ldc = ldz; p.epi = GM_ACT_ID;
+    p.a_slot = no_slot(); p.b_slot = no_slot();
+    p.rp_ml = ml; p.rp_ldml = ldml; p.rp_eps = eps; p.rp_slot = eps_slot; p.rp_dml = dml; p.rp_ldd = ldd;
+    p.rp_Z = Z;
+    const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0);
+    const bool xvec = aligned16(W) && (Z % 4 == 0);
+    return launch<MODE_DX>((hipStream_t)stream, p, vec, xvec);
+}
+
+extern "C" int gm_linear_bwd_dx_head_fold(void* stream, const float* H, int64_t ldh, const float* W,
+                                          float* dX, int64_t ldx, const float* below, int64_t ld_below,
+                                          int M, int K, int N, int epi, const gm_head_bwd_args* head,
+                                          const gm_head_fold_args* fold) {
+    GM_CHECK_ARG(head && fold && head->gen_mode && head->H == H && head->B == M && head->Hd == N);
+    GM_CHECK_ARG((const float*)dX != H && dX != fold->S && dX != fold->dS && dX != fold->rowloss);
+    HeadBwdP hp{};
+    const int rc = gm_head_from_args(*head, &hp, fold);
+    if (rc) return rc;
+    return dx_impl(stream, H, ldh, W, dX, ldx, below, ld_below, M, K, N, epi, nullptr, 0, 0.f, &hp, fold->snap);
 }
 
 extern "C" int gm_linear_bwd_dx(void* stream, const float* dA, int64_t lda, const float* W,
@@ -1241,7 +1505,8 @@ extern "C" int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, 
 
 static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, float* dX, int64_t ldx,
                    const float* below, int64_t ld_below, int M, int K, int N, int epi,
-                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head) {
+                   const float* add, int64_t ldadd, float add_scale, const HeadBwdP* head,
+                   const float* fold_w2) {
     GM_CHECK_ARG(dA && W && dX && M > 0 && K > 0 && N > 0 && lda >= N && ldx >= K);
     GM_CHECK_ARG(epi == GM_ACT_ID || (below && ld_below >= K));
     GemmP p{};
@@ -1249,8 +1514,9 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
     p.A = dA; p.B = W; p.C = dX; p.M = M; p.N = K; p.K = N;
     p.lda = lda; p.ldb = K; p.ldc = ldx; p.aux = below; p.ldaux = ld_below; p.epi = epi;
     p.add = add; p.ldadd = ldadd; p.add_scale = add_scale;
+    p.fold_w2 = fold_w2;
     p.a_slot = no_slot(); p.b_slot = no_slot();
-    const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0);
+    const bool vec = aligned16(dA) && (lda % 4 == 0) && (N % 4 == 0) && (!fold_w2 || aligned16(fold_w2));
     const bool xvec = aligned16(W) && (K % 4 == 0);
     Rider r;
     r.head = head;
@@ -1259,7 +1525,8 @@ static int dx_impl(void* stream, const float* dA, int64_t lda, const float* W, f
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam, const HeadBwdP* head = nullptr, int ones_from = 0);
+                   const gm_adam_epi* adam, const HeadBwdP* head = nullptr, int ones_from = 0,
+                   const float* fold_w2 = nullptr);
 static int dw_fill(const float* dA, int64_t lda, const float* X, int64_t ldx, gm_slot x_slot,
                    float* dW, float* db, int M, int K, int N, int accumulate,
                    const gm_adam_epi* adam, GemmP* out, bool* xvec);
@@ -1322,6 +1589,32 @@ extern "C" int gm_linear_bwd_dw_adam_head_ex(void* stream, const float* dA, int6
     return dw_impl(stream, dA, lda, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp, ones_from);
 }
 
+extern "C" int gm_linear_bwd_dw_adam_head_fold(void* stream, const float* H, int64_t ldh,
+                                               const float* X, int64_t ldx, gm_slot x_slot, float* dW,
+                                               float* db, int M, int K, int N, float* pW, float* mW,
+                                               float* vW, float* pb, float* mb, float* vb,
+                                               const float* sched, gm_slot sched_slot, double beta1,
+                                               double beta2, double eps, double weight_decay, float clamp,
+                                               const gm_head_bwd_args* head, const gm_head_fold_args* fold) {
+    GM_CHECK_ARG(head && fold && !head->gen_mode && head->H == H && 2 * head->B == M && head->Hd == N);
+    GM_CHECK_ARG(!sched || (db && pW && mW && vW && pb && mb && vb));
+    GM_CHECK_ARG((const float*)head->w2 != pW || !pW);
+    GM_CHECK_ARG(head->gw2 != dW && (const float*)dW != H);
+    // the GEMM workgroups read the SNAPSHOT of (w2, b2): the head workgroups may step the parameters
+    GM_CHECK_ARG(fold->snap != (const float*)head->w2 && fold->snap != (const float*)head->b2);
+    HeadBwdP hp{};
+    const int rc = gm_head_from_args(*head, &hp, fold);
+    if (rc) return rc;
+    gm_adam_epi a{};
+    if (sched) {
+        a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
+        a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+        a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
+        a.enabled = 1;
+    }
+    return dw_impl(stream, H, ldh, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp, 0, fold->snap);
+}
+
 static int dw_adam_fill(const gm_dw_adam_args& a, GemmP* p, bool* xvec) {
     if (!a.sched)            // plain gradient (no optimizer step in the epilogue)
         return dw_fill(a.dA, a.lda, a.X, a.ldx, a.x_slot, a.dW, a.db, a.M, a.K, a.N, 0, nullptr, p, xvec);
@@ -1356,13 +1649,15 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
 
 static int dw_impl(void* stream, const float* dA, int64_t lda, const float* X, int64_t ldx,
                    gm_slot x_slot, float* dW, float* db, int M, int K, int N, int accumulate,
-                   const gm_adam_epi* adam, const HeadBwdP* head, int ones_from) {
+                   const gm_adam_epi* adam, const HeadBwdP* head, int ones_from, const float* fold_w2) {
     GemmP p{};
     bool xvec = false;
     const int rc = dw_fill(dA, lda, X, ldx, x_slot, dW, db, M, K, N, accumulate, adam, &p, &xvec);
     if (rc) return rc;
     GM_CHECK_ARG(ones_from >= 0 && ones_from <= M && (ones_from == 0 || head));
     p.ones_from = ones_from;
+    p.fold_w2 = fold_w2;
+    if (fold_w2 && !aligned16(fold_w2)) xvec = false;
     Rider r;
     r.head = head;
     return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, r);

@@ -5,6 +5,62 @@
 #pragma once
 #include "gm_common.h"
 
+// ---- folded head (round 3) ---------------------------------------------------------------------
+// The N = 1 critic layer needs no launch of its own: the hidden layer's forward GEMM leaves per-
+// column-tile partial dots  part[r][j] = sum_{n in tile j} h[r,n] * w2[n]  (and a snapshot of w2 / b2
+// as it saw them) in its epilogue; every consumer rebuilds score, row loss and dS for the rows it
+// needs in a short prologue (`fold_row`: nparts loads per row, fixed summation order => the same bits
+// in every workgroup and from run to run), and the hidden-layer gradient dH[r,n] = dS_r * w2[n] *
+// [h[r,n] > 0] is formed in registers where the weight-gradient / input-gradient GEMM loads its A
+// operand (it loads h instead of a materialised dH).  ns_gan.py:57-60,191-192,214.
+struct FoldP {
+    const float* part; int64_t ldp; int nparts;    // part[r * ldp + j], j < nparts <= 16 <= ldp, ldp % 4 == 0
+    const float* snap;                          // [Hd]: w2 as the forward saw it; [Hd]: b2
+    int variant, gen_mode, out_act, B, R, Hd;
+    float hyper[8];
+    float inv_b;
+    const float* pen;                           // optional penalty rows (x rows)
+    float* S; float* dS; float* rowloss;        // optional [R] outputs (written by head workgroup 0)
+    int enabled;
+};
+
+// score, d loss / d (pre-activation score) and loss term of row r from the forward's partial dots.
+// A row's partials are CONTIGUOUS (part[r * ldp + j], ldp % 4 == 0, unused slots zero, at most 16): four
+// independent 16-byte loads, one memory round trip -- a loop of dependent-in-order scalar loads cost 13
+// serial trips to the fabric per row when the partials were fresh from another XCD (measured: the folded
+// step was 3 us SLOWER than the unfolded one until this changed).
+static __device__ __forceinline__ void fold_row(const FoldP& f, int r, float& s, float& ds, float& l) {
+    const float4* q = reinterpret_cast<const float4*>(f.part + (int64_t)r * f.ldp);
+    const int n4 = (f.nparts + 3) >> 2;
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = q[min(j, n4 - 1)];
+    const float bias = f.snap[f.Hd];
+    float a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < n4) { a2 += v[j].x; a2 += v[j].y; a2 += v[j].z; a2 += v[j].w; }
+    a2 += bias;
+    s = a2;
+    if (f.out_act == GM_ACT_SIGMOID) s = gm_sigmoid(a2);
+    else if (f.out_act == GM_ACT_RELU) s = fmaxf(a2, 0.f);
+    const bool D = !f.gen_mode;
+    const bool is_x = D && r < f.B;
+    float lx, lg, dx, dg;
+    sample_terms(f.variant, D, is_x ? s : 0.5f, is_x ? 0.5f : s, f.inv_b, f.hyper, lx, lg, dx, dg);
+    l = is_x ? lx : lg;
+    if (is_x && f.pen) l += f.hyper[7] * f.pen[r];
+    ds = act_grad(is_x ? dx : dg, s, f.out_act);
+}
+
+// dH of four consecutive columns from h, the row's dS and the columns' w2
+static __device__ __forceinline__ float4 fold_dh4(float4 h, float ds, float4 w) {
+    return make_float4((h.x > 0.f) ? ds * w.x : 0.f, (h.y > 0.f) ? ds * w.y : 0.f,
+                       (h.z > 0.f) ? ds * w.z : 0.f, (h.w > 0.f) ? ds * w.w : 0.f);
+}
+
+constexpr int FOLD_MAX_ROWS = 2048;             // rows whose dS a workgroup keeps in LDS (8 KB)
+
 struct HeadBwdP {
     const float* H; int64_t ldh;
     const float* dS; const float* w2; const float* rowloss;
@@ -17,6 +73,7 @@ struct HeadBwdP {
     int64_t* tick;                          // optional: *tick += 1 after the loss slot is written
     const float* gw2_add;                   // optional: added to gw2 before it is stored / stepped (the
                                             // gradient penalty's second-backward share, w_gp_gan.py:215)
+    FoldP fold;                             // folded head: dS / rowloss come from fold_row, not from memory
 };
 
 // 16 columns x 64 row-groups per 1024-thread workgroup: 25 workgroups for Hd=400, 8 rows per thread
@@ -24,13 +81,64 @@ struct HeadBwdP {
 constexpr int HB_COLS = 16, HB_RG = 64;
 
 // bid: index of this workgroup among the head workgroups (0 .. gm_head_bwd_blocks()-1); 1024 threads.
-static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid) {
+// the workgroup's LDS copy of dS for rows [0, R): every thread strides over the rows
+static __device__ __forceinline__ void fold_fill_lds(const FoldP& f, float* sds, int R) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float s, ds, l;
+        fold_row(f, r, s, ds, l);
+        sds[r] = ds;
+    }
+    __syncthreads();
+}
+
+// sds: folded head only -- LDS for the workgroup's copy of dS[0..R), filled HERE behind the first h loads
+static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid, float* sds = nullptr) {
     __shared__ float sh[HB_RG][HB_COLS + 1];
-    __shared__ double shd[16];
+    __shared__ double shd[3][16];
     const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
     const int c = bid * HB_COLS + cl;
+    const bool folded = p.fold.enabled != 0;
+    // the step's schedule scalars: uniform, two dependent scalar loads (counter -> table row) -- issued
+    // first so that the chain is over long before the Adam updates at the end need it
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (p.adam.enabled) {
+        const int64_t si = gm_slot_index(p.adam.sched_slot);
+        step_size = p.adam.sched[2 * si]; bc2_sqrt = p.adam.sched[2 * si + 1];
+    }
     float acc = 0.f;
-    if (c < p.Hd && (p.dH || p.gw2)) {
+    float pP = 0.f, pM = 0.f, pV = 0.f;                  // Adam state of w2[c], loaded behind the h loads
+    const bool col_adam = p.gw2 && p.adam.enabled && rg == 0 && c < p.Hd;
+    if (folded) {
+        if (p.gw2) {                                     // kernel-argument uniform: every thread takes this path
+            // Nothing to write per row (dH is formed in the GEMM's registers).  The first batch of a
+            // thread's h loads goes out back to back, unconditionally (clamped addresses); BEHIND them
+            // the workgroup rebuilds dS[0..R) from the forward's partial dots (one barrier, reached by
+            // all 1024 threads at this one place), so both trips to the fabric overlap; then the dot
+            // products in row order (same bits as the loop of the unfolded form).
+            constexpr int U = 8;
+            const bool active = c < p.Hd;
+            const int cc = min(c, p.Hd - 1);
+            float hv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) hv[u] = p.H[(int64_t)min(rg + u * HB_RG, p.R - 1) * p.ldh + cc];
+            if (col_adam) { pP = p.adam.pW[c]; pM = p.adam.mW[c]; pV = p.adam.vW[c]; }
+            fold_fill_lds(p.fold, sds, p.R);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = rg + u * HB_RG;
+                if (active && r < p.R) acc = fmaf(sds[r], hv[u], acc);
+            }
+            for (int r0 = rg + U * HB_RG; r0 < p.R; r0 += U * HB_RG) {       // R > 512
+#pragma unroll
+                for (int u = 0; u < U; ++u) hv[u] = p.H[(int64_t)min(r0 + u * HB_RG, p.R - 1) * p.ldh + cc];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + u * HB_RG;
+                    if (active && r < p.R) acc = fmaf(sds[r], hv[u], acc);
+                }
+            }
+        }
+    } else if (c < p.Hd && (p.dH || p.gw2)) {
         const float w = p.w2[c];
         for (int r = rg; r < p.R; r += HB_RG) {
             const float h = p.H[(int64_t)r * p.ldh + c];
@@ -38,6 +146,7 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid)
             if (p.dH) p.dH[(int64_t)r * p.lddh + c] = (h > 0.f) ? d * w : 0.f;
             acc = fmaf(d, h, acc);
         }
+        if (col_adam) { pP = p.adam.pW[c]; pM = p.adam.mW[c]; pV = p.adam.vW[c]; }
     }
     if (p.gw2) {
         sh[rg][cl] = acc;
@@ -48,45 +157,53 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid)
             if (p.gw2_add) v += p.gw2_add[c];
             p.gw2[c] = v;
             if (p.adam.enabled) {          // every thread of this block read w2[c] before the barrier
-                const int64_t si = gm_slot_index(p.adam.sched_slot);
-                float P = p.adam.pW[c], M = p.adam.mW[c], V = p.adam.vW[c];
-                adam_update(P, v, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1], p.adam.omb1,
-                            p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
-                p.adam.pW[c] = P; p.adam.mW[c] = M; p.adam.vW[c] = V;
+                adam_update(pP, v, pM, pV, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
+                            p.adam.eps, p.adam.wd, p.adam.clamp);
+                p.adam.pW[c] = pP; p.adam.mW[c] = pM; p.adam.vW[c] = pV;
             }
         }
     }
     if (bid == 0) {
         // scalars: loss = inv_b * sum l_r ; gb2 = fl(sum over x rows) + fl(sum over g rows)
+        float bP = 0.f, bM = 0.f, bV = 0.f;
+        const bool b_adam = p.gb2 && p.adam.enabled && threadIdx.x == 0;
+        if (b_adam) { bP = p.adam.pb[0]; bM = p.adam.mb[0]; bV = p.adam.vb[0]; }
         double sl = 0.0, sx = 0.0, sg = 0.0;
         for (int r = threadIdx.x; r < p.R; r += 1024) {
-            sl += (double)p.rowloss[r];
-            const double d = (double)p.dS[r];
+            double d;
+            if (folded) {
+                float s, ds, l;
+                fold_row(p.fold, r, s, ds, l);
+                sl += (double)l;
+                d = (double)ds;
+                if (p.fold.S) p.fold.S[r] = s;             // observability: nothing on the path reads these
+                if (p.fold.dS) p.fold.dS[r] = ds;
+                if (p.fold.rowloss) p.fold.rowloss[r] = l;
+            } else {
+                sl += (double)p.rowloss[r];
+                d = (double)p.dS[r];
+            }
             if (!p.gen_mode && r < p.B) sx += d; else sg += d;
         }
-        double v[3] = {sl, sx, sg};
-        float outv[3];
-        for (int k = 0; k < 3; ++k) {
-            double a = gm_wave_sum_d(v[k]);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = a;
-            __syncthreads();
-            double tot = 0.0;
-            for (int q = 0; q < 16; ++q) tot += shd[q];
-            outv[k] = (k == 0) ? (float)(tot * (double)p.inv_b) : (float)tot;
+        // the three block sums together: wave sums, one barrier, 16 partials each in wave order
+        const double a0 = gm_wave_sum_d(sl), a1 = gm_wave_sum_d(sx), a2 = gm_wave_sum_d(sg);
+        __syncthreads();                                   // (sh / shd reuse: everybody is past the column sums)
+        if ((threadIdx.x & 63) == 0) {
+            shd[0][threadIdx.x >> 6] = a0; shd[1][threadIdx.x >> 6] = a1; shd[2][threadIdx.x >> 6] = a2;
         }
+        __syncthreads();
         if (threadIdx.x == 0) {
-            p.loss_out[gm_slot_index(p.loss_slot)] = outv[0];
+            double tot[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < 3; ++k)
+                for (int q = 0; q < 16; ++q) tot[k] += shd[k][q];
+            p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot[0] * (double)p.inv_b);
             if (p.gb2) {
-                const float gb = outv[1] + outv[2];
+                const float gb = (float)tot[1] + (float)tot[2];
                 p.gb2[0] = gb;
                 if (p.adam.enabled) {
-                    const int64_t si = gm_slot_index(p.adam.sched_slot);
-                    float P = p.adam.pb[0], M = p.adam.mb[0], V = p.adam.vb[0];
-                    adam_update(P, gb, M, V, p.adam.sched[2 * si], p.adam.sched[2 * si + 1],
-                                p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd,
-                                p.adam.clamp);
-                    p.adam.pb[0] = P; p.adam.mb[0] = M; p.adam.vb[0] = V;
+                    adam_update(bP, gb, bM, bV, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
+                                p.adam.eps, p.adam.wd, p.adam.clamp);
+                    p.adam.pb[0] = bP; p.adam.mb[0] = bM; p.adam.vb[0] = bV;
                 }
             }
             // the per-graph tick folded into this single-writer point: kernels later in the same
@@ -97,7 +214,8 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid)
 }
 
 static __global__ __launch_bounds__(1024) void head_bwd_kernel(HeadBwdP p) {
-    head_bwd_body(p, blockIdx.x);
+    __shared__ float sds[FOLD_MAX_ROWS];
+    head_bwd_body(p, blockIdx.x, sds);
 }
 
 // number of head workgroups a launch needs (scalars only when neither dH nor gw2 is produced)
@@ -106,8 +224,10 @@ static inline int gm_head_bwd_blocks(const HeadBwdP& p) {
 }
 
 // Host side: validate the public argument block and turn it into the kernel's parameter block.
-static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out) {
-    GM_CHECK_ARG(a.H && a.dS && a.w2 && a.rowloss && a.loss_out && a.B > 0 && a.Hd > 0);
+static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out,
+                                    const gm_head_fold_args* fold = nullptr) {
+    GM_CHECK_ARG(a.H && a.w2 && a.loss_out && a.B > 0 && a.Hd > 0);
+    GM_CHECK_ARG(fold || (a.dS && a.rowloss));
     HeadBwdP p{};
     if (a.with_adam) {
         GM_CHECK_ARG(a.gw2 && a.gb2 && a.b2 && a.mW && a.vW && a.mb && a.vb && a.sched && !a.gen_mode);
@@ -123,6 +243,24 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out) {
     p.lddh = a.lddh; p.gw2 = a.gw2; p.gb2 = a.gb2; p.loss_out = a.loss_out;
     p.loss_slot = a.loss_slot; p.inv_b = a.inv_b; p.gen_mode = a.gen_mode; p.B = a.B;
     p.R = a.gen_mode ? a.B : 2 * a.B; p.Hd = a.Hd;
+    if (fold) {
+        const gm_head_fold_args& g = *fold;
+        GM_CHECK_ARG(g.part && g.snap && g.nparts > 0 && g.nparts <= 16 && g.ldp >= g.nparts && g.ldp % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(g.part) & 15) == 0 && g.n_hyper >= 0 && g.n_hyper <= 8);
+        GM_CHECK_ARG(g.nparts == (a.Hd + 31) / 32);
+        GM_CHECK_ARG(g.out_act >= GM_ACT_ID && g.out_act <= GM_ACT_SIGMOID);
+        GM_CHECK_ARG(g.variant != GM_LOSS_RA || a.gen_mode);
+        GM_CHECK_ARG(g.variant != GM_LOSS_FISHER || a.gen_mode);
+        GM_CHECK_ARG(!a.dH);                       // nothing materialises dH in the folded form
+        GM_CHECK_ARG(p.R <= FOLD_MAX_ROWS || !a.gw2);
+        FoldP& f = p.fold;
+        f.part = g.part; f.ldp = g.ldp; f.nparts = g.nparts; f.snap = g.snap;
+        f.variant = g.variant; f.gen_mode = a.gen_mode; f.out_act = g.out_act; f.B = a.B; f.R = p.R;
+        f.Hd = a.Hd; f.inv_b = a.inv_b; f.pen = g.pen;
+        for (int i = 0; i < 8; ++i) f.hyper[i] = (i < g.n_hyper) ? g.hyper[i] : 0.f;
+        f.S = g.S; f.dS = g.dS; f.rowloss = g.rowloss;
+        f.enabled = 1;
+    }
     *out = p;
     return 0;
 }

@@ -354,6 +354,10 @@ class GANEngine:
         self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
+        # folded critic head (round 3): no launch for the N = 1 layer -- partial dots in the hidden
+        # layer's forward epilogue, scores / losses / dS rebuilt in the consumers' prologues, dH formed
+        # in registers (csrc/gm_head.h).  "2": also where the forward would take the LDS macro-tile kernel
+        self.fold_env = os.environ.get("GM_FOLD_HEAD", "1")
         # iterations per graph (largest captured size; powers of two below it are captured too).  A
         # graph boundary costs ~14 us of idle GPU plus the ~9 us stage-in of its draws (measured,
         # profiles/r02_experiments.md): 32 iterations per graph amortise that to < 1 us / iteration
@@ -392,6 +396,7 @@ class GANEngine:
         self.dXg = z(Bl, I)
         self.dHg = z(Bl, H)
         self.rowloss = z(2 * Bl)
+        self.fold = ops.HeadFold(2 * Bl, Hd, dev) if (self.D2.W.shape[0] == 1 and Hd <= 512) else None
         self.done_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.aux = z(8)                    # Fisher lambda + moments
         self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
@@ -450,6 +455,28 @@ class GANEngine:
             return self.fuse_head and self.variant not in ("ra", "fisher", "dra") and \
                 (self.variant != "wgp" or self._wgp_stacked())
         return True
+
+    def _fold_ok(self, rows):
+        """The critic's N = 1 head without a launch of its own (ns_gan.py:57-60 + the loss lines):
+        the riding kernels, 16-byte aligned layer widths, row counts the consumers can keep in LDS;
+        by default only where the hidden layer's forward is a split-reduction launch anyway (rows
+        below the LDS macro-tile kernel's threshold; GM_FOLD_HEAD=2 lifts that)."""
+        if self.fold_env == "0" or self.fold is None or self.variant == "be":
+            return False
+        if not (self.fuse_head and self.group_head and self.ride_head_dx) or self.dag or self.head_final:
+            return False
+        if self.Hd_dim % 4 or self.I % 4 or rows > 2048 or self.Hd_dim > 512:
+            return False
+        return self.fold_env == "2" or rows < ops.lds_min_m()
+
+    def _fold_head(self):
+        """Critic step: the separable losses whose whole step runs on the fused head (not the
+        penalty variants' stacked / accumulating steps, not Ra / Fisher's two-phase losses)."""
+        return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl)
+
+    def _fold_head_G(self):
+        """Generator step: every variant's D(G(z)) pass is the plain fused head in generator mode."""
+        return self._fold_ok(self.Bl)
 
     def _wgp_stacked(self):
         """WGAN-GP critic step with the second backward folded into the first-order launches: the
@@ -568,9 +595,16 @@ class GANEngine:
 
     def _batch_gen(self):
         """Both generator forwards of an iteration (critic step's G(zD), generator step's G(zG))
-        read the same G parameters: with D_steps == 1 on one GPU they run as ONE launch pair on
-        2B rows (the noise ring stores [zD; zG] back to back)."""
-        return self.batch_gen_env and self.D_steps == 1 and self.world == 1 and not self.dag
+        read the same G parameters: with D_steps == 1 they run as ONE launch pair on 2B rows (the
+        noise ring stores [zD; zG] back to back -- on a data-parallel rank that needs the rank-local
+        device rings, where the rank's zD rows and zG rows of an iteration are adjacent)."""
+        return self.batch_gen_env and self.D_steps == 1 and not self.dag and \
+            (self.world == 1 or self._local_rings())
+
+    def _local_rings(self):
+        """Data parallel: device rings hold only this rank's rows of every draw (see _alloc_rings)."""
+        import os
+        return self.world > 1 and self.variant != "dra" and os.environ.get("GM_LOCAL_RINGS", "1") != "0"
 
     def _D_gen(self, st, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
@@ -604,6 +638,17 @@ class GANEngine:
         X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
         loss_slot = self._slot(it, d, j, 0, 1)
         grouped = False
+        if self._fold_head():
+            # 2 launches instead of 3: hidden layer forward (+ partial dots of the head), then the
+            # layer-1 weight gradient (+Adam) with the head's backward workgroups riding -- scores,
+            # row losses and dS are rebuilt from the partial dots in that launch's prologue
+            ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st)
+            adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
+            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss)
+            head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
+                        adam=adam)
+            ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
+            return
         ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
@@ -748,6 +793,15 @@ class GANEngine:
         D1, D2 = self.D1, self.D2
         Hd, S2, dS, dHd, Xg = self.Hd, self.S2, self.dS, self.dHd, self.Xg2
         loss_slot = self._slot(it, 1, self.g_off, 0, 1)
+        if self._fold_head_G():
+            tick = self.ctr if self._tick_in_head() else None
+            ops.linear_fwd_headpart(Xg, D1.W, D1.b, Hd, "relu", D2, self.fold, M=Bl, stream=st)
+            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss)
+            ops.linear_bwd_dx_head_fold(
+                Hd, D1.W, self.dXg, dict(H=Hd, lin=D2, loss_out=self.lossG, loss_slot=loss_slot,
+                                         inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
+                fa, below=Xg, epi="sigmoid", M=Bl, stream=st)
+            return
         ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
         if self.fuse_head:
             from . import ops_fused as of
@@ -960,9 +1014,7 @@ class GANEngine:
         # iteration does not grow with the number of ranks (at 8 x 256 rows the global slot is 344 KB =
         # 15.6 us of a ~85 us step; the rank's share is 43 KB).  DRAGAN's uniforms go through the copy
         # engine (_copy_U) in whole slots and keep the global layout.
-        import os
-        self.local_rings = self.world > 1 and self.variant != "dra" and \
-            os.environ.get("GM_LOCAL_RINGS", "1") != "0"
+        self.local_rings = self._local_rings()
         self.ring_B = self.Bl if self.local_rings else B          # rows per draw in the device rings
         self.ring_r0 = 0 if self.local_rings else self.rank * self.Bl   # my first row inside them
         shapes = {k: (lead + (B,) + tail, dt) for k, (lead, m, tail, dt) in layout.items()}
@@ -1803,6 +1855,9 @@ class VAEEngine:
         self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))   # batches per graph
         self.prefetch_gather = os.environ.get("GM_VAE_PREFETCH_GATHER", "1") != "0"
+        # launch fusions of round 3 (each replaces a ~5 us latency-bound launch by an epilogue)
+        self.fuse_sqerr = os.environ.get("GM_VAE_FUSE_SQERR", "1") != "0"
+        self.fuse_reparam_bwd = os.environ.get("GM_VAE_FUSE_REPARAM_BWD", "1") != "0"
 
     def _alloc(self, B):
         if self._bufB == B:
@@ -1814,6 +1869,7 @@ class VAEEngine:
         self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
         self.dHdec, self.dZ, self.dml, self.dHe = z(B, H), z(B, Z), z(B, 2 * Z), z(B, H)
         self.part = z(B)
+        self._sq_alloc(B)
         self.part_kl = z((B * Z + 255) // 256)
         self._bufB = B
         self.graphs = {}
@@ -1825,6 +1881,23 @@ class VAEEngine:
         if ring > 0:
             i %= ring
         return ops.slot(0, 0, i, 0, stride)
+
+    # -- reconstruction loss in the decoder's last forward (ops.linear_fwd_sqerr; GM_VAE_FUSE_SQERR=0: the
+    # separate gm_sqerr_sigmoid_bwd launch) -- per (row, 32-column tile) partials, rows ldp floats apart
+    def _sq_alloc(self, B):
+        ldp = _align4((self.I + 31) // 32)
+        self.part2 = torch.zeros(B, ldp, device=self.device)
+
+    def _recon_fwd(self, st, x_in, lin, X, b):
+        """x_hat = sigmoid(lin(x_in)), dA = d sum((X - x_hat)^2) / d (pre-sigmoid), and the loss partials.
+        Returns (partials tensor, number of floats to sum)."""
+        from . import ops_fused as of_
+        if self.fuse_sqerr:
+            ops.linear_fwd_sqerr(x_in, lin.W, lin.b, self.Xr, X, self.dA, self.part2, M=b, stream=st)
+            return self.part2, b * self.part2.shape[1]
+        ops.linear_fwd(x_in, lin.W, lin.b, self.Xr, "sigmoid", M=b, stream=st)
+        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
+        return self.part, b
 
     def _gather_plan(self, pos, of):
         """Batch `pos` of a graph of `of` equal-size batches: (its image buffer, whether it gathers its
@@ -1863,8 +1936,7 @@ class VAEEngine:
         eps_base = self.eps_ring.view(-1)[lo * Z:]
         n_kl = of_.vae_reparam_wide(self.ml, eps_base, self.Zs, self.part_kl, b, Z, eps_slot=eps_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
-        ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
+        part, n_part = self._recon_fwd(st, self.Hdec, D2, X, b)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             if self.fuse_adam and not self._dp():
@@ -1886,15 +1958,21 @@ class VAEEngine:
             else:
                 dw2 = lambda a1, a2: (dw(*a1), dw(*a2))
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
+            if self.fuse_reparam_bwd:
+                # dz and, in the same launch's epilogue, d loss / d [mu | log_var] (vae.py:100-106,210-212)
+                ops.linear_bwd_dx_reparam(self.dHdec, D1.W, self.dZ, self.ml, eps_base, self.dml, M=b,
+                                          eps_slot=eps_slot, stream=st)
+            else:
+                ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
             dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
-            of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
-                               eps_slot=eps_slot, stream=st)
+            if not self.fuse_reparam_bwd:
+                of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
+                                   eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             dw2((self.dHe, X, E1), (self.dml, self.He, ML))    # (the big GEMM first: its tile shape serves both)
             self._optimizer_step(st, sched_slot)
         # both loss sums (vae.py:203, :212) are the step's LAST launch, which also carries the counter tick
-        of_.sum_finalize2(self.part, b, recon_out, loss_slot, self.part_kl, n_kl, kl_out, loss_slot,
+        of_.sum_finalize2(part, n_part, recon_out, loss_slot, self.part_kl, n_kl, kl_out, loss_slot,
                           tick=self.ctr if self.use_graph else None, stream=st)
 
     def _optimizer_step(self, st, sched_slot):
@@ -2083,6 +2161,7 @@ class AEEngine(VAEEngine):
         self.X, self.He, self.Xr, self.dA = z(B, self.I), z(B, self.H), z(B, self.I), z(B, self.I)
         self.Xb = (self.X, z(B, self.I))
         self.dHe, self.part = z(B, self.H), z(B)
+        self._sq_alloc(B)
         self._bufB = B
         self.graphs = {}
 
@@ -2098,8 +2177,7 @@ class AEEngine(VAEEngine):
         if own:
             ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], X, B=b, idx_slot=idx_slot, stream=st)
         self._fwd_with_prefetch(st, t, lo, b, X, E1, self.He, "relu", nxt)
-        ops.linear_fwd(self.He, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
+        part, n_part = self._recon_fwd(st, self.He, D2, X, b)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
             adam = dict(sched=self.sched, sched_slot=sched_slot) if (self.fuse_adam and not self._dp()) else None
@@ -2109,7 +2187,7 @@ class AEEngine(VAEEngine):
                                         dict(dA=self.dHe, X=X, lin=E1, adam=adam, M=b),
                                         weight_decay=self.wd if adam is not None else 0.0, stream=st)
             self._optimizer_step(st, sched_slot)
-        of_.sum_finalize(self.part, b, self.recon if train else self.vrecon, out_slot=loss_slot,
+        of_.sum_finalize(part, n_part, self.recon if train else self.vrecon, out_slot=loss_slot,
                         tick=self.ctr if self.use_graph else None, stream=st)
 
 
@@ -2151,6 +2229,7 @@ class BIRVAEEngine(VAEEngine):
         self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
         self.dHdec, self.dZ, self.dZm, self.dHe = z(B, H), z(B, Z), z(B, Z), z(B, H)
         self.part, self.partm = z(B), z(B)
+        self._sq_alloc(B)
         self._bufB = B
         self.graphs = {}
 
@@ -2192,8 +2271,7 @@ class BIRVAEEngine(VAEEngine):
         self._fwd_with_prefetch(st, t, 0, b, self.He, MU, self.Mu, "id", nxt)
         of_.bir_reparam(self.Mu, self.eps_ring.view(-1), self.Zs, b, Z, eps_slot=eps_slot, stream=st)
         ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
-        ops.linear_fwd(self.Hdec, D2.W, D2.b, self.Xr, "sigmoid", M=b, stream=st)
-        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
+        part, n_part = self._recon_fwd(st, self.Hdec, D2, X, b)
         of_.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
                    self.LAMBDA, prior_slot=eps_slot, stream=st)
         if train:
@@ -2212,7 +2290,7 @@ class BIRVAEEngine(VAEEngine):
             dw2((self.dZ, self.He, MU), (self.dHe, X, E1))
             self._optimizer_step(st, sched_slot)
         # reconstruction sum and 1000 * MMD in the step's last launch, which also carries the tick
-        of_.sum_finalize2(self.part, b, recon_out, loss_slot, self.partm, b, mmd_out, loss_slot,
+        of_.sum_finalize2(part, n_part, recon_out, loss_slot, self.partm, b, mmd_out, loss_slot,
                           scale_b=self.LAMBDA, tick=self.ctr if self.use_graph else None, stream=st)
 
 

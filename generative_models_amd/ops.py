@@ -147,13 +147,15 @@ def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_
 
 def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
     """gm_head_bwd_args from dict(H, dS, lin (head _Linear), rowloss, loss_out, loss_slot, inv_b, B,
-    gen_mode=False, adam=None (dict(sched, sched_slot, clamp)), tick=None, grads=True)."""
+    gen_mode=False, adam=None (dict(sched, sched_slot, clamp)), tick=None, grads=True).  dS / rowloss
+    may be None for the folded head (they are rebuilt from the forward's partial dots)."""
     from ._lib import HeadBwdArgs
     hl, ha, H = head["lin"], head.get("adam"), head["H"]
     gen = bool(head.get("gen_mode", False))
     a = HeadBwdArgs()
-    a.H, a.ldh, a.dS = H.data_ptr(), _ld(H), head["dS"].data_ptr()
-    a.w2, a.b2, a.rowloss = hl.W.data_ptr(), hl.b.data_ptr(), head["rowloss"].data_ptr()
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    a.H, a.ldh, a.dS = H.data_ptr(), _ld(H), ptr(head.get("dS"))
+    a.w2, a.b2, a.rowloss = hl.W.data_ptr(), hl.b.data_ptr(), ptr(head.get("rowloss"))
     a.dH, a.lddh = None, 0                      # written by head_fwd_loss
     if not gen:
         a.gw2, a.gb2 = hl.gW.data_ptr(), hl.gb.data_ptr()
@@ -170,6 +172,119 @@ def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
     add = head.get("gw2_add")
     a.gw2_add = add.data_ptr() if add is not None else None
     return a
+
+
+def linear_fwd_sqerr(x, W, b, y, target, dA, part, M=None, stream=None):
+    """Sigmoid output layer + the reconstruction loss in its epilogue (vae.py:203): y = sigmoid(xW^T+b),
+    dA = d sum((target - y)^2) / d (pre-sigmoid), part[m, j] = the row's squared error inside 32-column
+    tile j (part: [>= M, >= ceil(N/32)], zero-initialised; sum it with ops_fused.sum_finalize*)."""
+    N, K = W.shape
+    M = x.shape[0] if M is None else M
+    assert part.dim() == 2 and part.shape[0] >= M and part.shape[1] >= (N + 31) // 32
+    _lib.call("gm_linear_fwd_sqerr", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
+              _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None, _chk(y, "y").data_ptr(), _ld(y),
+              M, K, N, _chk(target, "target").data_ptr(), _ld(target), _chk(dA, "dA").data_ptr(), _ld(dA),
+              part.data_ptr(), part.shape[1])
+    return y
+
+
+def linear_bwd_dx_reparam(dA, W, dZ, ml, eps, dml, M=None, eps_slot=NO_SLOT, stream=None):
+    """dZ = dA W through the decoder's first layer (W: [N, Z]) + the reparameterisation / KL backward in
+    the epilogue: dml = [dZ + mu | dZ*eps*exp(lv/2)/2 + (exp(lv)-1)/2]   (vae.py:100-106,210-212)."""
+    N, Z = W.shape
+    M = dA.shape[0] if M is None else M
+    _lib.call("gm_linear_bwd_dx_reparam", stream or stream_ptr(), _chk(dA, "dA").data_ptr(), _ld(dA),
+              _chk(W, "W").data_ptr(), _chk(dZ, "dZ").data_ptr(), _ld(dZ), M, Z, N, ml.data_ptr(), _ld(ml),
+              eps.data_ptr(), eps_slot, dml.data_ptr(), _ld(dml))
+    return dZ
+
+
+def lds_min_m():
+    """Rows from which forward / dX launches take the LDS macro-tile kernel (csrc/gm_gemm.hip)."""
+    import os
+    return int(os.environ.get("GM_LDS_MIN_M", "1024"))
+
+
+class HeadFold:
+    """Buffers of the folded critic head (gm_head_fold_args): the hidden layer's forward leaves per-
+    column-tile partial dots with w2 and a snapshot of (w2, b2); the launches either side of the N = 1
+    layer rebuild scores / losses / dS from them (ns_gan.py:57-60,191-192,214)."""
+
+    def __init__(self, rows, hidden, device):
+        self.nparts = (hidden + 31) // 32
+        assert self.nparts <= 16, "folded head: hidden layers up to 512 wide"
+        # part[r, j]: a row's partial dots are contiguous (one 64-byte line for <= 16 column tiles);
+        # entries j >= nparts are never written and stay zero
+        self.part = torch.zeros(rows, _al4(self.nparts), device=device)
+        self.snap = torch.zeros(_al4(hidden + 1), device=device)
+        self.hidden = hidden
+
+    def args(self, variant, out_act, hyper=(), pen=None, S=None, dS=None, rowloss=None):
+        from ._lib import HeadFoldArgs
+        a = HeadFoldArgs()
+        a.part, a.ldp, a.nparts, a.snap = self.part.data_ptr(), self.part.shape[1], self.nparts, self.snap.data_ptr()   # ldp = row stride
+        a.variant = LOSS[variant] if not isinstance(variant, int) else variant
+        a.out_act = ACT[out_act] if not isinstance(out_act, int) else out_act
+        hy = tuple(hyper)
+        assert len(hy) <= 8
+        for i, h in enumerate(hy):
+            a.hyper[i] = float(h)
+        a.n_hyper = len(hy)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        a.pen, a.S, a.dS, a.rowloss = ptr(pen), ptr(S), ptr(dS), ptr(rowloss)
+        return a
+
+
+def _al4(n):
+    return (n + 3) // 4 * 4
+
+
+def linear_fwd_headpart(x, W, b, y, act, head_lin, fold, M=None, x_slot=NO_SLOT, stream=None):
+    """linear_fwd of the critic's hidden layer that also leaves the folded head's partial dots and
+    the (w2, b2) snapshot in `fold` (HeadFold)."""
+    N, K = W.shape
+    M = x.shape[0] if M is None else M
+    assert fold.hidden == N and fold.part.shape[0] >= M
+    _lib.call("gm_linear_fwd_headpart", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x), x_slot,
+              _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None, _chk(y, "y").data_ptr(),
+              _ld(y), M, K, N, ACT[act] if not isinstance(act, int) else act, head_lin.W.data_ptr(),
+              head_lin.b.data_ptr(), fold.part.data_ptr(), fold.part.shape[1], fold.snap.data_ptr())
+    return y
+
+
+def linear_bwd_dx_head_fold(H, W, dX, head, fold_args, below=None, epi="id", M=None, stream=None):
+    """linear_bwd_dx_head in the folded form: A operand = the hidden activations H (dH is formed in
+    registers from the rows' dS and the snapshot of w2); head: see _head_args (dS / rowloss unused)."""
+    import ctypes
+    N, K = W.shape
+    M = H.shape[0] if M is None else M
+    a = _head_args(head)
+    _lib.call("gm_linear_bwd_dx_head_fold", stream or stream_ptr(), _chk(H, "H").data_ptr(), _ld(H),
+              _chk(W, "W").data_ptr(), _chk(dX, "dX").data_ptr(), _ld(dX),
+              below.data_ptr() if below is not None else None, _ld(below) if below is not None else 0,
+              M, K, N, ACT[epi] if not isinstance(epi, int) else epi, ctypes.byref(a), ctypes.byref(fold_args))
+    return dX
+
+
+def linear_bwd_dw_adam_head_fold(H, X, lin, adam, head, fold_args, M=None, x_slot=NO_SLOT,
+                                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, stream=None):
+    """linear_bwd_dw_adam_head in the folded form (see linear_bwd_dx_head_fold)."""
+    import ctypes
+    N, K = lin.gW.shape
+    M = H.shape[0] if M is None else M
+    a = _head_args(head, betas, eps)
+    if adam is None:
+        _lib.call("gm_linear_bwd_dw_adam_head_fold", stream or stream_ptr(), _chk(H, "H").data_ptr(),
+                  _ld(H), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
+                  lin.gb.data_ptr(), M, K, N, None, None, None, None, None, None, None, NO_SLOT,
+                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a), ctypes.byref(fold_args))
+        return
+    _lib.call("gm_linear_bwd_dw_adam_head_fold", stream or stream_ptr(), _chk(H, "H").data_ptr(),
+              _ld(H), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
+              lin.gb.data_ptr(), M, K, N, lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(),
+              lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr(), adam["sched"].data_ptr(),
+              adam["sched_slot"], betas[0], betas[1], eps, weight_decay, adam.get("clamp", 0.0),
+              ctypes.byref(a), ctypes.byref(fold_args))
 
 
 def linear_bwd_dx_head(dA, W, dX, head, below=None, epi="id", M=None, stream=None):

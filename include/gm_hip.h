@@ -287,6 +287,62 @@ int gm_linear_bwd_dw_adam_head_ex(void* stream, const float* dA, int64_t lda, co
 int gm_linear_bwd_dx_head(void* stream, const float* dA, int64_t lda, const float* W, float* dX,
                           int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
                           int epi, const gm_head_bwd_args* head);
+/* ---- FOLDED critic head (round 3): no launch for the N = 1 layer at all.
+ * Discriminator.forward's second layer (ns_gan.py:59: `discrimination = sigmoid(self.discriminate(
+ * activated))`, a [R, 400] x [400] product) is split over the launches on either side of it:
+ *  - gm_linear_fwd_headpart = gm_linear_fwd of the hidden layer whose epilogue also leaves, per
+ *    32-column tile j of the hidden layer, part[r * ldp + j] = sum_{n in tile j} Y[r, n] * w2[n]
+ *    (nparts = ceil(N / 32) <= 16 entries per row, rows ldp floats apart, ldp % 4 == 0, the unused
+ *    entries of a row stay zero) and a snapshot snap[0..N) = w2, snap[N] = b2[0] of the head
+ *    parameters it used (the consumers below may run in a launch that also steps w2 / b2);
+ *  - the consumers rebuild, per row, score = act(sum_j part[r][j] + b2), the row's loss term and
+ *    dS (the train_D / train_G loss lines: ns_gan.py:191-192,214 and the siblings gm_head_fwd_loss
+ *    lists) in a prologue, and form dH[r, n] = dS_r * w2[n] * [Y[r, n] > 0] in registers while loading
+ *    their A operand: gm_linear_bwd_dw_adam_head_fold (critic step: layer-1 weight gradient + Adam,
+ *    head backward workgroups riding: gw2, gb2, loss, Adam on (w2, b2)) and gm_linear_bwd_dx_head_fold
+ *    (generator step: dX through layer 1 + the loss / tick workgroup).  Both take the hidden
+ *    activations H where the unfolded entry points take dH; head->dS / head->rowloss are not read.
+ * Summation order of a score: 32-lane butterfly inside a tile, then tiles j = 0, 1, ... : fixed, so
+ * results are bitwise reproducible run to run (they differ from gm_head_fwd_loss's order in the last
+ * bits).  fold->S / dS / rowloss (optional, [R]) receive the per-row values for inspection. */
+typedef struct gm_head_fold_args {
+    const float* part; int64_t ldp; int nparts;
+    const float* snap;
+    int variant, out_act;
+    float hyper[8]; int n_hyper;
+    const float* pen;                     /* optional penalty rows added to the x rows' loss terms */
+    float* S; float* dS; float* rowloss;  /* optional outputs */
+} gm_head_fold_args;
+int gm_linear_fwd_headpart(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                           const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                           const float* w2, const float* b2, float* part, int64_t ldp, float* snap);
+int gm_linear_bwd_dw_adam_head_fold(void* stream, const float* H, int64_t ldh, const float* X,
+                                    int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
+                                    float* pW, float* mW, float* vW, float* pb, float* mb, float* vb,
+                                    const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                                    double eps, double weight_decay, float clamp,
+                                    const gm_head_bwd_args* head, const gm_head_fold_args* fold);
+int gm_linear_bwd_dx_head_fold(void* stream, const float* H, int64_t ldh, const float* W, float* dX,
+                               int64_t ldx, const float* below, int64_t ld_below, int M, int K, int N,
+                               int epi, const gm_head_bwd_args* head, const gm_head_fold_args* fold);
+/* VAE / AE reconstruction loss where the reconstruction is produced (vae.py:196-203: `recon_loss =
+ * torch.sum((images - outputs)**2)` behind Decoder.forward's sigmoid, vae.py:75-77; ae.py:147-160):
+ * gm_linear_fwd of the decoder's last layer (sigmoid) whose epilogue also writes
+ *   dA[m][n] = d loss / d (pre-sigmoid output) = (-2 (x - x_hat) (1 - x_hat)) x_hat   (as gm_sqerr_sigmoid_bwd)
+ *   part[m * ldp + j] = sum_{n in 32-column tile j} (x[m][n] - x_hat[m][n])^2,  j < ceil(N / 32) <= ldp
+ * (entries j >= ceil(N / 32) of a row are not written; gm_sum_finalize* over the whole `part` array adds
+ * them up in a fixed order).  Replaces the separate gm_sqerr_sigmoid_bwd launch. */
+int gm_linear_fwd_sqerr(void* stream, const float* X, int64_t ldx, const float* W, const float* bias,
+                        float* Y, int64_t ldy, int M, int K, int N, const float* target,
+                        int64_t ld_target, float* dA, int64_t lda, float* part, int64_t ldp);
+/* VAE reparameterisation backward where dz is produced (vae.py:100-106 `z = mu + eps * exp(log_var/2)`
+ * and kl_divergence :210-212, autograd of both): gm_linear_bwd_dx through the decoder's first layer
+ * (dZ = dA W, W: [N, Z]) whose epilogue also writes, with the expressions of gm_vae_reparam_bwd,
+ *   dml[m][c] = dz + mu,   dml[m][Z + c] = dz eps exp(lv/2) / 2 + (exp(lv) - 1) / 2.
+ * Replaces the separate gm_vae_reparam_bwd launch (bit-identical results). */
+int gm_linear_bwd_dx_reparam(void* stream, const float* dA, int64_t lda, const float* W, float* dZ,
+                             int64_t ldz, int M, int Z, int N, const float* ml, int64_t ldml,
+                             const float* eps, gm_slot eps_slot, float* dml, int64_t ldd);
 /* gm_linear_fwd that also writes WGAN-GP's interpolate for its first `rows` output rows
  * (w_gp_gan.py:197-201: x_hat = eps * x + (1 - eps) * G(z), computed where G(z) is produced):
  *   x_hat[m][n] = eps[m] * x_real[m][n] + (1 - eps[m]) * Y[m][n],  m < rows

@@ -298,8 +298,24 @@ def gen_vae_viz():
                                 train_kw=dict(num_epochs=3), rng=rng_digest(), torch=torch.__version__))
 
 
+def gen_round3():
+    """Round-3 fixture: BASELINE.json configs[4]'s NSGAN leg at its real batch,
+    NSGAN 784-400-20 B = 1024, 12 free-running D+G steps of the unmodified reference
+    (ns_gan.py:94-170) -- loss curves, per-tensor digests, final RNG position."""
+    tr, model = run_reference("ns", FULL, 1024, dict(num_epochs=1), steps_cap=12)
+    arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+    for k, v in model.state_dict().items():
+        arrays["digest:" + k] = digest(v)
+    save("ns_full_b1024", arrays, dict(variant="ns", cfg=FULL, batch=1024, steps=12,
+                                       train_kw=dict(num_epochs=1), rng=rng_digest(),
+                                       torch=torch.__version__))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["vae_viz"]:
+    if sys.argv[1:] == ["round3"]:
+        torch.set_num_threads(1)
+        gen_round3()
+    elif sys.argv[1:] == ["vae_viz"]:
         gen_vae_viz()
     elif sys.argv[1:] == ["round2"]:
         gen_round2()
@@ -312,3 +328,4 @@ if __name__ == "__main__":
         gen_ae()
         gen_bir()
         gen_round2()
+        gen_round3()

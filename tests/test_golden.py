@@ -23,7 +23,7 @@ def load(name):
 
 SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
                if not os.path.basename(p).startswith(("vae", "ae_", "bir_")))
-FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256", "ns_full_b256_50steps"]
+FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256", "ns_full_b256_50steps", "ns_full_b1024"]
 
 
 def run_port_gan(meta, batch, max_steps=None):

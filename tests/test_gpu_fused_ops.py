@@ -143,6 +143,65 @@ def test_sqerr_sigmoid_backward(B, I):
     assert abs(float(out[1]) - float(loss)) <= 1e-5 * float(loss) and float(out[0]) == 0.0
 
 
+@pytest.mark.parametrize("B,H,I", [(512, 400, 784), (336, 400, 784), (16, 48, 64), (40, 32, 36), (1024, 400, 784)])
+def test_reconstruction_loss_in_the_decoder_forward_epilogue(B, H, I):
+    """gm_linear_fwd_sqerr (vae.py:75-77 + :203): x_hat and dA bit-identical to gm_linear_fwd(sigmoid)
+    followed by gm_sqerr_sigmoid_bwd, the row-tile partials add up to sum (x - x_hat)^2, stale entries
+    of the partial array beyond this batch's rows are not read, and a relaunch reproduces every bit."""
+    torch.manual_seed(B + I)
+    x = (torch.rand(B, I) < 0.13).float().to(DEV)
+    h = torch.relu(torch.randn(B, H)).to(DEV)
+    W = (torch.randn(I, H) / H ** 0.5).to(DEV); b = (torch.randn(I) * 0.1).to(DEV)
+    y0, dA0, part0 = torch.empty(B, I, device=DEV), torch.empty(B, I, device=DEV), torch.empty(B, device=DEV)
+    ops.linear_fwd(h, W, b, y0, "sigmoid")
+    of.sqerr_sigmoid_bwd(x, y0, dA0, part0, B)
+    ldp = ((I + 31) // 32 + 3) // 4 * 4
+    part = torch.zeros(B + 8, ldp, device=DEV)
+    part[B:] = 77.0                                           # rows of an earlier, larger batch
+    y1, dA1 = torch.empty(B, I, device=DEV), torch.full((B, I), 5.0, device=DEV)
+    ops.linear_fwd_sqerr(h, W, b, y1, x, dA1, part, M=B)
+    torch.cuda.synchronize()
+    if B < 1024:
+        assert torch.equal(y0, y1) and torch.equal(dA0, dA1)
+    else:                                                     # gm_linear_fwd takes the LDS kernel there
+        assert rel(y1.cpu(), y0.cpu().double()) < 2e-6
+    ref_rows = ((x.double() - y1.double()) ** 2).sum(1).cpu()
+    assert rel(part[:B].double().sum(1).cpu(), ref_rows) < 2e-6
+    out = torch.zeros(2, device=DEV)
+    of.sum_finalize(part, B * ldp, out, out_slot=ops.slot(0, 0, 1, 0, 1))
+    assert abs(float(out[1]) - float(ref_rows.sum())) <= 2e-6 * float(ref_rows.sum()) and float(out[0]) == 0.0
+    p1 = part.clone()
+    ops.linear_fwd_sqerr(h, W, b, y1, x, dA1, part, M=B)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, part)
+
+
+@pytest.mark.parametrize("B,Z,H", [(512, 20, 400), (336, 20, 400), (16, 8, 48), (37, 4, 20)])
+def test_reparam_backward_in_the_dx_epilogue(B, Z, H):
+    """gm_linear_bwd_dx_reparam (autograd of vae.py:100-106,210-212 behind the decoder's first layer):
+    dz and d loss / d [mu | log_var] bit-identical to gm_linear_bwd_dx + gm_vae_reparam_bwd, reading the
+    noise through a ring slot."""
+    torch.manual_seed(B + Z)
+    dH = torch.randn(B, H).to(DEV)
+    W = (torch.randn(H, Z) / Z ** 0.5).to(DEV)
+    ml = (torch.randn(B, 2 * Z) * 0.5).to(DEV)
+    ring = torch.randn(3, B, Z).to(DEV)                       # eps ring, slot 2 is this step's
+    slot = ops.slot(0, 0, 2, 3, B * Z)
+    dz0, dml0 = torch.empty(B, Z, device=DEV), torch.empty(B, 2 * Z, device=DEV)
+    ops.linear_bwd_dx(dH, W, dz0)
+    of.vae_reparam_bwd(ml, ring.view(-1), dz0, dml0, B, Z, eps_slot=slot)
+    dz1, dml1 = torch.empty(B, Z, device=DEV), torch.full((B, 2 * Z), 3.0, device=DEV)
+    ops.linear_bwd_dx_reparam(dH, W, dz1, ml, ring.view(-1), dml1, eps_slot=slot)
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1) and torch.equal(dml0, dml1)
+    # and against autograd (fp64)
+    mu = ml[:, :Z].double().cpu().requires_grad_(True); lv = ml[:, Z:].double().cpu().requires_grad_(True)
+    z = mu + ring[2].double().cpu() * torch.exp(lv / 2)
+    kl = torch.sum(0.5 * (mu ** 2 + torch.exp(lv) - lv - 1))
+    (torch.sum(z * dz1.double().cpu()) + kl).backward()
+    assert rel(dml1[:, :Z].cpu(), mu.grad) < 5e-6 and rel(dml1[:, Z:].cpu(), lv.grad) < 5e-6
+
+
 @pytest.mark.parametrize("B,I", [(16, 64), (256, 784)])
 def test_std_all_is_the_unbiased_std_of_the_whole_batch(B, I):
     """images.data.std() (dra_gan.py:204): over all B*I elements, Bessel-corrected."""

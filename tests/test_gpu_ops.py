@@ -557,6 +557,171 @@ def test_dx_with_scalar_head_riding(B, I, Hd):
 
 
 # ---------------------------------------------------------------------------------------------
+# Folded critic head (round 3): the N = 1 layer has no launch of its own (include/gm_hip.h,
+# gm_head_fold_args): partial dots in the hidden layer's forward epilogue, scores / losses / dS rebuilt
+# in the consumers' prologues, dH formed in registers.  ns_gan.py:57-60,191-192,214.
+# ---------------------------------------------------------------------------------------------
+def _oracle_tail_loss(variant, s, B, gen_mode):
+    """The reference's loss lines on scores s (ns_gan.py:191-192,214; w_gan.py; ls_gan.py:192-193,213)."""
+    eps = 1e-8
+    if variant == "ns":
+        return -torch.mean(torch.log(s + eps)) if gen_mode else \
+            -torch.mean(torch.log(s[:B] + eps)) - torch.mean(torch.log(1 - s[B:] + eps))
+    if variant == "w":
+        return -torch.mean(s) if gen_mode else -(torch.mean(s[:B]) - torch.mean(s[B:]))
+    return 0.5 * torch.mean((s - 1.0) ** 2) if gen_mode else \
+        0.5 * torch.mean((s[:B] - 1.0) ** 2) + 0.5 * torch.mean((s[B:] - 0.0) ** 2)
+
+
+@pytest.mark.parametrize("M,I,Hd", [(512, 784, 400), (256, 784, 400), (48, 36, 20), (33, 30, 17), (2048, 784, 400)])
+def test_folded_head_forward_leaves_partial_dots_and_snapshot(M, I, Hd):
+    """gm_linear_fwd_headpart: the hidden layer is bit-identical to gm_linear_fwd's, the per-tile
+    partial dots add up to h . w2 (fp64 reference), the snapshot holds (w2, b2), and a second launch
+    reproduces every bit."""
+    from types import SimpleNamespace
+    torch.manual_seed(M + Hd)
+    X = torch.rand(M, I).to(DEV)
+    W1 = (torch.randn(Hd, I) / I ** 0.5).to(DEV); b1 = (torch.randn(Hd) * 0.1).to(DEV)
+    L2 = SimpleNamespace(W=(torch.randn(1, Hd) / Hd ** 0.5).to(DEV), b=torch.randn(1).to(DEV))
+    fold = ops.HeadFold(M, Hd, DEV)
+    Y0, Y1 = torch.empty(M, Hd, device=DEV), torch.full((M, Hd), -5.0, device=DEV)
+    ops.linear_fwd(X, W1, b1, Y0, "relu")
+    ops.linear_fwd_headpart(X, W1, b1, Y1, "relu", L2, fold)
+    torch.cuda.synchronize()
+    if M < 1024:
+        assert torch.equal(Y0, Y1)
+    else:                                           # gm_linear_fwd takes the LDS macro-tile kernel there: other summation order
+        close(Y1, Y0, 2e-6, "hidden layer")
+    assert torch.equal(fold.snap[:Hd], L2.W.view(-1)) and fold.snap[Hd].item() == L2.b.item()
+    ref = (Y1.double().cpu() @ L2.W.double().cpu().t())[:, 0]
+    assert bool((fold.part[:, fold.nparts:] == 0).all())
+    got = fold.part.double().cpu().sum(1)
+    scale = (Y1.abs().double().cpu() @ L2.W.abs().double().cpu().t())[:, 0].max().item()
+    assert (got - ref).abs().max().item() <= 2e-6 * scale
+    p1 = fold.part.clone()
+    fold.part[:, :fold.nparts].fill_(9.0)
+    ops.linear_fwd_headpart(X, W1, b1, Y1, "relu", L2, fold)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, fold.part)
+
+
+@pytest.mark.parametrize("variant,out_act", [("ns", "sigmoid"), ("w", "sigmoid"), ("ls", "sigmoid"), ("w", "id")])
+@pytest.mark.parametrize("B,I,Hd", [(256, 784, 400), (24, 36, 20), (512, 784, 400), (100, 64, 48)])
+def test_folded_head_critic_step(variant, out_act, B, I, Hd):
+    """Critic step tail, folded (2 launches: forward + partial dots; layer-1 weight gradient + Adam with
+    the head backward riding, dH formed in registers) against (a) autograd on the CPU through the
+    oracle's loss lines and (b) the unfolded 3-launch sequence: gradients, loss, Adam'd parameters."""
+    import torch.nn as nn
+    from generative_models_amd import ops_fused as of
+    from generative_models_amd.engine import FlatParams, _Linear
+    hyper = [0.0, 1.0, 1.0]
+
+    def run(folded):
+        torch.manual_seed(11)
+        net = nn.Sequential(nn.Linear(I, Hd), nn.Linear(Hd, 1))
+        ref = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+        fp = FlatParams(net.parameters(), DEV)
+        fp.m.normal_().mul_(1e-3); fp.v.uniform_(0.0, 1e-4)
+        L1, L2 = _Linear(fp, net[0]), _Linear(fp, net[1])
+        X2c = torch.bernoulli(torch.full((2 * B, I), 0.3))
+        X2 = X2c.to(DEV)
+        H = torch.empty(2 * B, Hd, device=DEV)
+        S = torch.zeros(2 * B, device=DEV); dS = torch.zeros_like(S); rl = torch.zeros_like(S)
+        loss = torch.zeros(1, device=DEV)
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(DEV)
+        adam = dict(sched=sched, sched_slot=ops.slot(0, 0, 2, 0, 1), clamp=0.0)
+        head = dict(H=H, lin=L2, loss_out=loss, loss_slot=ops.NO_SLOT, inv_b=1.0 / B, B=B, adam=adam)
+        if folded:
+            fold = ops.HeadFold(2 * B, Hd, DEV)
+            ops.linear_fwd_headpart(X2, L1.W, L1.b, H, "relu", L2, fold)
+            fa = fold.args(variant, out_act, hyper, S=S, dS=dS, rowloss=rl)
+            ops.linear_bwd_dw_adam_head_fold(H, X2, L1, adam, head, fa)
+        else:
+            dH = torch.empty(2 * B, Hd, device=DEV)
+            ops.linear_fwd(X2, L1.W, L1.b, H, "relu")
+            of.head_fwd_loss(variant, False, H, L2.W, L2.b, out_act, B, hyper, 1.0 / B, None, S, dS, rl, dH=dH)
+            ops.linear_bwd_dw_adam_head(dH, X2, L1, adam, dict(head, dS=dS, rowloss=rl))
+        torch.cuda.synchronize()
+        # CPU autograd through the reference's loss lines
+        h = torch.relu(X2c @ ref[0].t() + ref[1])
+        s = act_cpu(h @ ref[2].t() + ref[3], out_act)[:, 0]
+        lref = _oracle_tail_loss(variant, s, B, False)
+        lref.backward()
+        return dict(flat=fp.flat.clone(), grad=fp.grad.clone(), m=fp.m.clone(), v=fp.v.clone(), loss=loss.clone(),
+                    S=S.clone(), dS=dS.clone(), rl=rl.clone(), views=[g.clone() for g in fp.gviews],
+                    ref_grads=[p.grad for p in ref], ref_loss=lref.detach(), ref_s=s.detach())
+
+    a, b = run(True), run(False)
+    close(a["loss"][0], a["ref_loss"], 1e-5, "loss vs autograd", atol=1e-6)
+    close(a["S"], a["ref_s"], 1e-5, "scores vs autograd")
+    for g, r, n in zip(a["views"], a["ref_grads"], ("gW1", "gb1", "gw2", "gb2")):
+        close(g, r, 2e-5, n + " vs autograd", atol=2e-8)
+    for k in ("grad", "flat", "m", "v", "loss", "S", "dS", "rl"):
+        close(a[k], b[k], 2e-5, k + " folded vs unfolded", atol=2e-8)
+    a2 = run(True)                                  # bitwise reproducible launch after launch
+    for k in ("grad", "flat", "m", "v", "loss", "S", "dS", "rl"):
+        assert torch.equal(a[k], a2[k]), k
+
+
+@pytest.mark.parametrize("variant,out_act", [("ns", "sigmoid"), ("ls", "sigmoid"), ("w", "id")])
+@pytest.mark.parametrize("B,I,Hd", [(256, 784, 400), (24, 36, 20), (100, 64, 48), (33, 36, 20)])
+def test_folded_head_generator_step(variant, out_act, B, I, Hd):
+    """Generator step, folded: forward + partial dots, then dX through layer 1 with the loss / tick
+    workgroup riding (dH formed in registers) against autograd on the CPU and the unfolded sequence;
+    the counter advances exactly once."""
+    from types import SimpleNamespace
+    from generative_models_amd import ops_fused as of
+    torch.manual_seed(B + I)
+    hyper = [0.0, 1.0, 1.0]
+    Xc = torch.rand(B, I).requires_grad_(True)
+    W1c = torch.randn(Hd, I) / I ** 0.5; b1c = torch.randn(Hd) * 0.1
+    w2c = torch.randn(1, Hd) / Hd ** 0.5; b2c = torch.randn(1)
+    s = act_cpu(torch.relu(Xc @ W1c.t() + b1c) @ w2c.t() + b2c, out_act)[:, 0]
+    lref = _oracle_tail_loss(variant, s, B, True)
+    lref.backward()
+    Xg, W1, b1 = Xc.detach().to(DEV), W1c.to(DEV), b1c.to(DEV)
+    L2 = SimpleNamespace(W=w2c.to(DEV), b=b2c.to(DEV))
+    below = torch.rand(B, I).to(DEV)                      # sigmoid output of the layer below (its gradient epilogue)
+    H = torch.empty(B, Hd, device=DEV)
+    fold = ops.HeadFold(B, Hd, DEV)
+    S = torch.zeros(B, device=DEV); dS = torch.zeros(B, device=DEV); rl = torch.zeros(B, device=DEV)
+    ctr = torch.ones(1, dtype=torch.int64, device=DEV)
+    loss = torch.zeros(3, device=DEV); dX = torch.empty(B, I, device=DEV)
+    ops.linear_fwd_headpart(Xg, W1, b1, H, "relu", L2, fold)
+    ops.linear_bwd_dx_head_fold(H, W1, dX, dict(H=H, lin=L2, loss_out=loss, loss_slot=ops.slot(ctr.data_ptr(), 1, 0, 3, 1),
+                                                inv_b=1.0 / B, B=B, gen_mode=True, tick=ctr),
+                                fold.args(variant, out_act, hyper, S=S, dS=dS, rowloss=rl), below=below, epi="sigmoid")
+    torch.cuda.synchronize()
+    assert ctr.item() == 2
+    close(loss[1], lref.detach(), 1e-5, "loss vs autograd", atol=1e-6)
+    b_ = below.cpu()
+    close(dX, Xc.grad * (b_ * (1 - b_)), 2e-5, "dX vs autograd", atol=2e-9)
+    # unfolded sequence on the same inputs
+    S2 = torch.empty(B, device=DEV); dS2 = torch.empty(B, device=DEV); rl2 = torch.empty(B, device=DEV)
+    dH = torch.empty(B, Hd, device=DEV); dX2 = torch.empty(B, I, device=DEV); loss2 = torch.zeros(1, device=DEV)
+    of.head_fwd_loss(variant, True, H, L2.W, L2.b, out_act, B, hyper, 1.0 / B, None, S2, dS2, rl2, dH=dH)
+    of.head_bwd(H, dS2, L2.W, rl2, None, None, None, loss2, ops.NO_SLOT, 1.0 / B, True, B)
+    ops.linear_bwd_dx(dH, W1, dX2, below=below, epi="sigmoid")
+    close(dX, dX2, 2e-5, "dX folded vs unfolded", atol=2e-9)
+    close(S, S2, 1e-5, "scores"); close(dS, dS2, 2e-5, "dS", atol=1e-9); close(rl, rl2, 1e-5, "row losses", atol=1e-7)
+    close(loss[1], loss2[0], 1e-5, "loss folded vs unfolded", atol=1e-6)
+
+
+def test_folded_head_refuses_shapes_it_cannot_carry():
+    """No silent fallback: widths that are not multiples of 4 (no 16-byte operand path) raise."""
+    from types import SimpleNamespace
+    from generative_models_amd._lib import GMError
+    B, I, Hd = 8, 30, 17
+    H = torch.zeros(B, Hd, device=DEV); W1 = torch.zeros(Hd, I, device=DEV); dX = torch.zeros(B, I, device=DEV)
+    L2 = SimpleNamespace(W=torch.zeros(1, Hd, device=DEV), b=torch.zeros(1, device=DEV))
+    fold = ops.HeadFold(B, Hd, DEV)
+    loss = torch.zeros(1, device=DEV)
+    with pytest.raises(GMError):
+        ops.linear_bwd_dx_head_fold(H, W1, dX, dict(H=H, lin=L2, loss_out=loss, loss_slot=ops.NO_SLOT, inv_b=1.0 / B,
+                                                    B=B, gen_mode=True), fold.args("ns", "sigmoid"))
+
+
+# ---------------------------------------------------------------------------------------------
 # Bit-packed resident dataset (SURVEY.md 8f item 1; utils.py:31 binarises MNIST): the gather from
 # 1 bit / pixel rows must equal the gather from the fp32 rows, on its own and riding in a GEMM launch
 # ---------------------------------------------------------------------------------------------

@@ -300,8 +300,8 @@ def test_engine_vs_reference_golden(name):
         # 50-step FREE-RUNNING NSGAN B=256 curve.  Two fp32 summation orders of the
         # same math drift apart chaotically on this horizon (survey probe: 1.6e-5 between 1 and 8
         # CPU threads of the reference itself), so the bound here is stated, not the 1e-5 of the
-        # short horizons: first 24 steps <= 1e-5, all 50 steps <= 5e-5; the measured value is
-        # written to gpurun_out/parity_50step.json and quoted in DESIGN.md.
+        # short horizons on paper; the measured value is written to gpurun_out/parity_50step.json,
+        # quoted in DESIGN.md and asserted below with a 10x margin.
         g, d = np.asarray(p_tr.Glosses), np.asarray(p_tr.Dlosses)
         eg = np.abs(g - z["Glosses"]) / np.maximum(1, np.abs(z["Glosses"]))
         ed = np.abs(d - z["Dlosses"]) / np.maximum(1, np.abs(z["Dlosses"]))
@@ -311,7 +311,9 @@ def test_engine_vs_reference_golden(name):
                        "max_rel_err_G_24": float(eg[:24].max()), "max_rel_err_D_24": float(ed[:24].max())},
                       open(os.path.join(out, "parity_50step.json"), "w"))
         assert max(eg[:24].max(), ed[:24].max()) <= TOL, (eg[:24].max(), ed[:24].max())
-        assert max(eg.max(), ed.max()) <= 5e-5, (eg.max(), ed.max())
+        # the MEASURED margin is asserted, not the loose bound: 1.9e-7 in round 2's kernels; 2e-6 leaves
+        # room for a different summation order (e.g. the folded head's) without hiding a real defect
+        assert max(eg.max(), ed.max()) <= 2e-6, (eg.max(), ed.max())
     else:
         lclose(p_tr.Glosses, z["Glosses"], name + " Glosses")
         lclose(p_tr.Dlosses, z["Dlosses"], name + " Dlosses")
@@ -913,3 +915,80 @@ def test_full_size_engine_vs_oracle(variant, kw):
     for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
         d = (a.cpu() - b).abs()
         assert d.max().item() <= 2e-4 and d.mean().item() <= 1e-6, (k, d.max().item(), d.mean().item())
+
+
+# ---------------------------------------------------------------------------------------------
+# The four BASELINE.json GPU configurations, TENSOR BY TENSOR against the CPU oracle (oracle/port.py,
+# pinned bit for bit to the unmodified reference) after >= 12 free-running steps: NSGAN bs=256,
+# WGAN-GP bs=256, NSGAN / LSGAN bs=1024 (ns_gan.py:94-170, w_gp_gan.py:96-175, ls_gan.py:95-171) and
+# the VAE at bs=512 over epochs that end with the ragged 336 batch (vae.py:127-191).  The golden
+# fixtures of these configurations only carry per-tensor digests.
+# ---------------------------------------------------------------------------------------------
+BASELINE_GAN_CASES = [("ns", 256, dict(num_epochs=1)), ("wgp", 256, dict(num_epochs=1, D_steps=1)),
+                      ("ls", 1024, dict(num_epochs=1)), ("ns", 1024, dict(num_epochs=1))]
+
+
+def _param_check(model, o_model, what):
+    """One Adam step for the worst element (weights whose gradient is O(eps_adam) turn summation-order
+    noise into a fraction of a step), 1e-6 on average, and 2e-5 for all but a handful of elements."""
+    for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
+        d = (a.cpu() - b).abs()
+        frac = float((d > 2e-5).float().mean())
+        assert d.max().item() <= 2e-4 and d.mean().item() <= 1e-6 and frac <= 1e-4, \
+            (what, k, d.max().item(), d.mean().item(), frac)
+
+
+@pytest.mark.parametrize("variant,batch,kw", BASELINE_GAN_CASES,
+                         ids=["%s_b%d" % (v, b) for v, b, _ in BASELINE_GAN_CASES])
+def test_baseline_configs_parameters_tensor_by_tensor(variant, batch, kw):
+    steps = 12
+
+    class Capped(torch.utils.data.DataLoader):
+        def __len__(self):
+            return steps * kw.get("D_steps", 1)
+
+    def loaders():
+        ld = port.synthetic_loaders(batch, n_train=FULLCFG["n_train"], n_val=256, n_test=256,
+                                    image_shape=FULLCFG["image_shape"])
+        return (Capped(ld[0].dataset, batch_size=batch, shuffle=True),) + ld[1:]
+
+    o_model = port.build(variant, 784, 400, 20)
+    o = port.GANPort(variant, o_model, loaders()[0])
+    o.train(**kw)
+    o_rng = torch.get_rng_state()
+    tr, model = build_product(variant, FULLCFG, batch, loaders=loaders())
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**kw)
+    torch.cuda.synchronize()
+    assert tr._engine is not None and len(tr.Glosses) == steps
+    lclose(tr.Dlosses, o.Dlosses, "%s bs=%d Dlosses" % (variant, batch))
+    lclose(tr.Glosses, o.Glosses, "%s bs=%d Glosses" % (variant, batch))
+    assert torch.equal(o_rng, torch.get_rng_state())
+    _param_check(model, o_model, "%s bs=%d" % (variant, batch))
+
+
+def test_vae_b512_ragged_parameters_tensor_by_tensor():
+    """VAE 784-400-20, B = 512, n = 3 * 512 + 336: three epochs = 12 training batches, every epoch
+    ending with the ragged 336 batch of the real 50 000-image run, + the per-epoch validation pass."""
+    import vae
+    n_train = 512 * 3 + 336
+    mk = lambda: port.synthetic_loaders(512, n_train=n_train, n_val=512, n_test=512, image_shape=(1, 28, 28))
+    o_model = port.build("vae", 784, 400, 20)
+    o = port.VAEPort(o_model, *mk())
+    o.train(3)
+    o_rng = torch.get_rng_state()
+    ld = mk()
+    torch.manual_seed(1234)
+    model = vae.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = vae.VAETrainer(model, *ld, viz=False)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=3)
+    torch.cuda.synchronize()
+    assert len(tr.recon_loss) == 12
+    lclose(tr.recon_loss, o.recon_loss, "VAE recon", tol=2e-5)
+    lclose(tr.kl_loss, o.kl_loss, "VAE kl", tol=2e-5)
+    assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-5 * abs(o.best_val_loss)
+    assert torch.equal(o_rng, torch.get_rng_state())
+    _param_check(model, o_model, "VAE bs=512 ragged")
