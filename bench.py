@@ -83,18 +83,37 @@ def gemm_shapes(B, fused_head=True, batch_gen=True, group_head=True, ride_gather
             [("dxh" if (fused_head and ride_head_dx) else "dx", B, IMG, HID), ("dx", B, HID, IMG)] + g_dw)
 
 
+def gemm_shapes_wgp(B, fold_g=True):
+    """Every GEMM launch of one WGAN-GP iteration at D_steps = 1 (engine._issue_gp_forward / _D_rest with
+    the stacked layer-1 weight gradient): "dwhs" = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows + head."""
+    g = [("fwdp", B, IMG, HID), ("dxhf", B, IMG, HID)] if fold_g else [("fwd", B, IMG, HID), ("dxh", B, IMG, HID)]
+    return ([("fwdg", 2 * B, Z, HID), ("fwd", 2 * B, HID, IMG),           # G(zD), G(zG) (+ gather, + x_hat epilogue)
+             ("fwd", 2 * B, IMG, HID), ("fwd", B, IMG, HID),              # D on [x ; G(z)], D layer 1 on x_hat
+             ("dx", B, IMG, HID), ("fwd", B, IMG, HID),                   # g = u W1 ; t = gamma W1^T
+             ("dwhs", 3 * B, IMG, HID)] + g + [("dx", B, HID, IMG), ("dwp", B, HID, IMG)])
+
+
+def gemm_shapes_vae(B):
+    """Every GEMM launch of one VAE training batch (engine.VAEEngine._issue): "fwds" = decoder output
+    layer + reconstruction loss epilogue, "dxr" = dX through the decoder's first layer + reparameterisation
+    backward epilogue; the two weight-gradient pairs carry their second GEMM's (N2, K2)."""
+    return [("fwd", B, IMG, HID), ("fwdg", B, HID, 2 * Z), ("fwd", B, Z, HID), ("fwds", B, HID, IMG),
+            ("dx", B, HID, IMG), ("dxr", B, Z, HID), ("dwp", B, HID, IMG, (HID, Z)),
+            ("dx", B, HID, 2 * Z), ("dwp", B, IMG, HID, (2 * Z, HID))]
+
+
 def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
     load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
-    if kind in ("fwd", "fwdg", "fwdp"):
+    if kind in ("fwd", "fwdg", "fwdp", "fwds"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
-    elif kind in ("dx", "dxh", "dxhf"):
+    elif kind in ("dx", "dxh", "dxhf", "dxr"):
         mode, Mg, Ng, Kr, vec, xv = 1, M, K, N, N % 4 == 0, K % 4 == 0
     else:
         mode, Mg, Ng, Kr, vec = 2, N, K + 1, M, False
         xv = N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
-    if kind in ("fwd", "dx", "dxh", "fwdg") and Mg >= LDS_MIN_M and Kr >= 64 and Ng >= 32 and vec and (mode == 0 or xv):
+    if kind in ("fwd", "dx", "dxh", "fwdg", "dxr") and Mg >= LDS_MIN_M and Kr >= 64 and Ng >= 32 and vec and (mode == 0 or xv):
         # many-row launches: the LDS-staged macro-tile kernel (riders get their own launch)
         cands = [(64, 64, "64, 64, 32, 64, 4, 1, 4"), (32, 64, "32, 64, 32, 32, 4, 1, 4")]
         cost = lambda c: (-(-(-(-Mg // c[0]) * -(-Ng // c[1])) // 256)) * c[0] * c[1]
@@ -111,9 +130,10 @@ def gemm_variant(kind, M, K, N):
     elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
         mi, ni = 1, 2
     b = lambda v: "true" if v else "false"
-    if kind in ("dwh", "dwhf"):
+    if kind in ("dwh", "dwhf", "dwhs"):
         # last two arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded head
-        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, false, %s>" % (g, b(xv), mi, ni, b(kind == "dwhf"))
+        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, %s, %s>" % (g, b(xv), mi, ni, b(kind == "dwhs"),
+                                                                         b(kind == "dwhf"))
     if kind in ("dxh", "dxhf"):
         assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_dx_head_kernel<%d, %d, %d, %s>" % (g, mi, ni, b(kind == "dxhf"))
@@ -157,8 +177,10 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
     out = {}
     st = ops.stream_ptr()
     data = idx = xr = None
-    for kind, M, K, N in (shapes or gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather,
-                                                pair_dw, ride_head_dx, fold_head)):
+    for shape in (shapes or gemm_shapes(B, fused_head, batch_gen, group_head, ride_gather,
+                                        pair_dw, ride_head_dx, fold_head)):
+        kind, M, K, N = shape[:4]
+        extra = shape[4] if len(shape) > 4 else None
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         dA = torch.randn(M, N, device=dev)
@@ -170,6 +192,13 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
         flop = 2.0 * M * K * N
         if kind == "fwd":
             fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st)
+        elif kind == "fwds":                    # sigmoid output layer + reconstruction loss epilogue
+            tgt = (torch.rand(M, N, device=dev) < 0.13).float()
+            part2 = torch.zeros(M, (-(-N // 32) + 3) // 4 * 4, device=dev)
+            fn = lambda: ops.linear_fwd_sqerr(x, W, b, y, tgt, dA, part2, stream=st)
+        elif kind == "dxr":                     # dX (layer [N, K]: K = z_dim) + reparameterisation backward
+            mlz, epz, dmlz = torch.randn(M, 2 * K, device=dev), torch.randn(M * K, device=dev), torch.empty(M, 2 * K, device=dev)
+            fn = lambda: ops.linear_bwd_dx_reparam(dA, W, dX, mlz, epz, dmlz, stream=st)
         elif kind in ("fwdp", "dwhf", "dxhf"):
             # the folded head's launches on a consistent state: forward first (partial dots, snapshot)
             L1, L2 = _holder(N, K, dev), _holder(1, N, dev)
@@ -203,24 +232,31 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
                         inv_b=1.0 / M, B=M, gen_mode=True)
             fn = lambda: ops.linear_bwd_dx_head(dA, W, dX, head, below=x, epi="relu", stream=st)
         elif kind == "dwp":
-            L2, L1 = _holder(N, K, dev), _holder(K, Z, dev)
-            dH2, zz = torch.randn(M, K, device=dev), torch.randn(M, Z, device=dev)
+            N2, K2 = extra if extra is not None else (K, Z)       # second GEMM: dW of a [N2, K2] layer
+            L2, L1 = _holder(N, K, dev), _holder(N2, K2, dev)
+            dH2, zz = torch.randn(M, N2, device=dev), torch.randn(M, K2, device=dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
             ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
             fn = lambda: ops.linear_bwd_dw_adam_pair(dict(dA=dA, X=x, lin=L2, adam=ad),
                                                      dict(dA=dH2, X=zz, lin=L1, adam=ad), stream=st)
-            flop += 2.0 * M * Z * K
+            flop += 2.0 * M * N2 * K2
         elif kind == "dx":
             fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
-        elif kind == "dwh":
+        elif kind in ("dwh", "dwhs"):
             L1, L2 = _holder(N, K, dev), _holder(1, N, dev)
             Hh = torch.relu(torch.randn(M, N, device=dev))
             dS, rl, lo = torch.randn(M, device=dev) / M, torch.rand(M, device=dev), torch.zeros(1, device=dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
             ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
-            head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
-                        inv_b=2.0 / M, B=M // 2, adam=ad)
-            fn = lambda: ops.linear_bwd_dw_adam_head(dA, x, L1, ad, head, stream=st)
+            if kind == "dwhs":                  # stacked reduction: rows [0, M/3) do not reach db; head over 2M/3 rows
+                Hh, dS, rl = Hh[:2 * M // 3], dS[:2 * M // 3], rl[:2 * M // 3]
+                head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
+                            inv_b=3.0 / M, B=M // 3, adam=ad, gw2_add=torch.zeros(N, device=dev))
+                fn = lambda: ops.linear_bwd_dw_adam_head(dA, x, L1, ad, head, ones_from=M // 3, stream=st)
+            else:
+                head = dict(H=Hh, dS=dS, lin=L2, rowloss=rl, loss_out=lo, loss_slot=ops.NO_SLOT,
+                            inv_b=2.0 / M, B=M // 2, adam=ad)
+                fn = lambda: ops.linear_bwd_dw_adam_head(dA, x, L1, ad, head, stream=st)
         else:                                   # as in the step: Adam in the gradient epilogue
             L1 = _holder(N, K, dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
@@ -459,15 +495,40 @@ def mfma_busy_frac(kernel, launch_us, mhz):
         return None
 
 
-def dominant_gemm_roofline(M, K, N, reps=50):
-    """Isolated HIP-event timing of the forward GEMM [M,K]x[K,N] (the largest contraction of the
-    config) -> roofline entry."""
-    kt = time_kernels_isolated(0, reps=reps, shapes=[("fwd", M, K, N)])
-    (name, (us, flop, n)), = kt.items()
+def dominant_gemm_roofline(shapes, B, pmc_tag=None, reps=50):
+    """Roofline entry of a configuration: EVERY GEMM launch shape of its step is timed in isolation
+    (HIP events over graph-captured back-to-back launches, as for the headline) and the kernel
+    instantiation with the largest time share of the step is reported -- not a fixed forward shape.
+    traffic: that kernel's bytes per dispatch from the committed PMC pass of this configuration."""
+    kt = time_kernels_isolated(B, reps=reps, shapes=shapes)
+    name = max(kt, key=lambda k: kt[k][0])
+    us, flop, n = kt[name]
     ach = flop / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": name, "shape": "fwd %dx%dx%d" % (M, K, N), "avg_launch_us": us,
-            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP32_MFMA_TFLOPS}
+    e = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": us / n,
+         "us_per_step": us, "shapes": ["%s %dx%dx%d" % tuple(sh[:4]) for sh in shapes
+                                       if gemm_variant(*sh[:4]) == name],
+         "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+         "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}}
+    e["traffic"], e["traffic_source"] = pmc_traffic(name, pmc_tag)
+    return e
+
+
+def pmc_traffic(kernel, tag):
+    """Bytes per dispatch (2 x FETCH_SIZE gfx950 correction + WRITE_SIZE) of `kernel` from the committed
+    PMC pass profiles/<round>_<tag>_pmc_traffic.json (PMC counters cannot be read from inside this
+    process); (None, None) when the pass does not list the kernel."""
+    if tag is None:
+        return None, None
+    src = "%s_%s_pmc_traffic.json" % (PROFILE_ROUND, tag)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", src)))
+        rows = [v for k, v in pmc.items() if k.split("|")[0] == kernel]
+        if not rows:
+            return None, None
+        nd = sum(v["dispatches"] for v in rows)
+        return sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in rows) / nd, "profiles/" + src
+    except Exception:                                # noqa: BLE001
+        return None, None
 
 
 def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
@@ -484,7 +545,10 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
         e = {"workload": name, "img_s": K * B / dt, "ms_per_step": dt / K * 1e3, "steps": K,
              "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
              "step_mfma_frac": K * B / dt * flop_per_image / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-             "roofline": dominant_gemm_roofline(2 * B, IMG, HID)}
+             "roofline": dominant_gemm_roofline(
+                 gemm_shapes_wgp(B, eng._fold_head_G()) if variant == "wgp" else
+                 gemm_shapes(B, fold_head=eng._fold_head()), B,
+                 pmc_tag={"wgp": "wgp_b256", "ns": "ns_b1024"}.get(variant))}
         if cpu:
             e["cpu_baseline"] = cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)
         log("%s: %.0f img/s" % (name, e["img_s"]))
@@ -527,7 +591,7 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
                                                          if with_eval else "train loop only"),
              "img_s": img_s, "ms_per_step": ms, "steps": n,
              "step_mfma_frac": img_s * 3_280_000 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-             "roofline": dominant_gemm_roofline(512, IMG, HID)}
+             "roofline": dominant_gemm_roofline(gemm_shapes_vae(512), 512, pmc_tag="vae_b512")}
         if cpu and not with_eval:
             e["cpu_baseline"] = cpu_baseline_vae(512)
         log("%s: %.0f img/s" % (e["workload"], img_s))
@@ -700,18 +764,7 @@ def main():
         # HBM/fabric bytes per launch of that kernel from the COMMITTED PMC pass (profiles/: FETCH_SIZE
         # x2 gfx950 correction + WRITE_SIZE per dispatch; PMC counters cannot be read from inside this
         # process) -- the source file is named next to the number
-        traffic, traffic_src = None, None
-        for cand in (PROFILE_ROUND + "_nsgan_b256_pmc_traffic.json",):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                rows = [v for k, v in pmc.items() if k.split("|")[0] == dom]
-                if rows:
-                    nd = sum(v["dispatches"] for v in rows)
-                    traffic = sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in rows) / nd
-                    traffic_src = "profiles/" + cand
-                    break
-            except Exception:
-                continue
+        traffic, traffic_src = pmc_traffic(dom, "nsgan_b256")
         achieved = flop / (t_us * 1e-6) / 1e12
         line = {
             "metric": "images/sec (28x28 MNIST) per D+G step, NSGAN bs=256",

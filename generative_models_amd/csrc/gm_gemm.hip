@@ -38,6 +38,23 @@
 
 #include <cstdlib>
 
+// Compile-time experiment switches of the 16x16x4 body (tools/build_variant.sh builds a library per
+// setting; a RUNTIME flag inside the reduction loop distorts what it measures: with three such flags
+// in the loop the default path's dW at 2048 rows went from 32 to 50 us -- profiles/r03_experiments.md):
+//   GM_XDIRECT          x-contiguous operands as direct dword fragments: 1 everywhere, 2 in the dX GEMM only
+//                       (its W operand), 0: 16-byte loads + quad transposes
+//   GM_EXP_BATCH_LOADS  1: all of a wave's chunk loads issued back to back (measured slower)
+//   GM_EXP_ABLATE       timing only -- 1: no MFMA, 2: no operand loads, 3: no cross-wave reduction / epilogue
+#ifndef GM_XDIRECT
+#define GM_XDIRECT 0
+#endif
+#ifndef GM_EXP_BATCH_LOADS
+#define GM_EXP_BATCH_LOADS 0
+#endif
+#ifndef GM_EXP_ABLATE
+#define GM_EXP_ABLATE 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -72,7 +89,6 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
-    int batch_loads;          // gemm16 kernels: all of a wave's chunk loads up front (GM_BATCH_LOADS, experiment)
     // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
     // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
     const float* ip_eps; gm_slot ip_slot;
@@ -647,6 +663,21 @@ int launch_lds_cfg(hipStream_t s, GemmP p) {
     const int S = (p.K + C::BK - 1) / C::BK;
     static int unroll_on = -1;
     if (unroll_on < 0) { const char* e = getenv("GM_LDS_UNROLL"); unroll_on = e ? atoi(e) : 1; }
+    if constexpr (MODE == MODE_DW) {
+        // weight gradients reduce over the batch rows: fully unrolled stage counts for the row counts of
+        // this model's steps (B, 2B for B = 256 ... 1024): counted waits and static LDS addressing, as for
+        // the forward's K = 784 / 400 (the runtime loop drains vmcnt on its back-edge)
+        if (unroll_on && S * C::BK == p.K) {
+            switch (S) {
+#define GM_LDS_DW_NS(n) case n: hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, n>), grid, block, 0, s, p); GM_LAUNCH_RET();
+            GM_LDS_DW_NS(8) GM_LDS_DW_NS(16) GM_LDS_DW_NS(32) GM_LDS_DW_NS(64)
+#undef GM_LDS_DW_NS
+            default: break;
+            }
+        }
+        hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, 0>), grid, block, 0, s, p);
+        GM_LAUNCH_RET();
+    }
     if (unroll_on && S == NS784) hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, NS784>), grid, block, 0, s, p);
     else if (unroll_on && S == NS400) hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, NS400>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_lds_kernel<MODE, BM, BN, WTM, WTN, WK, KU, PD, 0>), grid, block, 0, s, p);
@@ -809,6 +840,18 @@ __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_
     return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
 }
 
+// DIRECT fragment of an x-contiguous operand (GM_XDIRECT): lane (i = lane & 15, g = lane >> 4) loads the four
+// dwords P[(kb + j) * ld + x], j = 0..3, kb = 16c + 4g -- exactly the element the j-th MFMA of the chunk wants
+// from this lane, so there is nothing to transpose (each load instruction is 4 k-rows x 64 coalesced bytes).
+// The 16-byte + quad-transpose form above costs ~30 VALU instructions per fragment; ISA count of the dW loop:
+// 250 VALU instructions per 32 MFMAs, and the ablation without operand loads still took 28 us of the 36 us
+// K = 2048 launch (pipe time of its MFMAs: 14.4 us) -- the transposes and the MFMAs do not overlap.
+__device__ __forceinline__ float4 raw_xd(const float* __restrict__ P, int64_t ld, int x, int X, int kb, int K) {
+    const float* col = P + min(x, X - 1);
+    return make_float4(col[(int64_t)min(kb + 0, K - 1) * ld], col[(int64_t)min(kb + 1, K - 1) * ld],
+                       col[(int64_t)min(kb + 2, K - 1) * ld], col[(int64_t)min(kb + 3, K - 1) * ld]);
+}
+
 // MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
 // (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
 // rounds of one workgroup per CU): one round, 6 fragment loads per 32 MFMAs instead of 4 per 16.
@@ -833,6 +876,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;
     const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
     const int nchunks = (p.K + 15) >> 4;
+    constexpr bool xdirect = (GM_XDIRECT == 1) || (GM_XDIRECT == 2 && MODE == MODE_DX);
 
     // folded head: what stays fixed per lane across the reduction
     float4 fw[FOLD == 1 ? MI : 1];
@@ -846,6 +890,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     auto load_a = [&](int c, int mi) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = m0 + 16 * mi;
         if (MODE == MODE_DW) {
+            if (XV && xdirect && FOLD == 0) return raw_xd(A, p.lda, x0 + i16, p.M, kb, p.K);
             if (XV) return raw_xc4_16(A, p.lda, x0, p.M, c, p.K, lane);
             return raw_xc(A, p.lda, x0 + i16, p.M, kb, p.K);
         }
@@ -854,6 +899,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     auto load_b = [&](int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = n0 + 16 * ni;
         if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
+        if (XV && xdirect) return raw_xd(B, p.ldb, x0 + i16, b_cols, kb, p.K);
         if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
         return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
     };
@@ -862,13 +908,13 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         if constexpr (FOLD == 1)                              // the loaded row is k = 16c + 4g + e (clamped)
             v = fold_dh4(v, sds[min(16 * c + 4 * g4 + (lane & 3), p.K - 1)], fw[mi]);
         if constexpr (FOLD == 2) v = fold_dh4(v, fds[mi], wk);
-        if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
+        if (MODE == MODE_DW) return fix_xc((XV && !(xdirect && FOLD == 0)) ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
         return fix_kc(v, x, p.M, kb, p.K);
     };
     auto fix_b = [&](float4 v, int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
         if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
+        return fix_xc((XV && !xdirect) ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
     };
 
     f32x4 acc[MI][NI];
@@ -891,6 +937,15 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[mi], cq, mi, wk);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ni] = fix_b(rb[ni], cq, ni);
+#if GM_EXP_ABLATE == 1                                       // experiment: operands arrive and are fixed up, no MFMA
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            asm volatile("" ::"v"(fa[mi].x), "v"(fa[mi].y), "v"(fa[mi].z), "v"(fa[mi].w));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            asm volatile("" ::"v"(fb[ni].x), "v"(fb[ni].y), "v"(fb[ni].z), "v"(fb[ni].w));
+        return;
+#endif
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -940,13 +995,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         if (have) consume(ra, rb, wk, 0);
         q_first = 1;
     }
-    // GM_BATCH_LOADS (experiment, off): a wave with at most BMAX chunks issues ALL its operand loads back to
-    // back (unconditional, clamped chunk index) and then consumes them in order -- one exposed trip to
-    // L2 / MALL instead of one per chunk.  Round 1 measured batching slower on back-to-back launches of
-    // one kernel; this switch exists to measure it inside the real step, where every launch starts
-    // with invalidated L2s.
+#if GM_EXP_BATCH_LOADS
+    // Experiment: a wave with at most BMAX chunks issues ALL its operand loads back to back (unconditional,
+    // clamped chunk index) and then consumes them in order.  Measured inside the real step: 75.1 -> 87.9 us.
     constexpr int BMAX = (MI * NI <= 4) ? 4 : 2;
-    if (FOLD == 0 && p.batch_loads && nq <= BMAX) {           // kernel-argument / wave uniform
+    if (FOLD == 0 && nq <= BMAX) {                            // wave uniform
         float4 ra[BMAX][MI], rb[BMAX][NI];
 #pragma unroll
         for (int q = 0; q < BMAX; ++q) {
@@ -959,18 +1012,37 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 #pragma unroll
         for (int q = 0; q < BMAX; ++q)
             if (q < nq) consume(ra[q], rb[q], make_float4(0.f, 0.f, 0.f, 0.f), q);
-    } else {
-        for (int q = q_first; q < nq; ++q) {
-            float4 ra[MI], rb[NI];
-            const int cc = w + q * WAVES;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
-            const float4 wk = load_wk(cc);
-            consume(ra, rb, wk, q);
-        }
+        q_first = nq;
     }
+#endif
+    for (int q = q_first; q < nq; ++q) {
+        float4 ra[MI], rb[NI];
+        const int cc = w + q * WAVES;
+#if GM_EXP_ABLATE == 2                                       // experiment: no operand loads, MFMA chain only
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = make_float4(1.f + lane, 2.f, 3.f + cc, 4.f);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) rb[ni] = make_float4(1.f, 1.f + cc, 1.f, 1.f + lane);
+#else
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+#endif
+        const float4 wk = load_wk(cc);
+        consume(ra, rb, wk, q);
+    }
+#if GM_EXP_ABLATE == 3                                       // experiment: no cross-wave reduction / epilogue
+    {
+        float sink = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sink += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (sink == 123456.789f) red[t] = sink;
+        return;
+    }
+#endif
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
     static_assert(NI % 2 == 0 && (MI == 1 || MI % 2 == 0), "tile shapes: 16xN or 32-multiples");
@@ -1098,11 +1170,6 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     // silently run without it
     const bool folded = head && head->fold.enabled;
     GemmP p = p_in;
-    {
-        static int bl = -1;
-        if (bl < 0) { const char* e = getenv("GM_BATCH_LOADS"); bl = e ? atoi(e) : 0; }
-        p.batch_loads = bl;
-    }
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
@@ -1245,7 +1312,6 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
                 GemmP pb = *rider.pair;
-                pb.batch_loads = p.batch_loads;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);

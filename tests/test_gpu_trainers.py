@@ -928,13 +928,14 @@ BASELINE_GAN_CASES = [("ns", 256, dict(num_epochs=1)), ("wgp", 256, dict(num_epo
                       ("ls", 1024, dict(num_epochs=1)), ("ns", 1024, dict(num_epochs=1))]
 
 
-def _param_check(model, o_model, what):
-    """One Adam step for the worst element (weights whose gradient is O(eps_adam) turn summation-order
-    noise into a fraction of a step), 1e-6 on average, and 2e-5 for all but a handful of elements."""
+def _param_check(model, o_model, what, lr=2e-4):
+    """One Adam step (lr) for the worst element -- weights whose gradient is O(eps_adam = 1e-8), e.g. hidden
+    units that fire for a handful of rows, turn fp32 summation-order noise into a fraction of a step --
+    1e-6 on average, and a tenth of a step for all but a handful (<= 1e-3) of the elements."""
     for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
         d = (a.cpu() - b).abs()
-        frac = float((d > 2e-5).float().mean())
-        assert d.max().item() <= 2e-4 and d.mean().item() <= 1e-6 and frac <= 1e-4, \
+        frac = float((d > 0.1 * lr).float().mean())
+        assert d.max().item() <= lr and d.mean().item() <= 1e-6 and frac <= 1e-3, \
             (what, k, d.max().item(), d.mean().item(), frac)
 
 
@@ -952,8 +953,9 @@ def test_baseline_configs_parameters_tensor_by_tensor(variant, batch, kw):
                                     image_shape=FULLCFG["image_shape"])
         return (Capped(ld[0].dataset, batch_size=batch, shuffle=True),) + ld[1:]
 
+    ld = loaders()                                  # (seeds the dataset generator: BEFORE the model's seed)
     o_model = port.build(variant, 784, 400, 20)
-    o = port.GANPort(variant, o_model, loaders()[0])
+    o = port.GANPort(variant, o_model, ld[0])
     o.train(**kw)
     o_rng = torch.get_rng_state()
     tr, model = build_product(variant, FULLCFG, batch, loaders=loaders())
@@ -965,7 +967,7 @@ def test_baseline_configs_parameters_tensor_by_tensor(variant, batch, kw):
     lclose(tr.Dlosses, o.Dlosses, "%s bs=%d Dlosses" % (variant, batch))
     lclose(tr.Glosses, o.Glosses, "%s bs=%d Glosses" % (variant, batch))
     assert torch.equal(o_rng, torch.get_rng_state())
-    _param_check(model, o_model, "%s bs=%d" % (variant, batch))
+    _param_check(model, o_model, "%s bs=%d" % (variant, batch), lr=2e-4)   # the largest of the lrs used here
 
 
 def test_vae_b512_ragged_parameters_tensor_by_tensor():
@@ -974,8 +976,9 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     import vae
     n_train = 512 * 3 + 336
     mk = lambda: port.synthetic_loaders(512, n_train=n_train, n_val=512, n_test=512, image_shape=(1, 28, 28))
+    ld0 = mk()                                      # (seeds the dataset generator: BEFORE the model's seed)
     o_model = port.build("vae", 784, 400, 20)
-    o = port.VAEPort(o_model, *mk())
+    o = port.VAEPort(o_model, *ld0)
     o.train(3)
     o_rng = torch.get_rng_state()
     ld = mk()
@@ -991,4 +994,4 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     lclose(tr.kl_loss, o.kl_loss, "VAE kl", tol=2e-5)
     assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-5 * abs(o.best_val_loss)
     assert torch.equal(o_rng, torch.get_rng_state())
-    _param_check(model, o_model, "VAE bs=512 ragged")
+    _param_check(model, o_model, "VAE bs=512 ragged", lr=1e-3)          # vae.py:127: lr = 1e-3

@@ -37,8 +37,9 @@ def time_shape(kind, M, K, N, reps=50):
     else:
         ref, got = dA.t() @ x, dW
     err = float((got - ref).abs().max() / ref.abs().max())
-    assert err < 2e-5, (kind, M, K, N, err)
-    if kind == "dw":
+    ablated = os.environ.get("GM_ABLATED_LIB", "0") != "0"    # timing-experiment build: results are meaningless
+    assert ablated or err < 2e-5, (kind, M, K, N, err)
+    if kind == "dw" and not ablated:
         rb = dA.sum(0)
         errb = float((db - rb).abs().max() / rb.abs().max())
         assert errb < 2e-5, (kind, M, K, N, "db", errb)
