@@ -54,6 +54,17 @@
 #ifndef GM_EXP_ABLATE
 #define GM_EXP_ABLATE 0
 #endif
+//   GM_MFMA_INTERLEAVE  1: the four k-steps of a chunk are the OUTER loop of the MFMA block, so consecutive MFMAs of a
+//                       wave go to different accumulators (no dependent back-to-back pairs); 0: accumulator by
+//                       accumulator, four dependent MFMAs in a row (what hipcc emits in source order)
+//   GM_EXP_PREFETCH     n > 0: weight-gradient launches whose waves own >= n chunks load chunk q + 1 before they
+//                       consume chunk q (two register sets, counted waits)
+#ifndef GM_EXP_PREFETCH
+#define GM_EXP_PREFETCH 0
+#endif
+#ifndef GM_MFMA_INTERLEAVE
+#define GM_MFMA_INTERLEAVE 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -946,6 +957,14 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             asm volatile("" ::"v"(fb[ni].x), "v"(fb[ni].y), "v"(fb[ni].z), "v"(fb[ni].w));
         return;
 #endif
+#if GM_MFMA_INTERLEAVE
+#define GM_MFMA_STEP(comp)                                                                         \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                      \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].comp, fb[ni].comp, acc[mi][ni], 0, 0, 0);
+        GM_MFMA_STEP(x) GM_MFMA_STEP(y) GM_MFMA_STEP(z) GM_MFMA_STEP(w)
+#undef GM_MFMA_STEP
+#else
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -957,6 +976,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].w, fb[ni].w, c4, 0, 0, 0);
                 acc[mi][ni] = c4;
             }
+#endif
     };
     static_assert(G == 1, "the 16x16x4 kernel runs the per-chunk schedule only");
     auto load_wk = [&](int cc) -> float4 {                    // FOLD == 2: w2 of the chunk's four reduction columns
@@ -1012,6 +1032,28 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 #pragma unroll
         for (int q = 0; q < BMAX; ++q)
             if (q < nq) consume(ra[q], rb[q], make_float4(0.f, 0.f, 0.f, 0.f), q);
+        q_first = nq;
+    }
+#endif
+#if GM_EXP_PREFETCH > 0
+    if (MODE == MODE_DW && FOLD == 0 && nq >= GM_EXP_PREFETCH) {        // wave uniform
+        float4 ra[2][MI], rb[2][NI];
+        auto issue = [&](int buf, int q) {
+            const int cc = min(w + q * WAVES, nchunks - 1);              // past-the-end: a valid, unused reload
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[buf][mi] = load_a(cc, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[buf][ni] = load_b(cc, ni);
+        };
+        issue(0, 0);
+        int q = 0;
+        for (; q + 1 < nq; q += 2) {                                      // two chunks per trip: static buffers
+            issue(1, q + 1);
+            consume(ra[0], rb[0], make_float4(0.f, 0.f, 0.f, 0.f), q);
+            issue(0, q + 2);
+            consume(ra[1], rb[1], make_float4(0.f, 0.f, 0.f, 0.f), q + 1);
+        }
+        if (q < nq) consume(ra[0], rb[0], make_float4(0.f, 0.f, 0.f, 0.f), q);
         q_first = nq;
     }
 #endif
