@@ -129,6 +129,17 @@ def gemm_variant(kind, M, K, N):
         mi, ni = (2, 4) if tn >= tm else (4, 2)
     elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
         mi, ni = 1, 2
+    if mode == 2 and os.environ.get("GM_DW_TILE48", "2") != "0":
+        # weight gradients: 32x48 / 48x32 instead of 32x64 / 64x32 where the narrower tile still fits one round
+        if (mi, ni) == (2, 4) and tm * -(-Ng // 48) <= 256:
+            mi, ni = 2, 3
+        elif (mi, ni) == (4, 2) and tn * -(-Mg // 48) <= 256:
+            mi, ni = 3, 2
+        elif os.environ.get("GM_DW_TILE48", "2") == "2" and (mi, ni) == (2, 2) and tm * tn > 256:
+            if tn >= tm and tm * -(-Ng // 48) <= 256:
+                mi, ni = 2, 3
+            elif tn < tm and tn * -(-Mg // 48) <= 256:
+                mi, ni = 3, 2
     b = lambda v: "true" if v else "false"
     if kind in ("dwh", "dwhf", "dwhs"):
         # last two arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded head

@@ -268,9 +268,11 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
 }
 
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
+// ncap: columns >= ncap are not this block's to store (the 16-column last block of a 48-wide tile);
+// rcap: rows of the block that belong to the tile (16 for the last block of a 48-row tile)
 template <int MODE, int WAVES, int ROWS = 32>
 __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* red, int t, int m0,
-                                                 int n0) {
+                                                 int n0, int ncap = 0x7fffffff, int rcap = 32) {
     if (MODE == MODE_FWD && p.hd_part) {                     // kernel-argument uniform
         // Folded critic head: every row of this 32-column block also leaves its partial dot with w2.
         // The 32 lanes that hold a row (one half of a wave) sum their products in a fixed butterfly;
@@ -278,14 +280,14 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
 #pragma unroll
         for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
             const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
-            const bool live = !(ROWS < 32 && row >= ROWS);
+            const bool live = !(ROWS < 32 && row >= ROWS) && row < rcap;
             float v = 0.f;
             if (live) {
 #pragma unroll
                 for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
             }
             const int m = m0 + row, n = n0 + col;
-            const bool ok = live && m < p.M && n < p.N;
+            const bool ok = live && m < p.M && n < p.N && n < ncap;
             float pv = 0.f;
             if (ok) {
                 const float w = p.hd_w2[n];
@@ -310,14 +312,14 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
 #pragma unroll
         for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
             const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
-            const bool live = !(ROWS < 32 && row >= ROWS);
+            const bool live = !(ROWS < 32 && row >= ROWS) && row < rcap;
             float v = 0.f;
             if (live) {
 #pragma unroll
                 for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
             }
             const int m = m0 + row, n = n0 + col;
-            const bool ok = live && m < p.M && n < p.N;
+            const bool ok = live && m < p.M && n < p.N && n < ncap;
             float pv = 0.f;
             if (ok) {
                 const float r = fwd_value(p, v, n);
@@ -336,12 +338,12 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
         const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
-        if (ROWS < 32 && row >= ROWS) continue;              // 16-row tiles: half the threads idle
+        if ((ROWS < 32 && row >= ROWS) || row >= rcap) continue;   // 16-row tiles / blocks: half the threads idle
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
         const int m = m0 + row, n = n0 + col;
-        if (m >= p.M || n >= p.N) continue;
+        if (m >= p.M || n >= p.N || n >= ncap) continue;
         store_element<MODE>(p, v, m, n);
     }
 }
@@ -1087,24 +1089,31 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 #endif
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    static_assert(NI % 2 == 0 && (MI == 1 || MI % 2 == 0), "tile shapes: 16xN or 32-multiples");
+    // NI odd (32x48 tiles): the last block is 16 columns wide -- its right half of the buffer is stale and the
+    // stores are capped at the tile's own columns (the neighbour tile owns the next ones).
+    // MI odd > 1 (48x32 tiles): the last block is 16 rows tall.
 #pragma unroll
     for (int bm = 0; bm < (MI + 1) / 2; ++bm)
 #pragma unroll
-        for (int bn = 0; bn < NI / 2; ++bn) {
+        for (int bn = 0; bn < (NI + 1) / 2; ++bn) {
             if (bm + bn > 0) __syncthreads();                // previous block fully consumed
 #pragma unroll
             for (int rgi = 0; rgi < 4; ++rgi) {
                 const int row = g4 * 4 + rgi;
                 red[(w * 32 + row) * 32 + i16] = acc[2 * bm][2 * bn][rgi];
-                red[(w * 32 + row) * 32 + 16 + i16] = acc[2 * bm][2 * bn + 1][rgi];
-                if constexpr (MI > 1) {
-                    red[(w * 32 + 16 + row) * 32 + i16] = acc[2 * bm + 1][2 * bn][rgi];
-                    red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[2 * bm + 1][2 * bn + 1][rgi];
+                if (2 * bn + 1 < NI) red[(w * 32 + row) * 32 + 16 + i16] = acc[2 * bm][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
+                if (2 * bm + 1 < MI) {
+                    constexpr int MIX = MI > 1 ? MI - 1 : 0;             // (keeps the index in range for MI == 1)
+                    const int mu = (2 * bm + 1 < MI) ? 2 * bm + 1 : MIX;
+                    red[(w * 32 + 16 + row) * 32 + i16] = acc[mu][2 * bn][rgi];
+                    if (2 * bn + 1 < NI)
+                        red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[mu][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
                 }
             }
             __syncthreads();
-            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn);
+            reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn,
+                                                              (2 * bn + 1 < NI) ? 0x7fffffff : n0 + 32 * bn + 16,
+                                                              (2 * bm + 1 < MI) ? 32 : 16);
         }
 }
 
@@ -1287,7 +1296,27 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         static int narrow_max = -1;
         if (narrow_max < 0) { const char* e = getenv("GM_NARROW_MAX_TILES"); narrow_max = e ? atoi(e) : 128; }
         if (narrow_on && !use8 && !wide && tm * tn <= narrow_max && p.M > 16) wide = 3;   // 3: 16x32
+        // GM_DW_NI3=1 (experiment): 32x48 tiles where 32x64 would be chosen for a weight gradient (221 instead of
+        // 169 workgroups on the 400 x 785 output: 86 % instead of 66 % of the CUs, three quarters of the MFMA chain each)
+        static int t48_on = -1;
+        if (t48_on < 0) { const char* e = getenv("GM_DW_TILE48"); t48_on = e ? atoi(e) : 2; }
+        if (MODE == MODE_DW && t48_on) {
+            // 32x48 / 48x32 instead of 32x64 / 64x32 where the narrower tile still fits one round: 221 instead
+            // of 169 workgroups on the 400 x 785 / 784 x 401 outputs (86 % instead of 66 % of the CUs, three
+            // quarters of the MFMA chain each).  Measured: dW at 512 rows 10.6 -> 9.1 us, 2048 rows 31.5 -> 27.4.
+            if (wide == 1 && tm * ((p.N + 47) / 48) <= 256) wide = 4;
+            if (wide == 2 && tn * ((p.M + 47) / 48) <= 256) wide = 5;
+            // (default 2) also for SHORT reductions (< 32 chunks, where the 64-wide tiles lose): more 32x32 tiles
+            // than CUs, but one round of 48-wide / 48-tall ones (the generator's 784 x 401 gradient at B = 256:
+            // 325 tiles -> 221; 6.99 -> 6.44 us).  GM_DW_TILE48=1: long reductions only; 0: round 2's shapes
+            if (t48_on >= 2 && wide == 0 && !use8 && tm * tn > 256) {
+                if (tn >= tm && tm * ((p.N + 47) / 48) <= 256) wide = 4;
+                else if (tn < tm && tn * ((p.M + 47) / 48) <= 256) wide = 5;
+            }
+        }
         if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
+        if (wide == 4) grid = dim3((p.N + 47) / 48, tm);
+        if (wide == 5) grid = dim3(tn, (p.M + 47) / 48);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
         if (wide == 3) grid = dim3(tn, (p.M + 15) / 16);
         if constexpr (MODE == MODE_DW) {
@@ -1297,6 +1326,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const dim3 hgrid(grid.x, grid.y + hrows);
 #define GM_LH(V, GG, X, OFV, FD) do {                                                              \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 3) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 1, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); } while (0)
@@ -1355,12 +1386,14 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             if (rider.pair) {
                 GemmP pb = *rider.pair;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
-                    const int mi = (wide == 2) ? 4 : 2, ni = (wide == 1) ? 4 : 2;
+                    const int mi = (wide == 2) ? 4 : (wide == 5 ? 3 : 2), ni = (wide == 1) ? 4 : (wide == 4 ? 3 : 2);
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                     const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                     const dim3 pgrid(na + tnb * tmb);
 #define GM_LP(GG) do {                                                                             \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); } while (0)
                     GM_LP(1);
@@ -1379,7 +1412,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             if (x16_on < 0) { const char* e = getenv("GM_XCD16"); x16_on = e ? atoi(e) : 0; }
             const int gtm = (int)grid.y, gtn = (int)grid.x;                  // tiles of the chosen shape
             if (x16_on && gtm * gtn >= 64) {
-                const int th = (wide == 2) ? 64 : (wide == 3 ? 16 : 32), tw = (wide == 1) ? 64 : 32;
+                const int th = (wide == 2) ? 64 : (wide == 3 ? 16 : (wide == 5 ? 48 : 32)), tw = (wide == 1) ? 64 : (wide == 4 ? 48 : 32);
                 int best = 1 << 30, bxr = 0;
                 for (int xr = 1; xr <= 8; xr <<= 1) {
                     const int xc = 8 / xr;
@@ -1395,6 +1428,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
 #define GM_L16(V, W, GG, X) do {                                                                   \
         if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 4) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 5) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 4, 2>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 3) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 1, 2>), grid, dim3(W * 64), 0, s, p); \
         else hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 2>), grid, dim3(W * 64), 0, s, p); } while (0)
