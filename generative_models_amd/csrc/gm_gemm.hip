@@ -65,6 +65,13 @@
 #ifndef GM_MFMA_INTERLEAVE
 #define GM_MFMA_INTERLEAVE 0
 #endif
+//   GM_SPREAD_TAIL      1: when the reduction leaves 1..4 chunks over after every wave had its equal share (K = 784:
+//                       49 chunks on 16 waves), those chunks are spread BY k-STEP over 4 waves each, loaded in the
+//                       waves' last regular round -- no wave pays an extra trip to memory for a quarter of the others'
+//                       work; 0: waves 0..r-1 take one more whole chunk
+#ifndef GM_SPREAD_TAIL
+#define GM_SPREAD_TAIL 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -936,7 +943,13 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nq = (nchunks - w + WAVES - 1) / WAVES;        // chunks w, w+WAVES, ... of this wave
+    int nq = (nchunks - w + WAVES - 1) / WAVES;              // chunks w, w+WAVES, ... of this wave
+#if GM_SPREAD_TAIL
+    const int nfull = nchunks / WAVES, rem = nchunks - nfull * WAVES;
+    const bool spread = FOLD == 0 && WAVES == 16 && rem > 0 && rem <= 4 && nfull >= 1;    // kernel uniform
+    const bool tail_mine = spread && w < 4 * rem;            // this wave takes k-step (w & 3) of leftover chunk w >> 2
+    if (spread) nq = nfull;
+#endif
     // G = 1: load a chunk's fragments, consume them, next chunk.  The four waves of a SIMD drift
     // apart and overlap each other's loads and MFMAs; batching G chunks of loads ahead of their
     // MFMAs (the 32x32x2 kernel's scheme) keeps the waves in lockstep -- load phase, then MFMA phase
@@ -1056,6 +1069,48 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             consume(ra[1], rb[1], make_float4(0.f, 0.f, 0.f, 0.f), q + 1);
         }
         if (q < nq) consume(ra[0], rb[0], make_float4(0.f, 0.f, 0.f, 0.f), q);
+        q_first = nq;
+    }
+#endif
+#if GM_SPREAD_TAIL
+    if (spread) {
+        // all rounds but the last as usual; the last one also brings in this wave's share of a leftover chunk
+        for (int q = 0; q + 1 < nq; ++q) {
+            float4 ra[MI], rb[NI];
+            const int cc = w + q * WAVES;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+            consume(ra, rb, make_float4(0.f, 0.f, 0.f, 0.f), q);
+        }
+        float4 ra[MI], rb[NI], ta[MI], tb[NI];
+        const int cc = w + (nq - 1) * WAVES, ct = nfull * WAVES + (w >> 2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+        if (tail_mine) {                                      // wave uniform
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ta[mi] = load_a(ct, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) tb[ni] = load_b(ct, ni);
+        }
+        consume(ra, rb, make_float4(0.f, 0.f, 0.f, 0.f), nq - 1);
+        if (tail_mine) {
+            const int j = w & 3;
+            auto pick = [&](float4 v) -> float { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+            float a1[MI], b1[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a1[mi] = pick(fix_a(ta[mi], ct, mi, make_float4(0.f, 0.f, 0.f, 0.f)));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b1[ni] = pick(fix_b(tb[ni], ct, ni));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+        }
         q_first = nq;
     }
 #endif
