@@ -559,7 +559,7 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
              "roofline": dominant_gemm_roofline(
                  gemm_shapes_wgp(B, eng._fold_head_G()) if variant == "wgp" else
                  gemm_shapes(B, fold_head=eng._fold_head()), B,
-                 pmc_tag={"wgp": "wgp_b256", "ns": "ns_b1024"}.get(variant))}
+                 pmc_tag={"wgp": "wgp_b256", "ns": "ns_b1024", "ls": "ns_b1024"}.get(variant))}   # (LSGAN: NSGAN's launches)
         if cpu:
             e["cpu_baseline"] = cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)
         log("%s: %.0f img/s" % (name, e["img_s"]))

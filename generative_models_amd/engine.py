@@ -472,11 +472,14 @@ class GANEngine:
     def _fold_head(self):
         """Critic step: the separable losses whose whole step runs on the fused head (not the
         penalty variants' stacked / accumulating steps, not Ra / Fisher's two-phase losses)."""
-        return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl)
+        import os
+        return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl) and \
+            os.environ.get("GM_FOLD_HEAD_D", "1") != "0"
 
     def _fold_head_G(self):
         """Generator step: every variant's D(G(z)) pass is the plain fused head in generator mode."""
-        return self._fold_ok(self.Bl)
+        import os
+        return self._fold_ok(self.Bl) and os.environ.get("GM_FOLD_HEAD_G", "1") != "0"
 
     def _wgp_stacked(self):
         """WGAN-GP critic step with the second backward folded into the first-order launches: the

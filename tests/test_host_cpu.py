@@ -213,6 +213,13 @@ def test_bench_kernel_names_match_the_committed_rocprof_summary():
     assert line["roofline"]["kernel"] in names
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"]
+    # no silent `traffic: null`: the dominant kernel of the headline and of every configuration that has a
+    # roofline entry must be listed in the committed PMC pass it names
+    assert line["roofline"]["traffic"] and line["roofline"]["traffic_source"].startswith("profiles/" + rnd)
+    for c in line.get("configs", []):
+        r = c.get("roofline")
+        if r is not None:
+            assert r["traffic"] and os.path.isfile(os.path.join(root, r["traffic_source"])), c["workload"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in line["cpu_baseline"]
     avg = {r["kernel"]: float(r["avg_us"]) for r in rows}
