@@ -72,6 +72,11 @@
 #ifndef GM_SPREAD_TAIL
 #define GM_SPREAD_TAIL 0
 #endif
+//   GM_FAST_INTERIOR    1: chunks that lie wholly below K of tiles that lie wholly inside the operands skip the bounds
+//                       selects of the fragment fix-up (they are most of the work: layer widths are multiples of 16)
+#ifndef GM_FAST_INTERIOR
+#define GM_FAST_INTERIOR 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -956,13 +961,30 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // -- and measured slower here (fwd 512x784x400: G=4 8.8 us, G=2 7.7, G=1 7.4-7.6); a rolling
     // prefetch of the next chunk was slower still (iteration 71.7 -> 76.3 us).  G stays a template
     // parameter (= 1) so that kernel names keep their shape across rounds.
+#if GM_FAST_INTERIOR
+    // workgroup-uniform: every row / column this tile touches exists in both operands (the dW ones column
+    // makes the last column tile an edge tile)
+    const bool tile_inside = (m0 + 16 * MI <= p.M) && (n0 + 16 * NI <= b_cols);
+#endif
     auto consume = [&](const float4 (&ra)[MI], const float4 (&rb)[NI], float4 wk, int q) {
         const int cq = w + q * WAVES;
         float4 fa[MI], fb[NI];
+#if GM_FAST_INTERIOR
+        if (FOLD == 0 && tile_inside && 16 * cq + 16 <= p.K) {           // wave uniform: nothing to zero
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = (MODE == MODE_DW && XV && !xdirect) ? quad_transpose(ra[mi], lane) : ra[mi];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = (MODE != MODE_FWD && XV && !xdirect) ? quad_transpose(rb[ni], lane) : rb[ni];
+        } else
+#endif
+        {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[mi], cq, mi, wk);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ni] = fix_b(rb[ni], cq, ni);
+        }
 #if GM_EXP_ABLATE == 1                                       // experiment: operands arrive and are fixed up, no MFMA
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
