@@ -97,7 +97,7 @@ _SIGNATURES = {
                                   c_float, _P, Slot, _P, _P, _P, _P, c_int, _P, c_float]),
     "gm_l1_rows_dp": (c_int, [_P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     "gm_began_dloss_dp": (c_int, [_P, _P, c_int, c_int, _P, _P, Slot]),
-    "gm_std_sums": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "gm_std_sums": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gm_std_from_sums": (c_int, [_P, _P, c_int64, _P]),
     "gm_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, Slot, ctypes.c_double, ctypes.c_double,
                         ctypes.c_double, ctypes.c_double, c_float]),
@@ -173,7 +173,7 @@ _SIGNATURES = {
                                ctypes.c_double, ctypes.c_double, c_float, _P]),
     "gm_linear_bwd_dx_add": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                      c_int, c_int, _P, c_int64, c_float]),
-    "gm_std_all": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "gm_std_all": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gm_dragan_xhat": (c_int, [_P, _P, c_int64, _P, Slot, _P, Slot, _P, c_float, _P, c_int64, c_int,
                                c_int]),
     "gm_dragan_rows": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, _P, c_float, c_float, c_float,

@@ -958,25 +958,76 @@ extern "C" int gm_began_update(void* stream, float* state, double* dstate, int64
 //           ds'_b = gamma_b . v_b,  da2_b = ds'_b * s'_b (1-2 s_b)
 //   head  : gw2 += colsum(m1 . T) + da2^T h ; gb2 += sum da2 ; da1 = (da2 w2) . m1   (T = dv W1^T)
 // ------------------------------------------------------------------------------------------
-// out[0] = unbiased std over n = R*I elements (two fp64 sums; one workgroup)
-// Data parallel: images.data.std() is over the GLOBAL batch (dra_gan.py:204) -> every rank
-// contributes (sum x, sum x^2) of its rows; after the scalar all-reduce std_from_sums finishes.
-__global__ __launch_bounds__(1024) void std_sums_kernel(const float* __restrict__ X, int64_t ldx, int R,
-                                                       int I, float* __restrict__ out2) {
-    __shared__ double sh[2][16];
+// Unbiased std over n = R*I elements (images.data.std(), dra_gan.py:204): two fp64 sums.
+// STD_NB workgroups sum float4 slices (a single workgroup walking 200 704 elements took 45 us -- a quarter
+// of DRAGAN's iteration); each publishes its pair of partial sums, bumps a counter in the workspace, and the
+// workgroup that observes STD_NB-1 adds the partials in index order (same bits whichever is last), writes
+// the result and re-arms the counter.  ws: 2*STD_NB doubles + one counter, zero-initialised once by the caller.
+// MODE 0: out[0] = std.  MODE 1 (data parallel: the std is over the GLOBAL batch -> every rank contributes
+// the sums of its rows, gm_std_from_sums finishes after the scalar all-reduce): out[0..1] = (sum x, sum x^2).
+constexpr int STD_NB = 64;
+template <bool VEC4, int MODE>
+__global__ __launch_bounds__(256) void std_multi_kernel(const float* __restrict__ X, int64_t ldx, int R, int I,
+                                                       double* __restrict__ ws, float* __restrict__ out) {
+    __shared__ double sh[2][4];
+    __shared__ int is_last;
     double s1 = 0.0, s2 = 0.0;
-    const int64_t n = (int64_t)R * I;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const double v = (double)X[(i / I) * ldx + (i % I)];
-        s1 += v; s2 += v * v;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = STD_NB * 256;
+    if (VEC4) {
+        const int I4 = I >> 2;
+        const int n4 = R * I4;
+        for (int i0 = tid; i0 < n4; i0 += 4 * nth) {            // four independent 16-byte loads in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * nth, n4 - 1);
+                v[u] = *reinterpret_cast<const float4*>(X + (int64_t)(i / I4) * ldx + 4 * (i % I4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * nth < n4) {
+                    const double a = v[u].x, b = v[u].y, c = v[u].z, d = v[u].w;
+                    s1 += (a + b) + (c + d);
+                    s2 += (a * a + b * b) + (c * c + d * d);
+                }
+        }
+    } else {
+        const int64_t n = (int64_t)R * I;
+        for (int64_t i = tid; i < n; i += nth) {
+            const double v = (double)X[(i / I) * ldx + (i % I)];
+            s1 += v; s2 += v * v;
+        }
     }
     s1 = gm_wave_sum_d(s1); s2 = gm_wave_sum_d(s2);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
     __syncthreads();
+    unsigned int* ctr = reinterpret_cast<unsigned int*>(ws + 2 * STD_NB);
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < 16; ++q) { a += sh[0][q]; b += sh[1][q]; }
-        out2[0] = (float)a; out2[1] = (float)b;
+        const double a = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+        const double b = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+        __hip_atomic_store(ws + 2 * blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == STD_NB - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 64) return;
+    __threadfence();
+    static_assert(STD_NB == 64, "one wave adds the partials");
+    double a = __hip_atomic_load(ws + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double b = __hip_atomic_load(ws + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = gm_wave_sum_d(a); b = gm_wave_sum_d(b);
+    if (threadIdx.x == 0) {
+        if (MODE == 0) {
+            const double n = (double)R * (double)I;
+            const double mean = a / n;
+            const double var = (b - n * mean * mean) / (n - 1.0);
+            out[0] = (float)sqrt(var > 0.0 ? var : 0.0);
+        } else {
+            out[0] = (float)a; out[1] = (float)b;
+        }
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ void std_from_sums_kernel(const float* __restrict__ sums2, int64_t n, float* __restrict__ out) {
@@ -985,42 +1036,28 @@ __global__ void std_from_sums_kernel(const float* __restrict__ sums2, int64_t n,
     const double var = (b - (double)n * mean * mean) / (double)(n - 1);
     out[0] = (float)sqrt(var > 0.0 ? var : 0.0);
 }
-extern "C" int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2) {
-    GM_CHECK_ARG(X && out2 && R > 0 && I > 0 && ldx >= I);
-    hipLaunchKernelGGL(std_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, X, ldx, R, I, out2);
+template <int MODE>
+static int std_launch(void* stream, const float* X, int64_t ldx, int R, int I, void* ws, float* out) {
+    GM_CHECK_ARG(X && out && ws && R > 0 && I > 0 && ldx >= I && (int64_t)R * I < (1ll << 31));
+    GM_CHECK_ARG((reinterpret_cast<uintptr_t>(ws) & 7) == 0);
+    const bool vec4 = (I % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (vec4) hipLaunchKernelGGL((std_multi_kernel<true, MODE>), dim3(STD_NB), dim3(256), 0, (hipStream_t)stream,
+                                 X, ldx, R, I, (double*)ws, out);
+    else hipLaunchKernelGGL((std_multi_kernel<false, MODE>), dim3(STD_NB), dim3(256), 0, (hipStream_t)stream,
+                            X, ldx, R, I, (double*)ws, out);
     GM_LAUNCH_RET();
+}
+extern "C" int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2, void* ws) {
+    return std_launch<1>(stream, X, ldx, R, I, ws, out2);
 }
 extern "C" int gm_std_from_sums(void* stream, const float* sums2, int64_t n_total, float* out) {
     GM_CHECK_ARG(sums2 && out && n_total > 1);
     hipLaunchKernelGGL(std_from_sums_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums2, n_total, out);
     GM_LAUNCH_RET();
 }
-
-__global__ __launch_bounds__(1024) void std_all_kernel(const float* __restrict__ X, int64_t ldx, int R,
-                                                      int I, float* __restrict__ out) {
-    __shared__ double sh[2][16];
-    double s1 = 0.0, s2 = 0.0;
-    const int64_t n = (int64_t)R * I;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const double v = (double)X[(i / I) * ldx + (i % I)];
-        s1 += v; s2 += v * v;
-    }
-    s1 = gm_wave_sum_d(s1); s2 = gm_wave_sum_d(s2);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < 16; ++q) { a += sh[0][q]; b += sh[1][q]; }
-        const double mean = a / (double)n;
-        const double var = (b - (double)n * mean * mean) / (double)(n - 1);
-        out[0] = (float)sqrt(var > 0.0 ? var : 0.0);
-    }
-}
-
-extern "C" int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out) {
-    GM_CHECK_ARG(X && out && R > 0 && I > 0 && (int64_t)R * I > 1);
-    hipLaunchKernelGGL(std_all_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, X, ldx, R, I, out);
-    GM_LAUNCH_RET();
+extern "C" int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out, void* ws) {
+    GM_CHECK_ARG((int64_t)R * I > 1);
+    return std_launch<0>(stream, X, ldx, R, I, ws, out);
 }
 
 __global__ __launch_bounds__(256) void dragan_xhat_kernel(const float* __restrict__ x, int64_t ldx,

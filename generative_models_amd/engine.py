@@ -411,6 +411,8 @@ class GANEngine:
             self.pen = z(Bl)
         if variant == "dra":
             self.da2, self.dA1, self.stdv = z(Bl), z(Bl, Hd), z(1)
+            from . import ops_fused as _of
+            self.std_ws = _of.std_workspace(dev)
         if variant == "info":
             # InfoGAN (info_gan.py:78-148): auxiliary net Q and a third optimizer over G u Q that
             # keeps its OWN Adam moments for G's parameters
@@ -948,11 +950,11 @@ class GANEngine:
         if self._dp():
             # images.data.std() is over the GLOBAL batch (dra_gan.py:204): (sum x, sum x^2) of my rows,
             # summed over ranks, then the unbiased std of B*I elements
-            of.std_sums(x, Bl, self.pre[8:], stream=st)
+            of.std_sums(x, Bl, self.pre[8:], ws=self.std_ws, stream=st)
             self._exchange_scalars(st, self.pre[8:], 2)
             of.std_from_sums(self.pre[8:], self.B * self.I, self.stdv, stream=st)
         else:
-            of.std_all(x, Bl, self.stdv, stream=st)                               # images.data.std()
+            of.std_all(x, Bl, self.stdv, ws=self.std_ws, stream=st)       # images.data.std()
         r0 = self.ring_r0                                                          # my rows of the draws
         of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.ring_B),
                        self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.ring_B * self.I),

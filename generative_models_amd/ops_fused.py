@@ -171,16 +171,29 @@ def began_update(state, dstate, istate, gamma, lam, patience, tick, stream=None)
               istate.data_ptr(), gamma, lam, patience, tick.data_ptr() if tick is not None else None)
 
 
-def std_sums(X, R, out2, stream=None):
-    _lib.call("gm_std_sums", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out2.data_ptr())
+STD_WS_BYTES = 1088                  # include/gm_hip.h GM_STD_WS_BYTES
+
+
+def std_workspace(device):
+    """Zeroed workspace of the multi-workgroup std kernels (allocate once, outside graph capture)."""
+    import torch
+    return torch.zeros(STD_WS_BYTES // 8, dtype=torch.float64, device=device)
+
+
+def std_sums(X, R, out2, ws=None, stream=None):
+    ws = std_workspace(X.device) if ws is None else ws
+    _lib.call("gm_std_sums", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out2.data_ptr(),
+              ws.data_ptr())
 
 
 def std_from_sums(sums2, n_total, out, stream=None):
     _lib.call("gm_std_from_sums", stream or stream_ptr(), sums2.data_ptr(), n_total, out.data_ptr())
 
 
-def std_all(X, R, out, stream=None):
-    _lib.call("gm_std_all", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out.data_ptr())
+def std_all(X, R, out, ws=None, stream=None):
+    ws = std_workspace(X.device) if ws is None else ws
+    _lib.call("gm_std_all", stream or stream_ptr(), X.data_ptr(), _ld(X), R, X.shape[1], out.data_ptr(),
+              ws.data_ptr())
 
 
 def dragan_xhat(x, delta, delta_slot, U, u_slot, std_dev, out, B, C=1.0, stream=None):

@@ -392,9 +392,13 @@ int gm_linear_bwd_dx_add(void* stream, const float* dA, int64_t lda, const float
  * gradient s'*v (v = (m1.w2) W1 from gm_gp_u + gm_linear_bwd_dx), penalty rows, dv and da2 of the
  * second backward; head_bwd: the w2/b2 accumulations and da1.  Penalty rows are added to the loss by
  * gm_head_fwd_loss / gm_gan_loss with weight hyper[7]. */
-int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out);
+/* ws: GM_STD_WS_BYTES of device memory (8-byte aligned), zeroed ONCE by the caller and then owned by these
+ * calls (partial sums of the launch's 64 workgroups + their arrival counter; launches sharing a ws must be
+ * stream-ordered). */
+#define GM_STD_WS_BYTES 1088
+int gm_std_all(void* stream, const float* X, int64_t ldx, int R, int I, float* out, void* ws);
 /* data parallel: (sum x, sum x^2) of this rank's rows -> scalar all-reduce -> std of the global batch */
-int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2);
+int gm_std_sums(void* stream, const float* X, int64_t ldx, int R, int I, float* out2, void* ws);
 int gm_std_from_sums(void* stream, const float* sums2, int64_t n_total, float* out);
 int gm_dragan_xhat(void* stream, const float* x, int64_t ldx, const float* delta, gm_slot delta_slot,
                    const float* U, gm_slot u_slot, const float* std_dev, float C, float* out,

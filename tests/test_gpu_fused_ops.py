@@ -212,6 +212,32 @@ def test_std_all_is_the_unbiased_std_of_the_whole_batch(B, I):
     assert abs(float(out) - float(x.double().std())) < 1e-6
 
 
+@pytest.mark.parametrize("B,I,ld", [(256, 784, 784), (64, 100, 128), (7, 33, 33), (3, 2, 5), (1024, 784, 784)])
+def test_std_kernels_share_a_workspace_across_launches(B, I, ld):
+    """The 64 workgroups' partial sums + arrival counter live in a caller-owned workspace that re-arms
+    itself: repeated launches (strided rows, widths that are not a multiple of 4, the data-parallel
+    (sum, sum of squares) form) keep giving the fp64 answer, and equal inputs give equal bits."""
+    torch.manual_seed(B + I)
+    ws = of.std_workspace(DEV)
+    out, sums, out2 = torch.empty(1, device=DEV), torch.empty(2, device=DEV), torch.empty(1, device=DEV)
+    first = None
+    for k in range(4):
+        buf = torch.rand(B, ld, device=DEV) * (k + 1)
+        x = buf[:, :I]
+        of.std_all(x, B, out, ws=ws)
+        want = float(x.double().cpu().std())
+        assert abs(float(out) - want) < 2e-6 * max(1.0, want)
+        of.std_sums(x, B, sums, ws=ws)
+        of.std_from_sums(sums, B * I, out2)
+        xd = x.double().cpu()
+        assert abs(float(sums[0]) - float(xd.sum())) <= 1e-6 * float(xd.sum())
+        assert abs(float(sums[1]) - float((xd * xd).sum())) <= 1e-6 * float((xd * xd).sum())
+        assert abs(float(out2) - want) < 1e-4 * max(1.0, want)      # the sums travel as fp32 (engine: exchanged)
+        of.std_all(x, B, out2, ws=ws)
+        assert torch.equal(out, out2)
+    assert int(ws.view(torch.int32)[2 * 2 * 64]) == 0               # counter re-armed
+
+
 def test_dragan_xhat():
     """x_hat = delta*x + (1-delta)*(x + C*std*U)  (dra_gan.py:200-205)."""
     B, I = 48, 100
