@@ -331,7 +331,7 @@ def test_head_gp_and_stacked_weight_gradient():
     assert rel(head_lin.gW.view(-1).cpu(), gw2_ref.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize("B,Z", [(256, 20), (37, 6), (100, 64)])
+@pytest.mark.parametrize("B,Z", [(256, 20), (512, 20), (336, 20), (37, 6), (100, 64), (48, 8), (70, 32)])
 def test_bir_mmd_matches_fp64_autograd(B, Z):
     """gm_bir_mmd: Gaussian-kernel MMD of bir_vae.py:201-221 and d(lam * mmd)/dz vs fp64 autograd."""
     torch.manual_seed(B + Z)

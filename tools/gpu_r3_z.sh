@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel stats of the variants the round never profiled (ra, fisher, be, info, w): is a helper kernel slow?
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"; mkdir -p gpurun_out/profiles_r03; export TMPDIR=/tmp
+OUT=$R/gpurun_out/profiles_r03
+cd /tmp
+for v in ${1:-ra fisher be info w}; do E=${2:-1}
+  tag=r03_${v}_b256
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pr_$tag -o ns -- python $R/tools/variant_times.py $v $E > $OUT/${tag}_variant_times.txt 2> $R/gpurun_out/pr_$tag.log; echo "$v rc=$?"
+  python $R/profiles/make_summary.py $R/gpurun_out/pr_$tag $tag $OUT > /dev/null
+  find $R/gpurun_out -name "*kernel_trace.csv" -delete
+  grep -v amdgpu $OUT/${tag}_variant_times.txt
+  sed -n 1,24p $OUT/${tag}_summary.md
+done
