@@ -37,6 +37,7 @@
 #include "gm_gather.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // Compile-time experiment switches of the 16x16x4 body (tools/build_variant.sh builds a library per
 // setting; a RUNTIME flag inside the reduction loop distorts what it measures: with three such flags
@@ -47,6 +48,11 @@
 //   GM_EXP_ABLATE       timing only -- 1: no MFMA, 2: no operand loads, 3: no cross-wave reduction / epilogue
 #ifndef GM_XDIRECT
 #define GM_XDIRECT 0
+#endif
+//   GM_DW_IL            1 (default): weight gradients take their x-contiguous operands as INTERLEAVED fragments
+//                       (gemm16_dw_il) -- no quad transposes; 0: round 2's 16-byte loads + transposes
+#ifndef GM_DW_IL
+#define GM_DW_IL 1
 #endif
 #ifndef GM_EXP_BATCH_LOADS
 #define GM_EXP_BATCH_LOADS 0
@@ -112,6 +118,13 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
+    // Balanced XCD tile map of the 16x16x4 kernels (xm_pw > 0; see xmap_tile): the grid keeps its shape and
+    // every workgroup its XCD, only WHICH tile a workgroup computes changes -- the workgroups of one XCD get a
+    // run of consecutive tiles of a panel-major order (panels of xm_pw tile columns), i.e. a compact block of
+    // the output whose operand columns fit that XCD's L2 instead of all eight L2s pulling both operands whole.
+    int xm_pw, xm_a, xm_tn, xm_tm;
+    int xm_start[8];
+    int il;                   // dw: interleaved fragments (gemm16_dw_il) instead of 16-byte loads + quad transposes
     // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
     // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
     const float* ip_eps; gm_slot ip_slot;
@@ -877,6 +890,154 @@ __device__ __forceinline__ float4 raw_xd(const float* __restrict__ P, int64_t ld
                        col[(int64_t)min(kb + 2, K - 1) * ld], col[(int64_t)min(kb + 3, K - 1) * ld]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient with INTERLEAVED fragments.  Both operands of dW[m][n] = sum_k dA[k][m] X[k][n] are
+// contiguous along the OUTPUT index, while a 16x16x4 MFMA wants from lane (i = lane & 15, g = lane >> 4) the
+// element (row i, k = g).  The 16-byte-load form above loads 4 output indices of one k per lane and transposes
+// 4x4 blocks across lane quads (250 VALU instructions per 32 MFMAs, and they do not overlap the MFMA pipe:
+// profiles/r03_experiments.md 4b).  Here lane (i, g) loads the W consecutive elements x0 + W*i .. + W-1 of row
+// k = 16c + 4s + g (one W-dword load per operand per k-step s) and the j-th of them feeds MFMA (.., j): output
+// sub-tile (e, f) then holds rows m0 + MI*i' + e and columns n0 + NI*j' + f -- every output exactly once, in an
+// interleaved order that only the write into the reduction buffer has to know.  No cross-lane traffic at all.
+// Lanes whose W elements do not all exist (last tile of a row / column, the virtual ones column) take a per-
+// element path; rows k >= K are zeroed in the A fragment only.
+// ------------------------------------------------------------------------------------------
+template <int W> struct __attribute__((aligned(4))) ILV { float v[W]; };
+
+// element j of a W-dword load, j a per-lane (loop-invariant) index; j >= W: `other`
+template <int W>
+__device__ __forceinline__ float il_pick(const ILV<W>& t, int j, float other) {
+    float v = other;
+#pragma unroll
+    for (int e = 0; e < W; ++e) v = (j == e) ? t.v[e] : v;
+    return v;
+}
+
+template <int MI, int NI, bool OF, int FOLD>
+__device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx, int by, float* sds,
+                                             const FoldP* fold) {
+    constexpr int WAVES = 16;
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int m0 = by * (16 * MI), n0 = bx * (16 * NI);
+    const int b_cols = p.n_real;
+    const int ones_col = p.db ? p.n_real : -1;
+    const int nchunks = (p.K + 15) >> 4;
+    const int lda = (int)p.lda, ldb = (int)p.ldb;           // (K - 1) * ld + width < 2^31: checked by the host
+    // This lane's W elements start at column am / bn; the load itself starts at a column clamped into the row
+    // (always legal), `shift` columns to the left of the wanted one: 0 everywhere except in the last tile.
+    const int am = m0 + MI * i16, bn = n0 + NI * i16;
+    const int a_x = max(min(am, p.M - MI), 0), b_x = max(min(bn, b_cols - NI), 0);
+    const int a_shift = am - a_x, b_shift = bn - b_x;
+    const float* pa = p.A + gm_slot_offset(p.a_slot) + a_x;
+    const float* pb = p.B + gm_slot_offset(p.b_slot) + b_x;
+    const int a_last = (p.K - 1) * lda, b_last = (p.K - 1) * ldb;
+    // workgroup-uniform: a tile whose every lane is in range over a reduction of whole chunks needs no fix-up
+    const bool edge = (m0 + 16 * MI > p.M) || (n0 + 16 * NI > b_cols) || (p.K & 15) || OF;
+
+    float fw[FOLD == 1 ? MI : 1];                            // folded head: w2 of this lane's A columns
+    if constexpr (FOLD == 1) {
+#pragma unroll
+        for (int e = 0; e < MI; ++e) fw[e] = (am + e < p.M) ? p.fold_w2[min(am + e, p.M - 1)] : 0.f;
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int e = 0; e < MI; ++e)
+#pragma unroll
+        for (int f = 0; f < NI; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nq = (nchunks - w + WAVES - 1) / WAVES;        // chunks w, w+16, ... of this wave
+    auto load_chunk = [&](int c, ILV<MI> (&ra)[4], ILV<NI> (&rb)[4]) {
+        const int k0 = 16 * c + g4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            ra[s] = *reinterpret_cast<const ILV<MI>*>(pa + min((k0 + 4 * s) * lda, a_last));
+            rb[s] = *reinterpret_cast<const ILV<NI>*>(pb + min((k0 + 4 * s) * ldb, b_last));
+        }
+    };
+    auto mfma_step = [&](const float (&fa)[MI], const float (&fb)[NI]) {
+#pragma unroll
+        for (int e = 0; e < MI; ++e)
+#pragma unroll
+            for (int f = 0; f < NI; ++f)
+                acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[f], acc[e][f], 0, 0, 0);
+    };
+    // EDGE (workgroup-uniform, its own copy of the loop): select the wanted element of the clamped load, zero what
+    // does not exist, put the ones column in; the interior copy feeds the loaded registers straight to the MFMAs.
+    auto consume = [&](const ILV<MI> (&ra)[4], const ILV<NI> (&rb)[4], int c, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * c + 4 * s + g4;
+            float fa[MI], fb[NI];
+#pragma unroll
+            for (int e = 0; e < MI; ++e) {
+                float v = ra[s].v[e];
+                if constexpr (EDGE) v = il_pick<MI>(ra[s], (am + e < p.M) ? e + a_shift : MI, 0.f);
+                if constexpr (FOLD == 1) v = (v > 0.f) ? sds[min(k, p.K - 1)] * fw[e] : 0.f;
+                if constexpr (EDGE) v = (k < p.K) ? v : 0.f;
+                fa[e] = v;
+            }
+#pragma unroll
+            for (int f = 0; f < NI; ++f) {
+                float v = rb[s].v[f];
+                if constexpr (EDGE) {
+                    float one = 1.f;
+                    if constexpr (OF) one = (k >= p.ones_from) ? 1.f : 0.f;
+                    v = il_pick<NI>(rb[s], (bn + f < b_cols) ? f + b_shift : NI, (bn + f == ones_col) ? one : 0.f);
+                }
+                fb[f] = v;
+            }
+            mfma_step(fa, fb);
+        }
+    };
+    auto run = [&](auto edge_tag) {
+        int q_first = 0;
+        if constexpr (FOLD == 1) {
+            // the workgroup's dS rows are rebuilt BEHIND the first chunk's operand loads (gm_head.h); waves
+            // without a chunk still take the barrier
+            ILV<MI> ra[4]; ILV<NI> rb[4];
+            const bool have = nq > 0;
+            if (have) load_chunk(w, ra, rb);
+            fold_fill_lds(*fold, sds, fold->R);
+            if (have) consume(ra, rb, w, edge_tag);
+            q_first = 1;
+        }
+        for (int q = q_first; q < nq; ++q) {
+            ILV<MI> ra[4]; ILV<NI> rb[4];
+            const int cc = w + q * WAVES;
+            load_chunk(cc, ra, rb);
+            consume(ra, rb, cc, edge_tag);
+        }
+    };
+    if (edge) run(std::true_type{}); else run(std::false_type{});
+
+    // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.  Accumulator
+    // (e, f) register r of lane (i16, g4) is output (row MI*(4*g4 + r) + e, column NI*i16 + f) of the tile.
+#pragma unroll
+    for (int bm = 0; bm < (MI + 1) / 2; ++bm)
+#pragma unroll
+        for (int bnk = 0; bnk < (NI + 1) / 2; ++bnk) {
+            if (bm + bnk > 0) __syncthreads();               // previous block fully consumed
+#pragma unroll
+            for (int e = 0; e < MI; ++e)
+#pragma unroll
+                for (int f = 0; f < NI; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = MI * (4 * g4 + r) + e, col = NI * i16 + f;
+                        if ((row >> 5) == bm && (col >> 5) == bnk)
+                            red[(w * 32 + (row & 31)) * 32 + (col & 31)] = acc[e][f][r];
+                    }
+            __syncthreads();
+            reduce_and_store<MODE_DW, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bnk,
+                                                                 (2 * bnk + 1 < NI) ? 0x7fffffff : n0 + 32 * bnk + 16,
+                                                                 (2 * bm + 1 < MI) ? 32 : 16);
+        }
+}
+
 // MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
 // (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
 // rounds of one workgroup per CU): one round, 6 fragment loads per 32 MFMAs instead of 4 per 16.
@@ -891,6 +1052,13 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
+    if constexpr (GM_DW_IL && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
+        // kernel-uniform: operands at least one fragment wide, 32-bit element offsets (else the form below)
+        if (p.il) {
+            gemm16_dw_il<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
+            return;
+        }
+    }
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -1194,6 +1362,56 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         }
 }
 
+// lp: linear index of this workgroup among the launch's GEMM workgroups (dispatch order).  Workgroup with
+// linear id L of the whole grid runs on XCD L % 8 (observed, tools/xcc_probe.hip; only speed depends on it);
+// xm_a = (number of workgroups dispatched before the GEMM's) % 8.  The k-th GEMM workgroup of XCD x takes
+// tile xm_start[x] + k of the panel-major order.
+static __device__ __forceinline__ void xmap_tile(const GemmP& p, int lp, int& bx, int& by) {
+    const int u = lp + p.xm_a, xcd = u & 7;
+    const int k = (u >> 3) - (xcd < p.xm_a ? 1 : 0);
+    const int t = p.xm_start[xcd] + k;
+    const int per = p.xm_pw * p.xm_tm;
+    const int panel = t / per, r = t - panel * per;
+    const int w = min(p.xm_pw, p.xm_tn - panel * p.xm_pw);
+    by = r / w;
+    bx = panel * p.xm_pw + (r - by * w);
+}
+// host side: fill the map for a launch of tn x tm tiles whose GEMM workgroups follow `before` others
+static inline void xmap_setup(GemmP& p, int tn, int tm, int before, int tile_w, int tile_h) {
+    const int T = tn * tm, a = before & 7;
+    int start = 0;
+    for (int x = 0; x < 8; ++x) {
+        // u in [a, T + a) with u % 8 == x
+        int cnt = 0;
+        if (T + a - 1 >= x) cnt = (T + a - 1 - x) / 8 + 1 - (x < a ? 1 : 0);
+        p.xm_start[x] = start;
+        start += cnt;
+    }
+    // block of h x pw tiles per XCD (h * pw ~ T / 8) with the fewest operand columns pw*tile_w + h*tile_h
+    const double seg = (double)T / 8.0;
+    int pw = (int)(sqrt(seg * (double)tile_h / (double)tile_w) + 0.5);
+    static int pw_env = -1;
+    if (pw_env < 0) { const char* e = getenv("GM_XMAP_PW"); pw_env = e ? atoi(e) : 0; }
+    if (pw_env > 0) pw = pw_env;
+    p.xm_pw = pw < 1 ? 1 : (pw > tn ? tn : pw);
+    p.xm_a = a; p.xm_tn = tn; p.xm_tm = tm;
+}
+// Interleaved fragments for weight gradients whose reduction has >= this many rows (0: never).  Measured
+// (profiles/r03_experiments.md 4c): 2048 rows 27.3 -> 26.3 us, 1024 rows 15.7 -> 15.3, but 512 rows 9.1 -> 9.7 and
+// 256 rows 6.3 -> 7.6 (one chunk per wave: the extra load instructions and the predicated reduction fill cost more
+// than the transposes they replace).
+static inline int dw_il_min_k() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_DW_IL_MIN_K"); v = e ? atoi(e) : 1024; }
+    return v;
+}
+// 0: off; otherwise the map is used by weight-gradient launches whose reduction has >= that many rows
+static inline int xmap_min_k() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_XMAP_MIN_K"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];
@@ -1207,6 +1425,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
         by = (xcd / p.xc) * pr + j / pc;
         bx = (xcd % p.xc) * pc + j % pc;
         if (j >= pr * pc || by >= p.tm || bx >= p.tn) return;   // workgroup-uniform
+    } else if (p.xm_pw) {
+        xmap_tile(p, blockIdx.y * gridDim.x + blockIdx.x, bx, by);
     }
     gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, bx, by);
 }
@@ -1227,7 +1447,9 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
+    int bx = blockIdx.x, by = blockIdx.y - hrows;
+    if (p.xm_pw) xmap_tile(p, by * gridDim.x + bx, bx, by);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD>(p, red, bx, by, sds, &hp.fold);
 }
 
 template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false>
@@ -1278,8 +1500,11 @@ __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb
                                                               int tnb) {
     __shared__ float red[16 * 32 * 32];
     const int id = blockIdx.x;
-    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pa, red, id % tna, id / tna);
-    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pb, red, (id - na) % tnb, (id - na) / tnb);
+    if (id < na) {
+        int bx = id % tna, by = id / tna;
+        if (pa.xm_pw) xmap_tile(pa, id, bx, by);
+        gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pa, red, bx, by);
+    } else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
 // Work that rides in (or pairs with) a GEMM launch.
@@ -1300,7 +1525,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     GemmP p = p_in;
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
-    p.xr = 0;
+    p.xr = 0; p.xm_pw = 0;
+    // (operands at least one fragment wide, 32-bit element offsets -- else the 16-byte form)
+    p.il = MODE == MODE_DW && dw_il_min_k() > 0 && p.K >= dw_il_min_k() && p.M >= 4 && p.n_real >= 4 &&
+           (int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
     {
         static int blocked = -1;
         if (blocked < 0) { const char* e = getenv("GM_CHUNK_BLOCKED"); blocked = e ? atoi(e) : 0; }
@@ -1396,11 +1624,17 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if (wide == 5) grid = dim3(tn, (p.M + 47) / 48);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
         if (wide == 3) grid = dim3(tn, (p.M + 15) / 16);
+        // balanced XCD tile map (weight gradients with long reductions: the operands no longer fit one L2)
+        const int tile_h = (wide == 2) ? 64 : (wide == 3 ? 16 : (wide == 5 ? 48 : 32));
+        const int tile_w = (wide == 1) ? 64 : (wide == 4 ? 48 : 32);
+        const bool xm = MODE == MODE_DW && xmap_min_k() > 0 && p.K >= xmap_min_k() && !use8 &&
+                        (int)(grid.x * grid.y) >= 64;
         if constexpr (MODE == MODE_DW) {
             if (head && !use8) {
                 const int hblocks = gm_head_bwd_blocks(*head);
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
+                if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, hrows * (int)grid.x, tile_w, tile_h);
 #define GM_LH(V, GG, X, OFV, FD) do {                                                              \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
@@ -1462,11 +1696,14 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
                 GemmP pb = *rider.pair;
+                pb.il = p.il && pb.M >= 4 && pb.n_real >= 4 &&
+                        (int64_t)pb.K * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31);
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : (wide == 5 ? 3 : 2), ni = (wide == 1) ? 4 : (wide == 4 ? 3 : 2);
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                     const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                     const dim3 pgrid(na + tnb * tmb);
+                    if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, 0, tile_w, tile_h);
 #define GM_LP(GG) do {                                                                             \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
@@ -1484,11 +1721,12 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 return launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
             }
         }
+        if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, 0, tile_w, tile_h);
         {
             static int x16_on = -1;
             if (x16_on < 0) { const char* e = getenv("GM_XCD16"); x16_on = e ? atoi(e) : 0; }
             const int gtm = (int)grid.y, gtn = (int)grid.x;                  // tiles of the chosen shape
-            if (x16_on && gtm * gtn >= 64) {
+            if (x16_on && !p.xm_pw && gtm * gtn >= 64) {
                 const int th = (wide == 2) ? 64 : (wide == 3 ? 16 : (wide == 5 ? 48 : 32)), tw = (wide == 1) ? 64 : (wide == 4 ? 48 : 32);
                 int best = 1 << 30, bxr = 0;
                 for (int xr = 1; xr <= 8; xr <<= 1) {
