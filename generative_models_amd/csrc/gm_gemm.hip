@@ -54,6 +54,10 @@
 #ifndef GM_DW_IL
 #define GM_DW_IL 1
 #endif
+//   GM_DW_IL_PREFETCH   1: the interleaved form loads chunk q + 1 before it consumes chunk q (measured: no change)
+#ifndef GM_DW_IL_PREFETCH
+#define GM_DW_IL_PREFETCH 0
+#endif
 #ifndef GM_EXP_BATCH_LOADS
 #define GM_EXP_BATCH_LOADS 0
 #endif
@@ -956,6 +960,9 @@ __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx,
             ra[s] = *reinterpret_cast<const ILV<MI>*>(pa + min((k0 + 4 * s) * lda, a_last));
             rb[s] = *reinterpret_cast<const ILV<NI>*>(pb + min((k0 + 4 * s) * ldb, b_last));
         }
+        // (measured: a sched_barrier here, which keeps the chunk's eight loads together ahead of the MFMAs -- left
+        // alone the scheduler sinks each pair next to its first use, four waits per chunk -- is SLOWER: 26.1 -> 27.5 us
+        // at 2048 rows; so is the double-buffered loop below with it, 28.3)
     };
     auto mfma_step = [&](const float (&fa)[MI], const float (&fb)[NI]) {
 #pragma unroll
@@ -1005,6 +1012,26 @@ __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx,
             if (have) consume(ra, rb, w, edge_tag);
             q_first = 1;
         }
+#if GM_DW_IL_PREFETCH
+        // Double-buffered: chunk q + 1's loads are in flight while chunk q's MFMAs run (two chunks per trip, static
+        // buffers; past-the-end positions re-load the wave's last chunk -- a valid, unused read).  With the
+        // transposes gone the loop's VALU + MFMA work is ~12 us of a 26 us launch at 2048 rows: the rest is exposed
+        // load latency, one round trip per chunk.
+        if (nq - q_first >= 2) {                              // wave uniform
+            ILV<MI> ra0[4], ra1[4]; ILV<NI> rb0[4], rb1[4];
+            const int last = w + (nq - 1) * WAVES;
+            load_chunk(w + q_first * WAVES, ra0, rb0);
+            int q = q_first;
+            for (; q + 1 < nq; q += 2) {
+                load_chunk(w + (q + 1) * WAVES, ra1, rb1);
+                consume(ra0, rb0, w + q * WAVES, edge_tag);
+                load_chunk(min(w + (q + 2) * WAVES, last), ra0, rb0);
+                consume(ra1, rb1, w + (q + 1) * WAVES, edge_tag);
+            }
+            if (q < nq) consume(ra0, rb0, w + q * WAVES, edge_tag);
+            return;
+        }
+#endif
         for (int q = q_first; q < nq; ++q) {
             ILV<MI> ra[4]; ILV<NI> rb[4];
             const int cc = w + q * WAVES;
