@@ -88,7 +88,7 @@ def gemm_shapes_wgp(B, fold_g=True):
     the stacked layer-1 weight gradient): "dwhs" = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows + head."""
     g = [("fwdp", B, IMG, HID), ("dxhf", B, IMG, HID)] if fold_g else [("fwd", B, IMG, HID), ("dxh", B, IMG, HID)]
     return ([("fwdg", 2 * B, Z, HID), ("fwd", 2 * B, HID, IMG),           # G(zD), G(zG) (+ gather, + x_hat epilogue)
-             ("fwd", 2 * B, IMG, HID), ("fwd", B, IMG, HID),              # D on [x ; G(z)], D layer 1 on x_hat
+             ("fwd", 3 * B, IMG, HID),                                    # D layer 1 on [x_hat ; x ; G(z)]: one launch
              ("dx", B, IMG, HID), ("fwd", B, IMG, HID),                   # g = u W1 ; t = gamma W1^T
              ("dwhs", 3 * B, IMG, HID)] + g + [("dx", B, HID, IMG), ("dwp", B, HID, IMG)])
 
@@ -129,6 +129,8 @@ def gemm_variant(kind, M, K, N):
         mi, ni = (2, 4) if tn >= tm else (4, 2)
     elif tm * tn <= 128 and Mg > 16:                   # 16-row tiles: twice the workgroups
         mi, ni = 1, 2
+    if mode == 0 and (mi, ni) == (4, 2) and kind == "fwd" and tn * -(-Mg // 48) <= 256:
+        mi, ni = 3, 2                                  # 3B-row forward: 208 tiles of 48x32 instead of 156 of 64x32
     if mode == 2 and os.environ.get("GM_DW_TILE48", "2") != "0":
         # weight gradients: 32x48 / 48x32 instead of 32x64 / 64x32 where the narrower tile still fits one round
         if (mi, ni) == (2, 4) and tm * -(-Ng // 48) <= 256:

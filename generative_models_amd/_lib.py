@@ -40,7 +40,8 @@ class HeadBwdArgs(ctypes.Structure):
                 ("vb", c_void_p), ("sched", c_void_p), ("sched_slot", Slot),
                 ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p),
-                ("gw2_add", c_void_p)]
+                ("gw2_add", c_void_p), ("pen_s", c_void_p), ("pen_h", c_void_p), ("pen_ldh", c_int64),
+                ("pen_t", c_void_p), ("pen_ldt", c_int64), ("pen_rows", c_int)]
 
 
 

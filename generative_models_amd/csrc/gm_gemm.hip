@@ -1620,7 +1620,9 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         int wide = 0;                                         // 0: 32x32, 1: 32x64, 2: 64x32
         // measured (profiles/r01_experiments.md): pays only when a wave still has >= 2 chunks of
         // reduction work per tile (dW over 2B = 512 rows: 11.65 -> 10.37 us), loses otherwise
-        if (wide_on && !use8 && tm * tn > 256 && (p.K + 15) / 16 >= 32) wide = (tn >= tm) ? 1 : 2;
+        static int wide_min = -1;
+        if (wide_min < 0) { const char* e = getenv("GM_WIDE_MIN_CHUNKS"); wide_min = e ? atoi(e) : 32; }
+        if (wide_on && !use8 && tm * tn > 256 && (p.K + 15) / 16 >= wide_min) wide = (tn >= tm) ? 1 : 2;
         // fewer than half as many 32x32 tiles as CUs: 16-row tiles double the workgroups and halve
         // each one's A-fragment loads and MFMA chain (the critic pass over B = 256 rows: 104 tiles)
         static int narrow_on = -1;
@@ -1646,6 +1648,11 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 else if (tn < tm && tn * ((p.M + 47) / 48) <= 256) wide = 5;
             }
         }
+        // forward over 3B = 768 rows (WGAN-GP / DRAGAN: D's hidden layer on [x_hat ; x ; G(z)] as one launch): 312
+        // tiles of 32x32 would be two rounds and 156 of 64x32 leave 40 % of the CUs idle -- 48x32 tiles: 208
+        static int f48_on = -1;
+        if (f48_on < 0) { const char* e = getenv("GM_FWD_TILE48"); f48_on = e ? atoi(e) : 1; }
+        if (MODE == MODE_FWD && f48_on && wide == 2 && !p.hd_part && !p.sq_part && tn * ((p.M + 47) / 48) <= 256) wide = 5;
         if (wide == 1) grid = dim3((p.N + 63) / 64, tm);
         if (wide == 4) grid = dim3((p.N + 47) / 48, tm);
         if (wide == 5) grid = dim3(tn, (p.M + 47) / 48);

@@ -73,6 +73,8 @@ struct HeadBwdP {
     int64_t* tick;                          // optional: *tick += 1 after the loss slot is written
     const float* gw2_add;                   // optional: added to gw2 before it is stored / stepped (the
                                             // gradient penalty's second-backward share, w_gp_gan.py:215)
+    const float* pen_s; const float* pen_h; int64_t pen_ldh;   // optional: the gradient penalty's share of gw2,
+    const float* pen_t; int64_t pen_ldt; int pen_rows;         // summed here (gm_hip.h gm_head_bwd_args)
     FoldP fold;                             // folded head: dS / rowloss come from fold_row, not from memory
 };
 
@@ -147,6 +149,15 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid,
             acc = fmaf(d, h, acc);
         }
         if (col_adam) { pP = p.adam.pW[c]; pM = p.adam.mW[c]; pV = p.adam.vW[c]; }
+        if (p.pen_t) {                                       // kernel-argument uniform
+            float a2 = 0.f;
+            for (int r = rg; r < p.pen_rows; r += HB_RG) {
+                const float sv = p.pen_s[r], hv = p.pen_h[(int64_t)r * p.pen_ldh + c];
+                const float tv = p.pen_t[(int64_t)r * p.pen_ldt + c];
+                if (sv > 0.f && hv > 0.f) a2 += tv;
+            }
+            acc += a2;
+        }
     }
     if (p.gw2) {
         sh[rg][cl] = acc;
@@ -239,6 +250,10 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out,
     }
     p.tick = a.tick;
     p.gw2_add = a.gw2_add;
+    GM_CHECK_ARG(!a.pen_t || (a.pen_s && a.pen_h && a.gw2 && !fold && a.pen_rows > 0 && a.pen_ldh >= a.Hd &&
+                              a.pen_ldt >= a.Hd));
+    p.pen_s = a.pen_s; p.pen_h = a.pen_h; p.pen_ldh = a.pen_ldh; p.pen_t = a.pen_t; p.pen_ldt = a.pen_ldt;
+    p.pen_rows = a.pen_rows;
     p.H = a.H; p.ldh = a.ldh; p.dS = a.dS; p.w2 = a.w2; p.rowloss = a.rowloss; p.dH = a.dH;
     p.lddh = a.lddh; p.gw2 = a.gw2; p.gb2 = a.gb2; p.loss_out = a.loss_out;
     p.loss_slot = a.loss_slot; p.inv_b = a.inv_b; p.gen_mode = a.gen_mode; p.B = a.B;

@@ -402,10 +402,19 @@ class GANEngine:
         self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
         if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
+            self.merge_fwd3 = os.environ.get("GM_MERGE_FWD3", "1") != "0"
+            if self.merge_fwd3:
+                # D's hidden layer on [x_hat ; x ; G(z)] as ONE 3B-row launch: x_hat lives in the first row block
+                # of XX4 (WGAN-GP writes gamma there LATER, when x_hat has been consumed), its hidden activations
+                # right in front of the other two blocks'
+                self.HH3 = z(3 * Bl, Hd)
+                self.Hh, self.Hd = self.HH3[:Bl], self.HH3[Bl:]
+                self.Xh = self.XX4[:Bl]
             self.Gr, self.T = z(Bl, I), z(Bl, Hd)
             if variant == "wgp":
                 self.U, self.Gam = self.DU[:Bl], self.XX4[:Bl]
                 self.gw2_pen = z(Hd)
+                self.pen_in_head = os.environ.get("GM_WGP_PEN_IN_HEAD", "1") != "0"
             else:
                 self.U, self.Gam = z(Bl, Hd), z(Bl, I)
             self.pen = z(Bl)
@@ -654,13 +663,21 @@ class GANEngine:
                         adam=adam)
             ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
             return
-        ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
+        merged = self.variant in ("wgp", "dra") and self.merge_fwd3 and not self.dag
+        if merged:
+            if self.variant == "wgp":
+                self._gp_prepare(st, it, j)
+            else:
+                self._dra_prepare(st, it, j)
+            ops.linear_fwd(self.XX4[:3 * Bl], D1.W, D1.b, self.HH3, "relu", M=3 * Bl, stream=st)
+        else:
+            ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
-            self._issue_gp_forward(st, it, j)
+            self._issue_gp_forward(st, it, j, fwd_done=merged)
             aux, hyper = self.pen, (0.0,) * 7 + (self.gp_lambda,)
         if self.variant == "dra":
-            self._issue_dra_forward(st, it, j)
+            self._issue_dra_forward(st, it, j, fwd_done=merged)
             aux, hyper = self.pen, tuple(self.hyper) + (0.0,) * (7 - len(self.hyper)) + (self.gp_lambda,)
         if self.fuse_head and self.variant not in ("ra", "fisher"):
             from . import ops_fused as of
@@ -675,7 +692,10 @@ class GANEngine:
                 if self._wgp_stacked():
                     # dW1 = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows (the penalty rows do not reach
                     # db1), gw2 += the penalty's share (computed by _issue_gp_forward)
-                    head["gw2_add"] = self.gw2_pen
+                    if self.pen_in_head:
+                        head["pen"] = dict(s=self.Sh, h=self.Hh, t=self.T)    # summed by the head workgroups
+                    else:
+                        head["gw2_add"] = self.gw2_pen
                     ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
                                                 stream=st)
                 else:
@@ -918,16 +938,22 @@ class GANEngine:
         ops.tick(self.ctr, 1, stream=st)
 
     # -- WGAN-GP penalty: w_gp_gan.py:195-218, hand-derived second backward -----
-    def _issue_gp_forward(self, st, it, j):
+    def _gp_prepare(self, st, it, j):
+        """x_hat, unless the generator's last launch already wrote it."""
         from . import ops_fused as ops_gp
         Bl, d, R = self.Bl, self.D_steps, self.R
-        D1, D2 = self.D1, self.D2
-        r0 = self.ring_r0
-        eps_slot = self._slot(it, d, j, R * d, self.ring_B)
         if not self._interp_in_gen():
-            ops_gp.interp(self.eps_ring.view(-1)[r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
+            eps_slot = self._slot(it, d, j, R * d, self.ring_B)
+            ops_gp.interp(self.eps_ring.view(-1)[self.ring_r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
                           stream=st)
-        ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
+
+    def _issue_gp_forward(self, st, it, j, fwd_done=False):
+        from . import ops_fused as ops_gp
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        if not fwd_done:
+            self._gp_prepare(st, it, j)
+            ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
         if self._wgp_stacked():
             ops_gp.head_gp(self.Hh, D2.W, D2.b, self.Sh, self.U, stream=st)     # D(x_hat), u: one launch
         else:
@@ -939,13 +965,14 @@ class GANEngine:
             # second backward, w2's share, BEFORE the stacked dW1 launch steps W1:
             # t = gamma W1^T, gw2_pen = sum_b m2 m1 . t   (w_gp_gan.py:215)
             ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)
-            ops_gp.gp_dw2_store(self.Sh, self.Hh, self.T, self.gw2_pen, stream=st)
+            if not self.pen_in_head:
+                ops_gp.gp_dw2_store(self.Sh, self.Hh, self.T, self.gw2_pen, stream=st)
 
     # -- DRAGAN penalty: dra_gan.py:198-223; sigmoid critic => second-order terms --
-    def _issue_dra_forward(self, st, it, j):
+    def _dra_prepare(self, st, it, j):
+        """x_hat = x + (1 - delta) * C * std(x) * U  (dra_gan.py:200-205)."""
         from . import ops_fused as of
         Bl, d, R = self.Bl, self.D_steps, self.R
-        D1, D2 = self.D1, self.D2
         x = self.X2[:Bl]
         if self._dp():
             # images.data.std() is over the GLOBAL batch (dra_gan.py:204): (sum x, sum x^2) of my rows,
@@ -959,7 +986,14 @@ class GANEngine:
         of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.ring_B),
                        self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.ring_B * self.I),
                        self.stdv, self.Xh, Bl, stream=st)
-        ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
+
+    def _issue_dra_forward(self, st, it, j, fwd_done=False):
+        from . import ops_fused as of
+        Bl = self.Bl
+        D1, D2 = self.D1, self.D2
+        if not fwd_done:
+            self._dra_prepare(st, it, j)
+            ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
         ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "sigmoid", M=Bl, stream=st)
         of.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)                          # m1 . w2 (sigma > 0)
         ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                   # v = (m1.w2) W1

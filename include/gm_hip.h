@@ -266,6 +266,10 @@ typedef struct gm_head_bwd_args {
     double beta1, beta2, eps, weight_decay; float clamp;
     int64_t* tick;
     const float* gw2_add;                 /* optional [Hd]: added to gw2 before it is stored / stepped */
+    /* optional (pen_t != NULL): gw2[c] += sum_{r < pen_rows} [pen_s[r] > 0][pen_h[r][c] > 0] pen_t[r][c] -- the
+     * gradient penalty's second-backward share of w2's gradient (w_gp_gan.py:215) summed by the
+     * head's own workgroups instead of a launch of gm_gp_dw2_store */
+    const float* pen_s; const float* pen_h; int64_t pen_ldh; const float* pen_t; int64_t pen_ldt; int pen_rows;
 } gm_head_bwd_args;
 int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const float* X,
                                int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,

@@ -329,6 +329,14 @@ def test_head_gp_and_stacked_weight_gradient():
     assert rel(lin.gb.cpu(), dH.double().sum(0).cpu()) < 2e-6          # no bias share from the u rows
     gw2_ref = dS.double() @ Hd.double() + add.double()
     assert rel(head_lin.gW.view(-1).cpu(), gw2_ref.cpu()) < 2e-6
+    # the penalty's share of w2's gradient summed by the head's own workgroups (no gm_gp_dw2_store launch):
+    # same gradient as handing over the stored sums
+    head2 = dict(head, gw2_add=None, pen=dict(s=s, h=h, t=t))
+    lin.gW.zero_(); lin.gb.zero_(); head_lin.gW.zero_()
+    ops.linear_bwd_dw_adam_head(DU, XX, lin, None, head2, M=3 * B, ones_from=B)
+    pen_ref = ((s_ref[:, None] > 0) & (h.double() > 0)).double().mul(t.double()).sum(0)
+    assert rel(head_lin.gW.view(-1).cpu(), (dS.double() @ Hd.double() + pen_ref).cpu()) < 2e-6
+    assert rel(lin.gW.cpu(), gW_ref.cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("B,Z", [(256, 20), (512, 20), (336, 20), (37, 6), (100, 64), (48, 8), (70, 32)])

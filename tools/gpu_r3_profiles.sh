@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 profiles: rocprofv3 kernel-trace stats + the PMC passes (each in its OWN run: --pmc with --kernel-trace
 # only) for the headline workload and the configs 3/4/5 legs; summaries land in gpurun_out/profiles_r03/.
-# usage: gpu_r3_profiles.sh [all | comma list of nsgan_b256,ns_b1024,wgp_b256,vae_b512,sq]
+# usage: gpu_r3_profiles.sh [all | comma list of nsgan_b256,ns_b1024,wgp_b256,dra_b256,vae_b512,sq]
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out/profiles_r03; export TMPDIR=/tmp
 OUT=$R/gpurun_out/profiles_r03
@@ -29,5 +29,6 @@ if want sq; then
 fi
 want ns_b1024 && prof r03_ns_b1024 "NSGAN bs=1024 (configs[4] single-GPU leg), bench.py --only ns_b1024" --only ns_b1024 --steps 200 --warmup 20 --reps 1
 want wgp_b256 && prof r03_wgp_b256 "WGAN-GP bs=256 D_steps=1 (configs[2]), bench.py --only wgp_b256" --only wgp_b256 --steps 200 --warmup 20 --reps 1
+want dra_b256 && prof r03_dra_b256 "DRAGAN bs=256 D_steps=1 (VERDICT r2 item 10), bench.py --only dra_b256" --only dra_b256 --steps 200 --warmup 20 --reps 1
 want vae_b512 && prof r03_vae_b512 "VAE bs=512 full epochs (configs[3]), bench.py --only vae_b512" --only vae_b512 --steps 200 --warmup 20 --reps 1
 ls $OUT | head -50; du -sh $R/gpurun_out

@@ -1,10 +1,10 @@
 #!/bin/bash
-# interleaved dW: double-buffered prefetch on (default lib) / off (variant), isolated shapes, IL forced for all sizes too
+# WGAN-GP: the penalty's w2 share summed by the head workgroups (13 launches): tests, then off / on alternating
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out
-S="dw:2048:784:400 dw:1024:400:784 dw:1024:784:400 dw:512:784:400 dw:256:400:784"
-for rep in 1 2; do
-echo "== prefetch on"; timeout 120 python tools/gemm_shapes_bench.py $S 2>&1 | grep -v amdgpu
-echo "== prefetch off"; GM_LIB_PATH=$R/generative_models_amd/ab_libs/nopf.so timeout 120 python tools/gemm_shapes_bench.py $S 2>&1 | grep -v amdgpu
-done
-echo "== prefetch on, IL for every size"; GM_DW_IL_MIN_K=1 timeout 120 python tools/gemm_shapes_bench.py $S dw:336:784:400 dw:37:100:70 2>&1 | grep -v amdgpu
+timeout 900 python -m pytest tests/test_gpu_fused_ops.py tests/test_gpu_ops.py -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -3
+timeout 900 python -m pytest tests/test_gpu_trainers.py tests/test_gpu_dp.py -q -m gpu -x -k "wgp" 2>&1 | grep -E "passed|failed|error" | tail -3
+for rep in 1 2 3; do
+for k in 0 1; do
+echo "== GM_WGP_PEN_IN_HEAD=$k"; GM_WGP_PEN_IN_HEAD=$k timeout 300 python bench.py --only wgp_b256 --steps 400 --warmup 50 --reps 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print([ (e['workload'][:28], round(e['ms_per_step']*1e3,2)) for e in d])"
+done; done
