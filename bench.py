@@ -143,10 +143,13 @@ def gemm_variant(kind, M, K, N):
             elif tn < tm and tn * -(-Mg // 48) <= 256:
                 mi, ni = 3, 2
     b = lambda v: "true" if v else "false"
+    # weight gradients over >= 1024 rows on 32x48 / 48x32 tiles: the interleaved-fragment instantiations
+    il = mode == 2 and xv and Kr >= int(os.environ.get("GM_DW_IL_MIN_K", "1024")) > 0 and (mi, ni) in ((2, 3), (3, 2))
     if kind in ("dwh", "dwhf", "dwhs"):
-        # last two arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded head
-        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, %s, %s>" % (g, b(xv), mi, ni, b(kind == "dwhs"),
-                                                                         b(kind == "dwhf"))
+        # last three arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded
+        # head; interleaved fragments
+        return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, %s, %s, %s>" % (
+            g, b(xv), mi, ni, b(kind == "dwhs"), b(kind == "dwhf"), b(il and kind != "dwhf"))
     if kind in ("dxh", "dxhf"):
         assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_dx_head_kernel<%d, %d, %d, %s>" % (g, mi, ni, b(kind == "dxhf"))
@@ -155,8 +158,8 @@ def gemm_variant(kind, M, K, N):
         return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
     if kind == "dwp":
         assert xv and (mi, ni) != (1, 2)
-        return "gemm16_dw_pair_kernel<%d, true, %d, %d>" % (g, mi, ni)
-    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d>" % (mode, b(vec), nw, g, b(xv), mi, ni)
+        return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s>" % (g, mi, ni, b(il))
+    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(il))
 
 
 def clock_probe():

@@ -122,12 +122,6 @@ struct GemmP {
     int cpw;                  // >0: wave w owns the CONTIGUOUS chunks [w*cpw, (w+1)*cpw)
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
-    // Balanced XCD tile map of the 16x16x4 kernels (xm_pw > 0; see xmap_tile): the grid keeps its shape and
-    // every workgroup its XCD, only WHICH tile a workgroup computes changes -- the workgroups of one XCD get a
-    // run of consecutive tiles of a panel-major order (panels of xm_pw tile columns), i.e. a compact block of
-    // the output whose operand columns fit that XCD's L2 instead of all eight L2s pulling both operands whole.
-    int xm_pw, xm_a, xm_tn, xm_tm;
-    int xm_start[8];
     int il;                   // dw: interleaved fragments (gemm16_dw_il) instead of 16-byte loads + quad transposes
     // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
     // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
@@ -1074,17 +1068,16 @@ __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx,
 // FOLD (folded critic head, gm_head.h): 1 = weight gradient whose A operand dH[k][x] is formed from
 // h[k][x], sds[k] (dS of reduction row k) and w2[x]; 2 = input gradient whose A operand dH[m][k] is
 // formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0>
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool IL = false>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
-    if constexpr (GM_DW_IL && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
-        // kernel-uniform: operands at least one fragment wide, 32-bit element offsets (else the form below)
-        if (p.il) {
-            gemm16_dw_il<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
-            return;
-        }
+    // IL: the launch chose the interleaved-fragment form (its own kernel instantiations: as a run-time branch
+    // inside the shared kernels it cost the bs=256 step 1.5 us in registers and code it never runs)
+    if constexpr (IL && GM_DW_IL && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
+        gemm16_dw_il<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
+        return;
     }
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -1389,40 +1382,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         }
 }
 
-// lp: linear index of this workgroup among the launch's GEMM workgroups (dispatch order).  Workgroup with
-// linear id L of the whole grid runs on XCD L % 8 (observed, tools/xcc_probe.hip; only speed depends on it);
-// xm_a = (number of workgroups dispatched before the GEMM's) % 8.  The k-th GEMM workgroup of XCD x takes
-// tile xm_start[x] + k of the panel-major order.
-static __device__ __forceinline__ void xmap_tile(const GemmP& p, int lp, int& bx, int& by) {
-    const int u = lp + p.xm_a, xcd = u & 7;
-    const int k = (u >> 3) - (xcd < p.xm_a ? 1 : 0);
-    const int t = p.xm_start[xcd] + k;
-    const int per = p.xm_pw * p.xm_tm;
-    const int panel = t / per, r = t - panel * per;
-    const int w = min(p.xm_pw, p.xm_tn - panel * p.xm_pw);
-    by = r / w;
-    bx = panel * p.xm_pw + (r - by * w);
-}
-// host side: fill the map for a launch of tn x tm tiles whose GEMM workgroups follow `before` others
-static inline void xmap_setup(GemmP& p, int tn, int tm, int before, int tile_w, int tile_h) {
-    const int T = tn * tm, a = before & 7;
-    int start = 0;
-    for (int x = 0; x < 8; ++x) {
-        // u in [a, T + a) with u % 8 == x
-        int cnt = 0;
-        if (T + a - 1 >= x) cnt = (T + a - 1 - x) / 8 + 1 - (x < a ? 1 : 0);
-        p.xm_start[x] = start;
-        start += cnt;
-    }
-    // block of h x pw tiles per XCD (h * pw ~ T / 8) with the fewest operand columns pw*tile_w + h*tile_h
-    const double seg = (double)T / 8.0;
-    int pw = (int)(sqrt(seg * (double)tile_h / (double)tile_w) + 0.5);
-    static int pw_env = -1;
-    if (pw_env < 0) { const char* e = getenv("GM_XMAP_PW"); pw_env = e ? atoi(e) : 0; }
-    if (pw_env > 0) pw = pw_env;
-    p.xm_pw = pw < 1 ? 1 : (pw > tn ? tn : pw);
-    p.xm_a = a; p.xm_tn = tn; p.xm_tm = tm;
-}
 // Interleaved fragments for weight gradients whose reduction has >= this many rows (0: never).  Measured
 // (profiles/r03_experiments.md 4c): 2048 rows 27.3 -> 26.3 us, 1024 rows 15.7 -> 15.3, but 512 rows 9.1 -> 9.7 and
 // 256 rows 6.3 -> 7.6 (one chunk per wave: the extra load instructions and the predicated reduction fill cost more
@@ -1432,14 +1391,7 @@ static inline int dw_il_min_k() {
     if (v < 0) { const char* e = getenv("GM_DW_IL_MIN_K"); v = e ? atoi(e) : 1024; }
     return v;
 }
-// 0: off; otherwise the map is used by weight-gradient launches whose reduction has >= that many rows
-static inline int xmap_min_k() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GM_XMAP_MIN_K"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI>
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool IL = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ float red[WAVES * 32 * 32];
     int bx = blockIdx.x, by = blockIdx.y;
@@ -1452,17 +1404,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
         by = (xcd / p.xc) * pr + j / pc;
         bx = (xcd % p.xc) * pc + j % pc;
         if (j >= pr * pc || by >= p.tm || bx >= p.tn) return;   // workgroup-uniform
-    } else if (p.xm_pw) {
-        xmap_tile(p, blockIdx.y * gridDim.x + blockIdx.x, bx, by);
     }
-    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI>(p, red, bx, by);
+    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI, false, 0, IL>(p, red, bx, by);
 }
 
 // The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false>
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool IL = false>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
     __shared__ float red[16 * 32 * 32];
@@ -1474,15 +1424,13 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body(hp, bid, sds);
         return;
     }
-    int bx = blockIdx.x, by = blockIdx.y - hrows;
-    if (p.xm_pw) xmap_tile(p, by * gridDim.x + bx, bx, by);
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD>(p, red, bx, by, sds, &hp.fold);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, IL>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
-template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false>
+template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool IL = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
-    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED>(p, hp, hrows, hblocks);
+    gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED, IL>(p, hp, hrows, hblocks);
 }
 
 // The generator step's dX GEMM carrying the one scalar workgroup of the head (loss + tick): the
@@ -1522,16 +1470,13 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
-template <int G, bool XV, int MI, int NI>
+template <int G, bool XV, int MI, int NI, bool IL = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
                                                               int tnb) {
     __shared__ float red[16 * 32 * 32];
     const int id = blockIdx.x;
-    if (id < na) {
-        int bx = id % tna, by = id / tna;
-        if (pa.xm_pw) xmap_tile(pa, id, bx, by);
-        gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pa, red, bx, by);
-    } else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI>(pb, red, (id - na) % tnb, (id - na) / tnb);
+    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pa, red, id % tna, id / tna);
+    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
 // Work that rides in (or pairs with) a GEMM launch.
@@ -1552,7 +1497,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     GemmP p = p_in;
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
-    p.xr = 0; p.xm_pw = 0;
+    p.xr = 0;
     // (operands at least one fragment wide, 32-bit element offsets -- else the 16-byte form)
     p.il = MODE == MODE_DW && dw_il_min_k() > 0 && p.K >= dw_il_min_k() && p.M >= 4 && p.n_real >= 4 &&
            (int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
@@ -1658,19 +1603,15 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if (wide == 5) grid = dim3(tn, (p.M + 47) / 48);
         if (wide == 2) grid = dim3(tn, (p.M + 63) / 64);
         if (wide == 3) grid = dim3(tn, (p.M + 15) / 16);
-        // balanced XCD tile map (weight gradients with long reductions: the operands no longer fit one L2)
-        const int tile_h = (wide == 2) ? 64 : (wide == 3 ? 16 : (wide == 5 ? 48 : 32));
-        const int tile_w = (wide == 1) ? 64 : (wide == 4 ? 48 : 32);
-        const bool xm = MODE == MODE_DW && xmap_min_k() > 0 && p.K >= xmap_min_k() && !use8 &&
-                        (int)(grid.x * grid.y) >= 64;
         if constexpr (MODE == MODE_DW) {
             if (head && !use8) {
                 const int hblocks = gm_head_bwd_blocks(*head);
                 const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
                 const dim3 hgrid(grid.x, grid.y + hrows);
-                if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, hrows * (int)grid.x, tile_w, tile_h);
 #define GM_LH(V, GG, X, OFV, FD) do {                                                              \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 4 && p.il && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, false, true>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 5 && p.il && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, false, true>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
@@ -1737,9 +1678,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                     const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                     const dim3 pgrid(na + tnb * tmb);
-                    if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, 0, tile_w, tile_h);
 #define GM_LP(GG) do {                                                                             \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 4 && p.il && pb.il) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3, true>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 5 && p.il && pb.il) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2, true>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
@@ -1755,12 +1697,11 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 return launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
             }
         }
-        if (xm) xmap_setup(p, (int)grid.x, (int)grid.y, 0, tile_w, tile_h);
         {
             static int x16_on = -1;
             if (x16_on < 0) { const char* e = getenv("GM_XCD16"); x16_on = e ? atoi(e) : 0; }
             const int gtm = (int)grid.y, gtn = (int)grid.x;                  // tiles of the chosen shape
-            if (x16_on && !p.xm_pw && gtm * gtn >= 64) {
+            if (x16_on && gtm * gtn >= 64) {
                 const int th = (wide == 2) ? 64 : (wide == 3 ? 16 : (wide == 5 ? 48 : 32)), tw = (wide == 1) ? 64 : (wide == 4 ? 48 : 32);
                 int best = 1 << 30, bxr = 0;
                 for (int xr = 1; xr <= 8; xr <<= 1) {
@@ -1777,6 +1718,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
 #define GM_L16(V, W, GG, X) do {                                                                   \
         if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 4 && MODE == MODE_DW && p.il && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3, (MODE == MODE_DW && (X) && W == 16)>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 5 && MODE == MODE_DW && p.il && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2, (MODE == MODE_DW && (X) && W == 16)>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 4, 2>), grid, dim3(W * 64), 0, s, p); \

@@ -498,8 +498,8 @@ def test_linear_fwd_with_gather_riding(M, K, N, B, I):
 @pytest.mark.parametrize("B,H,I,Z", [(256, 400, 784, 20), (1024, 400, 784, 20), (24, 20, 36, 8),
                                      (32, 31, 33, 5)])
 def test_dw_adam_pair_in_one_launch(B, H, I, Z):
-    """gm_linear_bwd_dw_adam_pair == two gm_linear_bwd_dw_adam launches, bit for bit (incl. the
-    wide-tile configuration at B = 1024 and the unaligned two-launch fallback)."""
+    """gm_linear_bwd_dw_adam_pair == two gm_linear_bwd_dw_adam launches, bit for bit below 1024 rows (incl. the
+    unaligned two-launch fallback), to rounding at B = 1024 (wide tiles, interleaved fragments)."""
     import torch.nn as nn
     from generative_models_amd.engine import FlatParams, _Linear
 
@@ -524,7 +524,12 @@ def test_dw_adam_pair_in_one_launch(B, H, I, Z):
 
     a, b = run(True), run(False)
     for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq")):
-        assert torch.equal(x, y), name
+        if B >= 1024:
+            # reductions of >= 1024 rows: the pair runs BOTH gradients on the interleaved-fragment kernel (a
+            # different order of the four k inside an MFMA step), a lone 400 x 21 gradient keeps the 16-byte form
+            assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max())), name
+        else:
+            assert torch.equal(x, y), name
     assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
 
 
