@@ -10,7 +10,7 @@ fi
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 timeout 900 python bench.py > $OUT/r03_bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r03_bench_steps20_warmup5.json 2> $OUT/bench_s20.err; echo "bench s20 rc=$?"
-for n in 2 4 8; do
+for n in ${DRY_NS:-2 4 8}; do
   GM_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus $n --steps 20 --warmup 5 > $OUT/r03_bench_dry_n$n.json 2> $OUT/bench_dry_n$n.err; echo "dry run N=$n rc=$?"
 done
 python - <<'PY'
