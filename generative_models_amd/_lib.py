@@ -204,6 +204,7 @@ _SIGNATURES = {
     "gm_host_device_ptr": (c_int, [_P, POINTER(c_void_p)]),
     "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),
     "gm_host_replay_threads": (c_int, [c_int]),
+    "gm_numpy_legacy_normal_f32": (c_int, [_P, _P, _P, _P, ctypes.c_double, ctypes.c_double, c_int64, _P, c_int]),
     "gm_fill_submit": (c_int64, [_P, c_int64, POINTER(DrawOp), c_int, c_int, _P, c_int64]),
     "gm_fill_wait": (c_int, [c_int64]),
     "gm_fill_completed": (c_int64, []),

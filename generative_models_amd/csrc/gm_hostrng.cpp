@@ -797,3 +797,95 @@ extern "C" int gm_fill_reset(void) {
     w->rc.store(0);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// numpy's LEGACY global generator (np.random.normal, what bir_vae.py:92-94 draws its noise from):
+// RandomState = MT19937 + the polar Box-Muller of numpy/random/src/legacy/legacy-distributions.c
+//     legacy_double: a = next32 >> 5, b = next32 >> 6, (a * 67108864.0 + b) / 9007199254740992.0
+//     legacy_gauss : cached second value first; else candidates x1, x2 = 2 u - 1 until 0 < r2 < 1,
+//                    f = sqrt(-2.0 * log(r2) / r2), keep f * x1, return f * x2
+//     legacy_normal: loc + scale * legacy_gauss
+// restated so that the 100 us of log / sqrt / divide per 10 240 samples can run on several threads: the
+// uniform stream and the accept / reject decisions are sequential (phase 1, ~4 ns per candidate), the
+// transform of the accepted pairs is not (phase 2, the pool).  Same libm, no FMA contraction (this file is
+// built with -ffp-contract=off): bit-identical doubles, rounded to float as `.float()` does.
+// state: key[624] / pos / has_gauss / gauss exactly as np.random.get_state(legacy=True) returns them.
+// ------------------------------------------------------------------------------------------------
+namespace {
+Pool* g_np_pool = nullptr;
+std::mutex g_np_mu;
+}
+
+extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_t* has_gauss_io, double* gauss_io,
+                                          double loc, double scale, int64_t n, float* out, int n_threads) {
+    if (!key || !pos_io || !has_gauss_io || !gauss_io || !out || n < 0 || *pos_io < 0 || *pos_io > 624) {
+        gm_set_error("gm_numpy_legacy_normal_f32: bad arguments");
+        return GM_EINVAL;
+    }
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> guard(g_np_mu);
+    int64_t i0 = 0;
+    if (*has_gauss_io) {                                   // the cached half of the previous pair comes first
+        out[0] = (float)(loc + scale * *gauss_io);
+        *has_gauss_io = 0; *gauss_io = 0.0;
+        i0 = 1;
+    }
+    const int64_t m = n - i0;                              // values still to produce
+    if (m == 0) return 0;
+    const int64_t P = (m + 1) / 2;                         // accepted pairs needed
+    // phase 1: tempered words -> candidates -> the first P accepted (x1, x2, r2).  Buffers persist across calls
+    // (guarded by g_np_mu): a chunk of 32 batches is 2 MB of them, and fresh pages cost more than the arithmetic.
+    alignas(64) uint32_t st[624 + 16];
+    std::memcpy(st, key, 624 * sizeof(uint32_t));
+    int pos = *pos_io;
+    alignas(64) static uint32_t wb[624 + 16];              // tempered words of the current block (+ <= 3 carried over)
+    int have = 0, rd = 0;
+    static std::vector<double> X1, X2, R2;
+    if ((int64_t)X1.size() < P) { X1.resize((size_t)P); X2.resize((size_t)P); R2.resize((size_t)P); }
+    int64_t got = 0;
+    while (got < P) {
+        if (have - rd < 4) {                               // next block: carry the unread words to the front
+            const int left = have - rd;
+            for (int i = 0; i < left; ++i) wb[i] = wb[rd + i];
+            if (pos >= 624) { twist(st); pos = 0; }
+            temper(st + pos, wb + left, 624 - pos);
+            have = left + (624 - pos); rd = 0; pos = 624;
+            continue;
+        }
+        const uint32_t* w = wb + rd;
+        rd += 4;
+        const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+        const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
+        const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+        const double r2 = x1 * x1 + x2 * x2;
+        if (r2 >= 1.0 || r2 == 0.0) continue;
+        X1[(size_t)got] = x1; X2[(size_t)got] = x2; R2[(size_t)got] = r2;
+        ++got;
+    }
+    // the generator's state after exactly the consumed words (the unread ones all belong to the last block)
+    std::memcpy(key, st, 624 * sizeof(uint32_t));
+    *pos_io = 624 - (have - rd);
+    // phase 2: the transform of the accepted pairs
+    float* o = out + i0;
+    double last_x1f = 0.0;
+    auto part = [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; ++j) {
+            const double r2 = R2[(size_t)j];
+            const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+            const double a = f * X2[(size_t)j], b = f * X1[(size_t)j];
+            o[2 * j] = (float)(loc + scale * a);
+            if (2 * j + 1 < m) o[2 * j + 1] = (float)(loc + scale * b);
+            else last_x1f = b;                             // (only the last pair, one writer)
+        }
+    };
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > 1 && P >= 512) {
+        if (!g_np_pool || g_np_pool->size() + 1 != n_threads) { delete g_np_pool; g_np_pool = new Pool(n_threads - 1); }
+        g_np_pool->run([&](int k, int np) { part(P * k / np, P * (k + 1) / np); });
+    } else {
+        part(0, P);
+    }
+    if (m & 1) { *has_gauss_io = 1; *gauss_io = last_x1f; }
+    return 0;
+}

@@ -551,6 +551,12 @@ int64_t gm_fill_completed(void);
 int gm_fill_reset(void);
 /* HOST: size of the worker pool of gm_host_replay's Box-Muller stage (1 = caller only). */
 int gm_host_replay_threads(int n_threads);
+/* numpy's LEGACY global generator (np.random.normal of bir_vae.py:92-94): n values loc + scale * legacy_gauss as
+ * float32, bit-identical to torch.from_numpy(np.random.normal(loc, scale, n)).float(); key[624] / pos / has_gauss /
+ * gauss are np.random.get_state(legacy=True)'s fields, advanced in place.  The log / sqrt stage of the polar
+ * method runs on n_threads. */
+int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos, int32_t* has_gauss, double* gauss, double loc,
+                               double scale, int64_t n, float* out, int n_threads);
 
 /* ---- graph capture helpers (HIP graphs instead of a tracing compiler) ------------------ */
 int gm_graph_begin(void* stream);

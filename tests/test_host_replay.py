@@ -299,3 +299,56 @@ def test_random_draw_programmes_match_torch_bit_for_bit(seed):
     for i, (r, o) in enumerate(zip(ref, outs)):
         assert torch.equal(r, o), (seed, i, seq[i])
     assert torch.equal(st, s1), (seed, seq)
+
+
+# ---- numpy's legacy global generator (BIR-VAE's noise, bir_vae.py:92-94) replayed in C ---------------------
+def _np_state(rs):
+    return engine.NumpyReplay._unpack(rs.get_state(legacy=True))
+
+
+def test_numpy_replay_selfcheck_passes_on_this_host():
+    assert engine.NumpyReplay.available()
+
+
+@pytest.mark.parametrize("seed", [0, 7, 2024])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_numpy_legacy_normal_bit_for_bit(seed, threads):
+    """gm_numpy_legacy_normal_f32 == torch.from_numpy(RandomState.normal(loc, scale, n)).float() bit for bit, for
+    odd and even counts (the cached second value of the polar method carries over between calls), positions
+    anywhere in the 624-word block, and the generator ends in exactly numpy's state."""
+    rs = np.random.RandomState(seed)
+    rs.random_sample(seed % 5)                         # position not a multiple of 4
+    state = _np_state(rs)
+    rnd = np.random.RandomState(seed + 1)
+    for _ in range(12):
+        n = int(rnd.choice([1, 2, 3, 7, 156, 623, 624, 1248, 4097, 10240, 20480]))
+        loc, scale = float(rnd.choice([0.0, 1.5])), float(rnd.choice([1.0, 0.37, 13.3]))
+        ref = torch.from_numpy(rs.normal(loc, scale, n)).float()
+        got = torch.empty(n)
+        engine.NumpyReplay._call(state, loc, scale, n, got.data_ptr(), threads)
+        assert torch.equal(ref.view(torch.int32), got.view(torch.int32)), (seed, n)
+        end = rs.get_state(legacy=True)
+        assert np.array_equal(end[1], state[0]) and (int(end[2]), int(end[3]), float(end[4])) == tuple(state[1:])
+        if rnd.rand() < 0.3:                           # other draws in between advance both alike
+            rs.random_sample(3)
+            state = _np_state(rs)
+
+
+def test_numpy_replay_fill_matches_the_reference_loop_on_the_global_generator():
+    """NumpyReplay.fill == the reference's per-batch np.random.normal(0, set_var, (b, Z)).float() on numpy's GLOBAL
+    generator (full batches as one call, the ragged one on its own), and leaves the generator where numpy does."""
+    B, Z, sizes = 64, 20, [64, 64, 64, 37]
+    saved = np.random.get_state()
+    try:
+        np.random.seed(99)
+        ref = [torch.from_numpy(np.random.normal(0.0, 0.5, size=(b, Z))).float() for b in sizes]
+        tail = np.random.normal(size=3)
+        np.random.seed(99)
+        dst = torch.zeros(6, B, Z)
+        assert engine.NumpyReplay.fill(0.5, dst, B, Z, sizes)
+        for k, b in enumerate(sizes):
+            assert torch.equal(dst[k].view(-1)[:b * Z], ref[k].view(-1)), k
+        assert not dst[3].view(-1)[37 * Z:].any() and not dst[4:].any()
+        assert np.array_equal(np.random.normal(size=3), tail)
+    finally:
+        np.random.set_state(saved)
