@@ -24,6 +24,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -814,6 +815,34 @@ extern "C" int gm_fill_reset(void) {
 namespace {
 Pool* g_np_pool = nullptr;
 std::mutex g_np_mu;
+
+// Eight candidates of the polar method (32 tempered words) at once: the same IEEE operations as the scalar loop
+// (every step before r2 is exact in double; r2 = x1*x1 + x2*x2 as two products and a sum -- this file is built
+// without FMA contraction), accepted ones appended in order.  Returns the number accepted.
+__attribute__((target("avx512f"))) int np_candidates8_avx512(const uint32_t* w, double* x1o, double* x2o, double* r2o) {
+    const __m512i A = _mm512_loadu_si512((const void*)w), B = _mm512_loadu_si512((const void*)(w + 16));
+    const __m512i i0 = _mm512_setr_epi32(0, 4, 8, 12, 16, 20, 24, 28, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m512i one_i = _mm512_set1_epi32(1);
+    const __m512i i1 = _mm512_add_epi32(i0, one_i), i2 = _mm512_add_epi32(i1, one_i), i3 = _mm512_add_epi32(i2, one_i);
+    const __m256i w0 = _mm512_castsi512_si256(_mm512_permutex2var_epi32(A, i0, B));
+    const __m256i w1 = _mm512_castsi512_si256(_mm512_permutex2var_epi32(A, i1, B));
+    const __m256i w2 = _mm512_castsi512_si256(_mm512_permutex2var_epi32(A, i2, B));
+    const __m256i w3 = _mm512_castsi512_si256(_mm512_permutex2var_epi32(A, i3, B));
+    const __m512d k26 = _mm512_set1_pd(67108864.0), k53 = _mm512_set1_pd(1.0 / 9007199254740992.0);
+    const __m512d two = _mm512_set1_pd(2.0), one = _mm512_set1_pd(1.0);
+    const __m512d a1 = _mm512_cvtepu32_pd(_mm256_srli_epi32(w0, 5)), b1 = _mm512_cvtepu32_pd(_mm256_srli_epi32(w1, 6));
+    const __m512d a2 = _mm512_cvtepu32_pd(_mm256_srli_epi32(w2, 5)), b2 = _mm512_cvtepu32_pd(_mm256_srli_epi32(w3, 6));
+    // (a * 2^26 + b) / 2^53: the product, the sum (< 2^53) and the scaling by a power of two are all exact
+    const __m512d u1 = _mm512_mul_pd(_mm512_add_pd(_mm512_mul_pd(a1, k26), b1), k53);
+    const __m512d u2 = _mm512_mul_pd(_mm512_add_pd(_mm512_mul_pd(a2, k26), b2), k53);
+    const __m512d x1 = _mm512_sub_pd(_mm512_mul_pd(two, u1), one), x2 = _mm512_sub_pd(_mm512_mul_pd(two, u2), one);
+    const __m512d r2 = _mm512_add_pd(_mm512_mul_pd(x1, x1), _mm512_mul_pd(x2, x2));
+    const __mmask8 m = _mm512_cmp_pd_mask(r2, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(r2, _mm512_setzero_pd(), _CMP_NEQ_OQ);
+    _mm512_mask_compressstoreu_pd(x1o, m, x1);
+    _mm512_mask_compressstoreu_pd(x2o, m, x2);
+    _mm512_mask_compressstoreu_pd(r2o, m, r2);
+    return __builtin_popcount((unsigned)m);
+}
 }
 
 extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_t* has_gauss_io, double* gauss_io,
@@ -843,6 +872,7 @@ extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_
     static std::vector<double> X1, X2, R2;
     if ((int64_t)X1.size() < P) { X1.resize((size_t)P); X2.resize((size_t)P); R2.resize((size_t)P); }
     int64_t got = 0;
+    static const bool wide = cpu_level() == 2 && !getenv("GM_NUMPY_SCALAR");
     while (got < P) {
         if (have - rd < 4) {                               // next block: carry the unread words to the front
             const int left = have - rd;
@@ -850,6 +880,11 @@ extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_
             if (pos >= 624) { twist(st); pos = 0; }
             temper(st + pos, wb + left, 624 - pos);
             have = left + (624 - pos); rd = 0; pos = 624;
+            continue;
+        }
+        if (wide && have - rd >= 32 && P - got >= 8) {       // eight candidates at once, never past the P-th pair
+            got += np_candidates8_avx512(wb + rd, X1.data() + got, X2.data() + got, R2.data() + got);
+            rd += 32;
             continue;
         }
         const uint32_t* w = wb + rd;

@@ -290,7 +290,8 @@ class NumpyReplay:
     """np.random.normal on numpy's LEGACY global generator (what bir_vae.py:92-94 draws from) replayed in C
     (csrc/gm_hostrng.cpp gm_numpy_legacy_normal_f32): same MT19937 stream, same polar method, same libm calls,
     float32 written straight into the pinned ring -- 10 240 samples cost numpy 188 us (+ 13 us for the .float()
-    copy), this 108 us; the log / sqrt stage can be split over GM_NUMPY_THREADS (default 1: no gain measured).  Checked bit for bit (values and final state)
+    copy), this 60 us (candidate stage on AVX-512); the log / sqrt stage can be split over GM_NUMPY_THREADS
+    (default 1: no gain measured).  Checked bit for bit (values and final state)
     against a private numpy RandomState before first use; if it does not match on this host the engine keeps
     calling numpy."""
     _ok = None
