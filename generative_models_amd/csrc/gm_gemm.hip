@@ -1500,7 +1500,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     p.xr = 0;
     // (operands at least one fragment wide, 32-bit element offsets -- else the 16-byte form)
     p.il = MODE == MODE_DW && dw_il_min_k() > 0 && p.K >= dw_il_min_k() && p.M >= 4 && p.n_real >= 4 &&
-           (int64_t)p.K * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
+           ((int64_t)p.K + 64) * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
     {
         static int blocked = -1;
         if (blocked < 0) { const char* e = getenv("GM_CHUNK_BLOCKED"); blocked = e ? atoi(e) : 0; }
@@ -1672,7 +1672,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
             if (rider.pair) {
                 GemmP pb = *rider.pair;
                 pb.il = p.il && pb.M >= 4 && pb.n_real >= 4 &&
-                        (int64_t)pb.K * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31);
+                        ((int64_t)pb.K + 64) * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31);
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : (wide == 5 ? 3 : 2), ni = (wide == 1) ? 4 : (wide == 4 ? 3 : 2);
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
