@@ -226,6 +226,10 @@ def test_bench_kernel_names_match_the_committed_rocprof_summary():
     # the live HIP-event duration and the profiler's average of the same kernel agree (different boxes:
     # this round's boxes differ by up to 8 % on the same kernel, and the profiler adds 0.3-0.8 us)
     assert abs(avg[line["roofline"]["kernel"]] - line["roofline"]["avg_launch_us"]) <= 1.5
+    # and its MFMA-busy fraction resolves against the committed SQ counter pass (which may predate the last
+    # template flag of the kernel's printed name)
+    busy = bench.mfma_busy_frac(line["roofline"]["kernel"], line["roofline"]["avg_launch_us"], 2300)
+    assert busy is not None and 0.05 < busy < 1.0, busy
 
 
 @pytest.mark.parametrize("kind", ["normal", "uniform"])
