@@ -232,6 +232,30 @@ def test_bench_kernel_names_match_the_committed_rocprof_summary():
     assert busy is not None and 0.05 < busy < 1.0, busy
 
 
+@pytest.mark.parametrize("tag", ["wgp_b256", "ns_b1024", "vae_b512"])
+def test_bench_kernel_names_of_the_other_configurations_match_their_summaries(tag):
+    """The per-configuration roofline entries are built from bench.py's mirror of the library's kernel choice
+    for that configuration's launch shapes (WGAN-GP incl. the 3B-row forward on 48x32 tiles and the stacked
+    weight gradient, bs=1024 incl. the interleaved-fragment instantiations, the VAE's epilogue forms): every name
+    must be one rocprofv3 recorded in the committed summary of that configuration."""
+    import csv
+    import importlib.util
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("gm_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stats = os.path.join(root, "profiles", "%s_%s_kernel_stats.csv" % (bench.PROFILE_ROUND, tag))
+    if not os.path.isfile(stats):
+        pytest.skip("no committed summary for " + tag)
+    profiled = {r["kernel"] for r in csv.DictReader(open(stats))}
+    shapes = {"wgp_b256": lambda: bench.gemm_shapes_wgp(256), "ns_b1024": lambda: bench.gemm_shapes(1024, fold_head=False),
+              "vae_b512": lambda: bench.gemm_shapes_vae(512)}[tag]()
+    names = {bench.gemm_variant(*sh[:4]) for sh in shapes}
+    assert len(names) >= 5
+    for n in names:
+        assert n in profiled, "bench names %r for %s, rocprofv3 saw %s" % (n, tag, sorted(profiled)[:14])
+
+
 @pytest.mark.parametrize("kind", ["normal", "uniform"])
 @pytest.mark.parametrize("B,W,r0,r1", [(2048, 20, 256, 512), (2048, 20, 0, 256), (512, 20, 384, 512),
                                        (256, 784, 64, 128), (2048, 1, 256, 512), (48, 8, 16, 32),
