@@ -352,3 +352,28 @@ def test_numpy_replay_fill_matches_the_reference_loop_on_the_global_generator():
         assert np.array_equal(np.random.normal(size=3), tail)
     finally:
         np.random.set_state(saved)
+
+
+def test_numpy_replay_scalar_candidate_stage_in_a_fresh_process():
+    """The candidate stage has an AVX-512 form and a scalar one (chosen once per process): the scalar one, forced
+    through GM_NUMPY_SCALAR=1 in a child process, reproduces numpy bit for bit too."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch\n"
+        "from generative_models_amd import engine\n"
+        "rs = np.random.RandomState(11); rs.random_sample(2)\n"
+        "st = engine.NumpyReplay._unpack(rs.get_state(legacy=True))\n"
+        "for n in (10240, 5, 4097):\n"
+        "    ref = torch.from_numpy(rs.normal(0.0, 0.5, n)).float(); got = torch.empty(n)\n"
+        "    engine.NumpyReplay._call(st, 0.0, 0.5, n, got.data_ptr(), 1)\n"
+        "    assert torch.equal(ref.view(torch.int32), got.view(torch.int32)), n\n"
+        "end = rs.get_state(legacy=True)\n"
+        "assert np.array_equal(end[1], st[0]) and (int(end[2]), int(end[3]), float(end[4])) == tuple(st[1:])\n"
+        "print('scalar ok')\n")
+    env = dict(os.environ, GM_NUMPY_SCALAR="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "scalar ok" in out.stdout, out.stderr[-2000:]
