@@ -35,6 +35,7 @@
 #include "gm_common.h"
 #include "gm_head.h"
 #include "gm_gather.h"
+#include "gm_slab.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -911,6 +912,40 @@ __device__ __forceinline__ float il_pick(const ILV<W>& t, int j, float other) {
     return v;
 }
 
+// Cross-wave reduction + epilogue shared by the interleaved-fragment weight-gradient bodies (gemm16_dw_il,
+// gemm16_dw_dma): accumulator (e, f) register r of lane (i16, g4) is output (row MI*(4*g4 + r) + e, column
+// NI*i16 + f) of the tile; one 32x32 block of the tile at a time through the first 64 KB of `red`.
+// sync_first: the buffer was in use inside the reduction loop (DMA rings): everybody must be out of it first.
+template <int MI, int NI>
+__device__ __forceinline__ void dw_il_reduce(const GemmP& p, float* red, f32x4 (&acc)[MI][NI], int m0, int n0,
+                                             bool sync_first) {
+    constexpr int WAVES = 16;
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    if (sync_first) __syncthreads();
+#pragma unroll
+    for (int bm = 0; bm < (MI + 1) / 2; ++bm)
+#pragma unroll
+        for (int bnk = 0; bnk < (NI + 1) / 2; ++bnk) {
+            if (bm + bnk > 0) __syncthreads();               // previous block fully consumed
+#pragma unroll
+            for (int e = 0; e < MI; ++e)
+#pragma unroll
+                for (int f = 0; f < NI; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = MI * (4 * g4 + r) + e, col = NI * i16 + f;
+                        if ((row >> 5) == bm && (col >> 5) == bnk)
+                            red[(w * 32 + (row & 31)) * 32 + (col & 31)] = acc[e][f][r];
+                    }
+            __syncthreads();
+            reduce_and_store<MODE_DW, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bnk,
+                                                                 (2 * bnk + 1 < NI) ? 0x7fffffff : n0 + 32 * bnk + 16,
+                                                                 (2 * bm + 1 < MI) ? 32 : 16);
+        }
+}
+
 template <int MI, int NI, bool OF, int FOLD>
 __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx, int by, float* sds,
                                              const FoldP* fold) {
@@ -1035,29 +1070,129 @@ __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx,
     };
     if (edge) run(std::true_type{}); else run(std::false_type{});
 
-    // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.  Accumulator
-    // (e, f) register r of lane (i16, g4) is output (row MI*(4*g4 + r) + e, column NI*i16 + f) of the tile.
-#pragma unroll
-    for (int bm = 0; bm < (MI + 1) / 2; ++bm)
-#pragma unroll
-        for (int bnk = 0; bnk < (NI + 1) / 2; ++bnk) {
-            if (bm + bnk > 0) __syncthreads();               // previous block fully consumed
-#pragma unroll
-            for (int e = 0; e < MI; ++e)
-#pragma unroll
-                for (int f = 0; f < NI; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = MI * (4 * g4 + r) + e, col = NI * i16 + f;
-                        if ((row >> 5) == bm && (col >> 5) == bnk)
-                            red[(w * 32 + (row & 31)) * 32 + (col & 31)] = acc[e][f][r];
-                    }
-            __syncthreads();
-            reduce_and_store<MODE_DW, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bnk,
-                                                                 (2 * bnk + 1 < NI) ? 0x7fffffff : n0 + 32 * bnk + 16,
-                                                                 (2 * bm + 1 < MI) ? 32 : 16);
-        }
+    dw_il_reduce<MI, NI>(p, red, acc, m0, n0, false);
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient with the operand chunks brought in by LDS-DMA (round 4).  What round 3 could not explain --
+// "a 32 x 48 tile streams 655 KB through its CU at ~25 GB/s whatever the instruction mix" -- is a price PER VECTOR
+// MEMORY INSTRUCTION: one CU retires about one wave-wide load per 40 cycles, whatever it carries (measured,
+// tools/slab_probe fill: 8 B per lane 22-24 GB/s per CU, 12 B 32-34, 16 B 43-45, global_load_lds_dwordx4 53-55;
+// profiles/r04_slab_probe.md).  The interleaved form above loads 8 / 12 bytes per lane -- eight instructions per 5 KB
+// chunk.  Here a wave's chunk (16 reduction rows x the tile's 16 MI + 16 NI columns = MI + NI KB) arrives as MI + NI
+// pieces of 64 lanes x 16 bytes, straight into the wave's PRIVATE LDS buffer (no VGPR round trip, no workgroup
+// barrier: the issuing wave's own vmcnt orders its reads), and the fragments are read back in the same interleaved
+// order as gemm16_dw_il (lane i takes MI / NI consecutive outputs of row k and feeds element j to sub-tile j), so the
+// accumulator layout, the reduction and every epilogue are shared with it.  One buffer per wave is enough: the chunk's
+// fragments are in registers (4 k-steps x (MI + NI) values) before the next chunk's pieces are issued into the same
+// buffer, and they land under this chunk's MFMAs; the other three waves of the SIMD cover the rest.
+// Out-of-range columns are clamped into the row in whole 16-byte groups (M, n_real are multiples of 4: a clamped
+// group never holds a real column) and only feed outputs nobody stores; the virtual ones column and rows past K are
+// selects on the fragment, compiled into their own copy of the loop for the (workgroup-uniform) tiles that need them.
+// ------------------------------------------------------------------------------------------
+template <int MI, int NI, bool OF, int FOLD>
+__device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx, int by, float* sds,
+                                              const FoldP* fold) {
+    constexpr int WAVES = 16, NP = MI + NI, CH = NP * 256;   // pieces / floats of a wave's chunk buffer
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int m0 = by * (16 * MI), n0 = bx * (16 * NI);
+    const int b_cols = p.n_real;
+    const int ones_col = p.db ? p.n_real : -1;
+    const int nchunks = (p.K + 15) >> 4;
+    float* buf = red + w * CH;
+    const uint32_t buf_b = (uint32_t)(uintptr_t)buf;
+    const int am = m0 + MI * i16, bn = n0 + NI * i16;        // this lane's first A / B column
+
+    // piece j: float4 units [64 j, 64 j + 64) of the chunk image [16][16 MI] ++ [16][16 NI]
+    const float* src[NP]; int srow[NP], sld[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const bool isA = j < MI;
+        const int idx = (isA ? j : j - MI) * 64 + lane;
+        const int row = isA ? idx / (4 * MI) : idx / (4 * NI);
+        const int c4 = isA ? idx % (4 * MI) : idx % (4 * NI);
+        const int col = isA ? min(m0 + 4 * c4, p.M - 4) : min(n0 + 4 * c4, b_cols - 4);
+        src[j] = (isA ? p.A + gm_slot_offset(p.a_slot) : p.B + gm_slot_offset(p.b_slot)) + col;
+        sld[j] = isA ? (int)p.lda : (int)p.ldb;
+        srow[j] = row;
+    }
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int k = min(16 * c + srow[j], p.K - 1);
+            slab::glds16(src[j] + (int64_t)k * sld[j], buf_b + j * 1024u);
+        }
+    };
+
+    float fw[FOLD == 1 ? MI : 1];                            // folded head: w2 of this lane's A columns
+    if constexpr (FOLD == 1) {
+#pragma unroll
+        for (int e = 0; e < MI; ++e) fw[e] = (am + e < p.M) ? p.fold_w2[min(am + e, p.M - 1)] : 0.f;
+    }
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int e = 0; e < MI; ++e)
+#pragma unroll
+        for (int f = 0; f < NI; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nq = (nchunks - w + WAVES - 1) / WAVES;        // chunks w, w+16, ... of this wave
+    // workgroup-uniform: does this tile hold the ones column / does the reduction end inside a chunk?
+    const bool special = (ones_col >= n0 && ones_col < n0 + 16 * NI) || (p.K & 15) || OF;
+    auto run = [&](auto special_tag) {
+        constexpr bool SPECIAL = decltype(special_tag)::value;
+        if (nq > 0) issue(w);
+        if constexpr (FOLD == 1) fold_fill_lds(*fold, sds, fold->R);   // behind the first chunk's loads; ends with a barrier
+        for (int q = 0; q < nq; ++q) {
+            const int c = w + q * WAVES;
+            slab::wait_vm<0>();                              // this wave's pieces have landed
+            ILV<MI> ra[4]; ILV<NI> rb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = 4 * s + g4;
+                ra[s] = *reinterpret_cast<const ILV<MI>*>(buf + row * (16 * MI) + MI * i16);
+                rb[s] = *reinterpret_cast<const ILV<NI>*>(buf + 256 * MI + row * (16 * NI) + NI * i16);
+            }
+            slab::wait_lgkm0();                              // ... and are in registers: the buffer is free
+            if (q + 1 < nq) issue(c + WAVES);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * c + 4 * s + g4;
+                float fa[MI], fb[NI];
+#pragma unroll
+                for (int e = 0; e < MI; ++e) {
+                    float v = ra[s].v[e];
+                    if constexpr (FOLD == 1) v = (v > 0.f) ? sds[min(k, p.K - 1)] * fw[e] : 0.f;
+                    if constexpr (SPECIAL) v = (k < p.K) ? v : 0.f;
+                    fa[e] = v;
+                }
+#pragma unroll
+                for (int f = 0; f < NI; ++f) {
+                    float v = rb[s].v[f];
+                    if constexpr (SPECIAL) {
+                        float one = 1.f;
+                        if constexpr (OF) one = (k >= p.ones_from) ? 1.f : 0.f;
+                        v = (bn + f == ones_col) ? one : v;
+                    }
+                    fb[f] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < MI; ++e)
+#pragma unroll
+                    for (int f = 0; f < NI; ++f)
+                        acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[f], acc[e][f], 0, 0, 0);
+            }
+        }
+    };
+    if (special) run(std::true_type{}); else run(std::false_type{});
+    dw_il_reduce<MI, NI>(p, red, acc, m0, n0, true);         // the ring shares `red`: everybody out of the loop first
+}
+
+// LDS floats of the 16-wave kernels: the 64 KB reduction buffer, or the DMA form's sixteen chunk buffers
+template <int IL, int MI, int NI> struct RedSize {
+    static constexpr int value = (IL == 2 && 16 * (MI + NI) * 256 > 16 * 32 * 32) ? 16 * (MI + NI) * 256 : 16 * 32 * 32;
+};
 
 // MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
 // (4,2) are 32x64 / 64x32 tiles used when a launch would otherwise have more tiles than CUs (two
@@ -1068,14 +1203,19 @@ __device__ __forceinline__ void gemm16_dw_il(const GemmP& p, float* red, int bx,
 // FOLD (folded critic head, gm_head.h): 1 = weight gradient whose A operand dH[k][x] is formed from
 // h[k][x], sds[k] (dS of reduction row k) and w2[x]; 2 = input gradient whose A operand dH[m][k] is
 // formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool IL = false>
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, int IL = 0>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
     // IL: the launch chose the interleaved-fragment form (its own kernel instantiations: as a run-time branch
     // inside the shared kernels it cost the bs=256 step 1.5 us in registers and code it never runs)
-    if constexpr (IL && GM_DW_IL && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
+    // IL: 1 = interleaved fragments loaded into VGPRs, 2 = the same fragments through LDS-DMA
+    if constexpr (IL == 2 && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
+        gemm16_dw_dma<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
+        return;
+    }
+    if constexpr (IL == 1 && GM_DW_IL && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
         gemm16_dw_il<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
         return;
     }
@@ -1391,9 +1531,9 @@ static inline int dw_il_min_k() {
     if (v < 0) { const char* e = getenv("GM_DW_IL_MIN_K"); v = e ? atoi(e) : 1024; }
     return v;
 }
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool IL = false>
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, int IL = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
-    __shared__ float red[WAVES * 32 * 32];
+    __shared__ __attribute__((aligned(16))) float red[(WAVES == 16) ? RedSize<IL, MI, NI>::value : WAVES * 32 * 32];
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.x16) {
         // workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): XCD (xi, xj) of
@@ -1412,10 +1552,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool IL = false>
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, int IL = 0>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
-    __shared__ float red[16 * 32 * 32];
+    __shared__ __attribute__((aligned(16))) float red[RedSize<IL, MI, NI>::value];
     __shared__ float sds[FOLDED ? FOLD_MAX_ROWS : 1];
     constexpr int FOLD = FOLDED ? (MODE == MODE_DW ? 1 : 2) : 0;
     // (folded head: the dS prologue runs inside the bodies, behind their first operand loads)
@@ -1427,7 +1567,7 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
     gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, IL>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
-template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool IL = false>
+template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, int IL = 0>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
     gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED, IL>(p, hp, hrows, hblocks);
@@ -1470,10 +1610,10 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
-template <int G, bool XV, int MI, int NI, bool IL = false>
+template <int G, bool XV, int MI, int NI, int IL = 0>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
                                                               int tnb) {
-    __shared__ float red[16 * 32 * 32];
+    __shared__ __attribute__((aligned(16))) float red[RedSize<IL, MI, NI>::value];
     const int id = blockIdx.x;
     if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pa, red, id % tna, id / tna);
     else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pb, red, (id - na) % tnb, (id - na) / tnb);
@@ -1499,8 +1639,20 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     dim3 grid(tn, tm);
     p.xr = 0;
     // (operands at least one fragment wide, 32-bit element offsets -- else the 16-byte form)
-    p.il = MODE == MODE_DW && dw_il_min_k() > 0 && p.K >= dw_il_min_k() && p.M >= 4 && p.n_real >= 4 &&
-           ((int64_t)p.K + 64) * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
+    {
+        // weight gradients on 16-byte aligned operands: 2 = chunks by LDS-DMA (gemm16_dw_dma, reductions of >=
+        // GM_DW_DMA_MIN_K rows), 1 = interleaved fragments in VGPRs (round 3; GM_DW_DMA_MIN_K=0 brings it back for
+        // reductions >= GM_DW_IL_MIN_K)
+        // Measured (profiles/r04_experiments.md): 2048 rows 26.0 -> 24.2 us, 1024 rows 15.3 -> 15.2, 768 rows 12.2 -> 11.9;
+        // below that the extra hop through LDS costs more than the load instructions it saves (512 rows 9.0 -> 9.2,
+        // 256 rows 6.3 -> 7.0): the 16-byte + quad-transpose form keeps the short reductions.
+        static int dma_min_k = -1;
+        if (dma_min_k < 0) { const char* e = getenv("GM_DW_DMA_MIN_K"); dma_min_k = e ? atoi(e) : 768; }
+        const bool fits = MODE == MODE_DW && p.M >= 4 && p.n_real >= 4 &&
+                          ((int64_t)p.K + 64) * (p.lda > p.ldb ? p.lda : p.ldb) < (1ll << 31);
+        p.il = !fits ? 0 : (dma_min_k > 0 && xvec && p.K >= dma_min_k) ? 2
+                         : (dw_il_min_k() > 0 && p.K >= dw_il_min_k()) ? 1 : 0;
+    }
     {
         static int blocked = -1;
         if (blocked < 0) { const char* e = getenv("GM_CHUNK_BLOCKED"); blocked = e ? atoi(e) : 0; }
@@ -1610,8 +1762,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const dim3 hgrid(grid.x, grid.y + hrows);
 #define GM_LH(V, GG, X, OFV, FD) do {                                                              \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 4, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 4 && p.il && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, false, true>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
-        else if (wide == 5 && p.il && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, false, true>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 4 && p.il == 2 && (X)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, FD, ((X) ? 2 : 0)>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 5 && p.il == 2 && (X)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, FD, ((X) ? 2 : 0)>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 4 && p.il == 1 && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, false, 1>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
+        else if (wide == 5 && p.il == 1 && !(FD)) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, false, 1>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 2, 3, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 3, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_head_kernel<V, GG, X, 4, 2, OFV, FD>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks); \
@@ -1671,8 +1825,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
                 GemmP pb = *rider.pair;
-                pb.il = p.il && pb.M >= 4 && pb.n_real >= 4 &&
-                        ((int64_t)pb.K + 64) * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31);
+                pb.il = (pb.M >= 4 && pb.n_real >= 4 && (p.il != 2 || rider.pair_xvec) &&
+                         ((int64_t)pb.K + 64) * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31)) ? p.il : 0;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {
                     const int mi = (wide == 2) ? 4 : (wide == 5 ? 3 : 2), ni = (wide == 1) ? 4 : (wide == 4 ? 3 : 2);
                     const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
@@ -1680,8 +1834,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                     const dim3 pgrid(na + tnb * tmb);
 #define GM_LP(GG) do {                                                                             \
         if (wide == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 4>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
-        else if (wide == 4 && p.il && pb.il) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3, true>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
-        else if (wide == 5 && p.il && pb.il) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2, true>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 4 && p.il == 2 && pb.il == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 5 && p.il == 2 && pb.il == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 4 && p.il == 1 && pb.il == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3, 1>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
+        else if (wide == 5 && p.il == 1 && pb.il == 1) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2, 1>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 2, 3>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 3, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_dw_pair_kernel<GG, true, 4, 2>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb); \
@@ -1718,8 +1874,10 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
 #define GM_L16(V, W, GG, X) do {                                                                   \
         if (wide == 1) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 4>), grid, dim3(W * 64), 0, s, p); \
-        else if (wide == 4 && MODE == MODE_DW && p.il && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3, (MODE == MODE_DW && (X) && W == 16)>), grid, dim3(W * 64), 0, s, p); \
-        else if (wide == 5 && MODE == MODE_DW && p.il && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2, (MODE == MODE_DW && (X) && W == 16)>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 4 && MODE == MODE_DW && p.il == 2 && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3, ((MODE == MODE_DW && (X) && W == 16) ? 2 : 0)>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 5 && MODE == MODE_DW && p.il == 2 && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2, ((MODE == MODE_DW && (X) && W == 16) ? 2 : 0)>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 4 && MODE == MODE_DW && p.il == 1 && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3, ((MODE == MODE_DW && (X) && W == 16) ? 1 : 0)>), grid, dim3(W * 64), 0, s, p); \
+        else if (wide == 5 && MODE == MODE_DW && p.il == 1 && (X) && W == 16) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2, ((MODE == MODE_DW && (X) && W == 16) ? 1 : 0)>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 4) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 2, 3>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 5) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 3, 2>), grid, dim3(W * 64), 0, s, p); \
         else if (wide == 2) hipLaunchKernelGGL((gemm16_kernel<MODE, V, W, GG, X, 4, 2>), grid, dim3(W * 64), 0, s, p); \

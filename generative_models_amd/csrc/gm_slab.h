@@ -33,6 +33,13 @@
 
 namespace slab {
 
+// 1: a unit's DMA pieces are spread between the accumulator rows of the MFMA block instead of issued back to back in
+// front of it.  Measured SLOWER (dW 32x48 tiles at 2048 rows 26.3 -> 28.9 us, with a 2-deep ring 26.8 -> 34.1:
+// profiles/r04_slab_probe.md): what the spread costs in prefetch distance outweighs the queueing it avoids.
+#ifndef GM_SLAB_SPREAD_DMA
+#define GM_SLAB_SPREAD_DMA 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,6 +50,7 @@ struct Split {
     float* ws;                // [tiles][S slices][S sources][slice floats]
     unsigned* cnt;            // [tiles][2] arrivals / departures; zero between launches
     unsigned* err;            // set to 1 when a wait ran out (never hangs the GPU)
+    unsigned long long* trace;  // probe only (else NULL): 8 s_memtime stamps per workgroup
 };
 
 struct CoreP {
@@ -67,6 +75,9 @@ __device__ __forceinline__ void sync_raw() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void stamp(const Split& sp, int i) {
+    if (sp.trace && threadIdx.x == 0) sp.trace[blockIdx.x * 8 + i] = __builtin_readcyclecounter();
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -141,6 +152,7 @@ __device__ __forceinline__ void finish_tile(const Split& sp, int tile, int s, fl
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(sp, 4);
     if (t == 0) {
         __hip_atomic_fetch_add(&sp.cnt[2 * tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
@@ -150,6 +162,7 @@ __device__ __forceinline__ void finish_tile(const Split& sp, int tile, int s, fl
         }
     }
     __syncthreads();
+    stamp(sp, 5);
     const int u0 = s * SLU, u1 = min(u0 + SLU, NU);
     for (int u = u0 + t; u < u1; u += 256) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -163,6 +176,7 @@ __device__ __forceinline__ void finish_tile(const Split& sp, int tile, int s, fl
         epi(u / Q, u % Q, v);
     }
     __syncthreads();
+    stamp(sp, 6);
     if (t == 0) {
         const unsigned old = __hip_atomic_fetch_add(&sp.cnt[2 * tile + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (unsigned)(S - 1)) {             // everybody has read: re-arm for the next launch
@@ -195,7 +209,7 @@ template <int T> __device__ __forceinline__ int il_local(int e, int i) {    // t
     return (e < 4 * a) ? 64 * (e / 4) + 4 * i + (e % 4) : 64 * a + 16 * (e - 4 * a) + i;
 }
 
-template <int TMW, int TNW, int NBUF, int KU, class Epi, class AXf>
+template <int TMW, int TNW, int NBUF, int KU, class Epi, class AXf, int ABL = 0>
 __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, int s, const Epi& epi, const AXf& axf) {
     using C = DwCfg<TMW, TNW, NBUF, KU>;
     constexpr int BM = C::BM, BN = C::BN, UR = C::UR, NP = C::NP;
@@ -226,13 +240,14 @@ __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, in
     const int ub = (int)(((long)units * s) / p.sp.S), ue = (int)(((long)units * (s + 1)) / p.sp.S);
     const int nU = ue - ub;
 
-    auto issue = [&](int u, int slot) {             // unit u (absolute) -> ring slot
-        const uint32_t sb = lds_base + (uint32_t)slot * (C::UNIT * 4u);
+    auto issue_piece = [&](int j, int u, int slot) {   // piece j of unit u (absolute) -> ring slot
+        if constexpr (ABL == 1) return;               // probe: no operand traffic
+        const int k = min(u * UR + prow[j], p.K - 1);
+        glds16(pbase[j] + (int64_t)k * pld[j], lds_base + (uint32_t)slot * (C::UNIT * 4u) + pdst[j]);
+    };
+    auto issue = [&](int u, int slot) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int k = min(u * UR + prow[j], p.K - 1);
-            glds16(pbase[j] + (int64_t)k * pld[j], sb + pdst[j]);
-        }
+        for (int j = 0; j < NP; ++j) issue_piece(j, u, slot);
     };
     float fa[2][KU][TMW], fb[2][KU][TNW];
     auto frags = [&](int slot, int u, float (&a)[KU][TMW], float (&b)[KU][TNW]) {
@@ -274,6 +289,16 @@ __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, in
 #pragma unroll
         for (int f = 0; f < TNW; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mfmas = [&](const float (&a)[KU][TMW], const float (&b)[KU][TNW]) {
+        if constexpr (ABL == 2) {                       // probe: operands arrive and are read, no MFMA
+#pragma unroll
+            for (int ks = 0; ks < KU; ++ks) {
+#pragma unroll
+                for (int e = 0; e < TMW; ++e) asm volatile("" ::"v"(a[ks][e]));
+#pragma unroll
+                for (int f = 0; f < TNW; ++f) asm volatile("" ::"v"(b[ks][f]));
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KU; ++ks)
 #pragma unroll
@@ -282,29 +307,49 @@ __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, in
                 for (int f = 0; f < TNW; ++f)
                     acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][e], b[ks][f], acc[e][f], 0, 0, 0);
     };
+    // The same MFMAs with the unit-after-next's DMA pieces SPREAD between the accumulator rows: a wave that issues
+    // its pieces back to back sits in the memory pipeline's queue (one 1 KB piece per ~40 cycles per CU, measured)
+    // and issues no MFMA meanwhile -- the fetch phase and the MFMA phase then add up instead of overlapping.
+    auto mfmas_issue = [&](const float (&a)[KU][TMW], const float (&b)[KU][TNW], bool more, int u, int slot) {
+        if constexpr (ABL != 0 || !GM_SLAB_SPREAD_DMA) { if (more) issue(u, slot); mfmas(a, b); return; }
+        constexpr int G = KU * TMW;
+#pragma unroll
+        for (int ks = 0; ks < KU; ++ks)
+#pragma unroll
+            for (int e = 0; e < TMW; ++e) {
+#pragma unroll
+                for (int f = 0; f < TNW; ++f)
+                    acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][e], b[ks][f], acc[e][f], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    if ((j * G) / NP == ks * TMW + e) { if (more) issue_piece(j, u, slot); }
+            }
+    };
 
     // prologue: NBUF units in flight, the first one's fragments in registers
+    stamp(p.sp, 0);
 #pragma unroll
     for (int j = 0; j < NBUF; ++j)
         if (j < nU) issue(ub + j, j);
     wait_units<NP, NBUF - 1>(min(NBUF - 1, nU - 1));
     sync_raw();
+    stamp(p.sp, 1);
     frags(0, ub, fa[1], fb[0]);
     fix(ub, fa[1], fa[0]);
     // steady state: one unit per trip, branch-free around the MFMAs (a conditional second step made hipcc shuttle all
     // accumulators between VGPRs and AGPRs every trip).  Past the range's end the wait is a full one and the
     // fragment read a harmless read of a stale slot.
     int slot = 0;                                   // ring slot of unit ub + i
+#pragma unroll 2
     for (int i = 0; i < nU; ++i) {
         const int nslot = (slot + 1 == NBUF) ? 0 : slot + 1;
         // units i+1 .. min(i+NBUF-1, nU-1) are in flight; unit i+1 must have landed
         wait_units<NP, NBUF - 2>(min(NBUF - 2, nU - 2 - i));
         wait_lgkm0();                               // this wave's reads of slot `slot` are complete
         sync_raw();                                 // ... everybody's; and unit i+1 landed for everybody
-        if (i + NBUF < nU) issue(ub + i + NBUF, slot);
         frags(nslot, ub + i + 1, fa[1], fb[1]);     // next unit's fragment reads go out first ...
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa[0], fb[0]);                        // ... and land under this unit's MFMAs
+        mfmas_issue(fa[0], fb[0], i + NBUF < nU, ub + i + NBUF, slot);   // ... and land under this unit's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         fix(ub + i + 1, fa[1], fa[0]);
 #pragma unroll
@@ -314,6 +359,7 @@ __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, in
         slot = nslot;
     }
     // partial tiles of the four waves -> LDS, row-major images
+    stamp(p.sp, 2);
     wait_vm<0>();
     __syncthreads();
     auto dump = [&](float* red, bool add) {
@@ -344,7 +390,9 @@ __device__ __forceinline__ void dw_tile(const CoreP& p, float* lds, int tile, in
         if (w < 2) dump(lds + w * (BM * BN), true);           // image w = wave w + wave w + 2
     }
     __syncthreads();
+    stamp(p.sp, 3);
     finish_tile<C::NRED, BM, BN>(p.sp, tile, s, lds, epi);
+    stamp(p.sp, 7);
 }
 
 struct NoAXf { __device__ __forceinline__ float operator()(float v, int, int, int) const { return v; } };
@@ -392,11 +440,12 @@ __device__ __forceinline__ void fwd_tile(const CoreP& p, float* lds, int tile, i
     const int sb = (int)(((long)steps * s) / p.sp.S), se = (int)(((long)steps * (s + 1)) / p.sp.S);
     const int nU = (se - sb + 1) / 2;
 
-    auto issue = [&](int i, int slot) {             // unit i of this workgroup's range
-        const uint32_t dst = lds_base + (uint32_t)slot * (C::UNIT * 4u);
-        const int k0 = 16 * (sb + 2 * i);
+    auto issue_piece = [&](int j, int i, int slot) { // piece j of unit i of this workgroup's range
+        glds16(pbase[j] + min(16 * (sb + 2 * i) + pk[j], p.K - 4), lds_base + (uint32_t)slot * (C::UNIT * 4u) + pdst[j]);
+    };
+    auto issue = [&](int i, int slot) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) glds16(pbase[j] + min(k0 + pk[j], p.K - 4), dst + pdst[j]);
+        for (int j = 0; j < NP; ++j) issue_piece(j, i, slot);
     };
     float4 fa[2][2][TMW], fb[2][2][TNW];
     auto frags = [&](int slot, float4 (&a)[2][TMW], float4 (&b)[2][TNW]) {
@@ -421,10 +470,12 @@ __device__ __forceinline__ void fwd_tile(const CoreP& p, float* lds, int tile, i
     for (int e = 0; e < TMW; ++e)
 #pragma unroll
         for (int f = 0; f < TNW; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfmas = [&](const float4 (&a)[2][TMW], const float4 (&b)[2][TNW], bool two) {
+    // MFMAs of one unit with the DMA pieces of unit i + NBUF spread between the accumulator rows (see dw_tile)
+    auto mfmas_issue = [&](const float4 (&a)[2][TMW], const float4 (&b)[2][TNW], bool more, int i, int slot) {
+        constexpr int G = 2 * TMW * TNW;
+        if constexpr (!GM_SLAB_SPREAD_DMA) { if (more) issue(i, slot); }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1 && !two) break;              // odd step count: the range's last unit is one step (wave uniform)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < TMW; ++e)
 #pragma unroll
@@ -435,8 +486,17 @@ __device__ __forceinline__ void fwd_tile(const CoreP& p, float* lds, int tile, i
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h][e].z, b[h][f].z, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h][e].w, b[h][f].w, c, 0, 0, 0);
                     acc[e][f] = c;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+                        if (GM_SLAB_SPREAD_DMA && (j * G) / NP == (h * TMW + e) * TNW + f) { if (more) issue_piece(j, i, slot); }
                 }
-        }
+    };
+    // an odd step count leaves the range's last unit one step short: its second step's A side is zeroed (the loads
+    // were clamped into the operand: finite values)
+    auto fix = [&](int i, float4 (&a)[2][TMW]) {
+        const bool two = sb + 2 * i + 1 < se;
+#pragma unroll
+        for (int e = 0; e < TMW; ++e) a[1][e] = two ? a[1][e] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 #pragma unroll
     for (int j = 0; j < NBUF; ++j)
@@ -444,17 +504,19 @@ __device__ __forceinline__ void fwd_tile(const CoreP& p, float* lds, int tile, i
     wait_units<NP, NBUF - 1>(min(NBUF - 1, nU - 1));
     sync_raw();
     frags(0, fa[0], fb[0]);
+    fix(0, fa[0]);
     int slot = 0;
+#pragma unroll 2
     for (int i = 0; i < nU; ++i) {
         const int nslot = (slot + 1 == NBUF) ? 0 : slot + 1;
         wait_units<NP, NBUF - 2>(min(NBUF - 2, nU - 2 - i));
         wait_lgkm0();
         sync_raw();
-        if (i + NBUF < nU) issue(i + NBUF, slot);
         frags(nslot, fa[1], fb[1]);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa[0], fb[0], sb + 2 * i + 1 < se);
+        mfmas_issue(fa[0], fb[0], i + NBUF < nU, i + NBUF, slot);
         __builtin_amdgcn_sched_barrier(0);
+        fix(i + 1, fa[1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll

@@ -467,13 +467,17 @@ class GANTrainer:
         torch.save(self.model.state_dict(), savepath)
 
     # ---- full checkpoint / resume (the reference saves weights only) ----
-    def save_checkpoint(self, savepath):
+    def save_checkpoint(self, savepath, collective=True):
         """Weights (same state_dict keys as save_model, loadable by the reference), Adam moments and
         step counts of the last train() call, the global CPU generator's state (= the cursor of the
         sampling / noise protocol) and the loss history.  After load_checkpoint() the next train()
-        continues as if the run had never stopped."""
+        continues as if the run had never stopped.
+
+        Under data parallelism the call is COLLECTIVE (every rank makes it; rank 0 writes, a failed write
+        raises on every rank); `collective=False` is for the `if rank == 0: save_checkpoint(p)` pattern:
+        rank 0 writes without synchronising, the other ranks' calls do nothing."""
         _save_checkpoint(self, savepath, tuple(n for n in ("Glosses", "Dlosses", "MIlosses", "K", "num_epochs")
-                                               if hasattr(self, n)))
+                                               if hasattr(self, n)), collective=collective)
 
     def load_checkpoint(self, loadpath, strict=True):
         """strict: refuse a checkpoint whose run settings (batch size, D_steps, learning rates ...)
@@ -511,7 +515,7 @@ def _plain(v):
     return v
 
 
-def _save_checkpoint(trainer, savepath, history, numpy_rng=False):
+def _save_checkpoint(trainer, savepath, history, numpy_rng=False, collective=True):
     eng = getattr(trainer, "_engine", None)
     if eng is None or not hasattr(eng, "steps_planned"):
         raise GMError("save_checkpoint needs a finished train() call on the fused engine")
@@ -528,12 +532,25 @@ def _save_checkpoint(trainer, savepath, history, numpy_rng=False):
         state["numpy_rng"] = {"keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),
                               "has_gauss": int(has_gauss), "cached": float(cached)}
     from . import dp
-    world, rank, _ = dp.current()
-    if rank == 0:                                # data parallel: replicas are identical, rank 0 writes
-        torch.save(state, savepath)
-    if world > 1:                                # nobody loads a half-written file
-        import torch.distributed as dist
-        dist.barrier()
+    world, rank, group = dp.current()
+    if world == 1 or not collective:
+        if rank == 0:                            # data parallel: replicas are identical, rank 0 writes
+            torch.save(state, savepath)
+        return
+    # COLLECTIVE under data parallelism: every rank of the trainer's group must make this call.  Rank 0 writes; its
+    # outcome is broadcast, so nobody loads a half-written file, a failed write (disk full, bad path) raises on
+    # EVERY rank instead of leaving the others in a barrier, and `if rank == 0: save_checkpoint(p)` -- a call only
+    # rank 0 makes -- has the documented escape `collective=False`.
+    import torch.distributed as dist
+    outcome = [None]
+    if rank == 0:
+        try:
+            torch.save(state, savepath)
+        except Exception as e:                   # noqa: BLE001 -- reported on every rank below
+            outcome[0] = "%s: %s" % (type(e).__name__, e)
+    dist.broadcast_object_list(outcome, src=0, group=group)
+    if outcome[0] is not None:
+        raise GMError("save_checkpoint(%r) failed on rank 0: %s" % (savepath, outcome[0]))
 
 
 def _load_checkpoint(trainer, loadpath, strict=True):
@@ -818,11 +835,11 @@ class VAETrainer:
     def load_model(self, loadpath):
         self.model.load_state_dict(torch.load(loadpath))
 
-    def save_checkpoint(self, savepath):
-        """See GANTrainer.save_checkpoint."""
+    def save_checkpoint(self, savepath, collective=True):
+        """See GANTrainer.save_checkpoint; collective under data parallelism."""
         hist = tuple(n for n in ("recon_loss", "kl_loss", "num_epochs", "best_val_loss")
                      if hasattr(self, n))
-        _save_checkpoint(self, savepath, hist)
+        _save_checkpoint(self, savepath, hist, collective=collective)
 
     def load_checkpoint(self, loadpath, strict=True):
         """strict: refuse a checkpoint whose run settings (batch size, D_steps, learning rates ...)
@@ -1015,11 +1032,11 @@ class BIRVAETrainer(VAETrainer):
         from . import viz
         viz.vae_viz_loss(self, "mmd_loss")
 
-    def save_checkpoint(self, savepath):
+    def save_checkpoint(self, savepath, collective=True):
         """See GANTrainer.save_checkpoint; also carries numpy's global generator state (the
         reparameterisation noise of bir_vae.py:92-94 comes from it)."""
         hist = tuple(n for n in ("recon_loss", "mmd_loss", "num_epochs", "best_val_loss") if hasattr(self, n))
-        _save_checkpoint(self, savepath, hist, numpy_rng=True)
+        _save_checkpoint(self, savepath, hist, numpy_rng=True, collective=collective)
 
 
 # ============================================================================================
