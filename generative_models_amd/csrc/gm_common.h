@@ -49,6 +49,17 @@ __device__ __forceinline__ double gm_wave_sum_d(double v) {
 
 __device__ __forceinline__ float gm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// eps * x + (1 - eps) * g as torch computes it (w_gp_gan.py:197-201): two rounded products and an add.  The pragma is
+// what keeps hipcc (-ffp-contract=fast) from fusing one product into the add wherever this gets inlined; HIP's
+// __fmul_rn / __fadd_rn are plain operators and do not.
+__device__ __forceinline__ float gm_interp_unfused(float ev, float x, float g) {
+#pragma clang fp contract(off)
+    const float a = ev * x;
+    const float om = 1.f - ev;
+    const float b = om * g;
+    return a + b;
+}
+
 // ---- shared by the loss kernels (gm_ops.hip) and the fused critic-head kernels (gm_fused.hip) ----
 constexpr float EPS = 1e-8f;
 
@@ -165,11 +176,19 @@ static __device__ __forceinline__ void adam_update(float& pp, float gg, float& m
                                                     float step_size, float bc2_sqrt, float omb1,
                                                     float b2, float omb2, float eps, float wd,
                                                     float clamp) {
-    if (wd != 0.f) gg = gg + wd * pp;
-    mm = mm + omb1 * (gg - mm);
+    // Every rounding is pinned (round 4): left to -ffp-contract=fast, the same source fused differently depending on
+    // what it was inlined into (the float2 epilogue and the element-wise one of gm_gemm.hip disagreed in the last bit
+    // of exp_avg / exp_avg_sq; HIP's __fmul_rn / __fadd_rn are plain operators and do NOT stop the fusion -- the pragma
+    // does).  The sequence is torch's _single_tensor_adam on CPU: lerp_ is ONE fused multiply-add (at::vec::fmadd,
+    // weight < 0.5), mul_ / addcmul_ / sqrt / div / add_ / addcdiv_ round after every operation.
+#pragma clang fp contract(off)
+    if (wd != 0.f) gg = __builtin_fmaf(wd, pp, gg);
+    mm = __builtin_fmaf(omb1, gg - mm, mm);
     vv = vv * b2;
-    vv = vv + (omb2 * gg) * gg;
+    const float g2 = (omb2 * gg) * gg;
+    vv = vv + g2;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    pp = pp + ((-step_size) * mm) / denom;
+    const float upd = ((-step_size) * mm) / denom;
+    pp = pp + upd;
     if (clamp > 0.f) pp = fminf(fmaxf(pp, -clamp), clamp);
 }

@@ -22,10 +22,8 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ e
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
     const float ev = e[b];
-    const float om = 1.f - ev;
     for (int i = lane; i < I; i += 64)      // two roundings and an add, never contracted (as torch computes it)
-        out[(int64_t)b * ldo + i] = __fadd_rn(__fmul_rn(ev, x[(int64_t)b * ldx + i]),
-                                              __fmul_rn(om, g[(int64_t)b * ldg + i]));
+        out[(int64_t)b * ldo + i] = gm_interp_unfused(ev, x[(int64_t)b * ldx + i], g[(int64_t)b * ldg + i]);
 }
 
 extern "C" int gm_interp(void* stream, const float* eps, gm_slot eps_slot, const float* x,

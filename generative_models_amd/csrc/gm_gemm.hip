@@ -124,6 +124,7 @@ struct GemmP {
     int lds_tm, lds_mpx;      // LDS macro-tile kernel: m-tiles in total / per XCD (n-tiles: tn)
     int x16;                  // gemm16_kernel: XCD-aware tile map on a 1-D grid (uses xr, xc, tm, tn)
     int il;                   // dw: interleaved fragments (gemm16_dw_il) instead of 16-byte loads + quad transposes
+    int vec_epi;              // every array the epilogue touches is 16-byte aligned with rows of whole float4s (host check)
     // fwd: second output for rows m < ip_rows (WGAN-GP's x_hat written by the generator's last
     // layer): ip_out[m][n] = eps[m] * ip_x[m][n] + (1 - eps[m]) * C[m][n]      (w_gp_gan.py:197-201)
     const float* ip_eps; gm_slot ip_slot;
@@ -242,8 +243,7 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
         if (p.ip_out && m < p.ip_rows) {
             // two roundings and an add, never contracted: torch's eps * x + (1 - eps) * g
             const float ev = (p.ip_eps + gm_slot_offset(p.ip_slot))[m];
-            p.ip_out[(int64_t)m * p.ip_ldo + n] =
-                __fadd_rn(__fmul_rn(ev, p.ip_x[(int64_t)m * p.ip_ldx + n]), __fmul_rn(1.f - ev, v));
+            p.ip_out[(int64_t)m * p.ip_ldo + n] = gm_interp_unfused(ev, p.ip_x[(int64_t)m * p.ip_ldx + n], v);
         }
     } else if (MODE == MODE_DX) {
         if (p.add) v += p.add_scale * p.add[(int64_t)m * p.ldadd + n];
@@ -289,6 +289,74 @@ __device__ __forceinline__ void store_element(const GemmP& p, float v, int m, in
             *pp = P; *mm = M; *vv = V;
         }
     }
+}
+
+// Four consecutive outputs C(m, n .. n+3), n % 4 == 0, all inside the real columns (p.vec_epi: every array involved is
+// 16-byte aligned with a leading dimension of whole float4s).  Same arithmetic per element as store_element, in the
+// same order -- bit-identical results; what changes is the number of vector-memory instructions: one CU retires about
+// one wave-wide load or store per 40 cycles whatever its width (profiles/r04_experiments.md), so the element-wise
+// epilogue of a 32 x 48 weight-gradient tile with Adam (3 loads + 4 stores per element on 16 waves) was ~170
+// instructions = 3 us of a 9 us launch; as float4s on 4 waves it is 42.
+__device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ void st4(float* q, float4 v) { *reinterpret_cast<float4*>(q) = v; }
+
+template <int MODE>
+__device__ __forceinline__ void store4(const GemmP& p, float4 v, int m, int n) {
+    if (MODE == MODE_FWD) {
+        if (p.bias) { const float4 b = ld4(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (p.epi == GM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (p.epi == GM_ACT_SIGMOID) { v.x = gm_sigmoid(v.x); v.y = gm_sigmoid(v.y); v.z = gm_sigmoid(v.z); v.w = gm_sigmoid(v.w); }
+        st4(p.C + (int64_t)m * p.ldc + n, v);
+        if (p.ip_out && m < p.ip_rows) {
+            const float ev = (p.ip_eps + gm_slot_offset(p.ip_slot))[m];
+            const float4 x = ld4(p.ip_x + (int64_t)m * p.ip_ldx + n);
+            st4(p.ip_out + (int64_t)m * p.ip_ldo + n,
+                make_float4(gm_interp_unfused(ev, x.x, v.x), gm_interp_unfused(ev, x.y, v.y),
+                            gm_interp_unfused(ev, x.z, v.z), gm_interp_unfused(ev, x.w, v.w)));
+        }
+    } else if (MODE == MODE_DX) {
+        if (p.add) {
+            const float4 a = ld4(p.add + (int64_t)m * p.ldadd + n);
+            v.x += p.add_scale * a.x; v.y += p.add_scale * a.y; v.z += p.add_scale * a.z; v.w += p.add_scale * a.w;
+        }
+        if (p.epi == GM_ACT_RELU) {
+            const float4 y = ld4(p.aux + (int64_t)m * p.ldaux + n);
+            v.x = (y.x > 0.f) ? v.x : 0.f; v.y = (y.y > 0.f) ? v.y : 0.f; v.z = (y.z > 0.f) ? v.z : 0.f; v.w = (y.w > 0.f) ? v.w : 0.f;
+        } else if (p.epi == GM_ACT_SIGMOID) {
+            const float4 y = ld4(p.aux + (int64_t)m * p.ldaux + n);
+            v.x = v.x * (y.x * (1.f - y.x)); v.y = v.y * (y.y * (1.f - y.y));
+            v.z = v.z * (y.z * (1.f - y.z)); v.w = v.w * (y.w * (1.f - y.w));
+        }
+        float* cp = p.C + (int64_t)m * p.ldc + n;
+        if (p.accumulate) { const float4 c = ld4(cp); v.x = c.x + v.x; v.y = c.y + v.y; v.z = c.z + v.z; v.w = c.w + v.w; }
+        st4(cp, v);
+    } else {
+        const int64_t o = (int64_t)m * p.ldc + n;
+        if (p.accumulate) { const float4 c = ld4(p.C + o); v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+        st4(p.C + o, v);
+        if (p.adam.enabled) {
+            const int64_t si = gm_slot_index(p.adam.sched_slot);
+            const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
+            float4 P = ld4(p.adam.pW + o), M = ld4(p.adam.mW + o), V = ld4(p.adam.vW + o);
+            adam_update(P.x, v.x, M.x, V.x, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+            adam_update(P.y, v.y, M.y, V.y, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+            adam_update(P.z, v.z, M.z, V.z, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+            adam_update(P.w, v.w, M.w, V.w, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+            st4(p.adam.pW + o, P); st4(p.adam.mW + o, M); st4(p.adam.vW + o, V);
+        }
+    }
+}
+
+// the float4 group (m, n .. n+3) as store4 where it is whole and real, element by element at the edges (the dW ones
+// column, a ragged last group)
+template <int MODE>
+__device__ __forceinline__ void store_group(const GemmP& p, float4 v, int m, int n, int ncap) {
+    const int nreal = (MODE == MODE_DW) ? p.n_real : p.N;
+    if (n + 3 < nreal && n + 3 < ncap) { store4<MODE>(p, v, m, n); return; }
+    if (n < p.N && n < ncap) store_element<MODE>(p, v.x, m, n);
+    if (n + 1 < p.N && n + 1 < ncap) store_element<MODE>(p, v.y, m, n + 1);
+    if (n + 2 < p.N && n + 2 < ncap) store_element<MODE>(p, v.z, m, n + 2);
+    if (n + 3 < p.N && n + 3 < ncap) store_element<MODE>(p, v.w, m, n + 3);
 }
 
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
@@ -359,6 +427,10 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
         }
         return;
     }
+    // (float4 groups on the first 256 threads were measured SLOWER here than one element per thread on all 1024:
+    // NSGAN bs=256 70.1 -> 77.6 us, the 784 x 400 weight gradient with Adam 8.6 -> 9.9 us -- four times the epilogue
+    // arithmetic behind one memory round trip on a quarter of the waves; profiles/r04_experiments.md.  The many-row
+    // LDS kernel, whose threads each own eight elements, does gain: store_group there.)
 #pragma unroll
     for (int e = 0; e < 1024 / (WAVES * 64); ++e) {
         const int row = (t >> 5) + e * (WAVES * 2), col = t & 31;
@@ -661,6 +733,20 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
                 lds[(wk * BM + wm * WTM + ti * 32 + row) * BN + wn * WTN + tj * 32 + r] = v;
             }
     __syncthreads();
+    if (p.vec_epi && !(MODE == MODE_DX && p.rp_dml)) {          // kernel-argument uniform: float4 groups (see store4)
+        for (int e = t; e < BM * (BN / 4); e += NT) {
+            const int row = e / (BN / 4), c4 = e % (BN / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kk = 0; kk < WK; ++kk) {
+                const float4 x = *reinterpret_cast<const float4*>(&lds[(kk * BM + row) * BN + 4 * c4]);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            const int m = m0 + row, n = n0 + 4 * c4;
+            if (m < p.M && n < p.N) store_group<MODE>(p, v, m, n, 0x7fffffff);
+        }
+        return;
+    }
     for (int e = t; e < BM * BN; e += NT) {
         const int row = e / BN, col = e % BN;
         float v = 0.f;
@@ -751,7 +837,7 @@ int launch_lds(hipStream_t s, const GemmP& p, int cfg) {
 
 template <int MODE, bool VEC, int WAVES, int G, bool XV>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmP p) {
-    __shared__ float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
+    __shared__ __attribute__((aligned(16))) float red[WAVES * 32 * 32];      // 64 / 32 KB: one 32x32 partial tile per wave
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -912,6 +998,67 @@ __device__ __forceinline__ float il_pick(const ILV<W>& t, int j, float other) {
     return v;
 }
 
+// Two consecutive weight-gradient outputs C(m, n), C(m, n + 1), n even, both real columns: store_element's arithmetic
+// per element, 8-byte accesses (p.vec_epi: C and the Adam arrays are 16-byte aligned, ldc % 4 == 0).
+__device__ __forceinline__ void store2_dw(const GemmP& p, float2 v, int m, int n) {
+    const int64_t o = (int64_t)m * p.ldc + n;
+    float2* cp = reinterpret_cast<float2*>(p.C + o);
+    if (p.accumulate) { const float2 c = *cp; v.x += c.x; v.y += c.y; }
+    *cp = v;
+    if (p.adam.enabled) {
+        const int64_t si = gm_slot_index(p.adam.sched_slot);
+        const float step_size = p.adam.sched[2 * si], bc2_sqrt = p.adam.sched[2 * si + 1];
+        float2* pp = reinterpret_cast<float2*>(p.adam.pW + o);
+        float2* mm = reinterpret_cast<float2*>(p.adam.mW + o);
+        float2* vv = reinterpret_cast<float2*>(p.adam.vW + o);
+        float2 P = *pp, M = *mm, V = *vv;
+        adam_update(P.x, v.x, M.x, V.x, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+        adam_update(P.y, v.y, M.y, V.y, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2, p.adam.eps, p.adam.wd, p.adam.clamp);
+        *pp = P; *mm = M; *vv = V;
+    }
+}
+
+// Weight-gradient tiles of more than one 32 x 32 block (32 x 48, 48 x 32, 32 x 64 ...) in ONE pass: every wave leaves
+// its whole partial tile in LDS (16 images of 16 MI x 16 NI floats: 96 KB for the 48-wide tiles), one barrier, and each
+// thread sums one PAIR of neighbouring columns over the sixteen images (wave order, as before: bit-identical) and runs
+// the epilogue once.  The block-by-block form (reduce_and_store) makes two or three trips -- barrier, sum, Adam state
+// in, parameters out -- one behind the other, and each trip is a memory round trip.  ILO: interleaved accumulator
+// layout of gemm16_dw_il / gemm16_dw_dma.
+template <int MI, int NI, bool ILO>
+__device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f32x4 (&acc)[MI][NI], int m0, int n0,
+                                                  bool sync_first) {
+    constexpr int RT = 16 * MI, CT = 16 * NI, IMG = RT * CT, G = IMG / 2;
+    static_assert(G <= 1024, "one pair of columns per thread");
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    if (sync_first) __syncthreads();
+    float* img = red + w * IMG;
+#pragma unroll
+    for (int e = 0; e < MI; ++e)
+#pragma unroll
+        for (int f = 0; f < NI; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ILO ? MI * (4 * g4 + r) + e : 16 * e + 4 * g4 + r;
+                const int col = ILO ? NI * i16 + f : 16 * f + i16;
+                img[row * CT + col] = acc[e][f][r];
+            }
+    __syncthreads();
+    if (t >= G) return;
+    const int row = t / (CT / 2), c2 = t % (CT / 2);
+    float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) {
+        const float2 x = *reinterpret_cast<const float2*>(&red[ww * IMG + row * CT + 2 * c2]);
+        v.x += x.x; v.y += x.y;
+    }
+    const int m = m0 + row, n = n0 + 2 * c2;
+    if (m >= p.M) return;
+    if (n + 1 < p.n_real) { store2_dw(p, v, m, n); return; }
+    if (n < p.N) store_element<MODE_DW>(p, v.x, m, n);       // the ones column (bias gradient) / a ragged edge
+    if (n + 1 < p.N) store_element<MODE_DW>(p, v.y, m, n + 1);
+}
+
 // Cross-wave reduction + epilogue shared by the interleaved-fragment weight-gradient bodies (gemm16_dw_il,
 // gemm16_dw_dma): accumulator (e, f) register r of lane (i16, g4) is output (row MI*(4*g4 + r) + e, column
 // NI*i16 + f) of the tile; one 32x32 block of the tile at a time through the first 64 KB of `red`.
@@ -920,6 +1067,10 @@ template <int MI, int NI>
 __device__ __forceinline__ void dw_il_reduce(const GemmP& p, float* red, f32x4 (&acc)[MI][NI], int m0, int n0,
                                              bool sync_first) {
     constexpr int WAVES = 16;
+    if (p.vec_epi) {                                         // kernel-argument uniform
+        dw_reduce_onepass<MI, NI, true>(p, red, acc, m0, n0, sync_first);
+        return;
+    }
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -1189,9 +1340,14 @@ __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx
     dw_il_reduce<MI, NI>(p, red, acc, m0, n0, true);         // the ring shares `red`: everybody out of the loop first
 }
 
-// LDS floats of the 16-wave kernels: the 64 KB reduction buffer, or the DMA form's sixteen chunk buffers
-template <int IL, int MI, int NI> struct RedSize {
-    static constexpr int value = (IL == 2 && 16 * (MI + NI) * 256 > 16 * 32 * 32) ? 16 * (MI + NI) * 256 : 16 * 32 * 32;
+// LDS floats of the 16-wave kernels: the 64 KB block-by-block reduction buffer; for weight gradients of multi-block
+// tiles the sixteen whole-tile images of dw_reduce_onepass; the DMA form's sixteen chunk buffers
+template <int MODE, int IL, int MI, int NI> struct RedSize {
+    static constexpr int base = 16 * 32 * 32;
+    static constexpr int onepass = (MODE == MODE_DW && MI * NI > 4) ? 16 * 256 * MI * NI : 0;
+    static constexpr int dma = (MODE == MODE_DW && IL == 2) ? 16 * (MI + NI) * 256 : 0;
+    static constexpr int m1 = base > onepass ? base : onepass;
+    static constexpr int value = m1 > dma ? m1 : dma;
 };
 
 // MI x NI = number of 16-row / 16-column sub-tiles per wave: (2,2) is the 32x32 tile; (2,4) and
@@ -1492,6 +1648,12 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         return;
     }
 #endif
+    if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
+        if (p.vec_epi) {                                     // kernel-argument uniform
+            dw_reduce_onepass<MI, NI, false>(p, red, acc, m0, n0, false);
+            return;
+        }
+    }
     // Cross-wave reduction, one 32x32 block of the tile at a time through the same 64 KB buffer.
     // C layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.
     // NI odd (32x48 tiles): the last block is 16 columns wide -- its right half of the buffer is stale and the
@@ -1533,7 +1695,7 @@ static inline int dw_il_min_k() {
 }
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, int IL = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) float red[(WAVES == 16) ? RedSize<IL, MI, NI>::value : WAVES * 32 * 32];
+    __shared__ __attribute__((aligned(16))) float red[(WAVES == 16) ? RedSize<MODE, IL, MI, NI>::value : WAVES * 32 * 32];
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.x16) {
         // workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): XCD (xi, xj) of
@@ -1555,7 +1717,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, int IL = 0>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
-    __shared__ __attribute__((aligned(16))) float red[RedSize<IL, MI, NI>::value];
+    __shared__ __attribute__((aligned(16))) float red[RedSize<MODE, IL, MI, NI>::value];
     __shared__ float sds[FOLDED ? FOLD_MAX_ROWS : 1];
     constexpr int FOLD = FOLDED ? (MODE == MODE_DW ? 1 : 2) : 0;
     // (folded head: the dS prologue runs inside the bodies, behind their first operand loads)
@@ -1598,7 +1760,7 @@ int xcd_mode() {
 template <bool VEC, int G, int MI, int NI>
 __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, GatherP gp, int grows,
                                                                  int gblocks) {
-    __shared__ float red[16 * 32 * 32];
+    __shared__ __attribute__((aligned(16))) float red[16 * 32 * 32];
     if ((int)blockIdx.y < grows) {                           // workgroup-uniform
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
         if (bid < gblocks) gather_body(gp, bid);
@@ -1613,10 +1775,29 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 template <int G, bool XV, int MI, int NI, int IL = 0>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
                                                               int tnb) {
-    __shared__ __attribute__((aligned(16))) float red[RedSize<IL, MI, NI>::value];
+    __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, IL, MI, NI>::value];
     const int id = blockIdx.x;
     if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pa, red, id % tna, id / tna);
     else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, IL>(pb, red, (id - na) % tnb, (id - na) / tnb);
+}
+
+// May the epilogue move whole float4s (store4)?  Every array it touches 16-byte aligned, leading dimensions in
+// whole float4s.  GM_VEC_EPI=0: element-wise epilogues everywhere (round 3).
+template <int MODE>
+int vec_epi_ok(const GemmP& p) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GM_VEC_EPI"); on = e ? atoi(e) : 1; }
+    if (!on || !aligned16(p.C) || p.ldc % 4 != 0) return 0;
+    if (MODE == MODE_FWD) {
+        if (p.bias && !aligned16(p.bias)) return 0;
+        if (p.ip_out && !(aligned16(p.ip_out) && aligned16(p.ip_x) && p.ip_ldo % 4 == 0 && p.ip_ldx % 4 == 0)) return 0;
+    } else if (MODE == MODE_DX) {
+        if (p.epi != GM_ACT_ID && !(aligned16(p.aux) && p.ldaux % 4 == 0)) return 0;
+        if (p.add && !(aligned16(p.add) && p.ldadd % 4 == 0)) return 0;
+    } else {
+        if (p.adam.enabled && !(aligned16(p.adam.pW) && aligned16(p.adam.mW) && aligned16(p.adam.vW))) return 0;
+    }
+    return 1;
 }
 
 // Work that rides in (or pairs with) a GEMM launch.
@@ -1635,6 +1816,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     // silently run without it
     const bool folded = head && head->fold.enabled;
     GemmP p = p_in;
+    p.vec_epi = vec_epi_ok<MODE>(p);
     const int tm = (p.M + TM - 1) / TM, tn = (p.N + TN - 1) / TN;
     dim3 grid(tn, tm);
     p.xr = 0;
@@ -1825,6 +2007,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         if constexpr (MODE == MODE_DW) {
             if (rider.pair) {
                 GemmP pb = *rider.pair;
+                pb.vec_epi = vec_epi_ok<MODE_DW>(pb);
                 pb.il = (pb.M >= 4 && pb.n_real >= 4 && (p.il != 2 || rider.pair_xvec) &&
                          ((int64_t)pb.K + 64) * (pb.lda > pb.ldb ? pb.lda : pb.ldb) < (1ll << 31)) ? p.il : 0;
                 if (xv && rider.pair_xvec && !use8 && wide != 3 && pb.K == p.K && p.xr == 0) {

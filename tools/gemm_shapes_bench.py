@@ -21,7 +21,19 @@ def time_shape(kind, M, K, N, reps=50):
     y, dX = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
     dW, db, b = torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.zeros(N, device=dev)
     st = [ops.stream_ptr()]
-    if kind == "fwd":
+    if kind == "dwadam":
+        # weight gradient with the optimizer in its epilogue (gm_linear_bwd_dw_adam), as the training steps launch it
+        import torch.nn as nn
+        from generative_models_amd.engine import FlatParams, _Linear
+        net = nn.Sequential(nn.Linear(K, N))
+        fp = FlatParams(net.parameters(), dev)
+        lin = _Linear(fp, net[0])
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
+        adam = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0)
+        fn = lambda: ops.linear_bwd_dw_adam(dA, x, lin, adam, stream=st[0])
+    elif kind == "fwdsig":
+        fn = lambda: ops.linear_fwd(x, W, b, y, "sigmoid", stream=st[0])
+    elif kind == "fwd":
         fn = lambda: ops.linear_fwd(x, W, b, y, "relu", stream=st[0])
     elif kind == "dx":
         fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st[0])
@@ -30,7 +42,11 @@ def time_shape(kind, M, K, N, reps=50):
     fn()
     torch.cuda.synchronize()
     # correctness of this launch against torch fp32 (relative to the output's scale)
-    if kind == "fwd":
+    if kind == "dwadam":
+        ref, got = dA.t() @ x, lin.gW
+    elif kind == "fwdsig":
+        ref, got = torch.sigmoid(x @ W.t() + b), y
+    elif kind == "fwd":
         ref, got = torch.relu(x @ W.t() + b), y
     elif kind == "dx":
         ref, got = (dA @ W) * (x > 0), dX
@@ -60,7 +76,7 @@ def time_shape(kind, M, K, N, reps=50):
     us = e0.elapsed_ms(e1) * 1e3 / reps
     # the vendor library on the same contraction (torch -> hipBLASLt / rocBLAS), same timing method;
     # fwd: bias fused by the library, relu not included; dx: without the relu mask; dw: without db
-    if kind == "fwd":
+    if kind in ("fwd", "fwdsig"):
         vfn = lambda: torch.addmm(b, x, W.t(), out=y)
     elif kind == "dx":
         vfn = lambda: torch.mm(dA, W, out=dX)
