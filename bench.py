@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
 LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip try_launch_lds
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
-PROFILE_ROUND = "r03"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
+PROFILE_ROUND = "r04"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
 FOLD_HEAD_DEFAULT = os.environ.get("GM_FOLD_HEAD", "1") != "0"   # engine default (folded critic head)
 
 
@@ -131,25 +131,25 @@ def gemm_variant(kind, M, K, N):
         mi, ni = 1, 2
     if mode == 0 and (mi, ni) == (4, 2) and kind == "fwd" and tn * -(-Mg // 48) <= 256:
         mi, ni = 3, 2                                  # 3B-row forward: 208 tiles of 48x32 instead of 156 of 64x32
-    if mode == 2 and os.environ.get("GM_DW_TILE48", "2") != "0":
-        # weight gradients: 32x48 / 48x32 instead of 32x64 / 64x32 where the narrower tile still fits one round
+    if mode == 2:
+        # weight gradients: 32x48 / 48x32 wherever that covers the output in one round of <= 256 workgroups
         if (mi, ni) == (2, 4) and tm * -(-Ng // 48) <= 256:
             mi, ni = 2, 3
         elif (mi, ni) == (4, 2) and tn * -(-Mg // 48) <= 256:
             mi, ni = 3, 2
-        elif os.environ.get("GM_DW_TILE48", "2") == "2" and (mi, ni) == (2, 2) and tm * tn > 256:
+        elif (mi, ni) == (2, 2) and tm * tn > 256:
             if tn >= tm and tm * -(-Ng // 48) <= 256:
                 mi, ni = 2, 3
             elif tn < tm and tn * -(-Mg // 48) <= 256:
                 mi, ni = 3, 2
     b = lambda v: "true" if v else "false"
-    # weight gradients over >= 1024 rows on 32x48 / 48x32 tiles: the interleaved-fragment instantiations
-    il = mode == 2 and xv and Kr >= int(os.environ.get("GM_DW_IL_MIN_K", "1024")) > 0 and (mi, ni) in ((2, 3), (3, 2))
+    # weight gradients over >= 768 rows on 32x48 / 48x32 tiles: the LDS-DMA instantiations (gemm16_dw_dma)
+    dma = mode == 2 and xv and Kr >= int(os.environ.get("GM_DW_DMA_MIN_K", "768")) > 0 and (mi, ni) in ((2, 3), (3, 2))
     if kind in ("dwh", "dwhf", "dwhs"):
         # last three arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded
-        # head; interleaved fragments
+        # head; LDS-DMA
         return "gemm16_dw_head_kernel<false, %d, %s, %d, %d, %s, %s, %s>" % (
-            g, b(xv), mi, ni, b(kind == "dwhs"), b(kind == "dwhf"), b(il and kind != "dwhf"))
+            g, b(xv), mi, ni, b(kind == "dwhs"), b(kind == "dwhf"), b(dma))
     if kind in ("dxh", "dxhf"):
         assert vec and xv and (mi, ni) in ((2, 2), (1, 2))
         return "gemm16_dx_head_kernel<%d, %d, %d, %s>" % (g, mi, ni, b(kind == "dxhf"))
@@ -158,8 +158,8 @@ def gemm_variant(kind, M, K, N):
         return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
     if kind == "dwp":
         assert xv and (mi, ni) != (1, 2)
-        return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s>" % (g, mi, ni, b(il))
-    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(il))
+        return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s>" % (g, mi, ni, b(dma))
+    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(dma))
 
 
 def clock_probe():
@@ -504,11 +504,6 @@ def mfma_busy_frac(kernel, launch_us, mhz):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_nsgan_b256_sq_pmc.json")))
         rows = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for k, v in pmc.items() if k.split("|")[0] == kernel]
-        if not rows and kernel.endswith(", false>"):
-            # the SQ pass predates the last template flag of the GEMM kernels (interleaved fragments, false for
-            # every launch of this workload): same instantiation, one argument fewer in its printed name
-            old = kernel[:-len(", false>")] + ">"
-            rows = [v["SQ_VALU_MFMA_BUSY_CYCLES"] for k, v in pmc.items() if k.split("|")[0] == old]
         if not rows:
             return None
         return (sum(rows) / len(rows) / 1024.0) / (launch_us * mhz)
