@@ -406,7 +406,7 @@ def test_vae_engine_vs_oracle(cfg, n_train):
     o_rng = torch.get_rng_state()
     p, p_model, p_rng = run_vae_product(cfg, cfg["batch"], n_train, 2)
     lclose(np.array(p.recon_loss) / 100, np.array(o.recon_loss) / 100, "vae recon")   # sums ~1e3
-    lclose(p.kl_loss, o.kl_loss, "vae kl", tol=2e-5)
+    lclose(p.kl_loss, o.kl_loss, "vae kl", tol=1e-5)
     assert abs(p.best_val_loss - o.best_val_loss) <= 1e-5 * max(1, abs(o.best_val_loss))
     assert torch.equal(o_rng, p_rng)
     for (k, a), (_, b) in zip(p_model.state_dict().items(), o_model.state_dict().items()):
@@ -428,7 +428,7 @@ def test_vae_engine_vs_reference_golden(name):
     got = np.array(p.recon_loss)
     assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
     ref, got = z["kl_loss"], np.array(p.kl_loss)
-    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 2e-5, (got[:4], ref[:4])
+    assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
     assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
 
 
@@ -468,6 +468,7 @@ def test_bir_vae_engine_vs_reference_golden(name):
     # ~1e-7 * B^2 * 1000 of rounding; same bound as the oracle's test in test_golden.py
     ref, got = z["mmd_loss"], np.array(p.mmd_loss)
     assert np.max(np.abs(got - ref) / np.maximum(10, np.abs(ref))) <= 1e-4, (got[:4], ref[:4])
+    # (the validation loss CONTAINS the 1000 * MMD term bounded just above: 2e-5, not the VAE's 1e-5)
     assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 2e-5 * abs(float(z["best_val_loss"]))
     for k, v in p_model.state_dict().items():
         if "param:" + k in z:
@@ -565,7 +566,7 @@ def test_vae_family_viz_stream_position_vs_reference_golden(name, tmp_path):
     ref, got = z["recon_loss"], np.array(tr.recon_loss)
     assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5
     ref, got = z[second], np.array(getattr(tr, second))
-    tol = 2e-5 if second == "kl_loss" else 1e-4
+    tol = 1e-5 if second == "kl_loss" else 1e-4
     assert np.max(np.abs(got - ref) / np.maximum(10 if second == "mmd_loss" else 1, np.abs(ref))) <= tol
     for k, v in model.state_dict().items():
         assert np.abs(v.cpu().numpy() - z["param:" + k]).max() <= 5e-5, k
@@ -874,10 +875,47 @@ FULLCFG = dict(image_size=784, hidden_dim=400, z_dim=20, n_train=50000, n_val=25
 FULL_CASES = [("dra", dict(num_epochs=1, D_steps=1)), ("be", dict(num_epochs=1)),
               ("info", dict(num_epochs=1)), ("ra", dict(num_epochs=1)), ("fisher", dict(num_epochs=1)),
               ("mm", dict(num_epochs=1, G_init=2)), ("w", dict(num_epochs=1, D_steps=2)),
-              ("f", dict(num_epochs=1, method="pearson"))]
+              ("f", dict(num_epochs=1, method="pearson")),
+              # round 4: the step counts the bench reports and the trainers default to (w_gp_gan.py:96,
+              # dra_gan.py:94, w_gan.py: D_steps = 5) and the other five f-divergences (f_gan.py:99-142)
+              ("wgp", dict(num_epochs=1, D_steps=5)), ("dra", dict(num_epochs=1, D_steps=5)),
+              ("w", dict(num_epochs=1, D_steps=5)),
+              ("f", dict(num_epochs=1, method="total_variation")), ("f", dict(num_epochs=1, method="forward_kl")),
+              ("f", dict(num_epochs=1, method="reverse_kl")), ("f", dict(num_epochs=1, method="hellinger")),
+              ("f", dict(num_epochs=1, method="jensen_shannon"))]
 
 
-@pytest.mark.parametrize("variant,kw", FULL_CASES, ids=[v for v, _ in FULL_CASES])
+def _case_id(v, kw):
+    return v + ("_" + kw["method"] if "method" in kw else "") + ("_d%d" % kw["D_steps"] if kw.get("D_steps", 1) > 2 else "")
+
+
+def _record(name, **vals):
+    """Measured deviations of the full-size parity tests, appended to gpurun_out/parity_full_size.jsonl (copied to
+    profiles/ per round: the asserted bounds say what is tolerated, this says what was seen)."""
+    import json
+    try:
+        d = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_full_size.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **vals)) + "\n")
+    except OSError:
+        pass
+
+
+def _loss_err(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+
+
+def _param_dev(model, o_model, lr):
+    out = {}
+    for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
+        d = (a.cpu() - b).abs()
+        out[k] = dict(max=float(d.max()), mean=float(d.mean()), frac_above_tenth_step=float((d > 0.1 * lr).float().mean()))
+    return out
+
+
+@pytest.mark.parametrize("variant,kw", FULL_CASES, ids=[_case_id(v, kw) for v, kw in FULL_CASES])
 def test_full_size_engine_vs_oracle(variant, kw):
     steps = 6
 
@@ -909,6 +947,9 @@ def test_full_size_engine_vs_oracle(variant, kw):
     if variant == "info":
         lclose(tr.MIlosses, o.MIlosses, "info full-size MIlosses")
     assert torch.equal(o_rng, torch.get_rng_state())
+    _record("full_size_engine_vs_oracle[%s]" % _case_id(variant, kw), steps=steps,
+            Dloss_err=_loss_err(tr.Dlosses, o.Dlosses), Gloss_err=_loss_err(tr.Glosses, o.Glosses),
+            params=_param_dev(model, o_model, 2e-4))
     # Parameters: weights whose gradient is O(eps_adam = 1e-8) (hidden units that fire for a handful
     # of rows) turn fp32 summation-order noise into a fraction of an Adam step (lr = 1e-4..2e-4),
     # so the bound is one step for the maximum and 1e-6 for the mean deviation.
@@ -967,6 +1008,9 @@ def test_baseline_configs_parameters_tensor_by_tensor(variant, batch, kw):
     lclose(tr.Dlosses, o.Dlosses, "%s bs=%d Dlosses" % (variant, batch))
     lclose(tr.Glosses, o.Glosses, "%s bs=%d Glosses" % (variant, batch))
     assert torch.equal(o_rng, torch.get_rng_state())
+    _record("baseline_configs_tensor_by_tensor[%s_b%d]" % (variant, batch), steps=steps,
+            Dloss_err=_loss_err(tr.Dlosses, o.Dlosses), Gloss_err=_loss_err(tr.Glosses, o.Glosses),
+            params=_param_dev(model, o_model, 2e-4))
     _param_check(model, o_model, "%s bs=%d" % (variant, batch), lr=2e-4)   # the largest of the lrs used here
 
 
@@ -990,8 +1034,14 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
         tr.train(num_epochs=3)
     torch.cuda.synchronize()
     assert len(tr.recon_loss) == 12
-    lclose(tr.recon_loss, o.recon_loss, "VAE recon", tol=2e-5)
-    lclose(tr.kl_loss, o.kl_loss, "VAE kl", tol=2e-5)
-    assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-5 * abs(o.best_val_loss)
+    _record("vae_b512_ragged_tensor_by_tensor", recon_err=_loss_err(tr.recon_loss, o.recon_loss),
+            kl_err=_loss_err(tr.kl_loss, o.kl_loss),
+            best_val_rel_err=abs(tr.best_val_loss - o.best_val_loss) / abs(o.best_val_loss),
+            params=_param_dev(model, o_model, 1e-3))
+    # measured (profiles/r04_parity_full_size.jsonl): recon 1.0e-7, kl 1.4e-7, best_val 7.6e-8 -- asserted with a
+    # 15-fold margin, an order below north_star's 1e-5
+    lclose(tr.recon_loss, o.recon_loss, "VAE recon", tol=2e-6)
+    lclose(tr.kl_loss, o.kl_loss, "VAE kl", tol=2e-6)
+    assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-6 * abs(o.best_val_loss)
     assert torch.equal(o_rng, torch.get_rng_state())
     _param_check(model, o_model, "VAE bs=512 ragged", lr=1e-3)          # vae.py:127: lr = 1e-3
