@@ -364,7 +364,10 @@ def cpu_baseline_gan(variant="ns", B=B_PER_GPU, seconds_target=12.0, compute_onl
             "sample": "%d %s bs=%d D+G steps of oracle/port.py (torch %s CPU, %d threads), %s, %.1f s"
                       % (done, variant, B, torch.__version__, cores,
                          "compute only (fixed pre-fetched batch)" if compute_only
-                         else "as-written incl. DataLoader reshuffle", dt)}
+                         else "as-written incl. DataLoader reshuffle", dt) +
+                      "; kind 'port' = the oracle's restatement, pinned bit for bit to the unmodified reference "
+                      "(tests/test_oracle_pin.py) and measured 16 % FASTER than it on 8 threads (10.3 vs 12.3 ms/step): "
+                      "a harder CPU baseline than the reference itself, which cannot travel to the GPU box"}
 
 
 def cpu_baseline_vae(B=512, seconds_target=5.0, cores=16):
@@ -411,8 +414,11 @@ def timed_reps(run_rep, reps, K, world, dev):
     return out
 
 
+SUSTAINED_MAX_STEPS = 120000      # room in the schedule / loss buffers for the sustained window below
+
+
 def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=True, force_dp=False,
-              lrs=(2e-4, 2e-4), D_steps=1, solo=False, long_steps=0):
+              lrs=(2e-4, 2e-4), D_steps=1, solo=False, long_steps=0, sustained_s=0.0):
     """W warm-up + reps x K timed iterations of the fused engine.  Returns (engine, [seconds]).
     solo: a 1-rank engine timed on this rank alone inside a multi-rank job (no barrier / max)."""
     import importlib
@@ -428,7 +434,7 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     data = ds.tensors[0].reshape(N_TRAIN, -1).to(dev).contiguous()          # resident in HBM
     eng = gm_engine.GANEngine(variant, trainer.model, data, B_global, dev, use_graph=use_graph,
                               world_size=world, rank=rank, force_dp=force_dp)
-    eng.configure(W + reps * K + long_steps, lrs[0], lrs[1], D_steps)
+    eng.configure(W + reps * K + long_steps + (SUSTAINED_MAX_STEPS if sustained_s else 0), lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
     marks = []
 
@@ -450,7 +456,17 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
         ls = timed_reps(lambda r: eng.run(long_steps, it_start=W + reps * K), 1, long_steps,
                         1 if solo else world, dev)
         eng.steady_us_per_step = ls[0] / long_steps * 1e6
-    G, D = eng.losses(W, W + reps * K + long_steps)
+    eng.sustained = None
+    n_sus = 0
+    if sustained_s and eng.steady_us_per_step:
+        # ONE uninterrupted window of >= sustained_s seconds of the same step (host draws inside, as everywhere): long
+        # enough for an outside observer sampling GPU activity every few seconds (the driver's gpu_busy) to see it
+        n_sus = int(min(SUSTAINED_MAX_STEPS, sustained_s * 1e6 / eng.steady_us_per_step + 1))
+        su = timed_reps(lambda r: eng.run(n_sus, it_start=W + reps * K + long_steps), 1, n_sus,
+                        1 if solo else world, dev)
+        eng.sustained = {"seconds": su[0], "steps": n_sus, "us_per_step": su[0] / n_sus * 1e6,
+                         "img_s": n_sus * B_global / su[0]}
+    G, D = eng.losses(W, W + reps * K + long_steps + n_sus)
     assert np.isfinite(G).all() and np.isfinite(D).all(), "non-finite losses"
     return eng, secs
 
@@ -526,6 +542,7 @@ def dominant_gemm_roofline(shapes, B, pmc_tag=None, reps=50):
          "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}}
     e["traffic"], e["traffic_source"] = pmc_traffic(name, pmc_tag)
+    e["hbm_gbps"] = (e["traffic"] / (e["avg_launch_us"] * 1e-6) / 1e9) if e["traffic"] else None
     return e
 
 
@@ -712,6 +729,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 3/4/5 section")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sustained", type=float, default=6.0,
+                    help="seconds of ONE uninterrupted window of the headline step behind the timed regions (0: skip)")
     ap.add_argument("--only", default=None, help="profiling: run ONE of the extra configs (wgp_b256, ns_b1024, "
                     "ls_b1024, dra_b256, vae_b512) and print its entry instead of the contract line")
     args = ap.parse_args()
@@ -751,7 +770,8 @@ def main():
         return
     B_global = B_PER_GPU * world
     eng, secs = bench_gan("ns", B_global, W, K, reps, dev, world=world, rank=rank,
-                          use_graph=not args.no_graph, force_dp=force_dp, long_steps=512)
+                          use_graph=not args.no_graph, force_dp=force_dp, long_steps=512,
+                          sustained_s=(args.sustained if world == 1 else 0.0))
     dt = float(np.median(secs))
     log('timed regions done: %s' % ["%.4f" % x for x in secs])
     img_s = K * B_global / dt
@@ -799,7 +819,13 @@ def main():
                        "gradient_exchange": comm_mode_of(eng),
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
-                       "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw"},
+                       "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw",
+                       # SURVEY 8d's ">= 200 timed steps after warm-up" figure of the SAME engine, right behind the
+                       # K-step regions (one 512-step region), and one uninterrupted multi-second window
+                       "steady_512_steps": ({"steps": 512, "us_per_step": eng.steady_us_per_step,
+                                             "img_s": B_global / eng.steady_us_per_step * 1e6}
+                                            if eng.steady_us_per_step else None),
+                       "sustained_window": eng.sustained},
             # steady-state step of the same engine (one 512-step region behind the timed ones) and what a
             # K-step run() costs on top of K of those: cold start of the host draws, graph boundaries, final sync
             "steady_us_per_step": eng.steady_us_per_step,
@@ -814,6 +840,9 @@ def main():
                          "traffic_source": traffic_src,
                          "shader_clock_mhz": round(mhz),
                          "mfma_busy_frac": mfma_busy_frac(dom, t_us / n, mhz),
+                         # fabric / HBM-side bytes of the committed PMC pass over this run's launch duration
+                         "hbm_gbps": (traffic / (t_us / n * 1e-6) / 1e9) if traffic else None,
+                         "hbm_frac_of_8tbs": (traffic / (t_us / n * 1e-6) / 8.0e12) if traffic else None,
                          "launches_per_step": n, "avg_launch_us": t_us / n,
                          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
         }

@@ -1,6 +1,7 @@
 """CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, host
 helpers are bit-exact against torch, drop-in modules expose the reference's surface, fast-path
 selection logic, and the product fails loudly instead of computing on CPU."""
+import json
 import os
 import sys
 
@@ -373,3 +374,58 @@ def test_committed_bench_records_follow_the_contract(record):
     names = " | ".join(e["workload"] for e in line.get("configs", []))
     for needle in ("WGAN-GP", "NSGAN MNIST bs=1024", "LSGAN MNIST bs=1024", "VAE MNIST bs=512"):
         assert needle in names, (needle, names)
+
+
+def _kernel_resources():
+    import importlib.util
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("gm_kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not (os.path.isfile(kr.LIB) and kr.tools_available()):
+        pytest.skip("needs the built libgm_hip.so and the ROCm LLVM binutils")
+    return kr
+
+
+def test_kernel_register_and_code_size_baseline():
+    """Every kernel of the built library against profiles/kernel_resources.json (VGPR / SGPR / spills / LDS / scratch /
+    code bytes, read from the code objects inside the .so).  Round 3's dominant forward kernel got 6 % slower across a
+    round in which nothing in it was meant to change -- template flags and sibling instantiations accumulating around
+    it.  A change here is not a failure of the code, it is a change that has to be LOOKED at: refresh the baseline with
+    `python tools/kernel_resources.py --write` in the same commit (and say why in its message)."""
+    kr = _kernel_resources()
+    table = kr.kernel_table()
+    base = json.load(open(kr.BASELINE))
+    d = kr.diff(table, base)
+    assert not d, "kernel resources moved against profiles/kernel_resources.json:\n" + "\n".join(d[:40])
+    # the hot kernels stay inside their occupancy class and out of scratch
+    for k, r in table.items():
+        assert r["scratch"] == 0 or "bir_mmd_kernel" in k, (k, r)
+        if k.startswith("gemm16_"):
+            assert r["vgpr"] <= 128, (k, r)          # 1024-thread workgroups: 4 waves per SIMD
+        if k.startswith("gemm_lds_kernel"):
+            assert r["vgpr"] <= 256, (k, r)          # 512-thread workgroups: 2 waves per SIMD
+
+
+def test_committed_counter_passes_name_kernels_the_library_contains():
+    """Every kernel named in a committed PMC / SQ counter pass of the round bench.py reads (profiles/<round>_*_pmc_traffic
+    .json, *_sq_pmc.json) must exist in the built library: a pass taken before a kernel was renamed or re-templated
+    would silently give the bench line `traffic: null` (or, worse, a number of another kernel)."""
+    import glob
+    import importlib.util
+    kr = _kernel_resources()
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("gm_bench2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    files = glob.glob(os.path.join(root, "profiles", bench.PROFILE_ROUND + "_*_pmc_traffic.json")) + \
+        glob.glob(os.path.join(root, "profiles", bench.PROFILE_ROUND + "_*_sq_pmc.json"))
+    if not files:
+        pytest.skip("no committed counter pass of round %s yet" % bench.PROFILE_ROUND)
+    have = set(kr.kernel_table())
+    for f in files:
+        for key in json.load(open(f)):
+            name = key.split("|")[0]
+            if name.startswith(("gemm", "head_", "gan_loss", "adam_", "stage_in", "ar_", "vae_", "std_", "gp_", "interp",
+                                "sum_finalize", "gather_rows", "tick", "dragan", "began", "info_q", "bir_", "l1_rows", "sqerr")):
+                assert name in have, "%s names %r, which the built library does not contain" % (os.path.basename(f), name)
