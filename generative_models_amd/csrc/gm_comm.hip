@@ -25,6 +25,7 @@
 // so a lost peer shows up as a Python exception at the next read-back, never as a hung GPU.
 #include "gm_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -58,6 +59,8 @@ struct Comm {
     unsigned long long* seq;   // device: number of completed all-reduces; [1]: copy for the gather phase
     unsigned long long* sseq;  // device: number of completed scalar exchanges
     int* err;                  // device: set when a bounded wait expired
+    unsigned* arrive;          // device: workgroups of the one-kernel exchange that have written their part of `out`
+    int two_kernels;           // 1: reduce and gather as two launches (ranks sharing ONE device: see gm_comm_set_exchange)
     int coarse;                // 1: the region is plain hipMalloc memory (fine-grained allocation refused)
 };
 
@@ -68,6 +71,7 @@ struct CommP {
     unsigned long long* seq;
     unsigned long long* sseq;
     int* err;
+    unsigned* arrive;
 };
 
 __device__ __forceinline__ unsigned long long* flag_ptr(const CommP& c, int owner, int phase, int src) {
@@ -190,6 +194,99 @@ __global__ __launch_bounds__(256) void gather_kernel(CommP c, float* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) c.seq[0] = s;
 }
 
+// wait (bounded) until every peer's flag of `phase` has reached s in MY flag array; one lane per workgroup
+__device__ void wait_peers(const CommP& c, int phase, unsigned long long s) {
+    bool dead = __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const unsigned long long t0 = wall_clock64();
+    for (int peer = 0; peer < c.world && !dead; ++peer) {
+        if (peer == c.rank) continue;
+        unsigned int spins = 0;
+        while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255u) == 0 && wall_clock64() - t0 > WAIT_TICKS) {
+                atomicExch(c.err, 1);
+                dead = true;
+                break;
+            }
+        }
+    }
+}
+
+// Round 4: reduce-scatter AND all-gather (+ Adam) as ONE kernel -- the data-parallel iteration is the single-GPU
+// iteration's 8 launches + one exchange per optimizer (round 3: + two).  What the kernel boundary between reduce and
+// gather provided -- "every workgroup of this rank has written its part of `out`" before the peers are told -- is an
+// arrival counter: every wave drains its stores, the workgroup's lane 0 releases and arrives, the LAST arriver re-arms
+// the counter and stores the "out ready" flags into the peers' regions.  Nobody waits on the counter: workgroup b
+// reduces and gathers the SAME indices of the rank's own slice (the thread that summed an element is the one that
+// reads it back), and the peers' slices are guarded by their flags.  All workgroups are co-resident (<= 320 x 256
+// threads on 256 CUs), so the flag waits cannot starve the arrivals they depend on.  One rank: the gradient is taken
+// straight from `in`, no `out`, no counter.
+__global__ __launch_bounds__(256) void xchg_kernel(CommP c, float* __restrict__ g, int64_t n, AdamP ad) {
+    const unsigned long long s = c.seq[0] + 1;
+    signal_and_wait(c, 0, s);                       // every rank's bucket is complete (kernel boundary + flags)
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c.world > 1) {
+        int64_t lo, hi;
+        slice_of(n4, c.world, c.rank, &lo, &hi);
+        float4* out = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.out);
+        for (int64_t i = lo + first; i < hi; i += stride) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < c.world; ++r) {                   // rank order: same bits on every rank
+                const float4 v = reinterpret_cast<const float4*>(c.base[r] + c.lay.in)[i];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            out[i] = a;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's `out` stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);              // system scope
+            const unsigned old = __hip_atomic_fetch_add(c.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {                           // last of this rank: tell the peers, re-arm
+                __hip_atomic_store(c.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the sequence number advances HERE: every workgroup of this launch has read it by now (it arrived).
+                // Written at the end of workgroup 0 instead, a workgroup that starts late -- several processes
+                // time-sharing one GPU -- would read the NEW value and wait for flags of the next exchange.
+                c.seq[0] = s;
+                for (int peer = 0; peer < c.world; ++peer)
+                    if (peer != c.rank)
+                        __hip_atomic_store(flag_ptr(c, peer, 1, c.rank), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            wait_peers(c, 1, s);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);              // system scope: see the peers' `out`
+        }
+        __syncthreads();
+    }
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (ad.enabled) {
+        const int64_t si = gm_slot_index(ad.sched_slot);
+        step_size = ad.sched[2 * si] * (ad.lr_scale ? ad.lr_scale[0] : 1.0f);
+        bc2_sqrt = ad.sched[2 * si + 1];
+    }
+    for (int r = 0; r < c.world; ++r) {
+        int64_t lo, hi;
+        slice_of(n4, c.world, r, &lo, &hi);
+        const float4* src = reinterpret_cast<const float4*>(c.base[r] + (c.world > 1 ? c.lay.out : c.lay.in));
+        for (int64_t i = lo + first; i < hi; i += stride) {
+            const float4 G = src[i];
+            if (c.world > 1 || reinterpret_cast<const float4*>(g) != src) reinterpret_cast<float4*>(g)[i] = G;
+            if (ad.enabled) {
+                float4 P = reinterpret_cast<float4*>(ad.p)[i];
+                float4 M = reinterpret_cast<float4*>(ad.m)[i];
+                float4 V = reinterpret_cast<float4*>(ad.v)[i];
+                adam_update(P.x, G.x, M.x, V.x, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.y, G.y, M.y, V.y, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.z, G.z, M.z, V.z, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.w, G.w, M.w, V.w, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                reinterpret_cast<float4*>(ad.p)[i] = P;
+                reinterpret_cast<float4*>(ad.m)[i] = M;
+                reinterpret_cast<float4*>(ad.v)[i] = V;
+            }
+        }
+    }
+}
+
 // Scalar exchange: vals[0..k) <- sum over ranks (rank order) of every rank's vals[0..k), k <= 16.
 // One workgroup: write mine into every peer's slot array (remote stores), signal, wait, sum locally.
 __global__ __launch_bounds__(64) void scalars_kernel(CommP c, float* __restrict__ vals, int k) {
@@ -218,6 +315,7 @@ __global__ __launch_bounds__(64) void scalars_kernel(CommP c, float* __restrict_
 CommP params_of(const Comm* cm) {
     CommP p{};
     p.rank = cm->rank; p.world = cm->world; p.lay = cm->lay; p.seq = cm->seq; p.sseq = cm->sseq; p.err = cm->err;
+    p.arrive = cm->arrive;
     for (int i = 0; i < MAXW; ++i) p.base[i] = cm->base[i];
     return p;
 }
@@ -256,6 +354,7 @@ static int comm_create_impl(Comm* cm, void* handle_out64) {
     GM_HIPC(hipMemset(ctr, 0, 64));
     cm->sseq = cm->seq + 2;
     cm->err = reinterpret_cast<int*>(cm->seq + 4);
+    cm->arrive = reinterpret_cast<unsigned*>(cm->seq + 6);
     hipIpcMemHandle_t h;
     std::memset(&h, 0, sizeof(h));
     if (cm->world > 1) GM_HIPC(hipIpcGetMemHandle(&h, p));
@@ -323,6 +422,18 @@ extern "C" int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out)
     return 0;
 }
 
+// The one-kernel exchange keeps ~300 workgroups of every rank spinning on their peers' flags; with a GPU per rank
+// that costs nothing, but ranks that SHARE one device (the single-GPU multi-process tests and dry runs) then hold
+// the registers the peers' 1024-thread GEMM workgroups need to get on a CU at all -- measured: 4 ranks x 256 rows of the
+// 784-400-20 model on one MI355X starve each other until the bounded waits expire.  two_kernels = 1 selects round 3's
+// reduce + gather pair, whose first wait is a 77-workgroup, 18-register kernel.
+extern "C" int gm_comm_set_exchange(void* comm, int two_kernels) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && (two_kernels == 0 || two_kernels == 1));
+    cm->two_kernels = two_kernels;
+    return 0;
+}
+
 extern "C" int gm_comm_error(void* comm, int* flag_out) {
     Comm* cm = static_cast<Comm*>(comm);
     GM_CHECK_ARG(cm && flag_out);
@@ -345,8 +456,14 @@ static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const 
     if (rblocks < 1) rblocks = 1;
     if (reinterpret_cast<char*>(buf) != cm->base[cm->rank] + cm->lay.in)    // the bucket lives elsewhere
         hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
-    hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
+    static int two = -1;                              // GM_DP_TWO_KERNELS=1: round 3's reduce + gather pair everywhere (A/B)
+    if (two < 0) { const char* e = getenv("GM_DP_TWO_KERNELS"); two = e ? atoi(e) : 0; }
+    if (two || cm->two_kernels) {
+        hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
+        hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
+    } else {
+        hipLaunchKernelGGL(xchg_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
+    }
     GM_LAUNCH_RET();
 }
 

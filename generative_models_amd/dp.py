@@ -124,6 +124,12 @@ class PeerComm:
                 _lib.call("gm_comm_connect", self.h, blob)
             except Exception as e:                   # noqa: BLE001
                 err = e
+            # ranks that share a device (single-GPU multi-process tests / dry runs): the two-launch exchange -- the
+            # one-kernel form's spinning workgroups would starve the co-located peers' GEMM kernels of registers
+            # (gm_comm_set_exchange).  GM_DP_ONE_KERNEL=1 keeps the one-kernel form (the direct exchange tests).
+            self.shared_device = len({g[2] for g in got}) < world
+            if err is None and self.shared_device and os.environ.get("GM_DP_ONE_KERNEL") != "1":
+                _lib.call("gm_comm_set_exchange", self.h, 1)
             oks = [None] * world
             dist.all_gather_object(oks, err is None, group=group)      # also: every rank has mapped every region
             if not all(oks):

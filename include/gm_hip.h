@@ -485,6 +485,11 @@ int gm_comm_error(void* comm, int* flag_out);
  * may store into it while a kernel polls it), 0 when the runtime refused that allocation and the
  * region is plain device memory: valid only when every rank shares one device. */
 int gm_comm_info(void* comm, int* fine_grained_out);
+/* two_kernels = 0 (default): an all-reduce is ONE kernel (reduce-scatter, arrival counter, all-gather + Adam);
+ * 1: two launches (reduce, gather).  Ranks that share one device must use 1: the one-kernel form keeps every
+ * rank's ~300 workgroups spinning on peer flags, which starves the peers' GEMM workgroups of registers when they
+ * run on the same CUs (dp.PeerComm sets it from the ranks' device identities). */
+int gm_comm_set_exchange(void* comm, int two_kernels);
 /* The region's own bucket (n_floats fp32, 256-byte aligned): a gradient buffer placed here is
  * all-reduced without a staging copy. */
 int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out);

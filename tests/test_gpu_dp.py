@@ -93,13 +93,20 @@ def _comm_worker(rank, world, port, q, real=False):
     dist.destroy_process_group()
 
 
-def _comm_case(world, real):
+def _comm_case(world, real, one_kernel=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, real)) for r in range(world)]
-    for p in procs:
-        p.start()
+    # ranks sharing one device default to the two-launch exchange (dp.PeerComm); GM_DP_ONE_KERNEL=1 keeps the
+    # one-kernel form, whose cross-rank protocol (arrival counter, last arriver signals) is what this case covers
+    if one_kernel:
+        os.environ["GM_DP_ONE_KERNEL"] = "1"
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        os.environ.pop("GM_DP_ONE_KERNEL", None)
     out = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
@@ -110,8 +117,9 @@ def _comm_case(world, real):
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
-def test_peer_allreduce_between_processes(world):
-    _comm_case(world, real=False)
+@pytest.mark.parametrize("one_kernel", [False, True], ids=["two_launches", "one_kernel"])
+def test_peer_allreduce_between_processes(world, one_kernel):
+    _comm_case(world, real=False, one_kernel=one_kernel)
 
 
 @needs_2_gpus
