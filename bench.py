@@ -820,6 +820,7 @@ def main():
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
                        "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw",
+                       "host_threads": __import__("generative_models_amd").host_thread_plan(),
                        # SURVEY 8d's ">= 200 timed steps after warm-up" figure of the SAME engine, right behind the
                        # K-step regions (one 512-step region), and one uninterrupted multi-second window
                        "steady_512_steps": ({"steps": 512, "us_per_step": eng.steady_us_per_step,

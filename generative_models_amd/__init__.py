@@ -39,7 +39,13 @@ def _respect_cpu_quota(force=True):
     import math
 
     import torch
+    # several ranks on one node share the quota: each takes its share, less the two threads every rank keeps busy
+    # whatever torch does -- the launch thread and the native fill worker (8 ranks x 2 = the 16-core quota of the
+    # MI355X boxes: a third busy thread per rank is what gets the launch threads throttled)
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
     cap = max(1, int(math.ceil(cores)))
+    if ranks > 1:
+        cap = max(1, int(cores // ranks) - 2)
     before = torch.get_num_threads()
     if before > cap:
         torch.set_num_threads(cap)
@@ -47,3 +53,18 @@ def _respect_cpu_quota(force=True):
         logging.getLogger("generative_models_amd").info(
             "torch intra-op threads %d -> %d (container CPU quota %.2f cores; GM_KEEP_THREADS=1 keeps them)",
             before, cap, cores)
+
+
+def host_thread_plan():
+    """What bench.py prints in `config.host_threads`: the container's CPU quota and the threads one rank keeps busy."""
+    import os
+
+    import torch
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    q = _cpu_quota_cores()
+    return {"cgroup_quota_cores": q, "host_cores": os.cpu_count(), "ranks_on_node": ranks,
+            "per_rank": {"launch_thread": 1, "native_fill_worker": 1,
+                         "replay_pool": max(1, int(os.environ.get("GM_HOST_THREADS", "1"))),
+                         "torch_intraop": torch.get_num_threads()},
+            "busy_threads_on_node": ranks * 2,
+            "fits_quota": (q is None) or (ranks * 2 <= q)}
