@@ -95,9 +95,10 @@ def gemm_shapes_wgp(B, fold_g=True):
 
 def gemm_shapes_vae(B):
     """Every GEMM launch of one VAE training batch (engine.VAEEngine._issue): "fwds" = decoder output
-    layer + reconstruction loss epilogue, "dxr" = dX through the decoder's first layer + reparameterisation
+    layer + reconstruction loss epilogue, "fwdz" = reparameterisation + the decoder's first layer (one launch; its GEMM
+    workgroups form z from mu, log_var, eps), "dxr" = dX through the decoder's first layer + reparameterisation
     backward epilogue; the two weight-gradient pairs carry their second GEMM's (N2, K2)."""
-    return [("fwd", B, IMG, HID), ("fwdg", B, HID, 2 * Z), ("fwd", B, Z, HID), ("fwds", B, HID, IMG),
+    return [("fwd", B, IMG, HID), ("fwdg", B, HID, 2 * Z), ("fwdz", B, Z, HID), ("fwds", B, HID, IMG),
             ("dx", B, HID, IMG), ("dxr", B, Z, HID), ("dwp", B, HID, IMG, (HID, Z)),
             ("dx", B, HID, 2 * Z), ("dwp", B, IMG, HID, (2 * Z, HID))]
 
@@ -106,6 +107,8 @@ def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
     load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
+    if kind == "fwdz":
+        return "vae_reparam_fwd_kernel"
     if kind in ("fwd", "fwdg", "fwdp", "fwds"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind in ("dx", "dxh", "dxhf", "dxr"):
@@ -212,6 +215,11 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             tgt = (torch.rand(M, N, device=dev) < 0.13).float()
             part2 = torch.zeros(M, (-(-N // 32) + 3) // 4 * 4, device=dev)
             fn = lambda: ops.linear_fwd_sqerr(x, W, b, y, tgt, dA, part2, stream=st)
+        elif kind == "fwdz":                    # reparameterisation + decoder layer 1 (K = z_dim) in one launch
+            from generative_models_amd import ops_fused
+            mlz, epz = torch.randn(M, 2 * K, device=dev) * 0.5, torch.randn(M * K, device=dev)
+            zz_, pk = torch.empty(M, K, device=dev), torch.empty((M * K + 255) // 256, device=dev)
+            fn = lambda: ops_fused.vae_reparam_fwd(mlz, epz, zz_, pk, M, K, W, b, y, "relu", stream=st)
         elif kind == "dxr":                     # dX (layer [N, K]: K = z_dim) + reparameterisation backward
             mlz, epz, dmlz = torch.randn(M, 2 * K, device=dev), torch.randn(M * K, device=dev), torch.empty(M, 2 * K, device=dev)
             fn = lambda: ops.linear_bwd_dx_reparam(dA, W, dX, mlz, epz, dmlz, stream=st)

@@ -62,6 +62,13 @@ class DwAdamArgs(ctypes.Structure):
                 ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("clamp", c_float)]
 
 
+class Finalize2Args(ctypes.Structure):
+    """gm_finalize2_args (include/gm_hip.h): the two loss sums + counter tick that ride in a VAE batch's last launch."""
+    _fields_ = [("pa", c_void_p), ("na", c_int), ("scale_a", c_float), ("out_a", c_void_p), ("slot_a", Slot),
+                ("pb", c_void_p), ("nb", c_int), ("scale_b", c_float), ("out_b", c_void_p), ("slot_b", Slot),
+                ("tick", c_void_p), ("done", c_void_p)]
+
+
 class DrawOp(ctypes.Structure):
     """gm_draw_op (include/gm_hip.h): one draw of the per-iteration host RNG program."""
     _fields_ = [("kind", c_int32), ("n", c_int32), ("a", c_int64), ("b", c_int32), ("c", c_int32),
@@ -117,6 +124,8 @@ _SIGNATURES = {
     "gm_sum_finalize_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P]),
     "gm_sum_finalize2_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P, c_int, c_float, _P, Slot, _P]),
     "gm_vae_reparam_wide": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int, c_int, c_int]),
+    "gm_vae_reparam_fwd": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int, c_int, c_int, _P, _P, _P,
+                                   c_int64, c_int, c_int]),
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float]),
@@ -142,6 +151,8 @@ _SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
                                                 POINTER(HeadBwdArgs), POINTER(HeadFoldArgs)]),
     "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),
+    "gm_linear_bwd_dw_adam_pair_finalize": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs),
+                                                    POINTER(Finalize2Args)]),
     "gm_linear_bwd_dw_adam_head": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
                                            c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,

@@ -49,6 +49,52 @@ __device__ __forceinline__ double gm_wave_sum_d(double v) {
 
 __device__ __forceinline__ float gm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Sum of n floats by one 1024-thread workgroup, this thread's share: fp64, fixed order, loads in batches of 8
+// INDEPENDENT ones (a row-tile partial array of the fused reconstruction loss has 14 336 entries at B = 512).
+__device__ __forceinline__ double gm_strided_sum_1024(const float* __restrict__ p, int n) {
+    double acc = 0.0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + u * 1024, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < n) acc += (double)v[u];
+    }
+    return acc;
+}
+
+// The two sums that close a VAE batch (vae.py:203, :212), by one 1024-thread workgroup; sh: 32 doubles of LDS.
+struct gm_fin2 {
+    const float* pa; int na; float sa; float* oa; gm_slot slot_a;
+    const float* pb; int nb; float sb; float* ob; gm_slot slot_b;
+    int64_t* tick;                 // device step counter to advance (or null)
+    unsigned int* done;            // arrival counter of the launch the sums ride in (gemm16_dw_pair_fin_kernel)
+};
+__device__ __forceinline__ void gm_fin2_sums(const gm_fin2& f, double* sh) {
+    double a = gm_strided_sum_1024(f.pa, f.na), b = gm_strided_sum_1024(f.pb, f.nb);
+    a = gm_wave_sum_d(a); b = gm_wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[16 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 16; ++w) { ta += sh[w]; tb += sh[16 + w]; }
+        f.oa[gm_slot_index(f.slot_a)] = (float)(ta * (double)f.sa);
+        f.ob[gm_slot_index(f.slot_b)] = (float)(tb * (double)f.sb);
+    }
+}
+
+// z = mu + eps * exp(log_var / 2) (vae.py:100-106) with the product rounded before the add, as torch's
+// `mu + eps * std` does; pinned (fp contract off) so that the two places that compute it -- the reparameterisation
+// workgroups, which store z for the backward pass, and the decoder's first-layer GEMM, which forms its A operand from
+// (mu, log_var, eps) on the fly (gm_vae_reparam_fwd) -- agree bit for bit.
+__device__ __forceinline__ float gm_reparam_z(float mu, float e, float lv) {
+#pragma clang fp contract(off)
+    const float s = expf(lv / 2.f);
+    const float t = e * s;
+    return mu + t;
+}
+
 // eps * x + (1 - eps) * g as torch computes it (w_gp_gan.py:197-201): two rounded products and an add.  The pragma is
 // what keeps hipcc (-ffp-contract=fast) from fusing one product into the add wherever this gets inlined; HIP's
 // __fmul_rn / __fadd_rn are plain operators and do not.

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(1024) void vae_reparam_kernel(const float* __restri
     for (int i = threadIdx.x; i < n; i += 1024) {
         const int b = i / Z, c = i % Z;
         const float mu = ml[(int64_t)b * ldml + c], lv = ml[(int64_t)b * ldml + Z + c];
-        z[(int64_t)b * ldz + c] = mu + e[i] * expf(lv / 2.f);
+        z[(int64_t)b * ldz + c] = gm_reparam_z(mu, e[i], lv);
         acc += (double)(0.5f * (((mu * mu) + expf(lv)) - lv - 1.f));
     }
     acc = gm_wave_sum_d(acc);
@@ -446,13 +446,106 @@ __global__ __launch_bounds__(256) void vae_reparam_wide_kernel(const float* __re
     if (i < n) {
         const int b = i / Z, c = i % Z;
         const float mu = ml[(int64_t)b * ldml + c], lv = ml[(int64_t)b * ldml + Z + c];
-        z[(int64_t)b * ldz + c] = mu + e[i] * expf(lv / 2.f);
+        z[(int64_t)b * ldz + c] = gm_reparam_z(mu, e[i], lv);
         acc = (double)(0.5f * (((mu * mu) + expf(lv)) - lv - 1.f));
     }
     acc = gm_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) kl_part[blockIdx.x] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// Reparameterisation + the decoder's first layer as ONE launch (round 4; vae.py:100-106 + :113):
+//   workgroups [0, nrp): exactly vae_reparam_wide_kernel's work for 256 elements each (z stored for the backward
+//                        pass, per-workgroup KL partials: same partition, same fp64 order, same bits);
+//   the others:          one 32 x 32 tile of h = act(z W^T + b) each, z formed from (mu, log_var, eps) right where the
+//                        A fragment is loaded -- nobody waits for the z the first group stores.
+// The layer is narrow (K = Z <= 32: two 16-deep chunks), so a tile is 4 waves x one 16x16 accumulator pair and there
+// is no cross-wave reduction: ((0 + chunk 0) + chunk 1) + bias through the same MFMA sequence as the 16-wave kernel
+// of gm_gemm.hip, whose waves 0 and 1 own the two chunks (bit-identical output).
+// ------------------------------------------------------------------------------------------
+typedef float rp_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void vae_reparam_fwd_kernel(const float* __restrict__ ml, int64_t ldml,
+                                                             const float* __restrict__ eps, gm_slot eps_slot,
+                                                             float* __restrict__ z, int64_t ldz,
+                                                             float* __restrict__ kl_part, int B, int Z, int nrp,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ H, int64_t ldh, int N, int act,
+                                                             int tiles_n) {
+    __shared__ double sh[4];
+    const float* e = eps + gm_slot_offset(eps_slot);
+    if ((int)blockIdx.x < nrp) {                             // workgroup-uniform
+        const int n = B * Z, i = blockIdx.x * 256 + threadIdx.x;
+        double acc = 0.0;
+        if (i < n) {
+            const int b = i / Z, c = i % Z;
+            const float mu = ml[(int64_t)b * ldml + c], lv = ml[(int64_t)b * ldml + Z + c];
+            z[(int64_t)b * ldz + c] = gm_reparam_z(mu, e[i], lv);
+            acc = (double)(0.5f * (((mu * mu) + expf(lv)) - lv - 1.f));
+        }
+        acc = gm_wave_sum_d(acc);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) kl_part[blockIdx.x] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        return;
+    }
+    const int tile = blockIdx.x - nrp;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int m0 = (tile / tiles_n) * 32 + 16 * (w >> 1), n0 = (tile % tiles_n) * 32 + 16 * (w & 1);
+    const int row = min(m0 + i16, B - 1), col = min(n0 + i16, N - 1);
+    float4 za[2], wb[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int kb = 16 * c + 4 * g4, kc = min(kb, Z - 4);    // Z % 4 == 0: a group is whole or absent
+        const float4 mu = *reinterpret_cast<const float4*>(ml + (int64_t)row * ldml + kc);
+        const float4 lv = *reinterpret_cast<const float4*>(ml + (int64_t)row * ldml + Z + kc);
+        const float4 ee = *reinterpret_cast<const float4*>(e + (int64_t)row * Z + kc);
+        const float4 ww = *reinterpret_cast<const float4*>(W + (int64_t)col * Z + kc);
+        const bool ka = kb < Z, ok_a = ka && (m0 + i16 < B), ok_b = ka && (n0 + i16 < N);
+        za[c] = make_float4(ok_a ? gm_reparam_z(mu.x, ee.x, lv.x) : 0.f, ok_a ? gm_reparam_z(mu.y, ee.y, lv.y) : 0.f,
+                            ok_a ? gm_reparam_z(mu.z, ee.z, lv.z) : 0.f, ok_a ? gm_reparam_z(mu.w, ee.w, lv.w) : 0.f);
+        wb[c] = make_float4(ok_b ? ww.x : 0.f, ok_b ? ww.y : 0.f, ok_b ? ww.z : 0.f, ok_b ? ww.w : 0.f);
+    }
+    rp_f32x4 a0 = rp_f32x4{0.f, 0.f, 0.f, 0.f}, a1 = rp_f32x4{0.f, 0.f, 0.f, 0.f};
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[0].x, wb[0].x, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[0].y, wb[0].y, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[0].z, wb[0].z, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[0].w, wb[0].w, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[1].x, wb[1].x, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[1].y, wb[1].y, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[1].z, wb[1].z, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[1].w, wb[1].w, a1, 0, 0, 0);
+    const int n = n0 + i16;
+    const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * g4 + r;
+        float v = 0.f;                                       // the 16-wave reduction's order: 0 + chunk 0 + chunk 1
+        v += a0[r];
+        if (Z > 16) v += a1[r];
+        v += bv;
+        if (act == GM_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == GM_ACT_SIGMOID) v = gm_sigmoid(v);
+        if (m < B && n < N) H[(int64_t)m * ldh + n] = v;
+    }
+}
+
+extern "C" int gm_vae_reparam_fwd(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
+                                  float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z, const float* W,
+                                  const float* bias, float* H, int64_t ldh, int N, int act) {
+    GM_CHECK_ARG(ml && eps && z && kl_part && W && H && B > 0 && Z > 0 && N > 0 && ldml >= 2 * Z && ldz >= Z && ldh >= N);
+    GM_CHECK_ARG(Z <= 32 && Z % 4 == 0 && ldml % 4 == 0 && eps_slot.stride % 4 == 0 &&
+                 ((reinterpret_cast<uintptr_t>(ml) | reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(W)) & 15) == 0);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID && (const float*)H != ml && H != z && (const float*)z != ml);
+    const int nrp = (B * Z + 255) / 256;
+    GM_CHECK_ARG(n_part >= nrp);
+    const int tiles_n = (N + 31) / 32, tiles_m = (B + 31) / 32;
+    hipLaunchKernelGGL(vae_reparam_fwd_kernel, dim3(nrp + tiles_m * tiles_n), dim3(256), 0, (hipStream_t)stream, ml,
+                       ldml, eps, eps_slot, z, ldz, kl_part, B, Z, nrp, W, bias, H, ldh, N, act, tiles_n);
+    GM_LAUNCH_RET();
 }
 
 extern "C" int gm_vae_reparam_wide(void* stream, const float* ml, int64_t ldml, const float* eps,
@@ -533,25 +626,14 @@ extern "C" int gm_sqerr_sigmoid_bwd(void* stream, const float* x, int64_t ldx, c
 // Strided fp64 sum of partial[0..n) by one 1024-thread workgroup: thread t takes elements t, t + 1024, ...
 // in batches of 8 INDEPENDENT loads (a row-tile partial array of the fused reconstruction loss has
 // 14 336 entries at B = 512: 14 per thread, two memory round trips instead of 14 dependent ones).
-static __device__ __forceinline__ double strided_sum_1024(const float* __restrict__ p, int n) {
-    double acc = 0.0;
-    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + u * 1024, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u * 1024 < n) acc += (double)v[u];
-    }
-    return acc;
-}
+// (gm_strided_sum_1024: gm_common.h -- the weight-gradient pair's finalize workgroup runs the same sum)
 
 // out[slot] = scale * sum_{i<n} partial[i]   (single workgroup, fp64 accumulate, fixed order)
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(const float* __restrict__ partial, int n,
                                                            float scale, float* __restrict__ out,
                                                            gm_slot out_slot, int64_t* tick) {
     __shared__ double sh[16];
-    double acc = gm_wave_sum_d(strided_sum_1024(partial, n));
+    double acc = gm_wave_sum_d(gm_strided_sum_1024(partial, n));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -579,31 +661,18 @@ extern "C" int gm_sum_finalize_tick(void* stream, const float* partial, int n, f
 }
 
 // Two sums in one launch (the VAE step's reconstruction partials and KL partials), optional tick.
-__global__ __launch_bounds__(1024) void sum_finalize2_kernel(const float* __restrict__ pa, int na, float sa,
-                                                            float* __restrict__ oa, gm_slot slot_a,
-                                                            const float* __restrict__ pb, int nb, float sb,
-                                                            float* __restrict__ ob, gm_slot slot_b,
-                                                            int64_t* tick) {
-    __shared__ double sh[2][16];
-    double a = strided_sum_1024(pa, na), b = strided_sum_1024(pb, nb);
-    a = gm_wave_sum_d(a); b = gm_wave_sum_d(b);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, tb = 0.0;
-        for (int w = 0; w < 16; ++w) { ta += sh[0][w]; tb += sh[1][w]; }
-        oa[gm_slot_index(slot_a)] = (float)(ta * (double)sa);
-        ob[gm_slot_index(slot_b)] = (float)(tb * (double)sb);
-        if (tick) *tick += 1;
-    }
+__global__ __launch_bounds__(1024) void sum_finalize2_kernel(gm_fin2 f) {
+    __shared__ double sh[32];
+    gm_fin2_sums(f, sh);
+    if (threadIdx.x == 0 && f.tick) *f.tick += 1;            // after both slots are resolved
 }
 
 extern "C" int gm_sum_finalize2_tick(void* stream, const float* pa, int na, float scale_a, float* out_a,
                                      gm_slot slot_a, const float* pb, int nb, float scale_b, float* out_b,
                                      gm_slot slot_b, int64_t* tick) {
     GM_CHECK_ARG(pa && pb && out_a && out_b && na > 0 && nb > 0);
-    hipLaunchKernelGGL(sum_finalize2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pa, na, scale_a,
-                       out_a, slot_a, pb, nb, scale_b, out_b, slot_b, tick);
+    const gm_fin2 f{pa, na, scale_a, out_a, slot_a, pb, nb, scale_b, out_b, slot_b, tick, nullptr};
+    hipLaunchKernelGGL(sum_finalize2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, f);
     GM_LAUNCH_RET();
 }
 

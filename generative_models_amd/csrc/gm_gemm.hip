@@ -1197,6 +1197,29 @@ __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb
     else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
+// The same launch closing a VAE batch (round 4): workgroup 0 adds up the batch's reconstruction and KL partials
+// (gm_fin2_sums: what gm_sum_finalize2_tick's own launch did, same order, same bits -- their producers finished
+// launches ago), the others are the pair's tiles.  The device step counter may only advance once every workgroup has
+// resolved its slots (Adam's schedule slot in the tiles' epilogues, the loss slot in workgroup 0): each workgroup
+// arrives on f.done when it is finished and the LAST arriver ticks and re-arms the counter.
+template <int G, bool XV, int MI, int NI, bool DMA = false>
+__global__ __launch_bounds__(1024) void gemm16_dw_pair_fin_kernel(GemmP pa, GemmP pb, int na, int tna, int tnb,
+                                                                  gm_fin2 f) {
+    __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, DMA, MI, NI>::value];
+    const int id = (int)blockIdx.x - 1;
+    if (id < 0) gm_fin2_sums(f, reinterpret_cast<double*>(red));
+    else if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
+    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
+    __syncthreads();                                         // every thread's slot reads are behind it
+    if (threadIdx.x == 0) {
+        const unsigned int arrived = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(f.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f.tick) *f.tick += 1;
+        }
+    }
+}
+
 // May the epilogue move whole float4s (store4)?  Every array it touches 16-byte aligned, leading dimensions in
 // whole float4s.  GM_VEC_EPI=0: element-wise epilogues everywhere (round 3).
 template <int MODE>
@@ -1222,6 +1245,7 @@ struct Rider {
     const GatherP* gather = nullptr;     // MODE_FWD: batch-gather workgroups
     const GemmP* pair = nullptr;         // MODE_DW: a second weight-gradient GEMM
     bool pair_xvec = false;
+    const gm_fin2* fin = nullptr;        // MODE_DW pair: the VAE batch's two loss sums + counter tick
 };
 
 // Tile shapes of the 16-wave kernels, as sub-tiles (16 x 16) per wave: MI x NI
@@ -1381,15 +1405,21 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                 const dim3 pgrid(na + tnb * tmb);
 #define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb)
-                GM_TILE_SWITCH(tile, dma, GM_LP);
+#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(pgrid.x + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
+                if (rider.fin) GM_TILE_SWITCH(tile, dma, GM_LPF);
+                else GM_TILE_SWITCH(tile, dma, GM_LP);
+#undef GM_LPF
 #undef GM_LP
                 GM_LAUNCH_RET();
             }
-            // not pairable in this configuration: the second GEMM gets its own launch afterwards
+            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums theirs)
             Rider none;
-            const int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
+            int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
             if (rc) return rc;
-            return launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
+            rc = launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
+            if (rc || !rider.fin) return rc;
+            const gm_fin2& f = *rider.fin;
+            return gm_sum_finalize2_tick(s, f.pa, f.na, f.sa, f.oa, f.slot_a, f.pb, f.nb, f.sb, f.ob, f.slot_b, f.tick);
         }
     }
     // template arguments: MODE, VEC, waves, G, XV, MI, NI, DMA
@@ -1727,6 +1757,29 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
     Rider r;
     r.pair = &pb;
     r.pair_xvec = xb;
+    return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
+}
+
+extern "C" int gm_linear_bwd_dw_adam_pair_finalize(void* stream, const gm_dw_adam_args* first,
+                                                   const gm_dw_adam_args* second, const gm_finalize2_args* fin) {
+    GM_CHECK_ARG(first && second && fin);
+    GM_CHECK_ARG(fin->pa && fin->pb && fin->out_a && fin->out_b && fin->na > 0 && fin->nb > 0 && fin->done);
+    GM_CHECK_ARG(first->dW != second->dW && (first->pW != second->pW || !first->pW));
+    GM_CHECK_ARG(!first->pW || ((const float*)first->pW != second->dA && (const float*)first->pW != second->X));
+    GM_CHECK_ARG(!second->pW || ((const float*)second->pW != first->dA && (const float*)second->pW != first->X));
+    GM_CHECK_ARG(first->dW != second->dA && first->dW != second->X && second->dW != first->dA && second->dW != first->X);
+    GemmP pa{}, pb{};
+    bool xa = false, xb = false;
+    int rc = dw_adam_fill(*first, &pa, &xa);
+    if (rc) return rc;
+    rc = dw_adam_fill(*second, &pb, &xb);
+    if (rc) return rc;
+    const gm_fin2 f{fin->pa, fin->na, fin->scale_a, fin->out_a, fin->slot_a, fin->pb, fin->nb, fin->scale_b,
+                    fin->out_b, fin->slot_b, fin->tick, fin->done};
+    Rider r;
+    r.pair = &pb;
+    r.pair_xvec = xb;
+    r.fin = &f;
     return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
 }
 

@@ -1980,6 +1980,9 @@ class VAEEngine:
         # launch fusions of round 3 (each replaces a ~5 us latency-bound launch by an epilogue)
         self.fuse_sqerr = os.environ.get("GM_VAE_FUSE_SQERR", "1") != "0"
         self.fuse_reparam_bwd = os.environ.get("GM_VAE_FUSE_REPARAM_BWD", "1") != "0"
+        self.fuse_reparam_fwd = os.environ.get("GM_VAE_FUSE_REPARAM_FWD", "1") != "0"
+        self.fin_in_dw = os.environ.get("GM_VAE_FINALIZE_IN_DW", "1") != "0"
+        self.fin_done = torch.zeros(1, dtype=torch.int32, device=device)
 
     def _alloc(self, B):
         if self._bufB == B:
@@ -2056,8 +2059,14 @@ class VAEEngine:
         ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
         self._fwd_with_prefetch(st, t, lo, b, self.He, ML, self.ml, "id", nxt)
         eps_base = self.eps_ring.view(-1)[lo * Z:]
-        n_kl = of_.vae_reparam_wide(self.ml, eps_base, self.Zs, self.part_kl, b, Z, eps_slot=eps_slot, stream=st)
-        ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
+        if self.fuse_reparam_fwd and Z <= 32 and Z % 4 == 0:
+            # reparameterisation + the decoder's first layer: ONE launch (the GEMM workgroups form z from
+            # (mu, log_var, eps) themselves; bit-identical to the two launches)
+            n_kl = of_.vae_reparam_fwd(self.ml, eps_base, self.Zs, self.part_kl, b, Z, D1.W, D1.b, self.Hdec, "relu",
+                                       eps_slot=eps_slot, stream=st)
+        else:
+            n_kl = of_.vae_reparam_wide(self.ml, eps_base, self.Zs, self.part_kl, b, Z, eps_slot=eps_slot, stream=st)
+            ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
         part, n_part = self._recon_fwd(st, self.Hdec, D2, X, b)
         if train:
             sched_slot = self._slot(t, 1, 0, 0, 1)
@@ -2091,6 +2100,15 @@ class VAEEngine:
                 of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
                                    eps_slot=eps_slot, stream=st)
             ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
+            if self.fin_in_dw and self.pair_dw and adam is not None and not self._dp():
+                # the batch's LAST launch: the encoder's two weight gradients + Adam, both loss sums (vae.py:203, :212)
+                # in one more workgroup of the same grid, the counter tick by the last workgroup to finish
+                ops.linear_bwd_dw_adam_pair_finalize(
+                    dict(dA=self.dHe, X=X, lin=E1, adam=adam, M=b), dict(dA=self.dml, X=self.He, lin=ML, adam=adam, M=b),
+                    dict(pa=part, na=n_part, out_a=recon_out, slot_a=loss_slot, pb=self.part_kl, nb=n_kl, out_b=kl_out,
+                         slot_b=loss_slot, done=self.fin_done, tick=self.ctr if self.use_graph else None),
+                    weight_decay=self.wd, stream=st)
+                return
             dw2((self.dHe, X, E1), (self.dml, self.He, ML))    # (the big GEMM first: its tile shape serves both)
             self._optimizer_step(st, sched_slot)
         # both loss sums (vae.py:203, :212) are the step's LAST launch, which also carries the counter tick

@@ -145,6 +145,29 @@ def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_
     _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
 
 
+def linear_bwd_dw_adam_pair_finalize(first, second, fin, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                                     stream=None):
+    """linear_bwd_dw_adam_pair as the LAST launch of a VAE batch: one more workgroup runs sum_finalize2's two sums and
+    the last workgroup to finish advances the step counter.  fin: dict(pa, na, out_a, slot_a, pb, nb, out_b, slot_b,
+    done (one zeroed int32 the launch counts its workgroups on), tick=None, scale_a=1.0, scale_b=1.0)."""
+    import ctypes
+    from ._lib import Finalize2Args
+    mk = lambda d: _dw_adam_args(d["dA"], d["X"], d["lin"], d.get("adam"), d.get("M"),
+                                 d.get("x_slot", NO_SLOT), betas, eps, weight_decay)
+    a, b = mk(first), mk(second)
+    f = Finalize2Args()
+    f.pa, f.na, f.scale_a, f.out_a, f.slot_a = fin["pa"].data_ptr(), fin["na"], fin.get("scale_a", 1.0), \
+        fin["out_a"].data_ptr(), fin["slot_a"]
+    f.pb, f.nb, f.scale_b, f.out_b, f.slot_b = fin["pb"].data_ptr(), fin["nb"], fin.get("scale_b", 1.0), \
+        fin["out_b"].data_ptr(), fin["slot_b"]
+    tick = fin.get("tick")
+    f.tick = tick.data_ptr() if tick is not None else None
+    assert fin["done"].dtype == torch.int32 and fin["done"].numel() >= 1
+    f.done = fin["done"].data_ptr()
+    _lib.call("gm_linear_bwd_dw_adam_pair_finalize", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b),
+              ctypes.byref(f))
+
+
 def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
     """gm_head_bwd_args from dict(H, dS, lin (head _Linear), rowloss, loss_out, loss_slot, inv_b, B,
     gen_mode=False, adam=None (dict(sched, sched_slot, clamp)), tick=None, grads=True).  dS / rowloss

@@ -70,6 +70,15 @@ def vae_reparam_wide(ml, eps, z, kl_part, B, Z, eps_slot=NO_SLOT, stream=None):
     return (B * Z + 255) // 256
 
 
+def vae_reparam_fwd(ml, eps, z, kl_part, B, Z, W, bias, H, act, eps_slot=NO_SLOT, stream=None):
+    """vae_reparam_wide + the decoder's first layer H = act(z W^T + bias) as ONE launch (gm_vae_reparam_fwd)."""
+    from .ops import ACT
+    _lib.call("gm_vae_reparam_fwd", stream or stream_ptr(), ml.data_ptr(), _ld(ml), eps.data_ptr(), eps_slot,
+              z.data_ptr(), _ld(z), kl_part.data_ptr(), kl_part.numel(), B, Z, W.data_ptr(),
+              bias.data_ptr() if bias is not None else None, H.data_ptr(), _ld(H), W.shape[0], ACT[act])
+    return (B * Z + 255) // 256
+
+
 def sum_finalize2(pa, na, out_a, slot_a, pb, nb, out_b, slot_b, scale_a=1.0, scale_b=1.0, tick=None, stream=None):
     """Two fixed-order fp64 sums in one launch; tick: device step counter to advance (last launch of a step)."""
     _lib.call("gm_sum_finalize2_tick", stream or stream_ptr(), pa.data_ptr(), na, scale_a, out_a.data_ptr(),

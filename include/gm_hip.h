@@ -177,6 +177,13 @@ int gm_vae_reparam(void* stream, const float* ml, int64_t ldml, const float* eps
  * sums in kl_part[0..n_part) for gm_sum_finalize2_tick to add up. */
 int gm_vae_reparam_wide(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
                         float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z);
+/* gm_vae_reparam_wide AND the decoder's first layer H = act(z W^T + b) (W: [N, Z], Z <= 32, Z % 4 == 0) as ONE
+ * launch: vae.py:100-106 + the `F.relu(self.linear(z))` of the decoder (:113).  The reparameterisation workgroups
+ * store z and the KL partials exactly as gm_vae_reparam_wide does; the GEMM workgroups form z from (mu, log_var, eps)
+ * themselves.  Bit-identical to gm_vae_reparam_wide + gm_linear_fwd. */
+int gm_vae_reparam_fwd(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
+                       float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z, const float* W,
+                       const float* bias, float* H, int64_t ldh, int N, int act);
 int gm_vae_reparam_bwd(void* stream, const float* ml, int64_t ldml, const float* eps,
                        gm_slot eps_slot, const float* dz, int64_t lddz, float* dml, int64_t ldd,
                        int B, int Z);
@@ -384,6 +391,17 @@ typedef struct gm_dw_adam_args {
 } gm_dw_adam_args;
 int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* first,
                                const gm_dw_adam_args* second);
+/* The pair as the LAST launch of a VAE batch (vae.py:162 + the loss sums of :203 / :212): one more workgroup adds up
+ * the two partial arrays exactly as gm_sum_finalize2_tick does, and the last workgroup of the launch to finish
+ * advances `tick` (every slot of the batch has been resolved by then).  done: one zero-initialised unsigned int the
+ * launch counts its workgroups on and re-arms.  Falls back to separate launches when the pair cannot share a tile. */
+typedef struct gm_finalize2_args {
+    const float* pa; int na; float scale_a; float* out_a; gm_slot slot_a;
+    const float* pb; int nb; float scale_b; float* out_b; gm_slot slot_b;
+    int64_t* tick; unsigned int* done;
+} gm_finalize2_args;
+int gm_linear_bwd_dw_adam_pair_finalize(void* stream, const gm_dw_adam_args* first, const gm_dw_adam_args* second,
+                                        const gm_finalize2_args* fin);
 /* gm_linear_bwd_dx with an additive term before the activation gradient:
  * dX = (dA*W + add_scale*add) * act'(below)   (BEGAN's generator sees G(z) both through D and
  * directly in |D(G(z)) - G(z)|, be_gan.py:256). */

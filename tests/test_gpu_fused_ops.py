@@ -389,3 +389,39 @@ def test_vae_reparam_wide_and_dual_finalize(B, Z):
     assert abs(out_a[1].item() - rows.double().sum().item()) <= 1e-6 * rows.double().sum().item()
     assert out_a[0].item() == 0.0 and out_b[0].item() == 0.0 and int(ctr) == 1
     assert bool((part_kl[n_kl:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,Z,N", [(512, 20, 400), (336, 20, 400), (100, 20, 400), (37, 8, 50), (512, 32, 400),
+                                    (64, 16, 33), (2048, 20, 400)])
+def test_vae_reparam_and_first_decoder_layer_in_one_launch(B, Z, N):
+    """gm_vae_reparam_fwd == gm_vae_reparam_wide followed by gm_linear_fwd (vae.py:100-106, :113): z and the KL
+    partials bit for bit (same workgroups, same code); h bit for bit wherever the separate forward runs the 16-wave
+    kernel (its waves 0 and 1 own the two 16-deep chunks and the reduction adds them in that order) and to fp32
+    rounding of a 20-term dot where it runs the many-row kernel.  The unfused product-then-add of z is what torch's
+    `mu + eps * std` computes."""
+    torch.manual_seed(B + Z)
+    ml = (torch.randn(B, 2 * Z) * 0.5).cuda()
+    ring = torch.randn(3, B * Z).cuda()
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    slot = ops.slot(ctr.data_ptr(), 1, 0, 3, B * Z)            # ring slot = the device counter's value
+    W = (torch.randn(N, Z) * 0.3).cuda()
+    bias = torch.randn(N).cuda()
+    n_part = (B * Z + 255) // 256
+    z0, z1 = torch.empty(B, Z, device="cuda"), torch.empty(B, Z, device="cuda")
+    p0, p1 = torch.full((n_part + 2,), 7.0, device="cuda"), torch.full((n_part + 2,), 7.0, device="cuda")
+    h0, h1 = torch.empty(B, N, device="cuda"), torch.full((B, N), -3.0, device="cuda")
+    for step in range(2):                                    # second ring slot on the second pass
+        ctr.fill_(step)
+        n0 = of.vae_reparam_wide(ml, ring.view(-1), z0, p0, B, Z, eps_slot=slot)
+        ops.linear_fwd(z0, W, bias, h0, "relu", M=B)
+        n1 = of.vae_reparam_fwd(ml, ring.view(-1), z1, p1, B, Z, W, bias, h1, "relu", eps_slot=slot)
+        torch.cuda.synchronize()
+        assert n0 == n1 == n_part
+        assert torch.equal(z0, z1) and torch.equal(p0, p1)
+        mu, lv = ml[:, :Z], ml[:, Z:]
+        assert torch.equal(z1, mu + ring[step].view(B, Z) * torch.exp(lv / 2))
+        if B < 1024:
+            assert torch.equal(h0, h1)
+        else:
+            ref = torch.relu(z1.double() @ W.double().t() + bias.double())
+            assert (h1.double() - ref).abs().max().item() <= 2 * (h0.double() - ref).abs().max().item() + 1e-6

@@ -550,6 +550,54 @@ def test_dw_adam_pair_in_one_launch(B, H, I, Z):
     assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
 
 
+@pytest.mark.parametrize("B,H,I,Z", [(512, 400, 784, 20), (336, 400, 784, 20), (1024, 400, 784, 20), (24, 20, 36, 8),
+                                     (32, 31, 33, 5)])
+def test_dw_adam_pair_closing_a_vae_batch(B, H, I, Z):
+    """gm_linear_bwd_dw_adam_pair_finalize == gm_linear_bwd_dw_adam_pair followed by gm_sum_finalize2_tick, bit for
+    bit (incl. the unaligned fallback to separate launches): parameters, gradients, both Adam moments, both sums at
+    the slot the counter named BEFORE the launch, counter advanced exactly once per launch, arrival counter re-armed.
+    The Adam schedule is read through the same counter the launch advances -- a tick ahead of a late workgroup's
+    epilogue would give that workgroup the next step's step size."""
+    import torch.nn as nn
+    from generative_models_amd import ops_fused as of
+    from generative_models_amd.engine import FlatParams, _Linear
+    steps = 3
+
+    def run(fused):
+        torch.manual_seed(11)
+        net = nn.Sequential(nn.Linear(H, 2 * Z), nn.Linear(I, H))       # the encoder's two layers (vae.py:80-98)
+        fp = FlatParams(net.parameters(), DEV)
+        fp.m.normal_().mul_(1e-3); fp.v.uniform_(0.0, 1e-4)
+        ML, E1 = _Linear(fp, net[0]), _Linear(fp, net[1])
+        X, dHe = torch.rand(B, I).to(DEV), torch.randn(B, H).to(DEV)
+        He, dml = torch.relu(torch.randn(B, H)).to(DEV), torch.randn(B, 2 * Z).to(DEV)
+        ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, steps + 1)).to(DEV)
+        adam = dict(sched=sched, sched_slot=ops.slot(ctr.data_ptr(), 1, 0, 0, 1), clamp=0.0)   # as VAEEngine._issue
+        pa, pb = (torch.rand(B * 28) * 30).to(DEV), torch.rand((B * Z + 255) // 256).to(DEV)
+        oa, ob = torch.zeros(steps + 1, device=DEV), torch.zeros(steps + 1, device=DEV)
+        slot = ops.slot(ctr.data_ptr(), 1, 0, 0, 1)
+        done = torch.zeros(1, dtype=torch.int32, device=DEV)
+        a1, a2 = dict(dA=dHe, X=X, lin=E1, adam=adam), dict(dA=dml, X=He, lin=ML, adam=adam)
+        for _ in range(steps):
+            if fused:
+                ops.linear_bwd_dw_adam_pair_finalize(a1, a2, dict(pa=pa, na=pa.numel(), out_a=oa, slot_a=slot, pb=pb,
+                                                                  nb=pb.numel(), out_b=ob, slot_b=slot, done=done,
+                                                                  tick=ctr))
+            else:
+                ops.linear_bwd_dw_adam_pair(a1, a2)
+                of.sum_finalize2(pa, pa.numel(), oa, slot, pb, pb.numel(), ob, slot, tick=ctr)
+            pa.mul_(0.5)                                     # the next batch's partials differ
+        torch.cuda.synchronize()
+        assert int(ctr) == steps and int(done) == 0
+        return [t.clone() for t in (fp.flat, fp.grad, fp.m, fp.v, oa, ob)]
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq", "sum a", "sum b")):
+        assert torch.equal(x, y), name
+    assert a[4][:steps].min().item() > 0 and a[4][steps].item() == 0.0 and torch.isfinite(a[0]).all()
+
+
 @pytest.mark.parametrize("B,I,Hd", [(256, 784, 400), (24, 36, 20), (33, 30, 17)])
 def test_dx_with_scalar_head_riding(B, I, Hd):
     """gm_linear_bwd_dx_head == gm_head_bwd (generator mode: loss scalar + tick) followed by
