@@ -48,30 +48,16 @@ struct StageP {
     int64_t* publish;       // optional: workgroup (0,0) stores the absolute iteration of it_slot here (a
                             // stable base for a second stage-in that runs concurrently with iterations
                             // that advance the step counter)
+    // pre-staging (gm_stage_in_prestaged): *range = (lo << 32) | hi, the iterations [lo, hi) an EARLIER launch on
+    // another stream has already brought into the device rings.  mark == 0: this launch returns at once when its
+    // own iterations are inside the range; mark == 1: this launch is such an earlier one -- its last workgroup to
+    // finish (arrive) extends the range (or restarts it at its own iterations when they do not continue it).
+    unsigned long long* range;
+    unsigned int* arrive;
+    int mark;
 };
 
-__global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
-    if (p.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.publish = gm_slot_index(p.it_slot);
-    if (p.gate) {
-        if (threadIdx.x == 0) {
-            // RELAXED system-scope loads: the gate and the rings are fine-grained (uncached) host
-            // memory, so nothing stale can sit in L2; an ACQUIRE here costs a system-scope cache
-            // invalidate per workgroup (measured: 9 -> 29 us per stage-in of 8 iterations).
-            const int64_t need = gm_slot_index(p.it_slot) + p.n_iters;
-            if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-                const uint64_t t0 = wall_clock64();
-                while (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > p.timeout) {
-                        __hip_atomic_store(const_cast<int64_t*>(p.gate) + 1, (int64_t)1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+__device__ __forceinline__ void stage_copy(const StageP& p) {
     const gm_stage_seg sg = p.seg[blockIdx.y];
     const int64_t first = gm_slot_index(p.slot);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -113,9 +99,57 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     }
 }
 
+__global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
+    if (p.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.publish = gm_slot_index(p.it_slot);
+    if (p.range && !p.mark) {
+        // already in the device rings?  (agent-scope load by every lane: one transaction; the kernels behind this
+        // one acquire at their own start)
+        const unsigned long long r = __hip_atomic_load(p.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t it0 = gm_slot_index(p.it_slot);
+        if ((int64_t)(r >> 32) <= it0 && it0 + p.n_iters <= (int64_t)(r & 0xffffffffull)) return;
+    }
+    if (p.gate) {
+        if (threadIdx.x == 0) {
+            // RELAXED system-scope loads: the gate and the rings are fine-grained (uncached) host
+            // memory, so nothing stale can sit in L2; an ACQUIRE here costs a system-scope cache
+            // invalidate per workgroup (measured: 9 -> 29 us per stage-in of 8 iterations).
+            const int64_t need = gm_slot_index(p.it_slot) + p.n_iters;
+            if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+                const uint64_t t0 = wall_clock64();
+                while (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > p.timeout) {
+                        __hip_atomic_store(const_cast<int64_t*>(p.gate) + 1, (int64_t)1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    stage_copy(p);
+    if (p.range && p.mark) {
+        __threadfence();                                      // this workgroup's ring writes: device-visible
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int total = gridDim.x * gridDim.y;
+            if (__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+                __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long r = __hip_atomic_load(p.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long it0 = (unsigned long long)gm_slot_index(p.it_slot);
+                const unsigned long long lo = ((r & 0xffffffffull) == it0) ? (r >> 32) : it0;
+                __hip_atomic_store(p.range, (lo << 32) | (it0 + (unsigned long long)p.n_iters), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                          const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish = nullptr,
-                         int max_blocks = 256) {
+                         int max_blocks = 256, unsigned long long* range = nullptr, unsigned int* arrive = nullptr,
+                         int mark = 0) {
     GM_CHECK_ARG(segs && n_segs > 0 && n_segs <= GM_STAGE_MAX_SEGS && n_iters > 0);
     StageP p{};
     int64_t most = 0;
@@ -132,6 +166,7 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
     }
     p.n_segs = n_segs; p.slot = slot; p.n_iters = n_iters;
     p.gate = gate; p.it_slot = it_slot; p.publish = publish;
+    p.range = range; p.arrive = arrive; p.mark = mark;
     p.timeout = (uint64_t)(timeout_s * 1e8);          // wall_clock64(): 100 MHz
     int64_t blocks = (most * n_iters / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -151,6 +186,15 @@ extern "C" int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_s
     GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0 && max_blocks >= 1);
     return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s, publish,
                          max_blocks > 256 ? 256 : max_blocks);
+}
+
+extern "C" int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
+                                     const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish,
+                                     int max_blocks, uint64_t* range, unsigned int* arrive, int mark) {
+    GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0 && max_blocks >= 1 && range && (mark == 0 || mark == 1));
+    GM_CHECK_ARG(!mark || arrive);
+    return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s, publish,
+                         max_blocks > 256 ? 256 : max_blocks, reinterpret_cast<unsigned long long*>(range), arrive, mark);
 }
 
 // Device-side address of pinned host memory (hipHostMalloc / torch pin_memory()).

@@ -451,6 +451,12 @@ class GANEngine:
         # the linear-chain fast path of the runtime, as the DAG experiment of round 1 did): off
         self.split_stage = os.environ.get("GM_SPLIT_STAGE", "0") != "0"
         self.stage_base = torch.zeros(1, dtype=torch.int64, device=device)
+        # pre-staging (gm_stage_in_prestaged): the host issues every piece's stage-in on a side stream as soon as its
+        # draws are submitted; the graph's own stage-in then finds its iterations inside _pre_range and returns
+        self.prestage = os.environ.get("GM_PRESTAGE", "1") != "0"
+        self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
+        self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
+        self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
         self._stage_side, self._stage_events = None, []
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
@@ -1103,6 +1109,7 @@ class GANEngine:
     # -- host prefetch of one chunk of iterations ---------------------------------------------
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
     STAGE_HEAD = 4      # iterations a long graph stages in serially; the rest overlaps their kernels
+    PRE_BLOCKS = 32     # workgroups per segment of a pre-staging launch (it runs beside the iteration kernels)
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
     FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
     GATE_TIMEOUT_S = 20.0
@@ -1269,12 +1276,47 @@ class GANEngine:
             it_slot = ops.slot(base.data_ptr(), 1, first, 0, 1)
         else:
             ring_slot, it_slot = self._slot(it, 1, first, self.R, 1), self._slot(it, 1, first, 0, 1)
-        if self.gated:
+        if self.gated and self._prestaging():
+            _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
+                      it_slot, self.GATE_TIMEOUT_S, publish.data_ptr() if publish is not None else None,
+                      max_blocks, self._pre_range.data_ptr(), None, 0)
+        elif self.gated:
             _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
                       it_slot, self.GATE_TIMEOUT_S, publish.data_ptr() if publish is not None else None,
                       max_blocks)
         else:
             _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
+
+    def _prestaging(self):
+        """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
+        return self.prestage and self.gated and self.use_graph and self._one_graph()
+
+    def _prestage(self, it, k):
+        """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
+        on the fill gate for them), their device ring slots are free (a fill is only submitted once the launch
+        that last read its slots has completed), and the graph that consumes them is still to be enqueued behind
+        whatever the launch stream is running -- the gate wait and the PCIe reads (12 us for one iteration, 99 us
+        for 32) leave the critical path.  Few workgroups: it shares the CUs with the iteration kernels."""
+        from . import _lib
+        if self._pre_stream is None:
+            import ctypes
+            h = ctypes.c_void_p()
+            _lib.call("gm_stream_create", ctypes.byref(h))
+            self._pre_stream, self._pre_event = h, ops.Event()
+        _lib.call("gm_stage_in_prestaged", self._pre_stream, self._segs, len(self._segs),
+                  ops.slot(0, 0, it % self.R, self.R, 1), k, self._gate_dev, ops.slot(0, 0, it, 0, 1),
+                  self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
+                  self._pre_arrive.data_ptr(), 1)
+        self._pre_dirty = True
+
+    def _join_prestage(self):
+        """The launch stream waits for the side stream's last pre-stage (end of run(): whoever synchronizes with the
+        launch stream afterwards has then synchronized with every kernel run() issued)."""
+        if self._pre_dirty:
+            from . import _lib
+            self._pre_event.record(self._pre_stream)
+            _lib.call("gm_stream_wait_event", ops.stream_ptr(), self._pre_event.h)
+            self._pre_dirty = False
 
     def _stage_stream(self):
         if self._stage_side is None:
@@ -1425,6 +1467,8 @@ class GANEngine:
         if self._gate is not None:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
+        self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
+        torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
         self._event_pool = []
@@ -1786,14 +1830,23 @@ class GANEngine:
         if trace is not None:
             import time
             trace.append(("run", it_start, time.perf_counter()))
+            tev = [torch.cuda.Event(enable_timing=True)]     # GPU-side completion time of every piece (trace mode only)
+            tev[0].record()
         self._check_gate()
         try:
-            for k in self._plan(it_start, n_iters, cold):
+            plan = self._plan(it_start, n_iters, cold)
+            if trace is not None:
+                trace.append(("plan", len(plan), time.perf_counter()))
+            for k in plan:
                 # the draws of [it, it+k) must be SUBMITTED before their graph is enqueued; gated: the
                 # graph's stage-in kernel waits for them on the fill gate, so the launch (~50 us of
                 # host time) overlaps the draws; ungated: wait for them here
                 self._reap()
+                if trace is not None:
+                    trace.append(("reaped", it, time.perf_counter()))
                 self._pump(limit, upto=it + k)
+                if trace is not None:
+                    trace.append(("pumped", it, time.perf_counter()))
                 while self._cursor < it + k:
                     self._reap(block=True)
                     self._pump(limit, upto=it + k)
@@ -1805,21 +1858,35 @@ class GANEngine:
                     self._copy_U(it + k)
                 if trace is not None:
                     trace.append(("got", it, time.perf_counter()))
+                if self._prestaging():
+                    self._prestage(it, k)
                 self._launch(it, k)
+                if trace is not None:
+                    trace.append(("graph", it, time.perf_counter()))
                 if gated:
                     self._pump(limit)                 # (gated: the launch itself overlaps this piece's draws)
+                if trace is not None:
+                    trace.append(("pump2", it, time.perf_counter()))
                 ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
                 ev.record()
                 self._launched.append((it + k, ev))
+                if trace is not None:
+                    tev.append(torch.cuda.Event(enable_timing=True))
+                    tev[-1].record()
                 while len(self._launched) > 4 * self.R:          # recycle what nobody waits for
                     self._event_pool.append(self._launched.popleft()[1])
                 if trace is not None:
                     trace.append(("launched", it + k, time.perf_counter()))
                 it += k
+            self._join_prestage()
             self._reap(upto=end)                      # a failed draw surfaces here, not as a GPU time-out
             self._pump(limit)
             self._reap()
             self._release_rng()                       # (draws still ahead of `end`: the state stays with them)
+            if trace is not None:
+                tev[-1].synchronize()
+                trace.append(("gpu_piece_ends_us", [round(tev[0].elapsed_time(e) * 1e3, 1) for e in tev[1:]],
+                              time.perf_counter()))
         except BaseException:
             if self._gate is not None:
                 self._gate_np[0] = 1 << 62            # open every gate: nothing on the GPU waits for draws that will not come

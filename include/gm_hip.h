@@ -482,6 +482,19 @@ int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot
 int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                       const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish,
                       int max_blocks);
+/* gm_stage_in_gated with PRE-STAGING (round 4).  *range (device memory, zero-initialised) = (lo << 32) | hi: the
+ * iterations [lo, hi) that launches with mark = 1 have already brought into the device rings.
+ *   mark = 1: issued by the host on a SIDE stream as soon as the iterations' draws are submitted, ahead of the graph
+ *             that consumes them -- its gate wait and its PCIe reads overlap the kernels of the graph in front;
+ *             it_slot must name the absolute iteration without the step counter (it belongs to the other stream);
+ *             the last workgroup to finish (arrive: one zeroed unsigned int) extends the range, or restarts it at
+ *             [it, it + n_iters) when they do not continue it;
+ *   mark = 0: the in-graph launch -- returns at once when [it, it + n_iters) lies inside the range and is
+ *             gm_stage_in_gated otherwise (a pre-stage that is late only costs the copy being made twice, with
+ *             the same bytes). */
+int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
+                          const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish, int max_blocks,
+                          uint64_t* range, unsigned int* arrive, int mark);
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 
