@@ -579,6 +579,10 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
     K, W = max(steps, 200), max(warmup, 20)
     out = []
     want = lambda tag: only is None or only == tag
+    # every CPU leg runs AFTER the last GPU leg: a 16-thread CPU baseline leaves the host (16-core quota on the GPU
+    # boxes) busy for a while, and the GPU legs behind it paid for that -- bs=1024 read 163-167 us with the CPU legs
+    # in between against 145-146 us alone or with --no-cpu-baseline (same box, round 4)
+    deferred = []
 
     def gan(name, variant, B, lrs, flop_per_image, cpu_variant):
         eng, secs = bench_gan(variant, B, W, K, reps, dev, lrs=lrs)
@@ -591,7 +595,7 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
                  gemm_shapes(B, fold_head=eng._fold_head()), B,
                  pmc_tag={"wgp": "wgp_b256", "ns": "ns_b1024", "ls": "ns_b1024"}.get(variant))}   # (LSGAN: NSGAN's launches)
         if cpu:
-            e["cpu_baseline"] = cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)
+            deferred.append((e, lambda: cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)))
         log("%s: %.0f img/s" % (name, e["img_s"]))
         del eng
         out.append(e)
@@ -634,9 +638,11 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
              "step_mfma_frac": img_s * 3_280_000 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
              "roofline": dominant_gemm_roofline(gemm_shapes_vae(512), 512, pmc_tag="vae_b512")}
         if cpu and not with_eval:
-            e["cpu_baseline"] = cpu_baseline_vae(512)
+            deferred.append((e, lambda: cpu_baseline_vae(512)))
         log("%s: %.0f img/s" % (e["workload"], img_s))
         out.append(e)
+    for e, fn in deferred:
+        e["cpu_baseline"] = fn()
     return out
 
 
@@ -864,12 +870,12 @@ def main():
         if world == 1 and not force_dp:
             if not args.no_configs:
                 line["trainer"] = bench_trainer()
+                # (GPU legs of the configs section first, every CPU baseline after them: see other_configs)
+                line["configs"] = other_configs(dev, min(K, 400), W, min(reps, 3), cpu=not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline_gan("ns", B_PER_GPU)
                 line["cpu_baseline_compute_only"] = cpu_baseline_gan(
                     "ns", B_PER_GPU, seconds_target=5.0, compute_only=True, cores=line["cpu_baseline"]["cores"])
-            if not args.no_configs:
-                line["configs"] = other_configs(dev, min(K, 400), W, min(reps, 3), cpu=not args.no_cpu_baseline)
         out_line = json.dumps(line)
     else:
         out_line = None

@@ -146,6 +146,26 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     }
 }
 
+// The gate wait of a pre-staging launch as its own one-wave kernel in front of the copy (same stream): ONE wave polls
+// the host's fill counter, not one per workgroup of the copy.  Measured with the wait inside the copy kernel: the
+// bs=1024 step went 145 -> 163 us -- its ~100 workgroups sat on ~100 CUs for as long as the host took to draw a
+// 32-iteration piece (1.6 ms), and a CU whose registers are committed to two 512-thread GEMM workgroups cannot take
+// the second one while a waiting workgroup holds its share.
+__global__ __launch_bounds__(64) void stage_gate_wait_kernel(const int64_t* gate, gm_slot it_slot, int n_iters,
+                                                             uint64_t timeout) {
+    if (threadIdx.x != 0) return;
+    const int64_t need = gm_slot_index(it_slot) + n_iters;
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeout) {
+            __hip_atomic_store(const_cast<int64_t*>(gate) + 1, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
 static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                          const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish = nullptr,
                          int max_blocks = 256, unsigned long long* range = nullptr, unsigned int* arrive = nullptr,
@@ -171,6 +191,11 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
     int64_t blocks = (most * n_iters / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > max_blocks) blocks = max_blocks;
+    if (mark && gate) {                                   // pre-staging: one wave waits, then the copy runs ungated
+        hipLaunchKernelGGL(stage_gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gate, it_slot, n_iters,
+                           p.timeout);
+        p.gate = nullptr;
+    }
     hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0,
                        (hipStream_t)stream, p);
     GM_LAUNCH_RET();
