@@ -871,6 +871,10 @@ extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_
     int have = 0, rd = 0;
     static std::vector<double> X1, X2, R2;
     if ((int64_t)X1.size() < P) { X1.resize((size_t)P); X2.resize((size_t)P); R2.resize((size_t)P); }
+    else if (X1.size() > ((size_t)1 << 20) && (size_t)P < X1.size() / 8) {
+        // one very large request must not pin 3 x 8 bytes per pair for the life of the process
+        std::vector<double>((size_t)P).swap(X1); std::vector<double>((size_t)P).swap(X2); std::vector<double>((size_t)P).swap(R2);
+    }
     int64_t got = 0;
     static const bool wide = cpu_level() == 2 && !getenv("GM_NUMPY_SCALAR");
     while (got < P) {
@@ -916,7 +920,9 @@ extern "C" int gm_numpy_legacy_normal_f32(uint32_t* key, int32_t* pos_io, int32_
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
     if (n_threads > 1 && P >= 512) {
-        if (!g_np_pool || g_np_pool->size() + 1 != n_threads) { delete g_np_pool; g_np_pool = new Pool(n_threads - 1); }
+        // grow-only: two engines asking for different thread counts share the larger pool instead of rebuilding it on
+        // every call (the partition of the pairs does not change a single output bit)
+        if (!g_np_pool || g_np_pool->size() + 1 < n_threads) { delete g_np_pool; g_np_pool = new Pool(n_threads - 1); }
         g_np_pool->run([&](int k, int np) { part(P * k / np, P * (k + 1) / np); });
     } else {
         part(0, P);

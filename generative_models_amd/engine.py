@@ -329,10 +329,21 @@ class NumpyReplay:
             return None
         return [np.ascontiguousarray(st[1], dtype=np.uint32).copy(), int(st[2]), int(st[3]), float(st[4])]
 
+    # numpy's own lock makes one np.random.normal call atomic; the replay reads the global state out, advances the
+    # copy in C and writes it back, so everything in this package that reads or writes that state (the fills on the
+    # prefetch thread, the BIR-VAE checkpoint) does it under this lock.  np.random calls made by OTHER code while a
+    # BIR-VAE engine is drawing ahead are outside it: do not use the global numpy generator concurrently with one.
+    STATE_LOCK = __import__("threading").RLock()
+
     @classmethod
     def fill(cls, scale, dst, B, Z, sizes):
         """dst[k].view(-1)[:b*Z] = float32(np.random.normal(0, scale, (b, Z))) for the chunk's batches, in order,
         on numpy's GLOBAL generator: the leading full batches as ONE call (they are contiguous in dst)."""
+        with cls.STATE_LOCK:
+            return cls._fill_locked(scale, dst, B, Z, sizes)
+
+    @classmethod
+    def _fill_locked(cls, scale, dst, B, Z, sizes):
         state = cls._unpack(np.random.get_state(legacy=True))
         if state is None:
             return False

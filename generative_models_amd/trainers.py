@@ -526,7 +526,9 @@ def _save_checkpoint(trainer, savepath, history, numpy_rng=False, collective=Tru
     if numpy_rng:
         # bir_vae.py:92-94 draws its reparameterisation noise from NUMPY's global generator: its
         # state is part of the protocol cursor (stored as plain tensors / numbers: weights_only load)
-        kind, keys, pos, has_gauss, cached = np.random.get_state()
+        from .engine import NumpyReplay
+        with NumpyReplay.STATE_LOCK:                 # never in the middle of a draw-ahead's read-advance-write
+            kind, keys, pos, has_gauss, cached = np.random.get_state()
         if kind != "MT19937":
             raise GMError("numpy's global generator is not the legacy MT19937 one")
         state["numpy_rng"] = {"keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),

@@ -195,6 +195,27 @@ def test_fp32_resident_dataset_equals_bit_packed(monkeypatch):
         assert torch.equal(x, y), k
 
 
+@pytest.mark.parametrize("variant,env", [("wgp", "GM_WGP_PEN_IN_HEAD"), ("wgp", "GM_WGP_STACK"), ("ns", "GM_FOLD_HEAD"),
+                                         ("wgp", "GM_FOLD_HEAD")])
+def test_summation_order_switches_agree_within_rounding(variant, env, monkeypatch):
+    """Three switches change the ORDER in which the same products are summed, not what is computed: the gradient
+    penalty's share of gw2 added per row group inside the head workgroups or after the column sum
+    (GM_WGP_PEN_IN_HEAD), the penalty's layer-1 gradient stacked into the critic's own launch or accumulated by
+    separate launches (GM_WGP_STACK), a score as 13 tile partials or as one wave's dot product (GM_FOLD_HEAD).  The
+    two settings of each must agree to fp32 rounding over a short run (results are bit-reproducible per setting, not
+    across settings -- and not across the rounds in which a default changed)."""
+    kw = dict(num_epochs=2) if variant == "ns" else dict(num_epochs=2, D_steps=2)
+    a = run_product(variant, SMALL, 16, kw)
+    monkeypatch.setenv(env, "0")
+    b = run_product(variant, SMALL, 16, kw)
+    lclose(np.array(a[0].Glosses), np.array(b[0].Glosses), env + " G losses", tol=2e-5)
+    lclose(np.array(a[0].Dlosses), np.array(b[0].Dlosses), env + " D losses", tol=2e-5)
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        # Adam turns a last-bit difference of a tiny gradient into a fraction of a step: bound by one step
+        assert float((x - y).abs().max()) <= 2.5e-4, (env, k)
+        assert float((x - y).abs().mean()) <= 2e-5, (env, k)
+
+
 def test_run_to_run_determinism():
     a = run_product("ls", SMALL, 16, dict(num_epochs=1))
     b = run_product("ls", SMALL, 16, dict(num_epochs=1))
