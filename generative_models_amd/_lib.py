@@ -41,7 +41,7 @@ class HeadBwdArgs(ctypes.Structure):
                 ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("weight_decay", ctypes.c_double), ("clamp", c_float), ("tick", c_void_p),
                 ("gw2_add", c_void_p), ("pen_s", c_void_p), ("pen_h", c_void_p), ("pen_ldh", c_int64),
-                ("pen_t", c_void_p), ("pen_ldt", c_int64), ("pen_rows", c_int)]
+                ("pen_t", c_void_p), ("pen_ldt", c_int64), ("pen_rows", c_int), ("gb2_add", c_void_p)]
 
 
 
@@ -191,6 +191,8 @@ _SIGNATURES = {
     "gm_dragan_rows": (c_int, [_P, _P, _P, c_int64, _P, c_int64, _P, _P, c_float, c_float, c_float,
                                c_int, c_int]),
     "gm_dragan_head_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int,
+                                   c_int]),
+    "gm_dragan_head_bwd_store": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int,
                                    c_int]),
     "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,
                                _P, c_int64, _P, Slot]),

@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(1024) void dragan_head_bwd_kernel(const float* __re
                                                               float* __restrict__ gw2,
                                                               float* __restrict__ gb2,
                                                               float* __restrict__ dA1, int64_t ldd,
-                                                              int B, int Hd) {
+                                                              int B, int Hd, int accumulate) {
     __shared__ float sh[HB_RG][HB_COLS + 1];
     __shared__ double shd[16];
     const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(1024) void dragan_head_bwd_kernel(const float* __re
     if (rg == 0 && c < Hd) {
         float v = 0.f;
         for (int q = 0; q < HB_RG; ++q) v += sh[q][cl];
-        gw2[c] += v;
+        gw2[c] = accumulate ? gw2[c] + v : v;
     }
     if (blockIdx.x == 0) {
         double sd = 0.0;
@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(1024) void dragan_head_bwd_kernel(const float* __re
         if (threadIdx.x == 0) {
             double tot = 0.0;
             for (int q = 0; q < 16; ++q) tot += shd[q];
-            gb2[0] += (float)tot;
+            gb2[0] = accumulate ? gb2[0] + (float)tot : (float)tot;
         }
     }
 }
@@ -1324,6 +1324,15 @@ extern "C" int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, con
                                   float* gb2, float* dA1, int64_t ldd, int B, int Hd) {
     GM_CHECK_ARG(H && T && da2 && w2 && gw2 && gb2 && dA1 && B > 0 && Hd > 0);
     hipLaunchKernelGGL(dragan_head_bwd_kernel, dim3((Hd + HB_COLS - 1) / HB_COLS), dim3(1024), 0,
-                       (hipStream_t)stream, H, ldh, T, ldt, da2, w2, gw2, gb2, dA1, ldd, B, Hd);
+                       (hipStream_t)stream, H, ldh, T, ldt, da2, w2, gw2, gb2, dA1, ldd, B, Hd, 1);
+    GM_LAUNCH_RET();
+}
+
+extern "C" int gm_dragan_head_bwd_store(void* stream, const float* H, int64_t ldh, const float* T,
+                                        int64_t ldt, const float* da2, const float* w2, float* gw2,
+                                        float* gb2, float* dA1, int64_t ldd, int B, int Hd) {
+    GM_CHECK_ARG(H && T && da2 && w2 && gw2 && gb2 && dA1 && B > 0 && Hd > 0);
+    hipLaunchKernelGGL(dragan_head_bwd_kernel, dim3((Hd + HB_COLS - 1) / HB_COLS), dim3(1024), 0,
+                       (hipStream_t)stream, H, ldh, T, ldt, da2, w2, gw2, gb2, dA1, ldd, B, Hd, 0);
     GM_LAUNCH_RET();
 }

@@ -75,6 +75,8 @@ struct HeadBwdP {
                                             // gradient penalty's second-backward share, w_gp_gan.py:215)
     const float* pen_s; const float* pen_h; int64_t pen_ldh;   // optional: the gradient penalty's share of gw2,
     const float* pen_t; int64_t pen_ldt; int pen_rows;         // summed here (gm_hip.h gm_head_bwd_args)
+    // (gm_head_bwd_args.gb2_add, DRAGAN: travels as pen_s with pen_rows == -1 -- the penalty-share members are
+    // unused then, and one more member in this block cost the NSGAN step 0.1 - 0.3 us: round 4, same-box A/B)
     FoldP fold;                             // folded head: dS / rowloss come from fold_row, not from memory
 };
 
@@ -209,7 +211,8 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid,
                 for (int q = 0; q < 16; ++q) tot[k] += shd[k][q];
             p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot[0] * (double)p.inv_b);
             if (p.gb2) {
-                const float gb = (float)tot[1] + (float)tot[2];
+                float gb = (float)tot[1] + (float)tot[2];
+                if (p.pen_rows < 0) gb += p.pen_s[0];      // gb2_add
                 p.gb2[0] = gb;
                 if (p.adam.enabled) {
                     adam_update(bP, gb, bM, bV, step_size, bc2_sqrt, p.adam.omb1, p.adam.b2, p.adam.omb2,
@@ -254,6 +257,8 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out,
                               a.pen_ldt >= a.Hd));
     p.pen_s = a.pen_s; p.pen_h = a.pen_h; p.pen_ldh = a.pen_ldh; p.pen_t = a.pen_t; p.pen_ldt = a.pen_ldt;
     p.pen_rows = a.pen_rows;
+    GM_CHECK_ARG(!a.gb2_add || (a.gb2 && !a.gen_mode && !a.pen_t));
+    if (a.gb2_add) { p.pen_s = a.gb2_add; p.pen_rows = -1; }
     p.H = a.H; p.ldh = a.ldh; p.dS = a.dS; p.w2 = a.w2; p.rowloss = a.rowloss; p.dH = a.dH;
     p.lddh = a.lddh; p.gw2 = a.gw2; p.gb2 = a.gb2; p.loss_out = a.loss_out;
     p.loss_slot = a.loss_slot; p.inv_b = a.inv_b; p.gen_mode = a.gen_mode; p.B = a.B;

@@ -520,6 +520,21 @@ class GANEngine:
             self.pen = z(Bl)
         if variant == "dra":
             self.da2, self.dA1, self.stdv = z(Bl), z(Bl, Hd), z(1)
+            self.dra_stack = self.merge_fwd3 and os.environ.get("GM_DRA_STACK", "1") != "0"
+            if self.dra_stack:
+                # round 4: the critic's three layer-1 weight gradients as ONE GEMM over 4B rows,
+                #   dW1 = [u ; dA1 ; dH_x ; dH_g]^T [dv ; x_hat ; x ; G(zD)]      (dra_gan.py:207-223)
+                # (u's rows do not reach db1: `ones_from` = B).  Both operands contiguous: dv and x_hat in front of
+                # [x ; G(zD) ; G(zG)] (the last two stay adjacent: both generator forwards are one launch), u and
+                # dA1 in front of dH.  The merged forward reads rows [B, 4B) = [x_hat ; x ; G(zD)].
+                self.XX5 = z(5 * Bl, I)
+                self.Gam, self.Xh = self.XX5[:Bl], self.XX5[Bl:2 * Bl]
+                self.XX = self.XX5[2 * Bl:]
+                self.XX4 = self.XX5[Bl:]                       # [x_hat ; x ; G(zD) ; G(zG)]: what the merged forward indexes
+                self.X2, self.Xg2 = self.XX[:2 * Bl], self.XX[2 * Bl:]
+                self.DU4 = z(4 * Bl, Hd)
+                self.U, self.dA1, self.dHd = self.DU4[:Bl], self.DU4[Bl:2 * Bl], self.DU4[2 * Bl:]
+                self.gw2_pen, self.gb2_pen = z(Hd), z(1)
             from . import ops_fused as _of
             self.std_ws = _of.std_workspace(dev)
         if variant == "info":
@@ -563,7 +578,9 @@ class GANEngine:
         if not (self.fuse_adam and self._single()) or self.dag:
             return False
         if net == "D":
-            return self.fuse_head and self.variant not in ("ra", "fisher", "dra") and \
+            if self.variant == "dra":
+                return self._dra_stacked()
+            return self.fuse_head and self.variant not in ("ra", "fisher") and \
                 (self.variant != "wgp" or self._wgp_stacked())
         return True
 
@@ -599,6 +616,12 @@ class GANEngine:
         import os
         return self.variant == "wgp" and self.fuse_head and self.group_head and not self.dag and \
             os.environ.get("GM_WGP_STACK", "1") != "0"
+
+    def _dra_stacked(self):
+        """DRAGAN critic step with its three layer-1 weight gradients as one stacked GEMM (+ Adam) and the sigma''
+        path's share of the head's gradient added inside the head's backward (round 4)."""
+        return self.variant == "dra" and getattr(self, "dra_stack", False) and self.fuse_head and \
+            self.group_head and not self.dag
 
     def _slot(self, it, mul, add, ring, stride, post=False):
         """Graph mode: resolved on device from the counter; eager mode: resolved here.
@@ -798,6 +821,14 @@ class GANEngine:
                         head["gw2_add"] = self.gw2_pen
                     ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
                                                 stream=st)
+                elif self._dra_stacked():
+                    # the penalty's second backward first (it reads W1 and w2, which this launch steps): t = dv W1^T,
+                    # then dA1 and the sigma'' path's share of (gw2, gb2) on their own; then ONE launch:
+                    # dW1 over 4B rows (+ db1 from the last 3B), the head's backward with both shares added, Adam x 2
+                    self._issue_dra_backward(st, stacked=True)
+                    head["gw2_add"], head["gb2_add"] = self.gw2_pen, self.gb2_pen
+                    ops.linear_bwd_dw_adam_head(self.DU4, self.XX5, D1, adam, head, M=4 * Bl, ones_from=Bl,
+                                                stream=st)
                 else:
                     ops.linear_bwd_dw_adam_head(dHd, X2, D1, adam, head, M=2 * Bl, stream=st)
                 grouped = True
@@ -835,7 +866,7 @@ class GANEngine:
             ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
         if self.variant == "wgp" and not self._wgp_stacked():
             self._issue_gp_backward(st)
-        if self.variant == "dra":
+        if self.variant == "dra" and not self._dra_stacked():
             self._issue_dra_backward(st)
 
     def _issue_D_pre(self, st, it, j):
@@ -1100,10 +1131,15 @@ class GANEngine:
         of.dragan_rows(self.Sh, self.Gr, self.Gam, self.da2, self.pen, self.gp_lambda, self.inv_b,
                        Bl, stream=st)                                               # Gam = dv
 
-    def _issue_dra_backward(self, st):
+    def _issue_dra_backward(self, st, stacked=False):
         from . import ops_fused as of
         Bl = self.Bl
         D1, D2 = self.D1, self.D2
+        if stacked:
+            ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)      # T = dv W1^T
+            of.dragan_head_bwd(self.Hh, self.T, self.da2, D2.W, self.gw2_pen, self.gb2_pen, self.dA1, Bl,
+                               store=True, stream=st)
+            return
         ops.linear_bwd_dw(self.U, self.Gam, D1.gW, None, M=Bl, accumulate=True, stream=st)
         ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)          # T = dv W1^T
         of.dragan_head_bwd(self.Hh, self.T, self.da2, D2.W, D2.gW, D2.gb, self.dA1, Bl, stream=st)

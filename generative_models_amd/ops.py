@@ -194,6 +194,8 @@ def _head_args(head, betas=(0.9, 0.999), eps=1e-8):
     a.tick = tick.data_ptr() if tick is not None else None
     add = head.get("gw2_add")
     a.gw2_add = add.data_ptr() if add is not None else None
+    addb = head.get("gb2_add")
+    a.gb2_add = addb.data_ptr() if addb is not None else None
     pen = head.get("pen")                       # dict(s=[rows], h=[rows, Hd], t=[rows, Hd]): see gm_hip.h
     if pen is not None:
         a.pen_s, a.pen_h, a.pen_ldh = pen["s"].data_ptr(), pen["h"].data_ptr(), _ld(pen["h"])

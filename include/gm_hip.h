@@ -277,6 +277,8 @@ typedef struct gm_head_bwd_args {
      * gradient penalty's second-backward share of w2's gradient (w_gp_gan.py:215) summed by the
      * head's own workgroups instead of a launch of gm_gp_dw2_store */
     const float* pen_s; const float* pen_h; int64_t pen_ldh; const float* pen_t; int64_t pen_ldt; int pen_rows;
+    const float* gb2_add;                 /* optional [1]: added to gb2 before it is stored / stepped (DRAGAN's sigma''
+                                           * path reaches the head bias, dra_gan.py:207-223; gm_dragan_head_bwd_store) */
 } gm_head_bwd_args;
 int gm_linear_bwd_dw_adam_head(void* stream, const float* dA, int64_t lda, const float* X,
                                int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
@@ -430,6 +432,11 @@ int gm_dragan_rows(void* stream, const float* s, const float* V, int64_t ldv, fl
 int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, const float* T, int64_t ldt,
                        const float* da2, const float* w2, float* gw2, float* gb2, float* dA1,
                        int64_t ldd, int B, int Hd);
+/* The same with gw2 / gb2 STORED instead of accumulated: the penalty's share of the head's gradient on its own, for
+ * gm_head_bwd_args.gw2_add / gb2_add of the stacked critic step (the head's backward adds them before Adam). */
+int gm_dragan_head_bwd_store(void* stream, const float* H, int64_t ldh, const float* T, int64_t ldt,
+                             const float* da2, const float* w2, float* gw2, float* gb2, float* dA1,
+                             int64_t ldd, int B, int Hd);
 
 /* ---- K15: InfoGAN mutual-information loss (train_Q, info_gan.py:269-304): cross-entropy of the
  * categorical code + mean-squared error of the continuous code, and d loss / d q.  noise rows are
