@@ -192,6 +192,7 @@ _SIGNATURES = {
                                c_int, c_int]),
     "gm_dragan_head_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int,
                                    c_int]),
+    "gm_fisher_commit": (c_int, [_P, _P]),
     "gm_dragan_head_bwd_store": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int,
                                    c_int]),
     "gm_info_q_loss": (c_int, [_P, _P, c_int64, _P, Slot, c_int64, c_int, c_int, c_int, c_int, c_float,

@@ -1328,6 +1328,16 @@ extern "C" int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, con
     GM_LAUNCH_RET();
 }
 
+// Fisher GAN, folded critic step: lambda's successor (left in aux[5] by head workgroup 0 of the launch in which every
+// workgroup read aux[0]) becomes lambda.  A launch of its own: the only ordering a late-starting workgroup respects.
+__global__ void fisher_commit_kernel(float* aux) { aux[0] = aux[5]; }
+
+extern "C" int gm_fisher_commit(void* stream, float* aux) {
+    GM_CHECK_ARG(aux);
+    hipLaunchKernelGGL(fisher_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, aux);
+    GM_LAUNCH_RET();
+}
+
 extern "C" int gm_dragan_head_bwd_store(void* stream, const float* H, int64_t ldh, const float* T,
                                         int64_t ldt, const float* da2, const float* w2, float* gw2,
                                         float* gb2, float* dA1, int64_t ldd, int B, int Hd) {

@@ -956,9 +956,12 @@ template <int MODE, bool DMA, int MI, int NI> struct RedSize {
 // FOLD (folded critic head, gm_head.h): 1 = weight gradient whose A operand dH[k][x] is formed from
 // h[k][x], sds[k] (dS of reduction row k) and w2[x]; 2 = input gradient whose A operand dH[m][k] is
 // formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool DMA = false>
+// TP (with FOLD == 1): the rows' dS come from the two-phase prologue (RaGAN / Fisher critic steps, gm_head.h).
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool DMA = false,
+          bool TP = false>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
+    static_assert(!TP || (FOLD == 1 && !DMA), "two-phase losses: folded weight gradient, operands through registers");
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
     static_assert(G == 1, "per-chunk schedule (G stays in the kernel names so that they keep their shape across rounds)");
@@ -1069,7 +1072,12 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             wk = load_wk(w);
         }
         if constexpr (FOLD == 1) {
-            fold_fill_lds(*fold, sds, fold->R);               // every reduction row (ends with the barrier)
+            if constexpr (TP) {                               // (the uniform results are head workgroup 0's business)
+                FoldTP tp_unused;
+                fold_fill_lds_tp(*fold, sds, fold->R, tp_unused);
+            } else {
+                fold_fill_lds(*fold, sds, fold->R);           // every reduction row (ends with the barrier)
+            }
         } else {
             if (t < 16 * MI) {                                // the tile's own rows
                 float s_, ds_, l_;
@@ -1139,7 +1147,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // rows [0, hrows) of the grid are head workgroups (dispatched first), the rest are GEMM tiles.  The
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
-template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false>
+template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false,
+          bool TP = false>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE, DMA, MI, NI>::value];
@@ -1148,16 +1157,24 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
     // (folded head: the dS prologue runs inside the bodies, behind their first operand loads)
     if ((int)blockIdx.y < hrows) {                           // workgroup-uniform
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (bid < hblocks) head_bwd_body(hp, bid, sds);
+        if (bid < hblocks) head_bwd_body<TP>(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
 template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
     gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED, DMA>(p, hp, hrows, hblocks);
+}
+
+// The same launch for the critic steps whose loss is not a mean of per-row terms (RaGAN, Fisher): folded head with
+// the two-phase prologue in every workgroup (gm_head.h fold_fill_lds_tp).  Its own kernels: the separable variants'
+// instantiations do not carry the block reductions.
+template <int MI, int NI>
+__global__ __launch_bounds__(1024) void gemm16_dw_head_tp_kernel(GemmP p, HeadBwdP hp, int hrows, int hblocks) {
+    gemm16_with_head<MODE_DW, false, 1, true, MI, NI, false, true, false, true>(p, hp, hrows, hblocks);
 }
 
 // The generator step's dX GEMM carrying the one scalar workgroup of the head (loss + tick): the
@@ -1344,7 +1361,14 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
 #define GM_LH1_true_false_false(MI_, NI_, D_) GM_LHK(true, false, false, MI_, NI_, D_)
 #define GM_LH1_false_true_false(MI_, NI_, D_) GM_LHK(false, true, false, MI_, NI_, D_)
 #define GM_LH1_false_false_false(MI_, NI_, D_) GM_LHK(false, false, false, MI_, NI_, D_)
-            if (folded) GM_LH(true, false, true);
+            if (folded && head->fold.enabled == 2) {
+                // RaGAN / Fisher: operands through registers (the two-phase prologue's scratch and the DMA form's
+                // chunk buffers would share LDS)
+                p.dma = false;
+#define GM_LHTP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_head_tp_kernel<MI_, NI_>), hgrid, dim3(1024), 0, s, p, *head, hrows, hblocks)
+                GM_TILE_SWITCH(tile, false, GM_LHTP);
+#undef GM_LHTP
+            } else if (folded) GM_LH(true, false, true);
             else if (xv) { if (p.ones_from > 0) GM_LH(true, true, false); else GM_LH(true, false, false); }
             else { if (p.ones_from > 0) GM_LH(false, true, false); else GM_LH(false, false, false); }
 #undef GM_LH1_false_false_false

@@ -29,7 +29,7 @@ struct FoldP {
 // independent 16-byte loads, one memory round trip -- a loop of dependent-in-order scalar loads cost 13
 // serial trips to the fabric per row when the partials were fresh from another XCD (measured: the folded
 // step was 3 us SLOWER than the unfolded one until this changed).
-static __device__ __forceinline__ void fold_row(const FoldP& f, int r, float& s, float& ds, float& l) {
+static __device__ __forceinline__ float fold_score(const FoldP& f, int r) {
     const float4* q = reinterpret_cast<const float4*>(f.part + (int64_t)r * f.ldp);
     const int n4 = (f.nparts + 3) >> 2;
     float4 v[4];
@@ -41,9 +41,14 @@ static __device__ __forceinline__ void fold_row(const FoldP& f, int r, float& s,
     for (int j = 0; j < 4; ++j)
         if (j < n4) { a2 += v[j].x; a2 += v[j].y; a2 += v[j].z; a2 += v[j].w; }
     a2 += bias;
-    s = a2;
+    float s = a2;
     if (f.out_act == GM_ACT_SIGMOID) s = gm_sigmoid(a2);
     else if (f.out_act == GM_ACT_RELU) s = fmaxf(a2, 0.f);
+    return s;
+}
+
+static __device__ __forceinline__ void fold_row(const FoldP& f, int r, float& s, float& ds, float& l) {
+    s = fold_score(f, r);
     const bool D = !f.gen_mode;
     const bool is_x = D && r < f.B;
     float lx, lg, dx, dg;
@@ -95,8 +100,118 @@ static __device__ __forceinline__ void fold_fill_lds(const FoldP& f, float* sds,
     __syncthreads();
 }
 
+// ---- folded head, losses that are NOT a mean of per-row terms (round 4): RaGAN and Fisher critic steps ------------
+// ra_gan.py:204-205 needs mean(D(G(z))) before any row's gradient and the sum of the x rows' du before the g rows';
+// fisher_gan.py:214-223 needs four moments of the scores.  Every consumer workgroup already rebuilds EVERY row's score
+// (it needs dS of all reduction rows), so the batch sums are block reductions in the same prologue: fp64, wave sums
+// then the sixteen waves' partials in wave order -- the same bits in every workgroup and from run to run.  The
+// expressions are gm_gan_loss's (gm_ops.hip), which stays the data-parallel form (its phases sit around scalar
+// exchanges).  Fisher's lambda is read from aux[0] by every workgroup while head workgroup 0 computes its successor:
+// that goes to aux[5] and is committed by a launch of its own (gm_fisher_commit) -- a workgroup that starts late must
+// not see it.  f.pen carries the aux pointer (Fisher; the penalty rows it normally names do not exist here).
+struct FoldTP { float loss, lam_next, m1x, m1g, m2x, m2g; };
+
+template <int N>
+static __device__ __forceinline__ void fold_block_sums(double (&v)[N], double (*sc)[16]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = gm_wave_sum_d(v[k]);
+    __syncthreads();                                          // sc: free again
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sc[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += sc[k][q];
+        v[k] = t;
+    }
+}
+
+// 1024 threads; R <= FOLD_MAX_ROWS = 2048 rows: at most two per thread, scores kept in registers across the phases
+static __device__ __forceinline__ void fold_fill_lds_tp(const FoldP& f, float* sds, int R, FoldTP& out) {
+    __shared__ double sc[4][16];
+    constexpr int Q = 2;
+    const int B = f.B;
+    const float ib = f.inv_b;
+    float sv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int r = threadIdx.x + q * 1024;
+        sv[q] = fold_score(f, min(r, R - 1));
+    }
+    out = FoldTP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (f.variant == GM_LOSS_RA) {
+        double a[1] = {0.0};
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = threadIdx.x + q * 1024;
+            if (r >= B && r < R) a[0] += (double)sv[q];
+        }
+        fold_block_sums<1>(a, sc);
+        const float mg = (float)(a[0] * (double)ib);
+        double b[2] = {0.0, 0.0};                             // loss terms; du of the x rows
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = threadIdx.x + q * 1024;
+            if (r < B) {
+                const float u = gm_sigmoid(sv[q] - mg);
+                b[0] += (double)logf(u + EPS);
+                const float gu = (-0.5f * ib) / (u + EPS);       // dL/du
+                const float du = (gu * (1.f - u)) * u;           // through the inner sigmoid
+                sds[r] = act_grad(du, sv[q], f.out_act);
+                b[1] += (double)du;
+            } else if (r < R) {
+                b[0] += (double)logf(gm_sigmoid(1.f - sv[q]) + EPS);
+            }
+        }
+        fold_block_sums<2>(b, sc);
+        const float sum_du = (float)b[1];                     // d/dmg = -sum_du ; dmg/dsg_j = 1/B
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = threadIdx.x + q * 1024;
+            if (r >= B && r < R) {
+                const float v = gm_sigmoid(1.f - sv[q]);
+                const float gv = (-0.5f * ib) / (v + EPS);
+                const float dv = -((gv * (1.f - v)) * v);         // d(1 - sg)/dsg = -1
+                sds[r] = act_grad(dv - sum_du * ib, sv[q], f.out_act);
+            }
+        }
+        out.loss = -(float)(b[0] * (double)ib) / 2.f;
+    } else {                                                  // GM_LOSS_FISHER
+        double m[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = threadIdx.x + q * 1024;
+            const float x = sv[q];
+            if (r < B) { m[0] += x; m[1] += (double)(x * x); }
+            else if (r < R) { m[2] += x; m[3] += (double)(x * x); }
+        }
+        fold_block_sums<4>(m, sc);
+        const float m1x = (float)(m[0] * (double)ib), m2x = (float)(m[1] * (double)ib);
+        const float m1g = (float)(m[2] * (double)ib), m2g = (float)(m[3] * (double)ib);
+        const float lam = f.pen[0], rho = f.hyper[0];
+        const float omega = 1.f - (0.5f * m2x + 0.5f * m2g);
+        const float dO = -(lam - rho * omega);                // dL/dOmega
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = threadIdx.x + q * 1024;
+            // dOmega/ds_i = -0.5 * 2 * s_i / B
+            if (r < B) sds[r] = act_grad(-ib + dO * (-(sv[q] * ib)), sv[q], f.out_act);
+            else if (r < R) sds[r] = act_grad(ib + dO * (-(sv[q] * ib)), sv[q], f.out_act);
+        }
+        out.loss = -((m1x - m1g) + lam * omega - (rho / 2.f) * (omega * omega));
+        out.lam_next = lam + rho * (-omega);                  // lambda += rho * lambda.grad
+        out.m1x = m1x; out.m1g = m1g; out.m2x = m2x; out.m2g = m2g;
+    }
+    __syncthreads();
+}
+
 // sds: folded head only -- LDS for the workgroup's copy of dS[0..R), filled HERE behind the first h loads
+template <bool TP = false>
 static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid, float* sds = nullptr) {
+    FoldTP tp{};
     __shared__ float sh[HB_RG][HB_COLS + 1];
     __shared__ double shd[3][16];
     const int cl = threadIdx.x & (HB_COLS - 1), rg = threadIdx.x / HB_COLS;
@@ -126,7 +241,8 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid,
 #pragma unroll
             for (int u = 0; u < U; ++u) hv[u] = p.H[(int64_t)min(rg + u * HB_RG, p.R - 1) * p.ldh + cc];
             if (col_adam) { pP = p.adam.pW[c]; pM = p.adam.mW[c]; pV = p.adam.vW[c]; }
-            fold_fill_lds(p.fold, sds, p.R);
+            if constexpr (TP) fold_fill_lds_tp(p.fold, sds, p.R, tp);
+            else fold_fill_lds(p.fold, sds, p.R);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = rg + u * HB_RG;
@@ -184,7 +300,11 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid,
         double sl = 0.0, sx = 0.0, sg = 0.0;
         for (int r = threadIdx.x; r < p.R; r += 1024) {
             double d;
-            if (folded) {
+            if (TP) {                                        // the workgroup's LDS copy is the final dS
+                d = (double)sds[r];
+                if (p.fold.S) p.fold.S[r] = fold_score(p.fold, r);
+                if (p.fold.dS) p.fold.dS[r] = sds[r];
+            } else if (folded) {
                 float s, ds, l;
                 fold_row(p.fold, r, s, ds, l);
                 sl += (double)l;
@@ -209,7 +329,12 @@ static __device__ __forceinline__ void head_bwd_body(const HeadBwdP& p, int bid,
             double tot[3] = {0.0, 0.0, 0.0};
             for (int k = 0; k < 3; ++k)
                 for (int q = 0; q < 16; ++q) tot[k] += shd[k][q];
-            p.loss_out[gm_slot_index(p.loss_slot)] = (float)(tot[0] * (double)p.inv_b);
+            p.loss_out[gm_slot_index(p.loss_slot)] = TP ? tp.loss : (float)(tot[0] * (double)p.inv_b);
+            if (TP && p.fold.variant == GM_LOSS_FISHER) {      // aux: [0] lambda (committed by gm_fisher_commit from [5])
+                float* aux = const_cast<float*>(p.fold.pen);
+                aux[5] = tp.lam_next;
+                aux[1] = tp.m1x; aux[2] = tp.m1g; aux[3] = tp.m2x; aux[4] = tp.m2g;
+            }
             if (p.gb2) {
                 float gb = (float)tot[1] + (float)tot[2];
                 if (p.pen_rows < 0) gb += p.pen_s[0];      // gb2_add
@@ -269,8 +394,9 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out,
                      (reinterpret_cast<uintptr_t>(g.part) & 15) == 0 && g.n_hyper >= 0 && g.n_hyper <= 8);
         GM_CHECK_ARG(g.nparts == (a.Hd + 31) / 32);
         GM_CHECK_ARG(g.out_act >= GM_ACT_ID && g.out_act <= GM_ACT_SIGMOID);
-        GM_CHECK_ARG(g.variant != GM_LOSS_RA || a.gen_mode);
-        GM_CHECK_ARG(g.variant != GM_LOSS_FISHER || a.gen_mode);
+        const bool two_phase = !a.gen_mode && (g.variant == GM_LOSS_RA || g.variant == GM_LOSS_FISHER);
+        // RaGAN / Fisher critic steps: only as riders of the weight gradient (every workgroup holds all rows' scores)
+        GM_CHECK_ARG(!two_phase || (a.gw2 && 2 * a.B <= FOLD_MAX_ROWS && (g.variant != GM_LOSS_FISHER || g.pen)));
         GM_CHECK_ARG(!a.dH);                       // nothing materialises dH in the folded form
         GM_CHECK_ARG(p.R <= FOLD_MAX_ROWS || !a.gw2);
         FoldP& f = p.fold;
@@ -279,7 +405,7 @@ static inline int gm_head_from_args(const gm_head_bwd_args& a, HeadBwdP* out,
         f.Hd = a.Hd; f.inv_b = a.inv_b; f.pen = g.pen;
         for (int i = 0; i < 8; ++i) f.hyper[i] = (i < g.n_hyper) ? g.hyper[i] : 0.f;
         f.S = g.S; f.dS = g.dS; f.rowloss = g.rowloss;
-        f.enabled = 1;
+        f.enabled = two_phase ? 2 : 1;                  // 2: fold_fill_lds_tp instantiations
     }
     *out = p;
     return 0;

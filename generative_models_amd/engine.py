@@ -580,8 +580,9 @@ class GANEngine:
         if net == "D":
             if self.variant == "dra":
                 return self._dra_stacked()
-            return self.fuse_head and self.variant not in ("ra", "fisher") and \
-                (self.variant != "wgp" or self._wgp_stacked())
+            if self.variant in ("ra", "fisher"):
+                return self._fold_head()
+            return self.fuse_head and (self.variant != "wgp" or self._wgp_stacked())
         return True
 
     def _fold_ok(self, rows):
@@ -599,8 +600,13 @@ class GANEngine:
 
     def _fold_head(self):
         """Critic step: the separable losses whose whole step runs on the fused head (not the
-        penalty variants' stacked / accumulating steps, not Ra / Fisher's two-phase losses)."""
+        penalty variants' stacked / accumulating steps); round 4: RaGAN's and Fisher's too, on one GPU -- every
+        consumer workgroup holds all rows' scores, so the batch means are block reductions in its prologue (under
+        data parallelism their phases sit around scalar exchanges: gm_gan_loss_phase)."""
         import os
+        if self.variant in ("ra", "fisher"):
+            return self._single() and not self.force_segments and self._fold_ok(2 * self.Bl) and \
+                os.environ.get("GM_FOLD_HEAD_TP", "1") != "0" and os.environ.get("GM_FOLD_HEAD_D", "1") != "0"
         return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl) and \
             os.environ.get("GM_FOLD_HEAD_D", "1") != "0"
 
@@ -781,10 +787,14 @@ class GANEngine:
             # row losses and dS are rebuilt from the partial dots in that launch's prologue
             ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st)
             adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss)
+            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss,
+                                pen=self.aux if self.variant == "fisher" else None)   # Fisher: lambda lives in aux
             head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
                         adam=adam)
             ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
+            if self.variant == "fisher":
+                from . import ops_fused as of
+                of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)
             return
         merged = self.variant in ("wgp", "dra") and self.merge_fwd3 and not self.dag
         if merged:

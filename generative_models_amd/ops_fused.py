@@ -216,6 +216,11 @@ def dragan_rows(s, V, dv, da2, pen, lam, inv_b, B, K=1.0, stream=None):
               dv.data_ptr(), _ld(dv), da2.data_ptr(), pen.data_ptr(), lam, inv_b, K, B, V.shape[1])
 
 
+def fisher_commit(aux, stream=None):
+    """aux[0] = aux[5]: lambda's successor, computed by the folded Fisher critic step, becomes lambda."""
+    _lib.call("gm_fisher_commit", stream or stream_ptr(), aux.data_ptr())
+
+
 def dragan_head_bwd(H, T, da2, w2, gw2, gb2, dA1, B, store=False, stream=None):
     """store: gw2 / gb2 receive the penalty's share alone (for the head backward's gw2_add / gb2_add)."""
     _lib.call("gm_dragan_head_bwd_store" if store else "gm_dragan_head_bwd", stream or stream_ptr(), H.data_ptr(), _ld(H), T.data_ptr(), _ld(T),

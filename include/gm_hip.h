@@ -432,6 +432,10 @@ int gm_dragan_rows(void* stream, const float* s, const float* V, int64_t ldv, fl
 int gm_dragan_head_bwd(void* stream, const float* H, int64_t ldh, const float* T, int64_t ldt,
                        const float* da2, const float* w2, float* gw2, float* gb2, float* dA1,
                        int64_t ldd, int B, int Hd);
+/* Fisher GAN (fisher_gan.py:155-156) on the folded critic head: gm_linear_bwd_dw_adam_head_fold with variant
+ * GM_LOSS_FISHER reads lambda = aux[0] in every workgroup and leaves lambda + rho * d loss / d lambda in aux[5]
+ * (and the four moments in aux[1..4]); this launch makes it lambda.  aux: 8 floats. */
+int gm_fisher_commit(void* stream, float* aux);
 /* The same with gw2 / gb2 STORED instead of accumulated: the penalty's share of the head's gradient on its own, for
  * gm_head_bwd_args.gw2_add / gb2_add of the stacked critic step (the head's backward adds them before Adam). */
 int gm_dragan_head_bwd_store(void* stream, const float* H, int64_t ldh, const float* T, int64_t ldt,

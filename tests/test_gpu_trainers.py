@@ -196,17 +196,20 @@ def test_fp32_resident_dataset_equals_bit_packed(monkeypatch):
 
 
 @pytest.mark.parametrize("variant,env", [("wgp", "GM_WGP_PEN_IN_HEAD"), ("wgp", "GM_WGP_STACK"), ("ns", "GM_FOLD_HEAD"),
-                                         ("wgp", "GM_FOLD_HEAD"), ("dra", "GM_DRA_STACK")])
+                                         ("wgp", "GM_FOLD_HEAD"), ("dra", "GM_DRA_STACK"), ("ra", "GM_FOLD_HEAD_TP"),
+                                         ("fisher", "GM_FOLD_HEAD_TP")])
 def test_summation_order_switches_agree_within_rounding(variant, env, monkeypatch):
     """Three switches change the ORDER in which the same products are summed, not what is computed: the gradient
     penalty's share of gw2 added per row group inside the head workgroups or after the column sum
     (GM_WGP_PEN_IN_HEAD), the penalty's layer-1 gradient stacked into the critic's own launch or accumulated by
     separate launches (GM_WGP_STACK; GM_DRA_STACK: DRAGAN's three layer-1 gradients as one 4B-row reduction, the
     sigma'' path's share of the head's gradient added inside the head's backward), a score as 13 tile partials or as
-    one wave's dot product (GM_FOLD_HEAD).  The
+    one wave's dot product (GM_FOLD_HEAD); GM_FOLD_HEAD_TP: RaGAN's / Fisher's critic step with the batch means formed
+    in every consumer workgroup's prologue (fp64 block sums over 1024 threads) or by the one-workgroup loss kernel
+    between separate head launches (fp64 sums over 256 threads) -- Fisher's lambda included through the losses.  The
     two settings of each must agree to fp32 rounding over a short run (results are bit-reproducible per setting, not
     across settings -- and not across the rounds in which a default changed)."""
-    kw = dict(num_epochs=2) if variant == "ns" else dict(num_epochs=2, D_steps=2)
+    kw = dict(num_epochs=2) if variant in ("ns", "ra", "fisher") else dict(num_epochs=2, D_steps=2)
     a = run_product(variant, SMALL, 16, kw)
     monkeypatch.setenv(env, "0")
     b = run_product(variant, SMALL, 16, kw)
