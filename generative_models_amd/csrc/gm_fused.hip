@@ -910,6 +910,44 @@ extern "C" int gm_head_bwd_fused(void* stream, const float* H, int64_t ldh, cons
 // q: [B, nd+nc] (Q's identity output); noise: [B, zd+nd+nc] rows = [z | one-hot c1 | c2] (the G
 // input of this step, info_gan.py:306-325), read through a ring slot.  One workgroup.
 // ------------------------------------------------------------------------------------------
+// One row's terms from register copies of the row (qr: nd + nc outputs of Q; cr: the one-hot block and the
+// continuous code of the noise row).  Expressions and their order are the generic loop's.
+template <int ND, int NC>
+__device__ __forceinline__ void info_q_row(const float (&qr)[ND + NC], const float (&cr)[ND + NC], float lambda,
+                                           float inv_b, float inv_bc, float* __restrict__ dr, double& acc_d,
+                                           double& acc_c) {
+    int tgt = 0;                                             // torch.max(..., 1)[1]: first maximal index
+    float best = cr[0];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) { if (cr[j] > best) { best = cr[j]; tgt = j; } }
+    float mx = qr[0];                                        // log_softmax (max-shifted, like at::log_softmax)
+#pragma unroll
+    for (int j = 1; j < ND; ++j) mx = fmaxf(mx, qr[j]);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) se += expf(qr[j] - mx);
+    const float lse = logf(se);
+    float qt = qr[0];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) qt = (j == tgt) ? qr[j] : qt;
+    acc_d += (double)(-((qt - mx) - lse));
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const float sm = expf((qr[j] - mx) - lse);
+        dr[j] = lambda * ((sm - (j == tgt ? 1.f : 0.f)) * inv_b);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const float d = qr[ND + j] - cr[ND + j];
+        acc_c += (double)(d * d);
+        dr[ND + j] = lambda * ((2.f * d) * inv_bc);
+    }
+}
+
+// ND / NC > 0: compile-time widths -- a thread's row lives in registers and ALL of its loads go out before the first
+// use (round 4: the generic loops made five dependent trips to memory per row; 11.8 us per launch at B = 256,
+// info_gan.py's 10 + 10 code).  ND == 0: any widths.
+template <int ND, int NC>
 __global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restrict__ q, int64_t ldq,
                                                          const float* __restrict__ noise,
                                                          gm_slot noise_slot, int64_t ldn, int B,
@@ -925,6 +963,14 @@ __global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restric
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* qr = q + (int64_t)b * ldq;
         const float* nr = nz + (int64_t)b * ldn;
+        float* dr = dq + (int64_t)b * lddq;
+        if constexpr (ND > 0) {
+            float qv[ND + NC], cv[ND + NC];
+#pragma unroll
+            for (int j = 0; j < ND + NC; ++j) { qv[j] = qr[j]; cv[j] = nr[zd + j]; }
+            info_q_row<ND, NC>(qv, cv, lambda, inv_b, inv_bc, dr, acc_d, acc_c);
+            continue;
+        }
         // target = argmax of the one-hot block (torch.max(...,1)[1]: first maximal index)
         int tgt = 0;
         float best = nr[zd];
@@ -936,7 +982,6 @@ __global__ __launch_bounds__(256) void info_q_loss_kernel(const float* __restric
         for (int j = 0; j < nd; ++j) se += expf(qr[j] - mx);
         const float lse = logf(se);
         acc_d += (double)(-((qr[tgt] - mx) - lse));
-        float* dr = dq + (int64_t)b * lddq;
         for (int j = 0; j < nd; ++j) {
             const float sm = expf((qr[j] - mx) - lse);
             dr[j] = lambda * ((sm - (j == tgt ? 1.f : 0.f)) * inv_b);
@@ -964,9 +1009,14 @@ extern "C" int gm_info_q_loss_dp(void* stream, const float* q, int64_t ldq, cons
                                  int disc_dim, int cont_dim, float lambda, float* dq, int64_t lddq,
                                  float* loss_out, gm_slot loss_slot) {
     GM_CHECK_ARG(q && noise && dq && loss_out && B > 0 && B_global >= B && disc_dim > 0 && cont_dim > 0 && z_dim >= 0);
-    hipLaunchKernelGGL(info_q_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
-                       noise_slot, ldn, B, B_global, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
-                       loss_slot);
+    if (disc_dim == 10 && cont_dim == 10)                       // info_gan.py:78-79's code widths
+        hipLaunchKernelGGL((info_q_loss_kernel<10, 10>), dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
+                           noise_slot, ldn, B, B_global, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
+                           loss_slot);
+    else
+        hipLaunchKernelGGL((info_q_loss_kernel<0, 0>), dim3(1), dim3(256), 0, (hipStream_t)stream, q, ldq, noise,
+                           noise_slot, ldn, B, B_global, z_dim, disc_dim, cont_dim, lambda, dq, lddq, loss_out,
+                           loss_slot);
     GM_LAUNCH_RET();
 }
 extern "C" int gm_info_q_loss(void* stream, const float* q, int64_t ldq, const float* noise,

@@ -916,12 +916,19 @@ class GANEngine:
             g1, g2 = G1, G2
         # every dX reads a layer's weights before that layer's dW(+Adam) launch
         ops.linear_bwd_dx(self.dQo, Q2.W, self.dHq, below=self.Hq, epi="relu", M=Bl, stream=st)
-        dw(self.dQo, self.Hq, Q2)
         ops.linear_bwd_dx(self.dHq, Q1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
-        dw(self.dHq, Xg, Q1)
         ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
-        dw(self.dXg, Hg, g2)
-        dw(self.dHg, zbase, g1, x_slot=z_slot)
+        if self.pair_dw and fused:
+            # the four weight gradients as two paired launches (round 4; the big GEMM first: its tile serves both)
+            ops.linear_bwd_dw_adam_pair(dict(dA=self.dHq, X=Xg, lin=Q1, adam=adam, M=Bl),
+                                        dict(dA=self.dQo, X=self.Hq, lin=Q2, adam=adam, M=Bl), stream=st)
+            ops.linear_bwd_dw_adam_pair(dict(dA=self.dXg, X=Hg, lin=g2, adam=adam, M=Bl),
+                                        dict(dA=self.dHg, X=zbase, lin=g1, adam=adam, M=Bl, x_slot=z_slot), stream=st)
+        else:
+            dw(self.dQo, self.Hq, Q2)
+            dw(self.dHq, Xg, Q1)
+            dw(self.dXg, Hg, g2)
+            dw(self.dHg, zbase, g1, x_slot=z_slot)
         if self._peer():
             # MI_optimizer.step (info_gan.py:148,207): G's gradient bucket with the MI optimizer's OWN
             # moments, and Q's bucket -- all-reduce + Adam in the gather kernels

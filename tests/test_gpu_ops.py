@@ -335,10 +335,11 @@ def test_began_update_matches_python_controller_and_plateau_scheduler():
     assert ctr.item() == 40
 
 
-def test_info_q_loss_vs_torch():
+@pytest.mark.parametrize("B,zd,nd,nc", [(48, 8, 10, 10), (256, 20, 10, 10), (300, 8, 7, 5)])
+def test_info_q_loss_vs_torch(B, zd, nd, nc):
+    """(10, 10): the register-resident instantiation for info_gan.py's code widths; other widths: the generic loops."""
     from generative_models_amd import ops_fused as of
     torch.manual_seed(2)
-    B, zd, nd, nc = 48, 8, 10, 10
     q = torch.randn(B, nd + nc, requires_grad=True)
     noise = torch.zeros(B, zd + nd + nc)
     noise[:, :zd] = torch.randn(B, zd)
