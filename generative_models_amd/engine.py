@@ -2632,8 +2632,14 @@ class BEGANEngine(GANEngine):
             # in st[1:3] are summed over ranks before the K controller / plateau schedulers read them
             self._exchange_scalars(st, self.st[1:], 2)
         ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
-        ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
+        if self.pair_dw and not self.dag:
+            # both weight gradients of the autoencoder critic as one launch (plain gradients: Adam needs the
+            # device-side lr scale and stays a launch of its own)
+            ops.linear_bwd_dw_adam_pair(dict(dA=dY, X=Hd, lin=D2, adam=None, M=2 * Bl),
+                                        dict(dA=dHd, X=X2, lin=D1, adam=None, M=2 * Bl), stream=st)
+        else:
+            ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
+            ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
 
     def _lr_scale(self, net):
         return self.st[4:5] if net == "D" else self.st[5:6]
