@@ -438,11 +438,8 @@ class GANEngine:
         assert self.D2.W.shape[0] == 1 or variant == "be", "score-based critics (BEGAN: autoencoder)"
         self.use_graph = use_graph
         self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
-        self.dag = os.environ.get("GM_DAG", "0") != "0"   # measured slower (profiles/r01_experiments.md)
         self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
         self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
-        # measured slower (agent-scope fences in every workgroup; profiles/r01_experiments.md)
-        self.head_final = os.environ.get("GM_HEAD_FINAL", "0") != "0"
         self.ride_head_dx = os.environ.get("GM_RIDE_HEAD_DX", "1") != "0"
         self.group_head = os.environ.get("GM_GROUP_HEAD", "1") != "0"
         self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
@@ -458,24 +455,18 @@ class GANEngine:
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
         self.gated = os.environ.get("GM_GATED", "1") != "0"
-        # forked tail stage-in: measured 72.4 -> 81.7 us / iteration (a graph with a parallel branch leaves
-        # the linear-chain fast path of the runtime, as the DAG experiment of round 1 did): off
-        self.split_stage = os.environ.get("GM_SPLIT_STAGE", "0") != "0"
-        self.stage_base = torch.zeros(1, dtype=torch.int64, device=device)
         # pre-staging (gm_stage_in_prestaged): the host issues every piece's stage-in on a side stream as soon as its
         # draws are submitted; the graph's own stage-in then finds its iterations inside _pre_range and returns
         self.prestage = os.environ.get("GM_PRESTAGE", "1") != "0"
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
-        self._stage_side, self._stage_events = None, []
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
             self.FIRST_PIECE = max(1, int(os.environ["GM_FIRST_PIECE"]))
         self._gate = None
         self._standalone_G = False
-        self.side = self.events = None
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
         dev = device
         z = lambda *s: torch.zeros(*s, device=dev)
@@ -497,7 +488,6 @@ class GANEngine:
         self.dHg = z(Bl, H)
         self.rowloss = z(2 * Bl)
         self.fold = ops.HeadFold(2 * Bl, Hd, dev) if (self.D2.W.shape[0] == 1 and Hd <= 512) else None
-        self.done_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.aux = z(8)                    # Fisher lambda + moments
         self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
         if variant in ("wgp", "dra"):
@@ -570,12 +560,12 @@ class GANEngine:
 
     def _tick_in_head(self):
         """The per-graph tick rides in the generator step's head_bwd kernel."""
-        return self.use_graph and self.fold_tick and self.fuse_head and not self.dag
+        return self.use_graph and self.fold_tick and self.fuse_head
 
     def _adam_in_epilogue(self, net):
         """Adam folded into the gradient-producing kernels (single GPU; not when later kernels
         still accumulate into the gradients, i.e. WGAN-GP's critic)."""
-        if not (self.fuse_adam and self._single()) or self.dag:
+        if not (self.fuse_adam and self._single()):
             return False
         if net == "D":
             if self.variant == "dra":
@@ -592,7 +582,7 @@ class GANEngine:
         below the LDS macro-tile kernel's threshold; GM_FOLD_HEAD=2 lifts that)."""
         if self.fold_env == "0" or self.fold is None or self.variant == "be":
             return False
-        if not (self.fuse_head and self.group_head and self.ride_head_dx) or self.dag or self.head_final:
+        if not (self.fuse_head and self.group_head and self.ride_head_dx):
             return False
         if self.Hd_dim % 4 or self.I % 4 or rows > 2048 or self.Hd_dim > 512:
             return False
@@ -620,14 +610,14 @@ class GANEngine:
         layer-1 weight gradient as one stacked GEMM (+Adam), the w2 share added in the head's
         backward, D(x_hat)'s head + u as one kernel."""
         import os
-        return self.variant == "wgp" and self.fuse_head and self.group_head and not self.dag and \
+        return self.variant == "wgp" and self.fuse_head and self.group_head and \
             os.environ.get("GM_WGP_STACK", "1") != "0"
 
     def _dra_stacked(self):
         """DRAGAN critic step with its three layer-1 weight gradients as one stacked GEMM (+ Adam) and the sigma''
         path's share of the head's gradient added inside the head's backward (round 4)."""
         return self.variant == "dra" and getattr(self, "dra_stack", False) and self.fuse_head and \
-            self.group_head and not self.dag
+            self.group_head
 
     def _slot(self, it, mul, add, ring, stride, post=False):
         """Graph mode: resolved on device from the counter; eager mode: resolved here.
@@ -723,7 +713,7 @@ class GANEngine:
     # ---- pieces of one critic step (composed sequentially, or as parallel graph branches) -----
     def _gather_rides(self):
         """The batch gather rides in the grid of the generator's first forward launch."""
-        return self.ride_gather and not self.dag
+        return self.ride_gather
 
     def _gather_args(self, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
@@ -741,7 +731,7 @@ class GANEngine:
         read the same G parameters: with D_steps == 1 they run as ONE launch pair on 2B rows (the
         noise ring stores [zD; zG] back to back -- on a data-parallel rank that needs the rank-local
         device rings, where the rank's zD rows and zG rows of an iteration are adjacent)."""
-        return self.batch_gen_env and self.D_steps == 1 and not self.dag and \
+        return self.batch_gen_env and self.D_steps == 1 and \
             (self.world == 1 or self._local_rings())
 
     def _local_rings(self):
@@ -773,7 +763,7 @@ class GANEngine:
     def _interp_in_gen(self):
         import os
         # (the DAG experiment runs the gather on a side stream, concurrently with this launch)
-        return self.variant == "wgp" and not self.dag and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
+        return self.variant == "wgp" and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
 
     def _D_rest(self, st, it, j):
         Bl, d = self.Bl, self.D_steps
@@ -796,7 +786,7 @@ class GANEngine:
                 from . import ops_fused as of
                 of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)
             return
-        merged = self.variant in ("wgp", "dra") and self.merge_fwd3 and not self.dag
+        merged = self.variant in ("wgp", "dra") and self.merge_fwd3
         if merged:
             if self.variant == "wgp":
                 self._gp_prepare(st, it, j)
@@ -817,7 +807,7 @@ class GANEngine:
             of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
                              self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
             adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            if self.group_head and not self.dag:
+            if self.group_head:
                 # head backward + first-layer weight gradient (+ both Adam steps when they are
                 # fused: one GPU, nothing accumulates into these gradients later): ONE launch
                 head = dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
@@ -979,25 +969,18 @@ class GANEngine:
         if self.fuse_head:
             from . import ops_fused as of
             tick = self.ctr if self._tick_in_head() else None
-            if self.head_final:
-                # the last workgroup of the head kernel writes the loss scalar and ticks
-                of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
-                                 self.inv_b, None, S2, dS, self.rowloss, dH=dHd,
-                                 final=dict(loss_out=self.lossG, loss_slot=loss_slot,
-                                            done=self.done_ctr, tick=tick), stream=st)
-            else:
-                of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
-                                 self.inv_b, None, S2, dS, self.rowloss, dH=dHd, stream=st)
-                if self.ride_head_dx and not self.dag:
-                    # the head's one scalar workgroup (loss + tick) rides in the dX launch
-                    ops.linear_bwd_dx_head(
-                        dHd, D1.W, self.dXg,
-                        dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossG,
-                             loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
-                        below=Xg, epi="sigmoid", M=Bl, stream=st)
-                    return
-                of.head_bwd(Hd, dS, D2.W, self.rowloss, None, None, None, self.lossG, loss_slot,
-                            self.inv_b, True, Bl, tick=tick, stream=st)
+            of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
+                             self.inv_b, None, S2, dS, self.rowloss, dH=dHd, stream=st)
+            if self.ride_head_dx:
+                # the head's one scalar workgroup (loss + tick) rides in the dX launch
+                ops.linear_bwd_dx_head(
+                    dHd, D1.W, self.dXg,
+                    dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossG,
+                         loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
+                    below=Xg, epi="sigmoid", M=Bl, stream=st)
+                return
+            of.head_bwd(Hd, dS, D2.W, self.rowloss, None, None, None, self.lossG, loss_slot,
+                        self.inv_b, True, Bl, tick=tick, stream=st)
         else:
             ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
             ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
@@ -1039,7 +1022,7 @@ class GANEngine:
         self._G_gen(st, it)
         self._G_critic(st, it)
         self._G_dh(st, it)                          # reads G2.W before _G_dw2 may update it
-        if self.pair_dw and not self.dag:
+        if self.pair_dw:
             # both weight gradients of the generator (+ their Adam steps on one GPU): ONE launch
             adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
             zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
@@ -1059,32 +1042,6 @@ class GANEngine:
                  self._G_sched_slot(it), stream=st)
 
     # ---- the same iteration as a DAG: independent pieces become parallel hipGraph branches ----
-    def _issue_iteration_dag(self, st, it):
-        from . import _lib
-        s1, s2 = self.side
-        ev = iter(self.events)
-        def fork(src, dst):
-            e = next(ev)
-            e.record(src)
-            _lib.call("gm_stream_wait_event", dst, e.h)
-        fork(st, s1)
-        self._G_gen(s1, it)                       # generator step's G(z): needs only G's params
-        for j in range(self.D_steps):
-            fork(st, s2)
-            self._D_gather(s2, it, j)             # gather || critic step's G(z)
-            self._D_gen(st, it, j)
-            fork(s2, st)
-            self._D_rest(st, it, j)
-            self._issue_D_post(st, it, j)
-        fork(s1, st)                              # join: Xg2/Hg2 ready, D updated
-        self._G_critic(st, it)
-        fork(st, s1)
-        self._G_dw2(s1, it)                       # dW2 || (dH -> dW1)
-        self._G_dh_dw1(st, it)
-        fork(s1, st)
-        self._issue_G_post(st, it)
-        ops.tick(self.ctr, 1, stream=st)
-
     # -- WGAN-GP penalty: w_gp_gan.py:195-218, hand-derived second backward -----
     def _gp_prepare(self, st, it, j):
         """x_hat, unless the generator's last launch already wrote it."""
@@ -1172,7 +1129,6 @@ class GANEngine:
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
-    STAGE_HEAD = 4      # iterations a long graph stages in serially; the rest overlaps their kernels
     PRE_BLOCKS = 32     # workgroups per segment of a pre-staging launch (it runs beside the iteration kernels)
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
     FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
@@ -1330,24 +1286,16 @@ class GANEngine:
             prog.append(op(DRAW_NORMAL, B * Z, s["zG"][0], gs, **rows(Z)))    # ns_gan.py:208
         return prog
 
-    def _issue_stage_in(self, st, it, k, first=0, base=None, publish=None, max_blocks=256):
-        """Stage-in of iterations [it+first, it+first+k): host ring -> device ring (first launch of a
-        graph).  base: device word holding `it` to resolve the slots from instead of the step counter
-        (the forked tail stage-in of a long graph); publish: device word this launch stores `it` to."""
+    def _issue_stage_in(self, st, it, k, max_blocks=256):
+        """Stage-in of iterations [it, it+k): host ring -> device ring (first launch of a graph)."""
         from . import _lib
-        if base is not None:
-            ring_slot = ops.slot(base.data_ptr(), 1, first, self.R, 1)
-            it_slot = ops.slot(base.data_ptr(), 1, first, 0, 1)
-        else:
-            ring_slot, it_slot = self._slot(it, 1, first, self.R, 1), self._slot(it, 1, first, 0, 1)
+        ring_slot, it_slot = self._slot(it, 1, 0, self.R, 1), self._slot(it, 1, 0, 0, 1)
         if self.gated and self._prestaging():
             _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
-                      it_slot, self.GATE_TIMEOUT_S, publish.data_ptr() if publish is not None else None,
-                      max_blocks, self._pre_range.data_ptr(), None, 0)
+                      it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
         elif self.gated:
             _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
-                      it_slot, self.GATE_TIMEOUT_S, publish.data_ptr() if publish is not None else None,
-                      max_blocks)
+                      it_slot, self.GATE_TIMEOUT_S, None, max_blocks)
         else:
             _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
 
@@ -1381,15 +1329,6 @@ class GANEngine:
             self._pre_event.record(self._pre_stream)
             _lib.call("gm_stream_wait_event", ops.stream_ptr(), self._pre_event.h)
             self._pre_dirty = False
-
-    def _stage_stream(self):
-        if self._stage_side is None:
-            import ctypes
-            from . import _lib
-            h = ctypes.c_void_p()
-            _lib.call("gm_stream_create", ctypes.byref(h))
-            self._stage_side = h
-        return self._stage_side
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -1544,7 +1483,7 @@ class GANEngine:
         # 16-iteration graph had to FINISH before its slots could be refilled -- 236 us per iteration.)
         R = max(1, min(ring, 64) if self.variant == "dra" else ring)
         key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
-               self.fuse_head, self.dag, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated)
+               self.fuse_head, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated)
         self.D_steps = D_steps
         if getattr(self, "_ring_key", None) != (D_steps, R, self._batch_gen()):
             self._alloc_rings(R)
@@ -1639,55 +1578,26 @@ class GANEngine:
             return
         torch.cuda.synchronize()
         if self._one_graph():
-            if self.dag:
-                import ctypes
-                from . import _lib
-                if self.side is None:
-                    self.side = []
-                    for _ in range(2):
-                        h = ctypes.c_void_p()
-                        _lib.call("gm_stream_create", ctypes.byref(h))
-                        self.side.append(h)
-                self.events = [ops.Event() for _ in range(4 + 2 * self.D_steps)]
-                self.graph = ops.Graph().capture(
-                    lambda st: (self._issue_stage_in(st, 0, 1), self._issue_iteration_dag(st, 0)))
-                self.graphs_by_size = [(1, self.graph)]
-            else:
-                # graphs of graph_iters, ..., 4, 2, 1 iterations (the device counter advances inside
-                # every iteration): any run length is a handful of launches
-                def body(k):
-                    # long graphs stage in their first STAGE_HEAD iterations up front and the rest on a
-                    # forked branch that overlaps those iterations' kernels (the PCIe reads of a
-                    # 32-iteration stage-in take ~60 us -- 1.9 us per iteration when serial)
-                    head = self.STAGE_HEAD if (self.gated and self.split_stage and k >= 2 * self.STAGE_HEAD) else k
-
-                    def fn(st):
-                        if head == k:
-                            self._issue_stage_in(st, 0, k)
-                        else:
-                            from . import _lib
-                            side = self._stage_stream()
-                            e0, e1 = ops.Event(), ops.Event()
-                            self._stage_events += [e0, e1]
-                            self._issue_stage_in(st, 0, head, publish=self.stage_base)
-                            e0.record(st)
-                            _lib.call("gm_stream_wait_event", side, e0.h)
-                            self._issue_stage_in(side, 0, k - head, first=head, base=self.stage_base,
-                                                 max_blocks=32)
-                            e1.record(side)
-                        for i in range(k):
-                            if i == head and head < k:
-                                _lib.call("gm_stream_wait_event", st, e1.h)
-                            self._issue_iteration(st, 0)
-                    return fn
-                self.graph = ops.Graph().capture(body(1))
-                self.graphs_by_size = [(1, self.graph)]
-                k = 2
-                while k <= self.graph_iters:
-                    self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
-                    k *= 2
-                if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
-                    self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
+            # graphs of graph_iters, ..., 4, 2, 1 iterations (the device counter advances inside every
+            # iteration): any run length is a handful of launches.  Each starts with the stage-in of its own
+            # iterations (round 4: normally a check that the side stream's pre-stage has been there).  Two forms
+            # that were measured and removed in round 4's clean-up: the iteration as a multi-stream DAG inside the
+            # graph (-35 %, profiles/r01_experiments.md) and the stage-in's tail on a forked branch of a long graph
+            # (72.4 -> 81.7 us per iteration, r02) -- any parallel branch leaves the runtime's linear-chain path.
+            def body(k):
+                def fn(st):
+                    self._issue_stage_in(st, 0, k)
+                    for _ in range(k):
+                        self._issue_iteration(st, 0)
+                return fn
+            self.graph = ops.Graph().capture(body(1))
+            self.graphs_by_size = [(1, self.graph)]
+            k = 2
+            while k <= self.graph_iters:
+                self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
+                k *= 2
+            if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
+                self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
@@ -2632,7 +2542,7 @@ class BEGANEngine(GANEngine):
             # in st[1:3] are summed over ranks before the K controller / plateau schedulers read them
             self._exchange_scalars(st, self.st[1:], 2)
         ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        if self.pair_dw and not self.dag:
+        if self.pair_dw:
             # both weight gradients of the autoencoder critic as one launch (plain gradients: Adam needs the
             # device-side lr scale and stays a launch of its own)
             ops.linear_bwd_dw_adam_pair(dict(dA=dY, X=Hd, lin=D2, adam=None, M=2 * Bl),
