@@ -96,11 +96,12 @@ def gemm_shapes_wgp(B, fold_g=True):
 def gemm_shapes_vae(B):
     """Every GEMM launch of one VAE training batch (engine.VAEEngine._issue): "fwds" = decoder output
     layer + reconstruction loss epilogue, "fwdz" = reparameterisation + the decoder's first layer (one launch; its GEMM
-    workgroups form z from mu, log_var, eps), "dxr" = dX through the decoder's first layer + reparameterisation
+    workgroups form z from mu, log_var, eps), "bmid" = the two narrow GEMMs between the decoder's and the encoder's wide
+    layers + the reparameterisation backward as one launch (round 4), "dxr" = dX through the decoder's first layer + reparameterisation
     backward epilogue; the two weight-gradient pairs carry their second GEMM's (N2, K2)."""
     return [("fwd", B, IMG, HID), ("fwdg", B, HID, 2 * Z), ("fwdz", B, Z, HID), ("fwds", B, HID, IMG),
-            ("dx", B, HID, IMG), ("dxr", B, Z, HID), ("dwp", B, HID, IMG, (HID, Z)),
-            ("dx", B, HID, 2 * Z), ("dwp", B, IMG, HID, (2 * Z, HID))]
+            ("dx", B, HID, IMG), ("bmid", B, Z, HID), ("dwp", B, HID, IMG, (HID, Z)),
+            ("dwp", B, IMG, HID, (2 * Z, HID))]
 
 
 def gemm_variant(kind, M, K, N):
@@ -109,6 +110,8 @@ def gemm_variant(kind, M, K, N):
     load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
     if kind == "fwdz":
         return "vae_reparam_fwd_kernel"
+    if kind == "bmid":
+        return "vae_bwd_mid_kernel"
     if kind in ("fwd", "fwdg", "fwdp", "fwds"):
         mode, Mg, Ng, Kr, vec, xv = 0, M, N, K, K % 4 == 0, False
     elif kind in ("dx", "dxh", "dxhf", "dxr"):
@@ -220,6 +223,13 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             mlz, epz = torch.randn(M, 2 * K, device=dev) * 0.5, torch.randn(M * K, device=dev)
             zz_, pk = torch.empty(M, K, device=dev), torch.empty((M * K + 255) // 256, device=dev)
             fn = lambda: ops_fused.vae_reparam_fwd(mlz, epz, zz_, pk, M, K, W, b, y, "relu", stream=st)
+        elif kind == "bmid":                    # dz, d[mu | log_var], dHe: K = z_dim, N = hidden
+            from generative_models_amd import ops_fused
+            mlz, epz = torch.randn(M, 2 * K, device=dev) * 0.5, torch.randn(M * K, device=dev)
+            dmlz, Wml_ = torch.empty(M, 2 * K, device=dev), torch.randn(2 * K, N, device=dev) / N ** 0.5
+            Hez, dHez = torch.relu(torch.randn(M, N, device=dev)), torch.empty(M, N, device=dev)
+            fn = lambda: ops_fused.vae_bwd_mid(dA, W, mlz, epz, dmlz, Wml_, Hez, dHez, M, stream=st)
+            flop = 2.0 * M * K * N + 2.0 * M * 2 * K * N
         elif kind == "dxr":                     # dX (layer [N, K]: K = z_dim) + reparameterisation backward
             mlz, epz, dmlz = torch.randn(M, 2 * K, device=dev), torch.randn(M * K, device=dev), torch.empty(M, 2 * K, device=dev)
             fn = lambda: ops.linear_bwd_dx_reparam(dA, W, dX, mlz, epz, dmlz, stream=st)

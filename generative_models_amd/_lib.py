@@ -124,6 +124,8 @@ _SIGNATURES = {
     "gm_sum_finalize_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P]),
     "gm_sum_finalize2_tick": (c_int, [_P, _P, c_int, c_float, _P, Slot, _P, c_int, c_float, _P, Slot, _P]),
     "gm_vae_reparam_wide": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int, c_int, c_int]),
+    "gm_vae_bwd_mid": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, Slot, _P, c_int64, _P, _P, c_int64, _P, c_int64,
+                               c_int, c_int, c_int]),
     "gm_vae_reparam_fwd": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, _P, c_int, c_int, c_int, _P, _P, _P,
                                    c_int64, c_int, c_int]),
     "gm_linear_bwd_dw_adam": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int, c_int,

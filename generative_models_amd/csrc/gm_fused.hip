@@ -533,6 +533,172 @@ __global__ __launch_bounds__(256) void vae_reparam_fwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The two narrow GEMMs in the middle of the VAE's backward pass as ONE launch (round 4):
+//   dz  = dHdec W_d1            [B, Hd] x [Hd, Z]      (decoder layer 1, vae.py:113 backwards)
+//   d[mu | log_var] from dz     (gm_vae_reparam_bwd's expressions: vae.py:100-106, 210-212)
+//   dHe = (dml W_ml) . [He > 0] [B, 2Z] x [2Z, Hd]     (encoder's mu / log_var layer, vae.py:93-98 backwards)
+// A row block's dHe needs only that block's dml, which needs only that block's dz: a workgroup owns 16 rows and runs
+// the chain for them; dml goes to memory (the encoder's weight gradient reads it) and stays in LDS for the second
+// product.  Summation orders are those of the separate launches: the Hd-deep reduction as sixteen chunk owners
+// (chunks w and w + 16 accumulate in one MFMA chain) added in owner order, the 2Z-deep one as up to four chunk
+// accumulators added in order -- what the 16-wave kernel's waves and cross-wave reduction do.
+// 256 threads: wave q plays chunk owners q, q + 4, q + 8, q + 12 of the first product and column tiles q, q + 4, ...
+// of the second.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_bwd_mid_kernel(const float* __restrict__ dHdec, int64_t lddh,
+                                                         const float* __restrict__ Wd1,      // [Hd, Z]
+                                                         const float* __restrict__ ml, int64_t ldml,
+                                                         const float* __restrict__ eps, gm_slot eps_slot,
+                                                         float* __restrict__ dml, int64_t lddml,
+                                                         const float* __restrict__ Wml,      // [2Z, Hd]
+                                                         const float* __restrict__ He, int64_t ldhe,
+                                                         float* __restrict__ dHe, int64_t lddhe,
+                                                         int B, int Hd, int Z) {
+    __shared__ float part[16][16][33];                       // chunk owner, row, column (padded)
+    __shared__ float sdml[16][68];                           // the block's dml rows (2Z <= 64)
+    const float* e = eps + gm_slot_offset(eps_slot);
+    const int t = threadIdx.x, lane = t & 63, q = t >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    // blockIdx.x: 16-row block; blockIdx.y: group of four 16-column tiles of dHe (one per wave).  Every column group
+    // recomputes the block's dz / dml (a 16 x Z product: cheap next to one more launch or a 32-workgroup grid --
+    // measured: one workgroup per row block alone made the batch 16 us SLOWER than the two launches); group 0
+    // stores dml.
+    const int m0 = blockIdx.x * 16;
+    const int row = min(m0 + i16, B - 1);
+    const bool row_ok = m0 + i16 < B;
+    const int nchunks = (Hd + 15) >> 4;
+    // ---- dz partials: owner w = q + 4 j accumulates chunks w, w + 16 (two column tiles: Z <= 32); all of a wave's
+    // operands are requested before the first MFMA (eight chunk slots: one memory round trip, not eight)
+    float4 av[4][2];
+    float b0[4][2][4], b1[4][2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = q + 4 * j + 16 * u;
+            const int kb = 16 * c + 4 * g4, kc = max(0, min(kb, Hd - 4));          // Hd % 4 == 0
+            const bool ka = c < nchunks && kb < Hd;
+            const float4 v = *reinterpret_cast<const float4*>(dHdec + (int64_t)row * lddh + kc);
+            av[j][u] = (ka && row_ok) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {                    // W_d1[k][col]: rows of Z floats
+                const int k = max(0, min(kb + x, Hd - 1));
+                const float w0 = Wd1[(int64_t)k * Z + min(i16, Z - 1)];
+                const float w1 = Wd1[(int64_t)k * Z + min(16 + i16, Z - 1)];
+                b0[j][u][x] = (ka && i16 < Z) ? w0 : 0.f;
+                b1[j][u][x] = (ka && 16 + i16 < Z) ? w1 : 0.f;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = q + 4 * j;
+        rp_f32x4 a0 = rp_f32x4{0.f, 0.f, 0.f, 0.f}, a1 = rp_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (w + 16 * u < nchunks) {                      // (an absent chunk adds nothing: skip its MFMAs -- +0 steps
+                                                             // would not change a bit either)
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].x, b0[j][u][0], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].y, b0[j][u][1], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].z, b0[j][u][2], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].w, b0[j][u][3], a0, 0, 0, 0);
+                if (Z > 16) {
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].x, b1[j][u][0], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].y, b1[j][u][1], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].z, b1[j][u][2], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][u].w, b1[j][u][3], a1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                        // C layout: column = lane & 15, row = 4 (lane >> 4) + r
+            part[w][4 * g4 + r][i16] = a0[r];
+            part[w][4 * g4 + r][16 + i16] = a1[r];
+        }
+    }
+    // this wave's operands of the second product, requested before the barrier: W_ml's fragment and the mask
+    const int K2 = 2 * Z, nch2 = (K2 + 15) >> 4, ntiles = (Hd + 15) >> 4;
+    const int ct = blockIdx.y * 4 + q;                       // this wave's column tile (wave-uniform)
+    const bool tile_ok = ct < ntiles;
+    const int hcol = min(16 * ct + i16, Hd - 1);
+    const bool col_ok = tile_ok && 16 * ct + i16 < Hd;
+    float bv[4][4], hmask[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int k = 16 * c + 4 * g4 + x;
+            const float w = Wml[(int64_t)min(k, K2 - 1) * Hd + hcol];
+            bv[c][x] = (k < K2 && col_ok) ? w : 0.f;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hmask[r] = He[(int64_t)min(m0 + 4 * g4 + r, B - 1) * ldhe + hcol];
+    __syncthreads();
+    // ---- dz -> d[mu | log_var] (one (row, column) per thread and pass), to LDS and -- column group 0 -- to memory
+    for (int o = t; o < 16 * Z; o += 256) {
+        const int r = o / Z, n = o - r * Z, m = m0 + r;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += part[w][r][n];
+        float dmu = 0.f, dlv = 0.f;
+        if (m < B) {
+            const float mu = ml[(int64_t)m * ldml + n], lv = ml[(int64_t)m * ldml + Z + n];
+            const float ev = e[(int64_t)m * Z + n];
+            dmu = v + 0.5f * (2.f * mu);
+            dlv = ((v * ev) * expf(lv / 2.f)) / 2.f + 0.5f * (expf(lv) - 1.f);
+            if (blockIdx.y == 0) {
+                dml[(int64_t)m * lddml + n] = dmu;
+                dml[(int64_t)m * lddml + Z + n] = dlv;
+            }
+        }
+        sdml[r][n] = dmu;
+        sdml[r][Z + n] = dlv;
+    }
+    for (int o = t; o < 16 * (64 - 2 * Z); o += 256) {        // the padding the last chunk reads: zeros
+        const int r = o / (64 - 2 * Z), n = 2 * Z + (o - r * (64 - 2 * Z));
+        sdml[r][n] = 0.f;
+    }
+    __syncthreads();
+    // ---- dHe = (dml W_ml) . [He > 0]: reduction 2Z <= 64 deep = up to four chunk accumulators, added in order
+    if (!tile_ok) return;                                    // wave-uniform; no barrier behind this point
+    rp_f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        acc[c] = rp_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nch2) {
+            const float4 af = make_float4(sdml[i16][16 * c + 4 * g4], sdml[i16][16 * c + 4 * g4 + 1],
+                                          sdml[i16][16 * c + 4 * g4 + 2], sdml[i16][16 * c + 4 * g4 + 3]);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bv[c][0], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bv[c][1], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bv[c][2], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bv[c][3], acc[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * g4 + r;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nch2) v += acc[c][r];
+        if (m < B && col_ok) dHe[(int64_t)m * lddhe + 16 * ct + i16] = (hmask[r] > 0.f) ? v : 0.f;
+    }
+}
+
+extern "C" int gm_vae_bwd_mid(void* stream, const float* dHdec, int64_t lddh, const float* Wd1, const float* ml,
+                              int64_t ldml, const float* eps, gm_slot eps_slot, float* dml, int64_t lddml,
+                              const float* Wml, const float* He, int64_t ldhe, float* dHe, int64_t lddhe, int B,
+                              int Hd, int Z) {
+    GM_CHECK_ARG(dHdec && Wd1 && ml && eps && dml && Wml && He && dHe && B > 0 && Hd > 0 && Z > 0);
+    GM_CHECK_ARG(Z <= 32 && Hd % 4 == 0 && lddh >= Hd && lddh % 4 == 0 && ldml >= 2 * Z && lddml >= 2 * Z &&
+                 ldhe >= Hd && lddhe >= Hd && (reinterpret_cast<uintptr_t>(dHdec) & 15) == 0);
+    GM_CHECK_ARG(dHe != dHdec && (const float*)dml != ml && (const float*)dHe != He);
+    GM_CHECK_ARG(Hd <= 16 * 32);                                 // 16 owners x 2 chunks of 16
+    hipLaunchKernelGGL(vae_bwd_mid_kernel, dim3((B + 15) / 16, ((Hd + 15) / 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, dHdec, lddh, Wd1,
+                       ml, ldml, eps, eps_slot, dml, lddml, Wml, He, ldhe, dHe, lddhe, B, Hd, Z);
+    GM_LAUNCH_RET();
+}
+
 extern "C" int gm_vae_reparam_fwd(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
                                   float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z, const float* W,
                                   const float* bias, float* H, int64_t ldh, int N, int act) {

@@ -2022,6 +2022,7 @@ class VAEEngine:
         self.fuse_sqerr = os.environ.get("GM_VAE_FUSE_SQERR", "1") != "0"
         self.fuse_reparam_bwd = os.environ.get("GM_VAE_FUSE_REPARAM_BWD", "1") != "0"
         self.fuse_reparam_fwd = os.environ.get("GM_VAE_FUSE_REPARAM_FWD", "1") != "0"
+        self.fuse_bwd_mid = os.environ.get("GM_VAE_BWD_MID", "1") != "0"
         self.fin_in_dw = os.environ.get("GM_VAE_FINALIZE_IN_DW", "1") != "0"
         self.fin_done = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -2130,7 +2131,13 @@ class VAEEngine:
             else:
                 dw2 = lambda a1, a2: (dw(*a1), dw(*a2))
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            if self.fuse_reparam_bwd:
+            mid = self.fuse_bwd_mid and self.fuse_reparam_bwd and Z <= 32 and self.H % 4 == 0
+            if mid:
+                # dz, d loss / d [mu | log_var] and dHe: the two narrow GEMMs between the decoder's and the encoder's
+                # wide ones as ONE launch, 16 rows per workgroup (reads D1.W and ML.W before the pairs step them)
+                of_.vae_bwd_mid(self.dHdec, D1.W, self.ml, eps_base, self.dml, ML.W, self.He, self.dHe, b,
+                                eps_slot=eps_slot, stream=st)
+            elif self.fuse_reparam_bwd:
                 # dz and, in the same launch's epilogue, d loss / d [mu | log_var] (vae.py:100-106,210-212)
                 ops.linear_bwd_dx_reparam(self.dHdec, D1.W, self.dZ, self.ml, eps_base, self.dml, M=b,
                                           eps_slot=eps_slot, stream=st)
@@ -2140,7 +2147,8 @@ class VAEEngine:
             if not self.fuse_reparam_bwd:
                 of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
                                    eps_slot=eps_slot, stream=st)
-            ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
+            if not mid:
+                ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
             if self.fin_in_dw and self.pair_dw and adam is not None and not self._dp():
                 # the batch's LAST launch: the encoder's two weight gradients + Adam, both loss sums (vae.py:203, :212)
                 # in one more workgroup of the same grid, the counter tick by the last workgroup to finish

@@ -70,6 +70,14 @@ def vae_reparam_wide(ml, eps, z, kl_part, B, Z, eps_slot=NO_SLOT, stream=None):
     return (B * Z + 255) // 256
 
 
+def vae_bwd_mid(dHdec, Wd1, ml, eps, dml, Wml, He, dHe, B, eps_slot=NO_SLOT, stream=None):
+    """dz = dHdec W_d1, d loss / d [mu | log_var] (-> dml), dHe = (dml W_ml) . [He > 0] as ONE launch (gm_vae_bwd_mid)."""
+    Hd, Z = Wd1.shape
+    _lib.call("gm_vae_bwd_mid", stream or stream_ptr(), dHdec.data_ptr(), _ld(dHdec), Wd1.data_ptr(), ml.data_ptr(),
+              _ld(ml), eps.data_ptr(), eps_slot, dml.data_ptr(), _ld(dml), Wml.data_ptr(), He.data_ptr(), _ld(He),
+              dHe.data_ptr(), _ld(dHe), B, Hd, Z)
+
+
 def vae_reparam_fwd(ml, eps, z, kl_part, B, Z, W, bias, H, act, eps_slot=NO_SLOT, stream=None):
     """vae_reparam_wide + the decoder's first layer H = act(z W^T + bias) as ONE launch (gm_vae_reparam_fwd)."""
     from .ops import ACT

@@ -184,6 +184,14 @@ int gm_vae_reparam_wide(void* stream, const float* ml, int64_t ldml, const float
 int gm_vae_reparam_fwd(void* stream, const float* ml, int64_t ldml, const float* eps, gm_slot eps_slot,
                        float* z, int64_t ldz, float* kl_part, int n_part, int B, int Z, const float* W,
                        const float* bias, float* H, int64_t ldh, int N, int act);
+/* The two narrow GEMMs in the middle of the VAE's backward pass as ONE launch (round 4): dz = dHdec W_d1
+ * (W_d1: [Hd, Z], decoder layer 1), d loss / d [mu | log_var] from dz exactly as gm_linear_bwd_dx_reparam's epilogue
+ * forms it (dml: [B, 2Z], written), dHe = (dml W_ml) . [He > 0] (W_ml: [2Z, Hd], the encoder's mu / log_var layer).
+ * One workgroup per 16 rows; same summation orders as gm_linear_bwd_dx_reparam followed by gm_linear_bwd_dx.
+ * Z <= 32, Hd % 4 == 0.  dz itself is not stored. */
+int gm_vae_bwd_mid(void* stream, const float* dHdec, int64_t lddh, const float* Wd1, const float* ml,
+                   int64_t ldml, const float* eps, gm_slot eps_slot, float* dml, int64_t lddml,
+                   const float* Wml, const float* He, int64_t ldhe, float* dHe, int64_t lddhe, int B, int Hd, int Z);
 int gm_vae_reparam_bwd(void* stream, const float* ml, int64_t ldml, const float* eps,
                        gm_slot eps_slot, const float* dz, int64_t lddz, float* dml, int64_t ldd,
                        int B, int Z);

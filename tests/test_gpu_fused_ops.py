@@ -425,3 +425,34 @@ def test_vae_reparam_and_first_decoder_layer_in_one_launch(B, Z, N):
         else:
             ref = torch.relu(z1.double() @ W.double().t() + bias.double())
             assert (h1.double() - ref).abs().max().item() <= 2 * (h0.double() - ref).abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("B,Z,H", [(512, 20, 400), (336, 20, 400), (100, 20, 400), (37, 8, 52), (64, 32, 128),
+                                    (17, 4, 20)])
+def test_vae_backward_mid_chain_in_one_launch(B, Z, H):
+    """gm_vae_bwd_mid == gm_linear_bwd_dx_reparam (dz, d loss / d [mu | log_var]) followed by gm_linear_bwd_dx
+    (dHe = (dml W_ml) . [He > 0]): vae.py:93-113 backwards between the two wide layers.  The summation orders are the
+    separate launches' (asserted: bit-identical dml and dHe), and both against fp64 autograd."""
+    torch.manual_seed(B + Z)
+    dHdec = torch.randn(B, H).to(DEV)
+    Wd1 = (torch.randn(H, Z) / Z ** 0.5).to(DEV)
+    Wml = (torch.randn(2 * Z, H) / H ** 0.5).to(DEV)
+    ml = (torch.randn(B, 2 * Z) * 0.5).to(DEV)
+    He = torch.relu(torch.randn(B, H)).to(DEV)
+    ring = torch.randn(3, B, Z).to(DEV)
+    slot = ops.slot(0, 0, 2, 3, B * Z)
+    dz0, dml0, dHe0 = torch.empty(B, Z, device=DEV), torch.empty(B, 2 * Z, device=DEV), torch.empty(B, H, device=DEV)
+    ops.linear_bwd_dx_reparam(dHdec, Wd1, dz0, ml, ring.view(-1), dml0, eps_slot=slot)
+    ops.linear_bwd_dx(dml0, Wml, dHe0, below=He, epi="relu")
+    dml1, dHe1 = torch.full((B, 2 * Z), 3.0, device=DEV), torch.full((B, H), -3.0, device=DEV)
+    of.vae_bwd_mid(dHdec, Wd1, ml, ring.view(-1), dml1, Wml, He, dHe1, B, eps_slot=slot)
+    torch.cuda.synchronize()
+    assert torch.equal(dml0, dml1)
+    assert torch.equal(dHe0, dHe1)
+    d = lambda t: t.double().cpu()
+    mu, lv, e = d(ml[:, :Z]), d(ml[:, Z:]), d(ring[2])
+    dz = d(dHdec) @ d(Wd1)
+    ref_dml = torch.cat([dz + mu, dz * e * torch.exp(lv / 2) / 2 + 0.5 * (torch.exp(lv) - 1)], 1)
+    ref_dHe = (ref_dml @ d(Wml)) * (d(He) > 0)
+    assert (d(dml1) - ref_dml).abs().max().item() <= 2e-5 * max(1.0, ref_dml.abs().max().item())
+    assert (d(dHe1) - ref_dHe).abs().max().item() <= 2e-5 * max(1.0, ref_dHe.abs().max().item())
