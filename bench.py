@@ -816,7 +816,7 @@ def main():
                                    group_head=eng.group_head, fold_head=eng._fold_head(),
                                    ride_gather=eng._gather_rides(),
                                    pair_dw=eng.pair_dw, fused_adam=eng._adam_in_epilogue("G"),
-                                   ride_head_dx=eng.ride_head_dx and not eng.head_final)
+                                   ride_head_dx=eng.ride_head_dx)
         mhz, cyc_per_mfma = clock_probe()
         log('clock probe: %.0f MHz effective, %.1f cycles per dependent v_mfma_f32_32x32x2_f32' % (mhz, cyc_per_mfma))
         dom = max(kt, key=lambda k: kt[k][0])

@@ -1071,3 +1071,25 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-6 * abs(o.best_val_loss)
     assert torch.equal(o_rng, torch.get_rng_state())
     _param_check(model, o_model, "VAE bs=512 ragged", lr=1e-3)          # vae.py:127: lr = 1e-3
+
+
+def test_bench_contract_line_end_to_end():
+    """`python bench.py` with the driver's flags (short: no CPU legs, no configs section) runs through and prints the
+    contract's JSON line last on stdout, with the roofline object -- the one command of the repo that no other test
+    executes, and the one the round is judged by (round 4: an engine clean-up removed an attribute only bench.py read)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--reps", "2", "--no-cpu-baseline", "--no-configs", "--sustained", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["value"] > 1e6
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "workload" in line["config"]
