@@ -64,14 +64,18 @@ def _device_identity():
     torch build exposes it, else PCI address, else the visible-device string + index)."""
     d = torch.cuda.current_device()
     pr = torch.cuda.get_device_properties(d)
-    for attr in ("uuid", "pci_bus_id"):
+    # EVERY attribute the build exposes, together: a runtime that reports one uuid for all GPUs of a node (seen on
+    # ROCm builds) must not make eight ranks look co-located -- that would pick the two-launch exchange for no reason
+    # and, worse, accept coarse-grained exchange regions across GPUs
+    parts = []
+    for attr in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):
         v = getattr(pr, attr, None)
         if v is not None:
-            if attr == "pci_bus_id":
-                v = (getattr(pr, "pci_domain_id", 0), v, getattr(pr, "pci_device_id", 0))
-            return "%s:%s" % (attr, v)
-    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", ""))
-    return "idx:%s:%d" % (vis, d)
+            parts.append("%s=%s" % (attr, v))
+    if not any(p.startswith("pci_bus_id") for p in parts):
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+        parts.append("idx=%s:%d" % (vis, d))
+    return "|".join(parts)
 
 
 class PeerComm:
