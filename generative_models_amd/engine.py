@@ -1321,6 +1321,16 @@ class GANEngine:
                   self._pre_arrive.data_ptr(), 1)
         self._pre_dirty = True
 
+    def __del__(self):
+        # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
+        try:
+            if getattr(self, "_pre_stream", None) is not None:
+                from . import _lib
+                _lib.load().gm_stream_destroy(self._pre_stream)
+                self._pre_stream = None
+        except Exception:                             # noqa: BLE001  (interpreter teardown)
+            pass
+
     def _join_prestage(self):
         """The launch stream waits for the side stream's last pre-stage (end of run(): whoever synchronizes with the
         launch stream afterwards has then synchronized with every kernel run() issued)."""

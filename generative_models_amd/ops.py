@@ -522,6 +522,13 @@ class Event:
         _lib.call("gm_event_elapsed_ms", self.h, stop.h, ctypes.byref(ms))
         return ms.value
 
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().gm_event_destroy(self.h)
+        except Exception:                             # noqa: BLE001  (interpreter teardown)
+            pass
+
 
 # ---- general autograd path (user-overridden train_D / train_G; README.md:29-31) -----------
 class _MM(torch.autograd.Function):
