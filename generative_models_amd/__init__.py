@@ -19,6 +19,17 @@ def _cpu_quota_cores():
 _QUOTA_APPLIED = False
 
 
+def _ranks_on_node():
+    """Ranks that share THIS node's CPU quota: LOCAL_WORLD_SIZE (torchrun sets it).  WORLD_SIZE alone says nothing
+    about this node -- a multi-node launcher, or independent single-rank jobs that inherited the variable, would make
+    one rank give away its threads to ranks that are not here -- so without LOCAL_WORLD_SIZE the answer is 1."""
+    import os
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or 1))
+    except ValueError:
+        return 1
+
+
 def _respect_cpu_quota(force=True):
     """torch sizes its OpenMP pool by the host's cores (128 on the MI355X boxes) even when the
     container may only use 16 of them: every parallel region then leaves 128 spinning threads that
@@ -42,7 +53,7 @@ def _respect_cpu_quota(force=True):
     # several ranks on one node share the quota: each takes its share, less the two threads every rank keeps busy
     # whatever torch does -- the launch thread and the native fill worker (8 ranks x 2 = the 16-core quota of the
     # MI355X boxes: a third busy thread per rank is what gets the launch threads throttled)
-    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    ranks = _ranks_on_node()
     cap = max(1, int(math.ceil(cores)))
     if ranks > 1:
         cap = max(1, int(cores // ranks) - 2)
@@ -60,7 +71,7 @@ def host_thread_plan():
     import os
 
     import torch
-    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    ranks = _ranks_on_node()
     q = _cpu_quota_cores()
     return {"cgroup_quota_cores": q, "host_cores": os.cpu_count(), "ranks_on_node": ranks,
             "per_rank": {"launch_thread": 1, "native_fill_worker": 1,

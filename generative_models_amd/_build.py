@@ -20,8 +20,10 @@ def needs_build():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, h) for h in HOST_SOURCES] + [os.path.join(CSRC, "gm_common.h"), os.path.join(CSRC, "gm_head.h"), os.path.join(CSRC, "gm_gather.h"),
-                        os.path.join(os.path.dirname(HERE), "include", "gm_hip.h")]
+    # every header under csrc/ (a header added later can never be forgotten here) + the public C-ABI header
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    deps = sources() + [os.path.join(CSRC, h) for h in HOST_SOURCES] + headers + \
+        [os.path.join(os.path.dirname(HERE), "include", "gm_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 

@@ -62,6 +62,7 @@ struct Comm {
     unsigned* arrive;          // device: workgroups of the one-kernel exchange that have written their part of `out`
     int two_kernels;           // 1: reduce and gather as two launches (ranks sharing ONE device: see gm_comm_set_exchange)
     int coarse;                // 1: the region is plain hipMalloc memory (fine-grained allocation refused)
+    int max_blocks;            // workgroups of an exchange launch: what can be co-resident on THIS device (or less)
 };
 
 struct CommP {
@@ -434,6 +435,27 @@ extern "C" int gm_comm_set_exchange(void* comm, int two_kernels) {
     return 0;
 }
 
+// Every workgroup of the one-kernel exchange spins until the last workgroup of every peer has arrived, so all of a
+// launch's workgroups must be co-resident.  Default: what the occupancy API says fits on this device (a CU-masked or
+// partitioned device -- CPX mode, HSA_CU_MASK -- reports fewer CUs), never more than 320; a caller whose ranks share a
+// device lowers it further.  The kernels loop over the bucket, so any positive count is correct.
+static int resident_blocks() {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 64;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xchg_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const long cap = (long)per_cu * pr.multiProcessorCount;
+    return (int)(cap < 320 ? (cap < 1 ? 1 : cap) : 320);
+}
+
+extern "C" int gm_comm_set_max_blocks(void* comm, int max_blocks) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && max_blocks >= 0);
+    const int cap = resident_blocks();
+    cm->max_blocks = (max_blocks == 0 || max_blocks > cap) ? cap : max_blocks;
+    return 0;
+}
+
 extern "C" int gm_comm_error(void* comm, int* flag_out) {
     Comm* cm = static_cast<Comm*>(comm);
     GM_CHECK_ARG(cm && flag_out);
@@ -448,11 +470,12 @@ static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const 
     // one 16-byte element per thread where the bucket allows it (a D+G step's buckets are ~80k
     // float4: 256 workgroups of 256 threads, one pass).  Waiting workgroups poll flags in THEIR OWN
     // memory (peers store remotely), so many pollers cost no xGMI traffic.
+    if (cm->max_blocks <= 0) cm->max_blocks = resident_blocks();
     int blocks = (int)((n / 4 + 255) / 256);
-    if (blocks > 320) blocks = 320;
+    if (blocks > cm->max_blocks) blocks = cm->max_blocks;
     if (blocks < 1) blocks = 1;
     int rblocks = (int)((n / 4 / cm->world + 255) / 256);     // a slice per rank
-    if (rblocks > 320) rblocks = 320;
+    if (rblocks > cm->max_blocks) rblocks = cm->max_blocks;
     if (rblocks < 1) rblocks = 1;
     if (reinterpret_cast<char*>(buf) != cm->base[cm->rank] + cm->lay.in)    // the bucket lives elsewhere
         hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);

@@ -32,7 +32,7 @@
 #include "gm_common.h"
 #include "gm_head.h"
 #include "gm_gather.h"
-#include "gm_slab.h"
+#include "gm_ldsdma.h"
 
 #include <cstdlib>
 #include <type_traits>

@@ -101,6 +101,8 @@ class PeerComm:
         except Exception as e:                       # noqa: BLE001
             err = e
         self.fine_grained = True
+        self.shared_device = False
+        self.two_kernels = False                     # which exchange form the launches take (gm_comm_set_exchange)
         if err is None:
             fg = ctypes.c_int(1)
             _lib.call("gm_comm_info", self.h, ctypes.byref(fg))
@@ -134,6 +136,11 @@ class PeerComm:
             self.shared_device = len({g[2] for g in got}) < world
             if err is None and self.shared_device and os.environ.get("GM_DP_ONE_KERNEL") != "1":
                 _lib.call("gm_comm_set_exchange", self.h, 1)
+                self.two_kernels = True
+            elif err is None and self.shared_device:
+                # the one-kernel form between ranks on ONE device (tests): few spinning workgroups per rank, so that
+                # the co-located ranks' GEMM workgroups still find room on every CU
+                _lib.call("gm_comm_set_max_blocks", self.h, int(os.environ.get("GM_DP_XCHG_BLOCKS", "32")))
             oks = [None] * world
             dist.all_gather_object(oks, err is None, group=group)      # also: every rank has mapped every region
             if not all(oks):

@@ -1567,6 +1567,16 @@ class GANEngine:
             warnings.warn("generative_models_amd: in-graph peer gradient exchange unavailable (%s); "
                           "falling back to host-launched RCCL all-reduces" % self.comm_fallback)
 
+    def exchange_form(self):
+        """Which gradient exchange a step takes: 'none' (one rank), 'one_kernel' / 'two_kernels' (in-graph peer
+        exchange, csrc/gm_comm.hip) or 'rccl' (host-launched fallback)."""
+        if not self._dp():
+            return "none"
+        if not self._peer():
+            return "rccl"
+        comms = getattr(self, "_comms", None) or {}
+        return "two_kernels" if any(c.two_kernels for c in comms.values()) else "one_kernel"
+
     def optim_state(self):
         """Everything the optimizers and controllers carry across steps, after the train() call that
         just finished (checkpointing): Adam moments + step counts per optimizer, InfoGAN's third
@@ -2141,7 +2151,10 @@ class VAEEngine:
             else:
                 dw2 = lambda a1, a2: (dw(*a1), dw(*a2))
             ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            mid = self.fuse_bwd_mid and self.fuse_reparam_bwd and Z <= 32 and self.H % 4 == 0
+            # gm_vae_bwd_mid keeps ONE hidden width (decoder's = encoder's) of at most 512 in its workgroup; other
+            # models (hidden_dim 800 / 1024, unequal widths) take the two generic dX launches below
+            mid = (self.fuse_bwd_mid and self.fuse_reparam_bwd and Z <= 32 and self.H % 4 == 0 and self.H <= 512
+                   and D1.W.shape[0] == self.H and ML.W.shape[1] == self.H)
             if mid:
                 # dz, d loss / d [mu | log_var] and dHe: the two narrow GEMMs between the decoder's and the encoder's
                 # wide ones as ONE launch, 16 rows per workgroup (reads D1.W and ML.W before the pairs step them)

@@ -73,6 +73,9 @@ def vae_reparam_wide(ml, eps, z, kl_part, B, Z, eps_slot=NO_SLOT, stream=None):
 def vae_bwd_mid(dHdec, Wd1, ml, eps, dml, Wml, He, dHe, B, eps_slot=NO_SLOT, stream=None):
     """dz = dHdec W_d1, d loss / d [mu | log_var] (-> dml), dHe = (dml W_ml) . [He > 0] as ONE launch (gm_vae_bwd_mid)."""
     Hd, Z = Wd1.shape
+    if Hd > 512 or Wml.shape[1] != Hd or He.shape[1] < Hd:
+        raise ValueError("vae_bwd_mid: one hidden width <= 512 for decoder and encoder (got %d / %d); use "
+                         "linear_bwd_dx_reparam + linear_bwd_dx" % (Hd, Wml.shape[1]))
     _lib.call("gm_vae_bwd_mid", stream or stream_ptr(), dHdec.data_ptr(), _ld(dHdec), Wd1.data_ptr(), ml.data_ptr(),
               _ld(ml), eps.data_ptr(), eps_slot, dml.data_ptr(), _ld(dml), Wml.data_ptr(), He.data_ptr(), _ld(He),
               dHe.data_ptr(), _ld(dHe), B, Hd, Z)

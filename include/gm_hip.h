@@ -540,6 +540,10 @@ int gm_comm_info(void* comm, int* fine_grained_out);
  * rank's ~300 workgroups spinning on peer flags, which starves the peers' GEMM workgroups of registers when they
  * run on the same CUs (dp.PeerComm sets it from the ranks' device identities). */
 int gm_comm_set_exchange(void* comm, int two_kernels);
+/* Upper bound on the workgroups of one exchange launch.  The one-kernel form needs ALL its workgroups co-resident
+ * (each spins until every peer's last workgroup has arrived): the default (max_blocks = 0) is what the occupancy API
+ * reports for this device or partition (CPX mode, HSA_CU_MASK), at most 320; ranks that share one device pass less. */
+int gm_comm_set_max_blocks(void* comm, int max_blocks);
 /* The region's own bucket (n_floats fp32, 256-byte aligned): a gradient buffer placed here is
  * all-reduced without a staging copy. */
 int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out);

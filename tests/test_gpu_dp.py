@@ -164,7 +164,7 @@ def _train_worker(rank, world, port, variant, kw, q, real=False, cfg=None):
     torch.cuda.synchronize()
     eng = tr._engine
     out = dict(rank=rank, G=list(tr.Glosses), D=list(tr.Dlosses), MI=list(getattr(tr, "MIlosses", [])),
-               mode=eng.comm_mode, world=eng.world,
+               mode=eng.comm_mode, world=eng.world, xchg=eng.exchange_form(),
                params={k: v.cpu().numpy() for k, v in model.state_dict().items()},
                rng=torch.get_rng_state().numpy().tobytes())
     q.put(out)
@@ -173,14 +173,24 @@ def _train_worker(rank, world, port, variant, kw, q, real=False, cfg=None):
         dist.destroy_process_group()
 
 
-def _run_world(world, variant, kw, real=False, cfg=None):
+def _run_world(world, variant, kw, real=False, cfg=None, env=None):
+    """env: extra environment of the rank processes (spawn copies os.environ at start())."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_train_worker, args=(r, world, port, variant, kw, q, real, cfg))
              for r in range(world)]
-    for p in procs:
-        p.start()
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o["rank"])
     for p in procs:
         p.join(timeout=60)
@@ -363,6 +373,34 @@ def test_n_rank_engine_equals_one_rank_full_size(variant, batch, world, kw):
     for o in many[1:]:
         for k, v in many[0]["params"].items():
             assert np.array_equal(v, o["params"][k]), k
+
+
+@pytest.mark.parametrize("variant,batch,world,kw", [("ns", 1024, 2, dict(num_epochs=2)), ("ls", 1024, 4, dict(num_epochs=2)),
+                                                   ("wgp", 256, 2, dict(num_epochs=2, D_steps=1))],
+                         ids=["ns1024-w2", "ls1024-w4", "wgp256-w2"])
+def test_n_rank_training_with_the_one_kernel_exchange(variant, batch, world, kw):
+    """The exchange form a node with one GPU per rank runs (`xchg_kernel`: reduce-scatter + all-gather + Adam in ONE
+    launch per optimizer, csrc/gm_comm.hip) driven through whole TRAINING runs: ranks that share a device default to
+    the two-launch form, GM_DP_ONE_KERNEL=1 keeps the one-kernel form.  N ranks == 1 rank as in the test above, and
+    the two forms agree bit for bit with each other (same per-element summation order over ranks)."""
+    one = _one_rank_full(variant, batch, kw)
+    many = _run_world(world, variant, kw, cfg=_full_cfg(batch), env={"GM_DP_ONE_KERNEL": "1"})
+    assert all(o["world"] == world and o["mode"] == "peer" and o["xchg"] == "one_kernel" for o in many), \
+        [(o["mode"], o["xchg"]) for o in many]
+    for o in many:
+        assert o["rng"] == one["rng"]
+        for key in ("G", "D"):
+            a, b = np.array(o[key]), np.array(one[key])
+            assert a.shape == b.shape and np.max(np.abs(a - b) / np.maximum(1, np.abs(b))) <= 1e-5, key
+        for k, v in o["params"].items():
+            assert np.max(np.abs(v - one["params"][k])) <= 2e-5, k
+    for o in many[1:]:
+        for k, v in many[0]["params"].items():
+            assert np.array_equal(v, o["params"][k]), k
+    two_launch = _run_world(world, variant, kw, cfg=_full_cfg(batch))
+    assert all(o["xchg"] == "two_kernels" for o in two_launch)
+    for k, v in many[0]["params"].items():
+        assert np.array_equal(v, two_launch[0]["params"][k]), "one-kernel vs two-launch exchange: %s" % k
 
 
 def test_two_rank_vae_equals_one_rank_full_size():

@@ -1073,6 +1073,216 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     _param_check(model, o_model, "VAE bs=512 ragged", lr=1e-3)          # vae.py:127: lr = 1e-3
 
 
+# ---------------------------------------------------------------------------------------------
+# Round 5 (VERDICT r4 "what's weak" 1-3).  (a) The reference's own default batch, get_data(BATCH_SIZE=100)
+# (/root/reference/src/utils.py:16), and BASELINE.json configs[0]'s B = 64 at the real widths: neither is a
+# multiple of the 16 / 32-row tiles, so they reach the row-tail paths of every kernel.  (b) LOCKSTEP
+# teacher-forced gradients at full size: before every step the product's parameters are overwritten with the
+# oracle's and both start from the same generator state, so every gradient tensor can be compared without an
+# optimizer in between -- this separates "a kernel computes a wrong gradient" from "Adam's 1 / (sqrt(v) + 1e-8)
+# amplifies a last-bit difference of an almost-zero gradient" (tools/adam_amplification_cpu.py shows two CPU
+# evaluations of the same loop differ by what the GPU path differs from the CPU by).
+# ---------------------------------------------------------------------------------------------
+def _capped_loaders(batch, n_batches, n_train=None):
+    class Capped(torch.utils.data.DataLoader):
+        def __len__(self):
+            return n_batches
+    ld = port.synthetic_loaders(batch, n_train=n_train or FULLCFG["n_train"], n_val=256, n_test=256,
+                                image_shape=FULLCFG["image_shape"])
+    return (Capped(ld[0].dataset, batch_size=batch, shuffle=True),) + ld[1:]
+
+
+# measured parameter deviations (profiles/r05_parity_full_size.jsonl), asserted with a 10-fold margin
+DEFAULT_BATCH_CASES = [("ns", 100, dict(num_epochs=1), 12), ("ns", 64, dict(num_epochs=1), 12),
+                       ("wgp", 100, dict(num_epochs=1, D_steps=5), 6), ("ls", 100, dict(num_epochs=1), 12)]
+DEFAULT_BATCH_PARAM_BOUND = {"ns_b100": 2e-4, "ns_b64": 2e-4, "wgp_b100": 1e-4, "ls_b100": 2e-4}
+
+
+@pytest.mark.parametrize("variant,batch,kw,steps", DEFAULT_BATCH_CASES,
+                         ids=["%s_b%d" % (v, b) for v, b, _, _ in DEFAULT_BATCH_CASES])
+def test_reference_default_batch_full_size(variant, batch, kw, steps):
+    """784-400-20 at B = 100 (utils.py:16: every number in BASELINE.md was taken at it) and B = 64: free-running
+    iterations against the CPU oracle; losses 1e-5, sampling protocol bit-exact, parameters tensor by tensor."""
+    nb = steps * kw.get("D_steps", 1)
+    ld = _capped_loaders(batch, nb)
+    o_model = port.build(variant, 784, 400, 20)
+    o = port.GANPort(variant, o_model, ld[0])
+    o.train(**kw)
+    o_rng = torch.get_rng_state()
+    tr, model = build_product(variant, FULLCFG, batch, loaders=_capped_loaders(batch, nb))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(**kw)
+    torch.cuda.synchronize()
+    assert tr._engine is not None and tr._stock() and len(tr.Glosses) == steps
+    lclose(tr.Dlosses, o.Dlosses, "%s bs=%d Dlosses" % (variant, batch))
+    lclose(tr.Glosses, o.Glosses, "%s bs=%d Glosses" % (variant, batch))
+    assert torch.equal(o_rng, torch.get_rng_state())
+    dev = _param_dev(model, o_model, 2e-4)
+    _record("reference_default_batch_full_size[%s_b%d]" % (variant, batch), steps=steps,
+            Dloss_err=_loss_err(tr.Dlosses, o.Dlosses), Gloss_err=_loss_err(tr.Glosses, o.Glosses), params=dev)
+    bound = DEFAULT_BATCH_PARAM_BOUND["%s_b%d" % (variant, batch)]
+    for k, v in dev.items():
+        assert v["max"] <= bound and v["mean"] <= 1e-6, (k, v)
+
+
+def test_vae_reference_default_batch_full_epoch():
+    """vae.py with the reference's default loaders: B = 100, 50 000 images = 500 batches per epoch, no ragged tail,
+    + the validation pass; one whole epoch free-running against the CPU oracle."""
+    import vae
+    mk = lambda: port.synthetic_loaders(100, n_train=50000, n_val=1000, n_test=200, image_shape=(1, 28, 28))
+    ld0 = mk()
+    o_model = port.build("vae", 784, 400, 20)
+    o = port.VAEPort(o_model, *ld0)
+    o.train(1)
+    o_rng = torch.get_rng_state()
+    ld = mk()
+    torch.manual_seed(1234)
+    model = vae.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = vae.VAETrainer(model, *ld, viz=False)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(num_epochs=1)
+    torch.cuda.synchronize()
+    assert len(tr.recon_loss) == 500 and tr._engine is not None
+    assert torch.equal(o_rng, torch.get_rng_state())
+    r, k = np.asarray(tr.recon_loss), np.asarray(tr.kl_loss)
+    er = np.abs(r - np.asarray(o.recon_loss)) / np.maximum(1, np.abs(o.recon_loss))
+    ek = np.abs(k - np.asarray(o.kl_loss)) / np.maximum(1, np.abs(o.kl_loss))
+    _record("vae_b100_full_epoch", recon_err_first50=float(er[:50].max()), kl_err_first50=float(ek[:50].max()),
+            recon_err_500=float(er.max()), kl_err_500=float(ek.max()),
+            best_val_rel_err=abs(tr.best_val_loss - o.best_val_loss) / abs(o.best_val_loss),
+            params=_param_dev(model, o_model, 1e-3))
+    assert max(er[:50].max(), ek[:50].max()) <= TOL, (er[:50].max(), ek[:50].max())
+    # 500 free-running Adam steps: stated, not north_star's short-horizon 1e-5 (the measured value is recorded)
+    assert max(er.max(), ek.max()) <= 1e-3, (er.max(), ek.max())
+    assert abs(tr.best_val_loss - o.best_val_loss) <= 1e-4 * abs(o.best_val_loss)
+
+
+def _grad_errs(pairs):
+    """[(name, got, ref)] -> {name: (abs err, scale)}"""
+    return {n: (float((g.cpu() - r).abs().max()), float(r.abs().max())) for n, g, r in pairs}
+
+
+LOCKSTEP_CASES = [("ns", 256, {}), ("wgp", 256, {}), ("ls", 1024, {}), ("ns", 1024, {}), ("ns", 100, {}),
+                  ("f", 256, dict(method="hellinger")), ("f", 256, dict(method="pearson"))]
+GRAD_TOL = 1e-5            # relative to the tensor's largest gradient element (VERDICT r4 item 1)
+GRAD_ABS = 1e-7            # + an absolute floor: the critic's output-bias gradient is two nearly cancelling half-sums
+
+
+@pytest.mark.parametrize("variant,batch,kw", LOCKSTEP_CASES,
+                         ids=["%s_b%d%s" % (v, b, "_" + k["method"] if "method" in k else "") for v, b, k in LOCKSTEP_CASES])
+def test_full_size_teacher_forced_gradients_lockstep(variant, batch, kw):
+    """784-400-20, three D+G iterations in lockstep: same parameters, same generator state, same batch and noise on
+    both sides before every iteration; dL_D / dD-parameters of the critic step and dL_G / dG-parameters of the
+    generator step (on the critic as updated by the step before it) against the oracle's autograd, tensor by
+    tensor (ns_gan.py:122-156, w_gp_gan.py:177-220, ls_gan.py:95-171, f_gan.py:99-142)."""
+    steps = 3
+    grads = {}
+
+    def tap(kind, tr_, info):
+        if kind in ("D", "G"):
+            grads[kind] = [p.grad.detach().clone() for p in getattr(tr_.model, kind).parameters()]
+    ld_o = _capped_loaders(batch, 1)
+    o_model = port.build(variant, 784, 400, 20)
+    okw = dict(kw)
+    o = port.GANPort(variant, o_model, ld_o[0], method=okw.pop("method", "jensen_shannon"), tap=tap)
+    tr, model = build_product(variant, FULLCFG, batch, loaders=_capped_loaders(batch, 1))
+    import contextlib, io
+    worst = {}
+    for step in range(steps):
+        model.load_state_dict(o_model.state_dict())               # teacher forcing: the oracle's parameters
+        s0 = torch.get_rng_state()
+        o.train(num_epochs=1, D_steps=1, max_steps=1, **okw)
+        s1 = torch.get_rng_state()
+        torch.set_rng_state(s0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(num_epochs=1, D_steps=1, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(s1, torch.get_rng_state()), "same draws on both sides (step %d)" % step
+        eng = tr._engine
+        assert eng is not None and tr._stock()
+        lclose(tr.Dlosses[-1:], o.Dlosses[-1:], "lockstep D loss")
+        lclose(tr.Glosses[-1:], o.Glosses[-1:], "lockstep G loss")
+        for net, fp in (("D", eng.fD), ("G", eng.fG)):
+            names = [n for n, _ in getattr(model, net).named_parameters()]
+            pairs = [("%s.%s" % (net, n), fp.grad[off:off + p_.numel()].view(p_.shape), ref)
+                     for n, p_, off, ref in zip(names, fp.params, fp.offsets, grads[net])]
+            for n, (aerr, scale) in _grad_errs(pairs).items():
+                rel = aerr / max(scale, 1e-30)
+                if rel > worst.get(n, (0, 0, 0))[0]:
+                    worst[n] = (rel, aerr, scale)
+    _record("full_size_teacher_forced_lockstep[%s_b%d%s]" % (variant, batch, "_" + kw["method"] if "method" in kw else ""),
+            steps=steps, grad_rel_err={n: v[0] for n, v in worst.items()}, grad_abs_err={n: v[1] for n, v in worst.items()},
+            grad_scale={n: v[2] for n, v in worst.items()})
+    for n, (rel, aerr, scale) in worst.items():
+        assert aerr <= GRAD_TOL * scale + GRAD_ABS, (variant, batch, n, rel, aerr, scale)
+
+
+@pytest.mark.parametrize("batch", [512, 100])
+def test_vae_full_size_teacher_forced_gradients_lockstep(batch):
+    """vae.py:193-212 at 784-400-20: four batches in lockstep (one training batch + the validation pass per call),
+    every parameter's gradient of recon + kl against the oracle's autograd."""
+    import vae
+    steps = 4
+    mk = lambda: port.synthetic_loaders(batch, n_train=batch, n_val=batch, n_test=batch, image_shape=(1, 28, 28))
+    ld0 = mk()
+    o_model = port.build("vae", 784, 400, 20)
+    o = port.VAEPort(o_model, *ld0)
+    ld = mk()
+    torch.manual_seed(1234)
+    model = vae.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = vae.VAETrainer(model, *ld, viz=False)
+    import contextlib, io
+    worst = {}
+    for step in range(steps):
+        model.load_state_dict(o_model.state_dict())
+        s0 = torch.get_rng_state()
+        o.train(1)
+        s1 = torch.get_rng_state()
+        torch.set_rng_state(s0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(num_epochs=1)
+        torch.cuda.synchronize()
+        assert torch.equal(s1, torch.get_rng_state())
+        lclose(tr.recon_loss[-1:], o.recon_loss[-1:], "lockstep recon", tol=2e-6)
+        lclose(tr.kl_loss[-1:], o.kl_loss[-1:], "lockstep kl", tol=2e-6)
+        fp = tr._engine.fp
+        ref = dict(o_model.named_parameters())
+        name_of = {id(p_): n for n, p_ in model.named_parameters()}
+        pairs = [(name_of[id(p_)], fp.grad[off:off + p_.numel()].view(p_.shape), ref[name_of[id(p_)]].grad)
+                 for p_, off in zip(fp.params, fp.offsets)]
+        assert len(pairs) == len(ref)
+        for n, (aerr, scale) in _grad_errs(pairs).items():
+            rel = aerr / max(scale, 1e-30)
+            if rel > worst.get(n, (0, 0, 0))[0]:
+                worst[n] = (rel, aerr, scale)
+    _record("vae_full_size_teacher_forced_lockstep[b%d]" % batch, steps=steps,
+            grad_rel_err={n: v[0] for n, v in worst.items()}, grad_abs_err={n: v[1] for n, v in worst.items()},
+            grad_scale={n: v[2] for n, v in worst.items()})
+    for n, (rel, aerr, scale) in worst.items():
+        assert aerr <= GRAD_TOL * scale + GRAD_ABS, (batch, n, rel, aerr, scale)
+
+
+@pytest.mark.parametrize("hidden", [528, 800])
+def test_vae_hidden_wider_than_the_fused_backward(hidden):
+    """gm_vae_bwd_mid keeps one hidden width <= 512 per workgroup (gm_fused.hip); VAE(hidden_dim=800) must take the
+    two generic dX launches instead of raising."""
+    cfg = dict(SMALL, hidden_dim=hidden)
+    loaders = port.synthetic_loaders(cfg["batch"], n_train=160, n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                     image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build("vae", cfg["image_size"], hidden, cfg["z_dim"])
+    o = port.VAEPort(o_model, *loaders)
+    o.train(1)
+    o_rng = torch.get_rng_state()
+    p, p_model, p_rng = run_vae_product(cfg, cfg["batch"], 160, 1)
+    lclose(np.array(p.recon_loss) / 100, np.array(o.recon_loss) / 100, "vae recon")
+    lclose(p.kl_loss, o.kl_loss, "vae kl", tol=1e-5)
+    assert torch.equal(o_rng, p_rng)
+    for (k, a), (_, b) in zip(p_model.state_dict().items(), o_model.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5, k
+
+
 def test_bench_contract_line_end_to_end():
     """`python bench.py` with the driver's flags (short: no CPU legs, no configs section) runs through and prints the
     contract's JSON line last on stdout, with the roofline object -- the one command of the repo that no other test

@@ -57,3 +57,13 @@ def test_import_has_no_side_effect():
     code = ("import torch; torch.set_num_threads(7); import sys; sys.path.insert(0, %r); "
             "import generative_models_amd; assert torch.get_num_threads() == 7" % ROOT)
     subprocess.run([sys.executable, "-c", code], check=True, timeout=300)
+
+
+def test_only_local_world_size_counts_as_ranks_on_this_node(monkeypatch):
+    """WORLD_SIZE alone (multi-node launchers, inherited environments) must not shrink this rank's thread share."""
+    import generative_models_amd as gm
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "64")
+    assert gm._ranks_on_node() == 1 and gm.host_thread_plan()["ranks_on_node"] == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert gm._ranks_on_node() == 8

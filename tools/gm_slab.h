@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../generative_models_amd/csrc/gm_ldsdma.h"
 
 namespace slab {
 
@@ -62,24 +63,9 @@ struct CoreP {
     Split sp;
 };
 
-// ---- LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_byte + 16 * lane -------------------------
-// (asm statement: hipcc does not count it -- every wait below is explicit; M0 is written and restored inside)
-__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_byte) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// raw workgroup barrier (no vmcnt drain: LDS-DMA stays in flight across it), fenced for the compiler on both sides
-__device__ __forceinline__ void sync_raw() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 __device__ __forceinline__ void stamp(const Split& sp, int i) {
     if (sp.trace && threadIdx.x == 0) sp.trace[blockIdx.x * 8 + i] = __builtin_readcyclecounter();
 }
-__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // wait until at most `units` * NP of this wave's DMA pieces are outstanding (units: wave-uniform, 0 .. MAXU)
 template <int NP, int MAXU>

@@ -1,4 +1,4 @@
-// slab_probe.hip -- stand-alone check + timing of the slab GEMM family (csrc/gm_slab.h) against an fp64 host
+// slab_probe.hip -- stand-alone check + timing of the slab GEMM family (tools/gm_slab.h) against an fp64 host
 // reference, the shipped split-reduction kernels (libgm_hip.so through the C-ABI) and the vendor's sgemm, all in one
 // process on one box.  Build: tools/build_slab_probe.sh ; run on the GPU box: tools/slab_probe.bin [reps]
 #include <hip/hip_runtime.h>
@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../generative_models_amd/csrc/gm_slab.h"
+#include "gm_slab.h"
 #include "../include/gm_hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
