@@ -384,8 +384,50 @@ def cpu_baseline_gan(variant="ns", B=B_PER_GPU, seconds_target=12.0, compute_onl
                          "compute only (fixed pre-fetched batch)" if compute_only
                          else "as-written incl. DataLoader reshuffle", dt) +
                       "; kind 'port' = the oracle's restatement, pinned bit for bit to the unmodified reference "
-                      "(tests/test_oracle_pin.py) and measured 16 % FASTER than it on 8 threads (10.3 vs 12.3 ms/step): "
-                      "a harder CPU baseline than the reference itself, which cannot travel to the GPU box"}
+                      "(tests/test_oracle_pin.py), used where the reference is not mounted (the GPU box); the two timed "
+                      "side by side on one host: profiles/r05_cpu_reference_vs_port.json"}
+
+
+def cpu_baseline_reference(B=B_PER_GPU, seconds_target=12.0, cores=None):
+    """SURVEY.md 8(d) as written: the UNMODIFIED reference's NSGANTrainer.train (/root/reference/src/ns_gan.py:94-170,
+    loaded by oracle/ref_harness.py) timed on this host's cores on the same synthetic data -- only where the reference is
+    mounted (GM_REFERENCE_ROOT, default /root/reference: the build container; never on the GPU box, which falls back
+    to the port).  Returns None when it is not."""
+    from oracle import ref_harness
+    if not ref_harness.available():
+        return None
+    mod = ref_harness.load("ns_gan")
+    ds = synthetic_dataset()
+
+    class Capped(torch.utils.data.DataLoader):
+        cap = 1
+
+        def __len__(self):
+            return self.cap
+    mk = lambda: torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True)
+    train_iter = Capped(ds, batch_size=B, shuffle=True)
+    torch.manual_seed(1234)
+    model = mod.NSGAN(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    tr = mod.NSGANTrainer(model, train_iter, mk(), mk(), viz=False)
+
+    def step(n):
+        train_iter.cap = n
+        with ref_harness.quiet():
+            tr.train(num_epochs=1)
+    if cores is None:
+        per_step, cores = _probe_threads(step)
+    else:
+        torch.set_num_threads(cores)
+        step(2)
+        t0 = time.perf_counter(); step(4); per_step = (time.perf_counter() - t0) / 4
+    total = int(max(8, min(2000, seconds_target / per_step)))
+    t0 = time.perf_counter()
+    step(total)
+    dt = time.perf_counter() - t0
+    return {"value": total * B / dt, "unit": "images/sec", "cores": cores, "kind": "reference",
+            "sample": "%d NSGAN bs=%d D+G steps of the unmodified reference's NSGANTrainer.train (ns_gan.py:94-170 via "
+                      "oracle/ref_harness.py, torch %s CPU, %d threads), as-written incl. the per-step DataLoader "
+                      "reshuffle, %.1f s" % (total, B, torch.__version__, cores, dt)}
 
 
 def cpu_baseline_vae(B=512, seconds_target=5.0, cores=16):
@@ -454,6 +496,9 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
                               world_size=world, rank=rank, force_dp=force_dp)
     eng.configure(W + reps * K + long_steps + (SUSTAINED_MAX_STEPS if sustained_s else 0), lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
+    # graphs of the exact lengths the timed runs launch exist before the clock starts (a trainer captures them during
+    # its first epoch; the other launch paths captured theirs in configure already: no-op there)
+    eng.prepare(K)
     marks = []
 
     def rep(r):
@@ -471,6 +516,7 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     if long_steps:
         # one long region right behind the timed ones: the steady-state step, so that the fixed cost
         # of a K-step run() (cold start of the host draws, graph boundaries, final sync) can be reported
+        eng.prepare(long_steps)
         ls = timed_reps(lambda r: eng.run(long_steps, it_start=W + reps * K), 1, long_steps,
                         1 if solo else world, dev)
         eng.steady_us_per_step = ls[0] / long_steps * 1e6
@@ -480,6 +526,7 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
         # ONE uninterrupted window of >= sustained_s seconds of the same step (host draws inside, as everywhere): long
         # enough for an outside observer sampling GPU activity every few seconds (the driver's gpu_busy) to see it
         n_sus = int(min(SUSTAINED_MAX_STEPS, sustained_s * 1e6 / eng.steady_us_per_step + 1))
+        eng.prepare(n_sus)
         su = timed_reps(lambda r: eng.run(n_sus, it_start=W + reps * K + long_steps), 1, n_sus,
                         1 if solo else world, dev)
         eng.sustained = {"seconds": su[0], "steps": n_sus, "us_per_step": su[0] / n_sus * 1e6,
@@ -561,7 +608,24 @@ def dominant_gemm_roofline(shapes, B, pmc_tag=None, reps=50):
          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}}
     e["traffic"], e["traffic_source"] = pmc_traffic(name, pmc_tag)
     e["hbm_gbps"] = (e["traffic"] / (e["avg_launch_us"] * 1e-6) / 1e9) if e["traffic"] else None
+    if pmc_tag is not None:
+        e.update(profile_check(name, e["avg_launch_us"], pmc_tag))
     return e
+
+
+def profile_check(kernel, live_us, tag):
+    """{"profile_kernel_us", "profile_source", "stale_profile"}: the committed rocprofv3 average duration of `kernel`
+    (profiles/<round>_<tag>_kernel_stats.csv) beside this run's HIP-event figure; stale when they differ by > 10 % or
+    the committed summary does not list the kernel at all."""
+    import csv
+    src = "%s_%s_kernel_stats.csv" % (PROFILE_ROUND, tag)
+    try:
+        rows = {r["kernel"]: float(r["avg_us"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", src)))}
+    except Exception:                                # noqa: BLE001
+        return {"profile_kernel_us": None, "profile_source": None, "stale_profile": True}
+    us = rows.get(kernel)
+    return {"profile_kernel_us": us, "profile_source": "profiles/" + src,
+            "stale_profile": us is None or abs(us - live_us) > 0.10 * live_us}
 
 
 def pmc_traffic(kernel, tag):
@@ -604,6 +668,7 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
                  gemm_shapes_wgp(B, eng._fold_head_G()) if variant == "wgp" else
                  gemm_shapes(B, fold_head=eng._fold_head()), B,
                  pmc_tag={"wgp": "wgp_b256", "ns": "ns_b1024", "ls": "ns_b1024"}.get(variant))}   # (LSGAN: NSGAN's launches)
+        e["roofline"]["step_frac"] = e["step_mfma_frac"]
         if cpu:
             deferred.append((e, lambda: cpu_baseline_gan(cpu_variant, B, seconds_target=4.0, cores=16)))
         log("%s: %.0f img/s" % (name, e["img_s"]))
@@ -647,6 +712,7 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
              "img_s": img_s, "ms_per_step": ms, "steps": n,
              "step_mfma_frac": img_s * 3_280_000 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
              "roofline": dominant_gemm_roofline(gemm_shapes_vae(512), 512, pmc_tag="vae_b512")}
+        e["roofline"]["step_frac"] = e["step_mfma_frac"]
         if cpu and not with_eval:
             deferred.append((e, lambda: cpu_baseline_vae(512)))
         log("%s: %.0f img/s" % (e["workload"], img_s))
@@ -850,15 +916,15 @@ def main():
                        "steady_512_steps": ({"steps": 512, "us_per_step": eng.steady_us_per_step,
                                              "img_s": B_global / eng.steady_us_per_step * 1e6}
                                             if eng.steady_us_per_step else None),
-                       "sustained_window": eng.sustained},
-            # steady-state step of the same engine (one 512-step region behind the timed ones) and what a
-            # K-step run() costs on top of K of those: cold start of the host draws, graph boundaries, final sync
+                       "sustained_window": eng.sustained,
+                       # steady-state step of the same engine (the 512-step region) and what a K-step run() costs on
+                       # top of K of those: cold start of the host draws, graph boundaries, final synchronize
+                       "steady_us_per_step": eng.steady_us_per_step,
+                       "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if eng.steady_us_per_step else None},
+            # (top-level copies of config.steady_us_per_step / run_fixed_cost_us / roofline.step_frac: tools read them)
             "steady_us_per_step": eng.steady_us_per_step,
             "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if eng.steady_us_per_step else None,
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-            # compulsory HBM bytes of a step (Adam 7 x 4 B/param + gradient write + image rows +
-            # noise = 82 944 B/image at B=256) against 8 TB/s: the path is nowhere near the HBM roof
-            "step_hbm_frac": img_s / world * BYTES_PER_IMAGE_B256 / 8.0e12,
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
@@ -869,8 +935,15 @@ def main():
                          "hbm_gbps": (traffic / (t_us / n * 1e-6) / 1e9) if traffic else None,
                          "hbm_frac_of_8tbs": (traffic / (t_us / n * 1e-6) / 8.0e12) if traffic else None,
                          "launches_per_step": n, "avg_launch_us": t_us / n,
-                         "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}},
+                         "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()},
+                         # the WHOLE step against the same peak (6 326 400 FLOP per image), and its compulsory HBM bytes
+                         # (82 944 B per image at B = 256) against 8 TB/s: nowhere near the HBM roof
+                         "step_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                         "step_hbm_frac": img_s / world * BYTES_PER_IMAGE_B256 / 8.0e12},
         }
+        # the committed rocprofv3 average of the same kernel beside the live figure: a profile that no longer
+        # describes the built kernels shows here, not in a reviewer's diff
+        line["roofline"].update(profile_check(dom, t_us / n, "nsgan_b256"))
         del eng
         if world > 1:
             line["config"]["n1_img_s_same_run"] = n1_img_s
@@ -879,13 +952,20 @@ def main():
                 line["dp_series"] = series
         if world == 1 and not force_dp:
             if not args.no_configs:
-                line["trainer"] = bench_trainer()
-                # (GPU legs of the configs section first, every CPU baseline after them: see other_configs)
-                line["configs"] = other_configs(dev, min(K, 400), W, min(reps, 3), cpu=not args.no_cpu_baseline)
+                # INSIDE `config`: the driver's record keeps the contract keys + config / roofline / cpu_baseline
+                line["config"]["trainer"] = bench_trainer()
+                # (GPU legs of the configs section first, every CPU baseline after them: see other_configs); each
+                # entry carries its own roofline and cpu_baseline
+                line["config"]["other_configs"] = other_configs(dev, min(K, 400), W, min(reps, 3),
+                                                                cpu=not args.no_cpu_baseline)
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline_gan("ns", B_PER_GPU)
-                line["cpu_baseline_compute_only"] = cpu_baseline_gan(
+                ref = cpu_baseline_reference(B_PER_GPU)          # the unmodified reference where it is mounted
+                line["cpu_baseline"] = ref if ref is not None else cpu_baseline_gan("ns", B_PER_GPU)
+                if ref is not None:
+                    line["cpu_baseline"]["port"] = cpu_baseline_gan("ns", B_PER_GPU, seconds_target=6.0, cores=ref["cores"])
+                line["cpu_baseline"]["compute_only"] = cpu_baseline_gan(
                     "ns", B_PER_GPU, seconds_target=5.0, compute_only=True, cores=line["cpu_baseline"]["cores"])
+                line["cpu_baseline"]["gpu_over_cpu"] = img_s / line["cpu_baseline"]["value"]
         out_line = json.dumps(line)
     else:
         out_line = None

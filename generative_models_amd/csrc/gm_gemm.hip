@@ -33,6 +33,7 @@
 #include "gm_head.h"
 #include "gm_gather.h"
 #include "gm_ldsdma.h"
+#include "gm_stage.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -1205,12 +1206,17 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
+// Round 5: workgroups [0, nstage) in front of the tiles are the stage-AHEAD rider (gm_stage.h): they bring the NEXT
+// iteration's draws into the device rings while the tiles run (nstage == 0: none, `sa` unused).  `sa` lives in DEVICE
+// memory (gm_stage_ahead_pack): its segment table is indexed by the rider's workgroup id, and a by-value kernel
+// argument indexed dynamically is copied to scratch by the compiler (392 bytes per lane of EVERY workgroup of the pair).
 template <int G, bool XV, int MI, int NI, bool DMA = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
-                                                              int tnb) {
+                                                              int tnb, const StageAheadP* sa, int nstage) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, DMA, MI, NI>::value];
-    const int id = blockIdx.x;
-    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
+    const int id = (int)blockIdx.x - nstage;
+    if (id < 0) stage_ahead_body(*sa, (int)blockIdx.x, reinterpret_cast<int*>(red));
+    else if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
     else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
@@ -1263,6 +1269,8 @@ struct Rider {
     const GemmP* pair = nullptr;         // MODE_DW: a second weight-gradient GEMM
     bool pair_xvec = false;
     const gm_fin2* fin = nullptr;        // MODE_DW pair: the VAE batch's two loss sums + counter tick
+    const StageAheadP* stage = nullptr;  // MODE_DW pair: the next iteration's draws, host ring -> device ring (DEVICE memory)
+    int stage_blocks = 0;                //               its workgroups (n_segs * parts)
 };
 
 // Tile shapes of the 16-wave kernels, as sub-tiles (16 x 16) per wave: MI x NI
@@ -1427,16 +1435,19 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 p.dma = pb.dma = dma;
                 const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                 const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
-                const dim3 pgrid(na + tnb * tmb);
-#define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb)
-#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(pgrid.x + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
+                const StageAheadP* sa = rider.stage;
+                const int nstage = rider.stage ? rider.stage_blocks : 0;
+                const dim3 pgrid(na + tnb * tmb + nstage);
+#define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb, sa, nstage)
+#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(na + tnb * tmb + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
                 if (rider.fin) GM_TILE_SWITCH(tile, dma, GM_LPF);
                 else GM_TILE_SWITCH(tile, dma, GM_LP);
 #undef GM_LPF
 #undef GM_LP
                 GM_LAUNCH_RET();
             }
-            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums theirs)
+            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums theirs;
+            // the stage-ahead rider is simply dropped: the next graph's first node stages that iteration itself)
             Rider none;
             int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
             if (rc) return rc;
@@ -1781,6 +1792,53 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
     Rider r;
     r.pair = &pb;
     r.pair_xvec = xb;
+    return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
+}
+
+extern "C" int gm_stage_ahead_pack(const gm_stage_ahead_args* st, void* dev_buf, int64_t dev_buf_bytes) {
+    GM_CHECK_ARG(st && dev_buf && dev_buf_bytes >= (int64_t)sizeof(StageAheadP));
+    GM_CHECK_ARG(st->segs && st->n_segs > 0 && st->n_segs <= GM_STAGE_MAX_SEGS && st->parts >= 1 && st->parts <= 8);
+    GM_CHECK_ARG(st->gate && st->range && st->arrive && st->timeout_s > 0.0 && st->timeout_s < 3600.0);
+    StageAheadP sa{};
+    for (int i = 0; i < st->n_segs; ++i) {
+        const gm_stage_seg& g = st->segs[i];
+        const int m = g.blocks > 1 ? g.blocks : 1;
+        GM_CHECK_ARG(g.src && g.dst && g.bytes_per_iter > 0 && g.blocks >= 0 && g.bytes_per_iter % (4 * m) == 0);
+        GM_CHECK_ARG(g.src_block_stride >= 0 && g.dst_block_stride >= 0 && g.src_block_stride % 4 == 0 &&
+                     g.dst_block_stride % 4 == 0);
+        GM_CHECK_ARG(!g.src_block_stride || g.src_block_stride >= g.bytes_per_iter / m);
+        GM_CHECK_ARG(!g.dst_block_stride || g.dst_block_stride >= g.bytes_per_iter / m);
+        sa.seg[i] = g;
+    }
+    sa.n_segs = st->n_segs; sa.parts = st->parts; sa.ring_slot = st->ring_slot; sa.it_slot = st->it_slot;
+    sa.gate = st->gate; sa.timeout = (uint64_t)(st->timeout_s * 1e8);           // wall_clock64(): 100 MHz
+    sa.range = reinterpret_cast<unsigned long long*>(st->range); sa.arrive = st->arrive;
+    const hipError_t e = hipMemcpy(dev_buf, &sa, sizeof(sa), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gm_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+extern "C" int gm_linear_bwd_dw_adam_pair_stage(void* stream, const gm_dw_adam_args* first,
+                                                const gm_dw_adam_args* second, const void* packed, int n_blocks) {
+    GM_CHECK_ARG(first && second && packed && n_blocks >= 1 && n_blocks <= 8 * GM_STAGE_MAX_SEGS);
+    GM_CHECK_ARG(first->dW != second->dW && (first->pW != second->pW || !first->pW));
+    GM_CHECK_ARG(!first->pW || ((const float*)first->pW != second->dA && (const float*)first->pW != second->X));
+    GM_CHECK_ARG(!second->pW || ((const float*)second->pW != first->dA && (const float*)second->pW != first->X));
+    GM_CHECK_ARG(first->dW != second->dA && first->dW != second->X && second->dW != first->dA && second->dW != first->X);
+    GemmP pa{}, pb{};
+    bool xa = false, xb = false;
+    int rc = dw_adam_fill(*first, &pa, &xa);
+    if (rc) return rc;
+    rc = dw_adam_fill(*second, &pb, &xb);
+    if (rc) return rc;
+    Rider r;
+    r.pair = &pb;
+    r.pair_xvec = xb;
+    r.stage = static_cast<const StageAheadP*>(packed);
+    r.stage_blocks = n_blocks;
     return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
 }
 

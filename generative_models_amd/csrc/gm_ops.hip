@@ -2,6 +2,7 @@
 // score gradients, flat Adam (+WGAN clamp), the per-graph tick, and HIP-graph / event helpers.
 #include "gm_common.h"
 #include "gm_gather.h"
+#include "gm_stage.h"
 
 #include <string>
 
@@ -33,72 +34,6 @@ extern "C" int gm_tick(void* stream, int64_t* ctr, int64_t inc) {
 // + DMA start-up per sub-chunk, 60-100 us at the head of a short run) by one ~2 us launch inside
 // the graph; the slot is resolved from the device counter like every other per-step address.
 // ------------------------------------------------------------------------------------------
-struct StageP {
-    gm_stage_seg seg[GM_STAGE_MAX_SEGS];
-    int n_segs;
-    gm_slot slot;
-    int n_iters;
-    // fill gate (gm_stage_in_gated): the graph may be launched BEFORE the host has finished writing
-    // its iterations' ring slots; every workgroup waits until *gate (pinned host memory, advanced by
-    // the host after each sub-chunk of draws) covers them.  Bounded: after `timeout` ticks of the
-    // 100 MHz wall clock the kernel raises gate[1] and copies what is there (the host checks it).
-    const int64_t* gate;
-    gm_slot it_slot;
-    uint64_t timeout;
-    int64_t* publish;       // optional: workgroup (0,0) stores the absolute iteration of it_slot here (a
-                            // stable base for a second stage-in that runs concurrently with iterations
-                            // that advance the step counter)
-    // pre-staging (gm_stage_in_prestaged): *range = (lo << 32) | hi, the iterations [lo, hi) an EARLIER launch on
-    // another stream has already brought into the device rings.  mark == 0: this launch returns at once when its
-    // own iterations are inside the range; mark == 1: this launch is such an earlier one -- its last workgroup to
-    // finish (arrive) extends the range (or restarts it at its own iterations when they do not continue it).
-    unsigned long long* range;
-    unsigned int* arrive;
-    int mark;
-};
-
-__device__ __forceinline__ void stage_copy(const StageP& p) {
-    const gm_stage_seg sg = p.seg[blockIdx.y];
-    const int64_t first = gm_slot_index(p.slot);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = sg.blocks > 1 ? sg.blocks : 1;
-    const int64_t bb = sg.bytes_per_iter / m;                     // bytes per piece
-    const int64_t ss = sg.src_block_stride ? sg.src_block_stride : bb;
-    const int64_t ds = sg.dst_block_stride ? sg.dst_block_stride : bb;
-    const int64_t nblk = (int64_t)p.n_iters * m;
-    const char* src = reinterpret_cast<const char*>(sg.src) + first * m * ss;
-    char* dst = reinterpret_cast<char*>(sg.dst) + first * m * ds;
-    if (ss == bb && ds == bb) {                                   // dense: one flat range
-        const int64_t bytes = bb * nblk;
-        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 15) == 0) {
-            const uint4* s4 = reinterpret_cast<const uint4*>(src);
-            uint4* d4 = reinterpret_cast<uint4*>(dst);
-            for (int64_t i = t; i < bytes / 16; i += stride) d4[i] = s4[i];
-        } else {                                      // odd test shapes: 4-byte granularity
-            const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
-            uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
-            for (int64_t i = t; i < bytes / 4; i += stride) d1[i] = s1[i];
-        }
-        return;
-    }
-    // strided pieces (a data-parallel rank's rows of every draw of the global batch)
-    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bb | (uintptr_t)ss |
-          (uintptr_t)ds) & 15) == 0) {
-        const int64_t upb = bb / 16;
-        for (int64_t u = t; u < nblk * upb; u += stride) {
-            const int64_t q = u / upb, o = u - q * upb;
-            reinterpret_cast<uint4*>(dst + q * ds)[o] = reinterpret_cast<const uint4*>(src + q * ss)[o];
-        }
-    } else {
-        const int64_t upb = bb / 4;
-        for (int64_t u = t; u < nblk * upb; u += stride) {
-            const int64_t q = u / upb, o = u - q * upb;
-            reinterpret_cast<uint32_t*>(dst + q * ds)[o] = reinterpret_cast<const uint32_t*>(src + q * ss)[o];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     if (p.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.publish = gm_slot_index(p.it_slot);
     if (p.range && !p.mark) {
@@ -110,21 +45,7 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     }
     if (p.gate) {
         if (threadIdx.x == 0) {
-            // RELAXED system-scope loads: the gate and the rings are fine-grained (uncached) host
-            // memory, so nothing stale can sit in L2; an ACQUIRE here costs a system-scope cache
-            // invalidate per workgroup (measured: 9 -> 29 us per stage-in of 8 iterations).
-            const int64_t need = gm_slot_index(p.it_slot) + p.n_iters;
-            if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-                const uint64_t t0 = wall_clock64();
-                while (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > p.timeout) {
-                        __hip_atomic_store(const_cast<int64_t*>(p.gate) + 1, (int64_t)1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
-                    }
-                }
-            }
+            stage_gate_wait(p.gate, gm_slot_index(p.it_slot) + p.n_iters, p.timeout);
         }
         __syncthreads();
     }
@@ -154,16 +75,7 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
 __global__ __launch_bounds__(64) void stage_gate_wait_kernel(const int64_t* gate, gm_slot it_slot, int n_iters,
                                                              uint64_t timeout) {
     if (threadIdx.x != 0) return;
-    const int64_t need = gm_slot_index(it_slot) + n_iters;
-    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > timeout) {
-            __hip_atomic_store(const_cast<int64_t*>(gate) + 1, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
+    stage_gate_wait(gate, gm_slot_index(it_slot) + n_iters, timeout);
 }
 
 static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,

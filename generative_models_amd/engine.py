@@ -461,6 +461,12 @@ class GANEngine:
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
+        # stage-ahead (round 5, gm_linear_bwd_dw_adam_pair_stage): the generator's last launch of iteration i brings
+        # iteration i + 1's draws into the device rings, a graph only stages its FIRST iteration itself, and a run is
+        # [32, 32, ..., remainder] graphs of exact length -- no small first pieces, no pre-staging side stream
+        self.stage_ahead = os.environ.get("GM_STAGE_AHEAD", "1") != "0"
+        self.STAGE_PARTS = max(1, min(8, int(os.environ.get("GM_STAGE_PARTS", "2"))))
+        self._graphs_exact = {}
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1027,10 +1033,11 @@ class GANEngine:
             adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
             zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
             zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
+            stage = self._stage_pack if self._stage_ahead() else None
             ops.linear_bwd_dw_adam_pair(
                 dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
                 dict(dA=self.dHg, X=zbase, lin=self.G1, adam=adam, M=self.Bl, x_slot=zG_slot),
-                stream=st)
+                stream=st, stage=stage)
             return
         self._G_dw2(st, it)
         self._G_dw1(st, it)
@@ -1212,7 +1219,8 @@ class GANEngine:
             # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
             # configure(), [1] = raised by a stage-in kernel whose wait timed out.  Allocated once per
             # engine: captured graphs hold its address.
-            self._gate = torch.zeros(2, dtype=torch.int64).pin_memory()
+            # [2] = iterations whose draws have been SUBMITTED (stage-ahead rider: _pump)
+            self._gate = torch.zeros(4, dtype=torch.int64).pin_memory()
             self._gate_np = self._gate.numpy()
             gp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", self._gate.data_ptr(), ctypes.byref(gp))
@@ -1290,7 +1298,12 @@ class GANEngine:
         """Stage-in of iterations [it, it+k): host ring -> device ring (first launch of a graph)."""
         from . import _lib
         ring_slot, it_slot = self._slot(it, 1, 0, self.R, 1), self._slot(it, 1, 0, 0, 1)
-        if self.gated and self._prestaging():
+        if self._stage_ahead():
+            # only the graph's FIRST iteration: the others arrive with the iteration in front of them, and this one too
+            # when the graph in front was launched after its draws were submitted (then this launch just returns)
+            _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, 1, self._gate_dev,
+                      it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
+        elif self.gated and self._prestaging():
             _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
                       it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
         elif self.gated:
@@ -1299,9 +1312,17 @@ class GANEngine:
         else:
             _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
 
+    def _stage_ahead(self):
+        """The next iteration's draws ride in the generator's weight-gradient pair (the iteration's last launch on
+        one GPU with Adam in the epilogues).  Not: DRAGAN (its uniforms go through the copy engine a piece at a time),
+        BEGAN / InfoGAN (launches behind the pair), data parallel (the exchange follows the pair), eager mode."""
+        return (self.stage_ahead and self.gated and self.use_graph and self._one_graph() and self._single()
+                and self.pair_dw and self._adam_in_epilogue("G") and not getattr(self, "_u_copy", False)
+                and self.variant not in ("be", "info") and not self._standalone_G)
+
     def _prestaging(self):
         """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
-        return self.prestage and self.gated and self.use_graph and self._one_graph()
+        return self.prestage and self.gated and self.use_graph and self._one_graph() and not self._stage_ahead()
 
     def _prestage(self, it, k):
         """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
@@ -1610,14 +1631,27 @@ class GANEngine:
                     for _ in range(k):
                         self._issue_iteration(st, 0)
                 return fn
+            self._graph_body = body
+            self._graphs_exact = {}
+            self._stage_pack = None
+            if self._stage_ahead():
+                # (graph mode: the slots are resolved on the device from the step counter, which the generator step's
+                # head has already advanced when the pair runs)
+                self._stage_pack = ops.stage_ahead_pack(
+                    self._segs, len(self._segs), self._slot(0, 1, 1, self.R, 1, post=True),
+                    self._slot(0, 1, 1, 0, 1, post=True), self._gate_dev, self.GATE_TIMEOUT_S, self._pre_range,
+                    self._pre_arrive, parts=self.STAGE_PARTS)
             self.graph = ops.Graph().capture(body(1))
             self.graphs_by_size = [(1, self.graph)]
+            self._graphs_exact[1] = self.graph
             k = 2
-            while k <= self.graph_iters:
+            while k <= self.graph_iters and not self._stage_ahead():
                 self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
                 k *= 2
             if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
                 self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
+            for k_, g_ in self.graphs_by_size:
+                self._graphs_exact[k_] = g_
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
@@ -1627,6 +1661,22 @@ class GANEngine:
             self.seg_graphs = [(ops.Graph().capture(lambda st, run=run: run(st, 0)), ar)
                                for run, ar in segs]
         self._graph_key = self._key
+
+    def _graph_of(self, k):
+        """The graph of exactly k iterations (stage-ahead: captured on first use and kept; prepare() does it ahead)."""
+        g = self._graphs_exact.get(k)
+        if g is None:
+            torch.cuda.synchronize()
+            g = self._graphs_exact[k] = ops.Graph().capture(self._graph_body(k))
+        return g
+
+    def prepare(self, n_iters):
+        """Capture the graphs a run(n_iters) will launch (stage-ahead: [graph_iters] * q + [remainder]) so that the
+        first such run does not pay for the capture.  A no-op on the other paths (their graphs exist already)."""
+        self._ensure_graph()
+        if self.use_graph and self._one_graph() and self._stage_ahead():
+            for k in set(self._plan(self._next_it, n_iters, False)):
+                self._graph_of(k)
 
     def _drain(self):
         """Wait for host fills still in flight (configure / error paths)."""
@@ -1672,6 +1722,8 @@ class GANEngine:
             self._fills.append((it, n, fut))
             self._cursor += n
             unfinished += n
+        if self._gate is not None:
+            self._gate_np[2] = self._cursor           # (pinned: the stage-ahead rider reads it)
 
     def _slots_free_now(self, c0, n, wait):
         """True when the ring slots of [c0, c0+n) can be rewritten (the launch that last staged them in has completed); wait=True blocks for it."""
@@ -1729,6 +1781,16 @@ class GANEngine:
         while cap * 2 <= min(self.graph_iters, self.R):
             cap *= 2
         out, done = [], 0
+        if self._stage_ahead():
+            # graphs of EXACT length: whole `cap`s and one remainder per ring segment; a graph needs only its first
+            # iteration's draws before it starts (the others ride in), so nothing is cut small for a cold start
+            while n > 0:
+                seg = min(n, self.R - it % self.R)
+                q, r = divmod(seg, cap)
+                out += [cap] * q + ([r] if r else [])
+                it += seg
+                n -= seg
+            return out
         while n > 0:
             seg = min(n, self.R - it % self.R)
             q, r = divmod(seg, cap)
@@ -1776,7 +1838,9 @@ class GANEngine:
 
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
-        if self.use_graph and self._one_graph():
+        if self.use_graph and self._one_graph() and self._stage_ahead():
+            self._graph_of(k).launch()
+        elif self.use_graph and self._one_graph():
             for size, g in self.graphs_by_size:           # largest first: 32, 16, ..., 1 iterations
                 while k >= size:
                     g.launch()

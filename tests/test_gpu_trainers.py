@@ -1303,3 +1303,6 @@ def test_bench_contract_line_end_to_end():
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "workload" in line["config"]
+    # the evidence lives inside the objects the driver's record keeps (config / roofline), not in extra top-level keys
+    assert 0.02 < rf["step_frac"] < rf["frac"] and "profile_kernel_us" in rf and isinstance(rf["stale_profile"], bool)
+    assert line["config"]["steady_us_per_step"] > 10 and line["config"]["run_fixed_cost_us"] is not None

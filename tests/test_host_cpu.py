@@ -217,7 +217,7 @@ def test_bench_kernel_names_match_the_committed_rocprof_summary():
     # no silent `traffic: null`: the dominant kernel of the headline and of every configuration that has a
     # roofline entry must be listed in the committed PMC pass it names
     assert line["roofline"]["traffic"] and line["roofline"]["traffic_source"].startswith("profiles/" + rnd)
-    for c in line.get("configs", []):
+    for c in line["config"].get("other_configs", line.get("configs", [])):      # (round <= 4 records: top level)
         r = c.get("roofline")
         if r is not None:
             assert r["traffic"] and os.path.isfile(os.path.join(root, r["traffic_source"])), c["workload"]
@@ -331,6 +331,7 @@ def test_launch_planner_invariants(R, graph_iters):
         pass
     e = E()
     e.graph_iters, e.R, e.FIRST_PIECE = graph_iters, R, 2
+    e._stage_ahead = lambda: False             # the pre-round-5 planner (data parallel, DRAGAN, BEGAN, InfoGAN)
     plan = lambda it, n, cold: engine.GANEngine._plan(e, it, n, cold)
     cap = min(graph_iters, R)
     for it in (0, 5, R - 1, R, 3 * R + 2):
@@ -347,6 +348,32 @@ def test_launch_planner_invariants(R, graph_iters):
                     done += x
     if R >= 32 and graph_iters >= 16:
         assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
+
+
+@pytest.mark.parametrize("R,graph_iters", [(128, 32), (25, 32), (7, 8), (16, 32)])
+def test_launch_planner_stage_ahead(R, graph_iters):
+    """Stage-ahead planner (round 5): graphs of exact length -- whole caps and ONE remainder per ring segment -- that
+    cover the run, never cross the end of the ring, and do not depend on whether the run starts cold."""
+    class E:
+        pass
+    e = E()
+    e.graph_iters, e.R, e.FIRST_PIECE = graph_iters, R, 2
+    e._stage_ahead = lambda: True
+    cap = 1
+    while cap * 2 <= min(graph_iters, R):
+        cap *= 2
+    for it in (0, 5, R - 1, R, 3 * R + 2):
+        for n in (0, 1, 2, 3, 20, 25, 64, 200, 2000):
+            p = engine.GANEngine._plan(e, it, n, True)
+            assert p == engine.GANEngine._plan(e, it, n, False)
+            assert sum(p) == n and all(1 <= x <= cap for x in p), (it, n, p)
+            pos = it
+            for x in p:
+                assert pos % R + x <= R, (it, n, p)
+                pos += x
+    if R >= 32 and graph_iters >= 32:
+        assert engine.GANEngine._plan(e, 5, 20, True) == [20]          # the driver's 20-step run: ONE graph
+        assert engine.GANEngine._plan(e, 0, 200, True) == [32] * 6 + [8]
 
 
 @pytest.mark.parametrize("record", ["r02_bench_default.json", "r02_bench_steps20_warmup5.json"])

@@ -13,8 +13,14 @@
 // WAVES per workgroup; the launch is one workgroup per CU (256) or two (512, "x2": 2 x 8 waves)
 // DEPTH loads in flight per wave (issue DEPTH, then: wait for the oldest, consume, issue the next)
 // PAT   0: a wave instruction reads 1 KB contiguous
-//       1: 16 rows x 64 B at a 3136-byte row stride -- the 16x16x4 fragment load of the 784-wide operands
+//       1: 16 rows x 64 B at a 3136-byte row stride, lane (r = lane & 15, g = lane >> 4) -> row r, bytes 16 g ..: the
+//          16x16x4 fragment load of the k-contiguous 784-wide operands as shipped until round 4 (ADJACENT LANES read
+//          DIFFERENT rows; the four lanes that share a row's 64 bytes are 16 lanes apart)
 //       2: as 0, every workgroup inside its own 16 KB window (L1-resident: the TA/TCP/TD path without L2)
+//       3: the same 16 rows x 64 B, lane -> row lane >> 2, bytes 16 (lane & 3) ..: adjacent lanes read adjacent bytes
+//       4: 8 rows x 128 B (whole cache lines), lane -> row lane >> 3, bytes 16 (lane & 7) ..
+//       5: the x-contiguous operand load as shipped until round 4 (gm_gemm.hip raw_xc4_16): k-row 4 (lane >> 4) +
+//          (lane & 3), bytes 16 ((lane >> 2) & 3) ..: the four lanes of a QUAD read four different rows
 // Footprint for PAT 0 / 1: all workgroups walk ONE shared 3 MB buffer (the D layer-1 GEMM's 2.85 MB of operands) from
 // different offsets, 192 KB per pass -- L2 / MALL resident, the real kernels' situation.
 #include <hip/hip_runtime.h>
@@ -52,15 +58,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_fill(const float* __restrict__ s
     const uint32_t wg_off = (PAT == 2) ? blockIdx.x * 16384u : (blockIdx.x * 98304u) % (uint32_t)(BUF_BYTES - PASS_BYTES);
     uint32_t off = (uint32_t)w * 1024u;          // PAT 0 / 2: byte offset of this wave's next piece inside the window
     int pc = w, pr = 0;                          // PAT 1: piece column (0..48) and row block (0..2)
-    if (PAT == 1) { while (pc >= 49) { pc -= 49; pr = pr == 2 ? 0 : pr + 1; } }
+    if (PAT == 1 || PAT == 3 || PAT == 5) { while (pc >= 49) { pc -= 49; pr = pr == 2 ? 0 : pr + 1; } }
+    if (PAT == 4) { while (pc >= 24) { pc -= 24; pr = pr == 5 ? 0 : pr + 1; } }
     auto next = [&]() -> const float* {          // address of this wave's next piece, then advance by WAVES pieces
         uint32_t o;
-        if (PAT == 1) {
-            // 16 rows x 64 B: lane (r = lane & 15, g = lane >> 4) reads bytes 16 g .. of row r; consecutive pieces walk
-            // along the rows (64 B further), 49 pieces per row block, then the next 16 rows
-            o = (uint32_t)((pr * 16 + (lane & 15)) * 3136 + pc * 64 + (lane >> 4) * 16);
+        if (PAT == 1 || PAT == 3 || PAT == 5) {
+            // 16 rows x 64 B; consecutive pieces walk along the rows (64 B further), 49 pieces per row block, then the
+            // next 16 rows
+            const int row = PAT == 1 ? (lane & 15) : PAT == 3 ? (lane >> 2) : (4 * (lane >> 4) + (lane & 3));
+            const int b16 = PAT == 1 ? (lane >> 4) : PAT == 3 ? (lane & 3) : ((lane >> 2) & 3);
+            o = (uint32_t)((pr * 16 + row) * 3136 + pc * 64 + b16 * 16);
             pc += WAVES;
             if (pc >= 49) { pc -= 49; pr = pr == 2 ? 0 : pr + 1; }
+        } else if (PAT == 4) {
+            // 8 rows x 128 B: 24 pieces per row block (3072 of the 3136 bytes), 6 row blocks of 8
+            o = (uint32_t)((pr * 8 + (lane >> 3)) * 3136 + pc * 128 + (lane & 7) * 16);
+            pc += WAVES;
+            if (pc >= 24) { pc -= 24; pr = pr == 5 ? 0 : pr + 1; }
         } else {
             o = off + lane * 16u;
             off += WAVES * 1024u;
@@ -152,21 +166,26 @@ int main(int argc, char** argv) {
     HIPC(hipMemcpy(d_src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     const int KB = 6144;                                                            // bytes per workgroup per launch: 6 MB
 #define RUN(M, W, D, P, WGS) run<M, W, D, P>(#M "/" #W "w/d" #D "/p" #P "/" #WGS, d_src, d_sink, WGS, (WGS) > 256 ? KB * 256 / (WGS) : KB)
-    // VGPR loads: waves per CU x depth
-    RUN(0, 4, 2, 0, 256); RUN(0, 4, 4, 0, 256); RUN(0, 4, 8, 0, 256);
-    RUN(0, 8, 2, 0, 256); RUN(0, 8, 4, 0, 256); RUN(0, 8, 8, 0, 256);
-    RUN(0, 16, 2, 0, 256); RUN(0, 16, 4, 0, 256); RUN(0, 16, 8, 0, 256);
-    // two workgroups of 8 waves per CU
-    RUN(0, 8, 4, 0, 512);
-    // LDS-DMA
-    RUN(1, 4, 2, 0, 256); RUN(1, 4, 4, 0, 256); RUN(1, 4, 8, 0, 256);
-    RUN(1, 8, 2, 0, 256); RUN(1, 8, 4, 0, 256); RUN(1, 8, 8, 0, 256);
-    RUN(1, 16, 2, 0, 256); RUN(1, 16, 4, 0, 256); RUN(1, 16, 8, 0, 256);
-    // the GEMM's fragment pattern (16 rows x 64 B), 16 waves x 4 in flight = the shipped kernel's window
-    RUN(0, 16, 4, 1, 256); RUN(1, 16, 4, 1, 256);
-    // L1-resident: the TA / TCP / TD path alone
-    RUN(0, 4, 4, 2, 256); RUN(0, 16, 4, 2, 256); RUN(1, 16, 4, 2, 256);
-    // fewer CUs active (is it a per-CU or a shared-fabric bound?)
-    RUN(0, 16, 4, 0, 32); RUN(1, 16, 4, 0, 32);
+    const bool all = argc > 2 && !strcmp(argv[2], "all");
+    if (all) {
+        // VGPR loads: waves per CU x depth
+        RUN(0, 4, 2, 0, 256); RUN(0, 4, 4, 0, 256); RUN(0, 4, 8, 0, 256);
+        RUN(0, 8, 2, 0, 256); RUN(0, 8, 4, 0, 256); RUN(0, 8, 8, 0, 256);
+        RUN(0, 16, 2, 0, 256); RUN(0, 16, 4, 0, 256); RUN(0, 16, 8, 0, 256);
+        // two workgroups of 8 waves per CU
+        RUN(0, 8, 4, 0, 512);
+        // LDS-DMA
+        RUN(1, 4, 2, 0, 256); RUN(1, 4, 4, 0, 256); RUN(1, 4, 8, 0, 256);
+        RUN(1, 8, 2, 0, 256); RUN(1, 8, 4, 0, 256); RUN(1, 8, 8, 0, 256);
+        RUN(1, 16, 2, 0, 256); RUN(1, 16, 4, 0, 256); RUN(1, 16, 8, 0, 256);
+        // L1-resident: the TA / TCP / TD path alone
+        RUN(0, 4, 4, 2, 256); RUN(0, 16, 4, 2, 256); RUN(1, 16, 4, 2, 256);
+        // fewer CUs active (is it a per-CU or a shared-fabric bound?)
+        RUN(0, 16, 4, 0, 32); RUN(1, 16, 4, 0, 32);
+    }
+    // the access PATTERN of one wave instruction, 16 waves x 4 in flight = the shipped kernels' window
+    RUN(0, 16, 4, 0, 256); RUN(0, 16, 4, 1, 256); RUN(0, 16, 4, 3, 256); RUN(0, 16, 4, 4, 256); RUN(0, 16, 4, 5, 256);
+    RUN(1, 16, 4, 1, 256); RUN(1, 16, 4, 3, 256); RUN(1, 16, 4, 4, 256);
+    RUN(0, 4, 2, 0, 256);
     return 0;
 }
