@@ -1446,13 +1446,18 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
 #undef GM_LP
                 GM_LAUNCH_RET();
             }
-            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums theirs;
-            // the stage-ahead rider is simply dropped: the next graph's first node stages that iteration itself)
+            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums / the
+            // stage-ahead rider theirs)
             Rider none;
             int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
             if (rc) return rc;
             rc = launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
-            if (rc || !rider.fin) return rc;
+            if (rc) return rc;
+            if (rider.stage) {                       // the rider as its own launch: the caller relies on it
+                hipLaunchKernelGGL(stage_ahead_kernel, dim3(rider.stage_blocks), dim3(1024), 0, s, rider.stage);
+                GM_LAUNCH_RET();
+            }
+            if (!rider.fin) return rc;
             const gm_fin2& f = *rider.fin;
             return gm_sum_finalize2_tick(s, f.pa, f.na, f.sa, f.oa, f.slot_a, f.pb, f.nb, f.sb, f.ob, f.slot_b, f.tick);
         }
@@ -1813,6 +1818,8 @@ extern "C" int gm_stage_ahead_pack(const gm_stage_ahead_args* st, void* dev_buf,
     sa.n_segs = st->n_segs; sa.parts = st->parts; sa.ring_slot = st->ring_slot; sa.it_slot = st->it_slot;
     sa.gate = st->gate; sa.timeout = (uint64_t)(st->timeout_s * 1e8);           // wall_clock64(): 100 MHz
     sa.range = reinterpret_cast<unsigned long long*>(st->range); sa.arrive = st->arrive;
+    sa.poll_ticks = (uint64_t)((st->poll_us > 0.0 ? st->poll_us : 0.0) * 100.0);
+    sa.may_skip = st->may_skip ? 1 : 0;
     const hipError_t e = hipMemcpy(dev_buf, &sa, sizeof(sa), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         gm_set_error(hipGetErrorString(e));

@@ -96,9 +96,11 @@ __device__ __forceinline__ void stage_gate_wait(const int64_t* gate, int64_t nee
 // small first pieces that each wait for all of their draws (the 21 - 33 us piece boundaries and the ~60 us until the
 // first kernel of a cold 20-step run, profiles/history/r04_experiments.md section 7).
 //   gate[0] = iterations the host has WRITTEN, gate[1] = time-out flag, gate[2] = iterations whose draws the host has
-//   SUBMITTED (written before any graph that could stage them is enqueued): the rider skips an iteration that was not
-//   submitted -- the next graph's first node stages it then, as before.
+//   SUBMITTED: the rider of a graph's last iteration (may_skip) skips an iteration that was not submitted -- the next
+//   graph's first node stages it then; inner riders always deliver (the host submits a graph's draws right behind its
+//   launch).
 //   range = (lo << 32) | hi: iterations in the device rings (the word gm_stage_in_prestaged checks).
+// The struct lives in DEVICE memory (gm_stage_ahead_pack): the segment table is indexed by the rider's workgroup id.
 struct StageAheadP {
     gm_stage_seg seg[GM_STAGE_MAX_SEGS];
     int n_segs;
@@ -109,14 +111,34 @@ struct StageAheadP {
     uint64_t timeout;
     unsigned long long* range;
     unsigned int* arrive;      // low 16 bits: rider workgroups that are through; high bits: those that copied
+    uint64_t poll_ticks;       // how long a rider waits for the side stream's pre-stage before it copies itself
+    int may_skip;              // 1: the rider of a graph's LAST iteration -- the next iteration belongs to another graph,
+                               //    which stages it itself if the host had not even submitted its draws when this ran
+                               // 0: an inner iteration of a graph: the draws WILL be written (bounded gate wait)
 };
 
 // rid: rider workgroup 0 .. n_segs * parts - 1; scratch: >= 1 int of the workgroup's LDS
+//
+// Normally the host has ALREADY brought the iteration in: every fill it submits is followed by a pre-stage on a side
+// stream (gm_stage_in_prestaged, mark = 1), which publishes `range`.  The rider then only has to see that (one load
+// of device memory; polled for up to poll_ticks of the 100 MHz clock) -- the kernel boundary behind it is what orders
+// the next iteration's kernels after the pre-stage.  Only when the range does not arrive in time does the rider read
+// the host's gate words over PCIe and make the copy itself (three PCIe round trips: measured +4 us per iteration when
+// every rider did that, round 5 call B).
 __device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid, int* scratch) {
     const int64_t next = gm_slot_index(sa.it_slot);
     if (threadIdx.x == 0) {
         int go = 0;
-        if (next < __hip_atomic_load(sa.gate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        const uint64_t t0 = wall_clock64();
+        bool in = false;
+        while (true) {
+            const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            in = (int64_t)(r >> 32) <= next && next < (int64_t)(r & 0xffffffffull);
+            if (in || wall_clock64() - t0 > sa.poll_ticks) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!in && (!sa.may_skip ||
+                    next < __hip_atomic_load(sa.gate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
             go = 1;
             stage_gate_wait(sa.gate, next + 1, sa.timeout);
         }
@@ -126,11 +148,7 @@ __device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid,
     const int go = scratch[0];
     if (go) {
         const int si = rid / sa.parts, part = rid - si * sa.parts;
-        gm_stage_seg sg = sa.seg[0];                      // (never index a kernel-argument array dynamically: scratch)
-#pragma unroll
-        for (int i = 1; i < GM_STAGE_MAX_SEGS; ++i)
-            if (i == si) sg = sa.seg[i];
-        stage_copy_seg(sg, gm_slot_index(sa.ring_slot), 1, (int64_t)part * blockDim.x + threadIdx.x,
+        stage_copy_seg(sa.seg[si], gm_slot_index(sa.ring_slot), 1, (int64_t)part * blockDim.x + threadIdx.x,
                        (int64_t)sa.parts * blockDim.x);
         __threadfence();                                  // this workgroup's ring writes: device-visible
     }
@@ -141,7 +159,7 @@ __device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid,
                                                         __HIP_MEMORY_SCOPE_AGENT);
         if ((old & 0xffffu) == total - 1) {               // last rider workgroup of this launch
             __hip_atomic_store(sa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((old >> 16) + (unsigned int)go == total) {    // every segment part was copied
+            if ((old >> 16) + (unsigned int)go == total) {    // every segment part was copied HERE
                 const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long it0 = (unsigned long long)next;
                 const unsigned long long lo = ((r & 0xffffffffull) == it0) ? (r >> 32) : it0;
@@ -149,4 +167,11 @@ __device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid,
             }
         }
     }
+}
+
+// the rider as a launch of its own (the pair it should ride in could not share a tile shape); static: the header is
+// included by two translation units
+static __global__ __launch_bounds__(1024) void stage_ahead_kernel(const StageAheadP* sa) {
+    __shared__ int scratch[1];
+    stage_ahead_body(*sa, (int)blockIdx.x, scratch);
 }

@@ -460,12 +460,15 @@ class GANEngine:
         self.prestage = os.environ.get("GM_PRESTAGE", "1") != "0"
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ride_arrive = torch.zeros(1, dtype=torch.int32, device=device)   # the stage-ahead riders' own counter
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
         # stage-ahead (round 5, gm_linear_bwd_dw_adam_pair_stage): the generator's last launch of iteration i brings
         # iteration i + 1's draws into the device rings, a graph only stages its FIRST iteration itself, and a run is
         # [32, 32, ..., remainder] graphs of exact length -- no small first pieces, no pre-staging side stream
         self.stage_ahead = os.environ.get("GM_STAGE_AHEAD", "1") != "0"
         self.STAGE_PARTS = max(1, min(8, int(os.environ.get("GM_STAGE_PARTS", "2"))))
+        self.STAGE_POLL_US = float(os.environ.get("GM_STAGE_POLL_US", "20"))
+        self._last_of_graph = True
         self._graphs_exact = {}
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
@@ -1033,7 +1036,9 @@ class GANEngine:
             adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
             zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
             zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
-            stage = self._stage_pack if self._stage_ahead() else None
+            # (the rider of a graph's last iteration may find the next iteration not even submitted: _issue_iteration
+            # says which one is being captured)
+            stage = (self._stage_pack[1 if self._last_of_graph else 0] if self._stage_ahead() else None)
             ops.linear_bwd_dw_adam_pair(
                 dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
                 dict(dA=self.dHg, X=zbase, lin=self.G1, adam=adam, M=self.Bl, x_slot=zG_slot),
@@ -1322,7 +1327,7 @@ class GANEngine:
 
     def _prestaging(self):
         """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
-        return self.prestage and self.gated and self.use_graph and self._one_graph() and not self._stage_ahead()
+        return self.prestage and self.gated and self.use_graph and self._one_graph()
 
     def _prestage(self, it, k):
         """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
@@ -1341,6 +1346,17 @@ class GANEngine:
                   self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
                   self._pre_arrive.data_ptr(), 1)
         self._pre_dirty = True
+
+    def _prestage_submitted(self, lo):
+        """Stage-ahead: pre-stage every submitted iteration >= lo that has not been yet, on the side stream.  The first
+        few go alone (the GPU reaches them within tens of microseconds; a pre-stage delivers only once ALL its
+        iterations are drawn), the rest in one launch; never across the end of the ring (contiguous slots)."""
+        a = max(lo, self._pre_upto)
+        while a < self._cursor:
+            n = min(self._cursor - a, self.R - a % self.R, 3 if a < lo + 3 else 1 << 30)
+            self._prestage(a, n)
+            a += n
+        self._pre_upto = max(self._pre_upto, a)
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
@@ -1501,7 +1517,8 @@ class GANEngine:
         if self._gate is not None:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
-        self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
+        self._pre_range.zero_(); self._pre_arrive.zero_(); self._ride_arrive.zero_()   # iterations restart at 0: nothing is pre-staged
+        self._pre_upto = 0
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1628,7 +1645,8 @@ class GANEngine:
             def body(k):
                 def fn(st):
                     self._issue_stage_in(st, 0, k)
-                    for _ in range(k):
+                    for i in range(k):
+                        self._last_of_graph = (i == k - 1)
                         self._issue_iteration(st, 0)
                 return fn
             self._graph_body = body
@@ -1636,11 +1654,12 @@ class GANEngine:
             self._stage_pack = None
             if self._stage_ahead():
                 # (graph mode: the slots are resolved on the device from the step counter, which the generator step's
-                # head has already advanced when the pair runs)
-                self._stage_pack = ops.stage_ahead_pack(
+                # head has already advanced when the pair runs); [0]: inner iterations of a graph, [1]: its last one
+                self._stage_pack = [ops.stage_ahead_pack(
                     self._segs, len(self._segs), self._slot(0, 1, 1, self.R, 1, post=True),
                     self._slot(0, 1, 1, 0, 1, post=True), self._gate_dev, self.GATE_TIMEOUT_S, self._pre_range,
-                    self._pre_arrive, parts=self.STAGE_PARTS)
+                    self._ride_arrive, parts=self.STAGE_PARTS, poll_us=self.STAGE_POLL_US, may_skip=bool(last))
+                    for last in (0, 1)]
             self.graph = ops.Graph().capture(body(1))
             self.graphs_by_size = [(1, self.graph)]
             self._graphs_exact[1] = self.graph
@@ -1782,15 +1801,11 @@ class GANEngine:
             cap *= 2
         out, done = [], 0
         if self._stage_ahead():
-            # graphs of EXACT length: whole `cap`s and one remainder per ring segment; a graph needs only its first
+            # graphs of EXACT length: whole `cap`s and one remainder; a graph needs only its first
             # iteration's draws before it starts (the others ride in), so nothing is cut small for a cold start
-            while n > 0:
-                seg = min(n, self.R - it % self.R)
-                q, r = divmod(seg, cap)
-                out += [cap] * q + ([r] if r else [])
-                it += seg
-                n -= seg
-            return out
+            # (they may cross the end of the ring: every in-graph copy is one iteration's slot)
+            q, r = divmod(n, cap)
+            return [cap] * q + ([r] if r else [])
         while n > 0:
             seg = min(n, self.R - it % self.R)
             q, r = divmod(seg, cap)
@@ -1902,12 +1917,17 @@ class GANEngine:
                 self._reap()
                 if trace is not None:
                     trace.append(("reaped", it, time.perf_counter()))
-                self._pump(limit, upto=it + k)
+                sa = self._stage_ahead()
+                # stage-ahead: only the piece's FIRST iteration has to be submitted before its graph is enqueued (its
+                # first node waits for that one); the rest are submitted right behind the launch and arrive through
+                # the side stream's pre-stages / the riders
+                need = it + 1 if sa else it + k
+                self._pump(limit, upto=need)
                 if trace is not None:
                     trace.append(("pumped", it, time.perf_counter()))
-                while self._cursor < it + k:
+                while self._cursor < need:
                     self._reap(block=True)
-                    self._pump(limit, upto=it + k)
+                    self._pump(limit, upto=need)
                 if not gated:
                     self._reap(upto=it + k)
                     self._pump(limit)                 # further draws overlap the launch below
@@ -1916,13 +1936,19 @@ class GANEngine:
                     self._copy_U(it + k)
                 if trace is not None:
                     trace.append(("got", it, time.perf_counter()))
-                if self._prestaging():
+                if self._prestaging() and not sa:
                     self._prestage(it, k)
                 self._launch(it, k)
                 if trace is not None:
                     trace.append(("graph", it, time.perf_counter()))
                 if gated:
                     self._pump(limit)                 # (gated: the launch itself overlaps this piece's draws)
+                if sa:
+                    while self._cursor < it + k:      # every iteration of a launched graph WILL be drawn
+                        self._reap(block=True)
+                        self._pump(limit, upto=it + k)
+                    self._prestage_submitted(it + 1)
+                    self._join_prestage()             # (the piece's event below then also covers the side stream)
                 if trace is not None:
                     trace.append(("pump2", it, time.perf_counter()))
                 ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()

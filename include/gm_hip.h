@@ -519,16 +519,21 @@ int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm
  * the next iteration's ring slots host -> device while the GEMM tiles run, so that a graph of any length needs only
  * its first iteration staged before it starts.
  *   gate (device-visible pinned host memory, FOUR int64): [0] iterations written by the host, [1] time-out flag,
- *   [2] iterations whose draws have been SUBMITTED (the rider skips an iteration that was not: the next graph's
+ *   [2] iterations whose draws have been SUBMITTED (a may_skip rider skips an iteration that was not: the next graph's
  *   gm_stage_in_prestaged(mark = 0) stages it then); ring_slot / it_slot: the NEXT iteration's ring slot and absolute
  *   index (resolved from the step counter where the launch runs); range / arrive: the words of gm_stage_in_prestaged
  *   (arrive: one zeroed unsigned int owned by these launches); parts: workgroups per segment (1..8).
- * When the pair cannot share a tile shape the two GEMMs are launched separately and the rider is dropped. */
+ * When the pair cannot share a tile shape the two GEMMs and the rider are three launches. */
 typedef struct gm_stage_ahead_args {
     const gm_stage_seg* segs; int n_segs; int parts;
     gm_slot ring_slot, it_slot;
     const int64_t* gate; double timeout_s;
     uint64_t* range; unsigned int* arrive;
+    double poll_us;             /* how long a rider waits for a pre-stage (gm_stage_in_prestaged, mark = 1, issued by the
+                                 * host on a side stream) to publish the iteration in `range` before it reads the host
+                                 * gate and copies the slots itself; 0: at once */
+    int may_skip;               /* 1: rider of a graph's LAST iteration (skips an iteration whose draws were not submitted:
+                                 * gate[2]); 0: inner iteration (waits for the draws, bounded by timeout_s) */
 } gm_stage_ahead_args;
 /* The rider's description is packed ONCE into caller-owned device memory (>= GM_STAGE_AHEAD_BYTES; synchronous copy,
  * not inside a stream capture) and named by every launch: n_blocks = n_segs * parts. */

@@ -352,8 +352,9 @@ def test_launch_planner_invariants(R, graph_iters):
 
 @pytest.mark.parametrize("R,graph_iters", [(128, 32), (25, 32), (7, 8), (16, 32)])
 def test_launch_planner_stage_ahead(R, graph_iters):
-    """Stage-ahead planner (round 5): graphs of exact length -- whole caps and ONE remainder per ring segment -- that
-    cover the run, never cross the end of the ring, and do not depend on whether the run starts cold."""
+    """Stage-ahead planner (round 5): graphs of exact length -- whole caps and ONE remainder -- that cover the run and do
+    not depend on whether the run starts cold or where in the ring it starts (every in-graph copy is one iteration's
+    slot, so a graph may cross the end of the ring)."""
     class E:
         pass
     e = E()
@@ -365,14 +366,10 @@ def test_launch_planner_stage_ahead(R, graph_iters):
     for it in (0, 5, R - 1, R, 3 * R + 2):
         for n in (0, 1, 2, 3, 20, 25, 64, 200, 2000):
             p = engine.GANEngine._plan(e, it, n, True)
-            assert p == engine.GANEngine._plan(e, it, n, False)
-            assert sum(p) == n and all(1 <= x <= cap for x in p), (it, n, p)
-            pos = it
-            for x in p:
-                assert pos % R + x <= R, (it, n, p)
-                pos += x
+            assert p == engine.GANEngine._plan(e, it, n, False) == engine.GANEngine._plan(e, 0, n, True)
+            assert sum(p) == n and all(1 <= x <= cap for x in p) and sum(1 for x in p if x != cap) <= 1, (it, n, p)
     if R >= 32 and graph_iters >= 32:
-        assert engine.GANEngine._plan(e, 5, 20, True) == [20]          # the driver's 20-step run: ONE graph
+        assert engine.GANEngine._plan(e, 125, 20, True) == [20]        # the driver's 20-step run: ONE graph, anywhere
         assert engine.GANEngine._plan(e, 0, 200, True) == [32] * 6 + [8]
 
 
