@@ -86,8 +86,7 @@ class StageAheadArgs(ctypes.Structure):
     """gm_stage_ahead_args (include/gm_hip.h): the next iteration's draws riding in the generator's last launch."""
     _fields_ = [("segs", ctypes.POINTER(StageSeg)), ("n_segs", c_int), ("parts", c_int),
                 ("ring_slot", Slot), ("it_slot", Slot), ("gate", c_void_p), ("timeout_s", ctypes.c_double),
-                ("range", c_void_p), ("arrive", c_void_p), ("poll_us", ctypes.c_double),
-                ("may_skip", c_int)]
+                ("range", c_void_p), ("arrive", c_void_p), ("may_skip", c_int)]
 
 
 DRAW_SAMPLER, DRAW_NORMAL, DRAW_UNIFORM, DRAW_INFO = 0, 1, 2, 3

@@ -713,12 +713,72 @@ int launch_lds(hipStream_t s, const GemmP& p, int cfg) {
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- coalesced fragment loads (round 5) -------------------------------------------------------------------------
+// What a wave-wide 16-byte load costs the CU's vector cache depends on WHICH LANES read adjacent bytes
+// (tools/fill_probe, profiles/r05_fill_law.md; 16 waves x 4 loads in flight, L2-resident operands):
+//     1 KB contiguous                                   21 cycles per instruction, 16 cache accesses
+//     16 rows x 64 B, the four lanes of a QUAD adjacent   30 cycles, 16 accesses
+//     16 rows x 64 B, adjacent bytes 16 LANES APART       44 cycles, 64 accesses + tag-conflict stalls   <- rounds 1-4
+// The MFMA 16x16x4 fragment wants lane (i = lane & 15, g = lane >> 4) to hold row i, k-group g, so a load straight into
+// fragment layout puts a row's four 16-byte pieces 16 lanes apart: every lane is its own cache access.  Rounds 1-4
+// loaded that way (and round 4 read its 44 cycles as a law of the machine).  Now the four lanes of a quad read one
+// row's 64 contiguous bytes and the fragment layout is restored in registers:
+//   k-contiguous operands (X / W in the forward, dA in the input gradient): lane -> row lane >> 2, k-quad lane & 3;
+//     four ds_bpermute_b32 (the LDS crossbar, no LDS memory) bring row i, k-quad g to lane 16 g + i;
+//   x-contiguous operands (both operands of the weight gradient, W in the input gradient): lane -> k-row
+//     4 (lane >> 4) + ((lane >> 2) & 3), x-quad lane & 3; the 4x4 transpose that turns "four x at one k" into "four k
+//     at one x" runs over lane bits 3:2 (lanes l, l^4, l^8, l^12) instead of the quad, for the same number of VALU
+//     operations; the lane then holds output index SIGMA(lane & 15) = 4 (lane & 3) + ((lane >> 2) & 3) of its
+//     16-wide sub-tile instead of lane & 15 -- a fixed permutation of the tile's rows / columns that the epilogue
+//     undoes when it writes the accumulators out (XMAP below).
+#ifndef GM_COALESCED_LOADS
+#define GM_COALESCED_LOADS 1
+#endif
+constexpr bool COALESCED = GM_COALESCED_LOADS != 0;
+
+__device__ __forceinline__ int sigma16(int i) { return ((i & 3) << 2) | ((i >> 2) & 3); }
+
 __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_t ld, int x0, int X,
                                              int c, int K, int lane) {
-    const int e = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
+    // e: which of the 4 k-rows of lane-group g; q: which x-quad of the 16-wide sub-tile
+    const int e = COALESCED ? (lane >> 2) & 3 : lane & 3, q = COALESCED ? lane & 3 : (lane >> 2) & 3, g = lane >> 4;
     const int k = min(16 * c + 4 * g + e, K - 1);
     const int x = min(x0 + 4 * q, X - 4);
     return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
+}
+
+// k-contiguous, coalesced: the 4 values k = 16 c + 4 (lane & 3) .. of row x0 + (lane >> 2)
+__device__ __forceinline__ float4 raw_kc_co(const float* __restrict__ P, int64_t ld, int x0, int X, int c, int K,
+                                            int lane) {
+    const float* row = P + (int64_t)min(x0 + (lane >> 2), X - 1) * ld;
+    return *reinterpret_cast<const float4*>(row + min(16 * c + 4 * (lane & 3), K - 4));
+}
+// ... and into fragment layout: lane 16 g + i takes what lane 4 i + g loaded (row i, k-quad g)
+__device__ __forceinline__ float4 kc_to_fragment(float4 v, int lane) {
+    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;          // byte address of the source lane's dword
+    return make_float4(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.z))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.w))));
+}
+
+// lane ^ 8 and lane ^ 4 inside a row of 16 lanes, from direction-free DPP controls only (a rotation by half a row;
+// a mirror of 8 lanes followed by a mirror of 4)
+__device__ __forceinline__ float dpp_xor8(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));   // row_ror:8
+}
+__device__ __forceinline__ float dpp_xor4(float v) {
+    const int t = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true);            // row_half_mirror: l ^ 7
+    return __int_as_float(__builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true));                    // quad_perm [3,2,1,0]: ^ 3
+}
+// new[lane c][reg j] = old[lane j][reg c] over the 4 lanes {l, l^4, l^8, l^12} (c = (lane >> 2) & 3)
+__device__ __forceinline__ float4 lane48_transpose(float4 v, int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4;
+    const float s0 = dpp_xor8(b3 ? v.x : v.z), s1 = dpp_xor8(b3 ? v.y : v.w);
+    if (b3) { v.x = s0; v.y = s1; } else { v.z = s0; v.w = s1; }
+    const float t0 = dpp_xor4(b2 ? v.x : v.y), t1 = dpp_xor4(b2 ? v.z : v.w);
+    if (b2) { v.x = t0; v.z = t1; } else { v.y = t0; v.w = t1; }
+    return v;
 }
 
 // W consecutive floats as one load (interleaved fragments of the LDS-DMA weight gradient below)
@@ -750,7 +810,7 @@ __device__ __forceinline__ void store2_dw(const GemmP& p, float2 v, int m, int n
 // the epilogue once.  The block-by-block form (reduce_and_store) makes two or three trips -- barrier, sum, Adam state
 // in, parameters out -- one behind the other, and each trip is a memory round trip.  ILO: interleaved accumulator
 // layout of gemm16_dw_dma.
-template <int MI, int NI, bool ILO>
+template <int MI, int NI, bool ILO, bool XMAP = false>
 __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f32x4 (&acc)[MI][NI], int m0, int n0,
                                                   bool sync_first) {
     constexpr int RT = 16 * MI, CT = 16 * NI, IMG = RT * CT, G = IMG / 2;
@@ -765,8 +825,9 @@ __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f3
         for (int f = 0; f < NI; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = ILO ? MI * (4 * g4 + r) + e : 16 * e + 4 * g4 + r;
-                const int col = ILO ? NI * i16 + f : 16 * f + i16;
+                // XMAP: the coalesced x-contiguous loads leave output index sigma16(.) of each 16-wide sub-tile in a lane
+                const int row = ILO ? MI * (4 * g4 + r) + e : 16 * e + (XMAP ? sigma16(4 * g4 + r) : 4 * g4 + r);
+                const int col = ILO ? NI * i16 + f : 16 * f + (XMAP ? sigma16(i16) : i16);
                 img[row * CT + col] = acc[e][f][r];
             }
     __syncthreads();
@@ -986,11 +1047,17 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // folded head: what stays fixed per lane across the reduction
     float4 fw[FOLD == 1 ? MI : 1];
     float fds[FOLD == 2 ? MI : 1];
+    // x-contiguous 16-byte operands: which x-quad / which of its lane-group's four k-rows this lane LOADS
+    const int xq_ld = COALESCED ? lane & 3 : (lane >> 2) & 3, xe_ld = COALESCED ? (lane >> 2) & 3 : lane & 3;
+    // ... and which output index of the 16-wide sub-tile it then HOLDS (XMAP: sigma16 when coalesced)
+    constexpr bool XMAP_A = COALESCED && MODE == MODE_DW && XV, XMAP_B = COALESCED && MODE != MODE_FWD && XV;
+    constexpr bool KCO = COALESCED && VEC;                    // k-contiguous operands by coalesced quads + bpermute
+    const int ia = XMAP_A ? sigma16(i16) : i16, ib = XMAP_B ? sigma16(i16) : i16;
     if constexpr (FOLD == 1) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)                       // w2 of this lane's four A columns
             fw[mi] = *reinterpret_cast<const float4*>(
-                p.fold_w2 + min(m0 + 16 * mi + 4 * ((lane >> 2) & 3), p.M - 4));
+                p.fold_w2 + min(m0 + 16 * mi + 4 * xq_ld, p.M - 4));
     }
     auto load_a = [&](int c, int mi) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = m0 + 16 * mi;
@@ -998,26 +1065,33 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             if (XV) return raw_xc4_16(A, p.lda, x0, p.M, c, p.K, lane);
             return raw_xc(A, p.lda, x0 + i16, p.M, kb, p.K);
         }
+        if constexpr (KCO) return raw_kc_co(A, p.lda, x0, p.M, c, p.K, lane);
         return raw_kc<VEC>(A, p.lda, x0 + i16, p.M, kb, p.K);
     };
     auto load_b = [&](int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = n0 + 16 * ni;
-        if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
+        if (MODE == MODE_FWD) {
+            if constexpr (KCO) return raw_kc_co(B, p.ldb, x0, p.N, c, p.K, lane);
+            return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
+        }
         if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
         return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
     };
     auto fix_a = [&](float4 v, int c, int mi, float4 wk) -> float4 {
-        const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + i16;
+        const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + ia;
         if constexpr (FOLD == 1)                              // the loaded row is k = 16c + 4g + e (clamped)
-            v = fold_dh4(v, sds[min(16 * c + 4 * g4 + (lane & 3), p.K - 1)], fw[mi]);
+            v = fold_dh4(v, sds[min(16 * c + 4 * g4 + xe_ld, p.K - 1)], fw[mi]);
+        if constexpr (MODE != MODE_DW && KCO) v = kc_to_fragment(v, lane);
         if constexpr (FOLD == 2) v = fold_dh4(v, fds[mi], wk);
-        if (MODE == MODE_DW) return fix_xc(XV ? quad_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
+        if (MODE == MODE_DW)
+            return fix_xc(XV ? (COALESCED ? lane48_transpose(v, lane) : quad_transpose(v, lane)) : v, x, p.M, kb, p.K, -1);
         return fix_kc(v, x, p.M, kb, p.K);
     };
     auto fix_b = [&](float4 v, int c, int ni) -> float4 {
-        const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + i16;
-        if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
-        return fix_xc(XV ? quad_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
+        const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + ib;
+        if (MODE == MODE_FWD) return fix_kc(KCO ? kc_to_fragment(v, lane) : v, x, p.N, kb, p.K);
+        return fix_xc(XV ? (COALESCED ? lane48_transpose(v, lane) : quad_transpose(v, lane)) : v, x, b_cols, kb, p.K,
+                      ones_col, OF ? p.ones_from : 0);
     };
 
     f32x4 acc[MI][NI];
@@ -1104,7 +1178,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     }
     if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
         if (p.vec_epi) {                                     // kernel-argument uniform
-            dw_reduce_onepass<MI, NI, false>(p, red, acc, m0, n0, false);
+            dw_reduce_onepass<MI, NI, false, XMAP_A>(p, red, acc, m0, n0, false);
             return;
         }
     }
@@ -1120,15 +1194,16 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             if (bm + bn > 0) __syncthreads();                // previous block fully consumed
 #pragma unroll
             for (int rgi = 0; rgi < 4; ++rgi) {
-                const int row = g4 * 4 + rgi;
-                red[(w * 32 + row) * 32 + i16] = acc[2 * bm][2 * bn][rgi];
-                if (2 * bn + 1 < NI) red[(w * 32 + row) * 32 + 16 + i16] = acc[2 * bm][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
+                // (XMAP: rows follow the A operand's lane -> output map, columns the B operand's)
+                const int row = XMAP_A ? sigma16(g4 * 4 + rgi) : g4 * 4 + rgi;
+                red[(w * 32 + row) * 32 + ib] = acc[2 * bm][2 * bn][rgi];
+                if (2 * bn + 1 < NI) red[(w * 32 + row) * 32 + 16 + ib] = acc[2 * bm][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
                 if (2 * bm + 1 < MI) {
                     constexpr int MIX = MI > 1 ? MI - 1 : 0;             // (keeps the index in range for MI == 1)
                     const int mu = (2 * bm + 1 < MI) ? 2 * bm + 1 : MIX;
-                    red[(w * 32 + 16 + row) * 32 + i16] = acc[mu][2 * bn][rgi];
+                    red[(w * 32 + 16 + row) * 32 + ib] = acc[mu][2 * bn][rgi];
                     if (2 * bn + 1 < NI)
-                        red[(w * 32 + 16 + row) * 32 + 16 + i16] = acc[mu][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
+                        red[(w * 32 + 16 + row) * 32 + 16 + ib] = acc[mu][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
                 }
             }
             __syncthreads();
@@ -1818,7 +1893,6 @@ extern "C" int gm_stage_ahead_pack(const gm_stage_ahead_args* st, void* dev_buf,
     sa.n_segs = st->n_segs; sa.parts = st->parts; sa.ring_slot = st->ring_slot; sa.it_slot = st->it_slot;
     sa.gate = st->gate; sa.timeout = (uint64_t)(st->timeout_s * 1e8);           // wall_clock64(): 100 MHz
     sa.range = reinterpret_cast<unsigned long long*>(st->range); sa.arrive = st->arrive;
-    sa.poll_ticks = (uint64_t)((st->poll_us > 0.0 ? st->poll_us : 0.0) * 100.0);
     sa.may_skip = st->may_skip ? 1 : 0;
     const hipError_t e = hipMemcpy(dev_buf, &sa, sizeof(sa), hipMemcpyHostToDevice);
     if (e != hipSuccess) {

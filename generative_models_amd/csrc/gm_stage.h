@@ -111,7 +111,6 @@ struct StageAheadP {
     uint64_t timeout;
     unsigned long long* range;
     unsigned int* arrive;      // low 16 bits: rider workgroups that are through; high bits: those that copied
-    uint64_t poll_ticks;       // how long a rider waits for the side stream's pre-stage before it copies itself
     int may_skip;              // 1: the rider of a graph's LAST iteration -- the next iteration belongs to another graph,
                                //    which stages it itself if the host had not even submitted its draws when this ran
                                // 0: an inner iteration of a graph: the draws WILL be written (bounded gate wait)
@@ -119,28 +118,24 @@ struct StageAheadP {
 
 // rid: rider workgroup 0 .. n_segs * parts - 1; scratch: >= 1 int of the workgroup's LDS
 //
-// Normally the host has ALREADY brought the iteration in: every fill it submits is followed by a pre-stage on a side
-// stream (gm_stage_in_prestaged, mark = 1), which publishes `range`.  The rider then only has to see that (one load
-// of device memory; polled for up to poll_ticks of the 100 MHz clock) -- the kernel boundary behind it is what orders
-// the next iteration's kernels after the pre-stage.  Only when the range does not arrive in time does the rider read
-// the host's gate words over PCIe and make the copy itself (three PCIe round trips: measured +4 us per iteration when
-// every rider did that, round 5 call B).
+// Every PCIe round trip of the rider (~3 us) sits inside the launch it rides in, so it makes as few as it can: the two
+// gate words it may need are requested TOGETHER (one round trip), the copy is the second.  (Measured, round 5: three
+// sequential round trips made the pair launch 4 us longer; riders that instead polled a range pre-staged by the host on
+// a side stream were free in steady state and lost 24 us per iteration whenever the host was late -- removed.)
 __device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid, int* scratch) {
     const int64_t next = gm_slot_index(sa.it_slot);
     if (threadIdx.x == 0) {
         int go = 0;
-        const uint64_t t0 = wall_clock64();
-        bool in = false;
-        while (true) {
-            const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            in = (int64_t)(r >> 32) <= next && next < (int64_t)(r & 0xffffffffull);
-            if (in || wall_clock64() - t0 > sa.poll_ticks) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (!in && (!sa.may_skip ||
-                    next < __hip_atomic_load(sa.gate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
-            go = 1;
-            stage_gate_wait(sa.gate, next + 1, sa.timeout);
+        const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool in = (int64_t)(r >> 32) <= next && next < (int64_t)(r & 0xffffffffull);     // already on the device
+        if (!in) {
+            // both loads are in flight before either is used
+            const int64_t filled = __hip_atomic_load(sa.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int64_t submitted = __hip_atomic_load(sa.gate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!sa.may_skip || next < submitted) {
+                go = 1;
+                if (filled < next + 1) stage_gate_wait(sa.gate, next + 1, sa.timeout);
+            }
         }
         scratch[0] = go;
     }

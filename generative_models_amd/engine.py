@@ -467,7 +467,6 @@ class GANEngine:
         # [32, 32, ..., remainder] graphs of exact length -- no small first pieces, no pre-staging side stream
         self.stage_ahead = os.environ.get("GM_STAGE_AHEAD", "1") != "0"
         self.STAGE_PARTS = max(1, min(8, int(os.environ.get("GM_STAGE_PARTS", "2"))))
-        self.STAGE_POLL_US = float(os.environ.get("GM_STAGE_POLL_US", "20"))
         self._last_of_graph = True
         self._graphs_exact = {}
         if os.environ.get("GM_RAMP"):
@@ -1327,7 +1326,7 @@ class GANEngine:
 
     def _prestaging(self):
         """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
-        return self.prestage and self.gated and self.use_graph and self._one_graph()
+        return self.prestage and self.gated and self.use_graph and self._one_graph() and not self._stage_ahead()
 
     def _prestage(self, it, k):
         """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
@@ -1346,17 +1345,6 @@ class GANEngine:
                   self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
                   self._pre_arrive.data_ptr(), 1)
         self._pre_dirty = True
-
-    def _prestage_submitted(self, lo):
-        """Stage-ahead: pre-stage every submitted iteration >= lo that has not been yet, on the side stream.  The first
-        few go alone (the GPU reaches them within tens of microseconds; a pre-stage delivers only once ALL its
-        iterations are drawn), the rest in one launch; never across the end of the ring (contiguous slots)."""
-        a = max(lo, self._pre_upto)
-        while a < self._cursor:
-            n = min(self._cursor - a, self.R - a % self.R, 3 if a < lo + 3 else 1 << 30)
-            self._prestage(a, n)
-            a += n
-        self._pre_upto = max(self._pre_upto, a)
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
@@ -1518,7 +1506,6 @@ class GANEngine:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
         self._pre_range.zero_(); self._pre_arrive.zero_(); self._ride_arrive.zero_()   # iterations restart at 0: nothing is pre-staged
-        self._pre_upto = 0
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1658,7 +1645,7 @@ class GANEngine:
                 self._stage_pack = [ops.stage_ahead_pack(
                     self._segs, len(self._segs), self._slot(0, 1, 1, self.R, 1, post=True),
                     self._slot(0, 1, 1, 0, 1, post=True), self._gate_dev, self.GATE_TIMEOUT_S, self._pre_range,
-                    self._ride_arrive, parts=self.STAGE_PARTS, poll_us=self.STAGE_POLL_US, may_skip=bool(last))
+                    self._ride_arrive, parts=self.STAGE_PARTS, may_skip=bool(last))
                     for last in (0, 1)]
             self.graph = ops.Graph().capture(body(1))
             self.graphs_by_size = [(1, self.graph)]
@@ -1919,8 +1906,8 @@ class GANEngine:
                     trace.append(("reaped", it, time.perf_counter()))
                 sa = self._stage_ahead()
                 # stage-ahead: only the piece's FIRST iteration has to be submitted before its graph is enqueued (its
-                # first node waits for that one); the rest are submitted right behind the launch and arrive through
-                # the side stream's pre-stages / the riders
+                # first node waits for that one); the rest are submitted right behind the launch and arrive with the
+                # riders
                 need = it + 1 if sa else it + k
                 self._pump(limit, upto=need)
                 if trace is not None:
@@ -1941,19 +1928,17 @@ class GANEngine:
                 self._launch(it, k)
                 if trace is not None:
                     trace.append(("graph", it, time.perf_counter()))
+                ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
+                ev.record()
+                self._launched.append((it + k, ev))
                 if gated:
                     self._pump(limit)                 # (gated: the launch itself overlaps this piece's draws)
                 if sa:
                     while self._cursor < it + k:      # every iteration of a launched graph WILL be drawn
                         self._reap(block=True)
                         self._pump(limit, upto=it + k)
-                    self._prestage_submitted(it + 1)
-                    self._join_prestage()             # (the piece's event below then also covers the side stream)
                 if trace is not None:
                     trace.append(("pump2", it, time.perf_counter()))
-                ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
-                ev.record()
-                self._launched.append((it + k, ev))
                 if trace is not None:
                     tev.append(torch.cuda.Event(enable_timing=True))
                     tev[-1].record()

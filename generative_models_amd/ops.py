@@ -155,8 +155,7 @@ def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_
 STAGE_AHEAD_BYTES = 512
 
 
-def stage_ahead_pack(segs, n_segs, ring_slot, it_slot, gate, timeout_s, range_, arrive, parts=2, poll_us=20.0,
-                     may_skip=True):
+def stage_ahead_pack(segs, n_segs, ring_slot, it_slot, gate, timeout_s, range_, arrive, parts=2, may_skip=True):
     """(device buffer, workgroups) naming the stage-ahead rider of linear_bwd_dw_adam_pair(stage=...): segs (ctypes array
     of StageSeg), the NEXT iteration's ring slot / absolute index, gate (device-visible address of the pinned fill
     gate, 4 int64), range / arrive (device tensors).  Synchronous; not inside a capture."""
@@ -167,7 +166,7 @@ def stage_ahead_pack(segs, n_segs, ring_slot, it_slot, gate, timeout_s, range_, 
     sa.ring_slot, sa.it_slot = ring_slot, it_slot
     sa.gate, sa.timeout_s = gate, timeout_s
     assert range_.dtype == torch.int64 and arrive.dtype == torch.int32
-    sa.range, sa.arrive, sa.poll_us = range_.data_ptr(), arrive.data_ptr(), poll_us
+    sa.range, sa.arrive = range_.data_ptr(), arrive.data_ptr()
     sa.may_skip = 1 if may_skip else 0
     buf = torch.zeros(STAGE_AHEAD_BYTES, dtype=torch.uint8, device=range_.device)
     _lib.call("gm_stage_ahead_pack", ctypes.byref(sa), buf.data_ptr(), buf.numel())

@@ -529,9 +529,6 @@ typedef struct gm_stage_ahead_args {
     gm_slot ring_slot, it_slot;
     const int64_t* gate; double timeout_s;
     uint64_t* range; unsigned int* arrive;
-    double poll_us;             /* how long a rider waits for a pre-stage (gm_stage_in_prestaged, mark = 1, issued by the
-                                 * host on a side stream) to publish the iteration in `range` before it reads the host
-                                 * gate and copies the slots itself; 0: at once */
     int may_skip;               /* 1: rider of a graph's LAST iteration (skips an iteration whose draws were not submitted:
                                  * gate[2]); 0: inner iteration (waits for the draws, bounded by timeout_s) */
 } gm_stage_ahead_args;

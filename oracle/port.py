@@ -611,8 +611,8 @@ def rounded_exp():
     last bit of exp() decides the fourth digit of every term.  torch's CPU exp (SLEEF, <= 1 ulp) and the device's
     expf are both legitimate fp32 exponentials and differ in that last bit now and then.  With this context the oracle
     uses the correctly rounded value -- the two CPU evaluations (with / without it) drift apart over a 500-batch epoch
-    exactly as far as the HIP path drifts from the stock oracle (profiles/r05_vae_exp_rounding.json), and the HIP path
-    stays with THIS oracle to rounding: the deviation is the reference's own sensitivity to exp(), not a kernel's."""
+    as far as the HIP path drifts from either (profiles/r05_vae_exp_rounding.json; 6e-2 in the parameters): the deviation
+    is the reference's own sensitivity to the last bit of exp(), not a kernel's."""
     orig = torch.exp
 
     def exp64(x, *a, **k):
