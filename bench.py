@@ -727,9 +727,27 @@ def comm_mode_of(eng):
     if eng.world == 1 and not eng.force_segments:
         return "none (1 rank)"
     if eng._peer():
-        return "in-graph peer kernels over hipIpc/xGMI mappings, %s exchange regions" % eng.comm_memory
+        return "in-graph peer kernels over hipIpc/xGMI mappings (%s), %s exchange regions" % (
+            eng.exchange_form(), eng.comm_memory)
     why = (" (peer exchange refused: %s)" % eng.comm_fallback) if getattr(eng, "comm_fallback", None) else ""
+    if eng._rccl_in_graph():
+        return "RCCL all-reduce captured inside the iteration's hipGraph" + why
     return "host-launched RCCL all-reduce between segment graphs" + why
+
+
+def dp_identity(eng, world):
+    """config.ranks: what every rank drives and how it exchanges -- one line of evidence per rank that the job really
+    ran one process per GPU over the exchange it claims (device identity, exchange form, self-check outcome)."""
+    from generative_models_amd import dp
+    mine = {"rank": eng.rank, "device": dp._device_identity() if torch.cuda.is_available() else "cpu",
+            "exchange": eng.exchange_form(), "exchange_memory": eng.comm_memory,
+            "peer_selfcheck": "refused: %s" % eng.comm_fallback if getattr(eng, "comm_fallback", None)
+            else ("passed" if eng._peer() else "not used")}
+    if world <= 1 or not torch.distributed.is_initialized():
+        return [mine]
+    out = [None] * world
+    torch.distributed.all_gather_object(out, mine)
+    return out
 
 
 def dp_series(dev, world, rank, ranks_seen, K, W, reps):
@@ -864,6 +882,7 @@ def main():
                           sustained_s=(args.sustained if world == 1 else 0.0))
     dt = float(np.median(secs))
     log('timed regions done: %s' % ["%.4f" % x for x in secs])
+    ranks_info = dp_identity(eng, world) if (world > 1 or force_dp) else None          # (collective: every rank)
     img_s = K * B_global / dt
     n1_img_s, series = None, None
     if world > 1:
@@ -907,6 +926,7 @@ def main():
                        if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
                        "gradient_exchange": comm_mode_of(eng),
+                       "ranks": ranks_info,
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
                        "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw",

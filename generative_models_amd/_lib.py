@@ -218,6 +218,10 @@ _SIGNATURES = {
     "gm_comm_destroy": (c_int, [_P]),
     "gm_comm_error": (c_int, [_P, POINTER(c_int)]),
     "gm_comm_info": (c_int, [_P, POINTER(c_int)]),
+    "gm_rccl_unique_id": (c_int, [_P]),
+    "gm_rccl_comm_create": (c_int, [c_int, c_int, _P, POINTER(c_void_p)]),
+    "gm_rccl_allreduce_f32": (c_int, [_P, _P, _P, c_int64]),
+    "gm_rccl_comm_destroy": (c_int, [_P]),
     "gm_comm_set_exchange": (c_int, [_P, c_int]),
     "gm_comm_set_max_blocks": (c_int, [_P, c_int]),
     "gm_comm_buffer": (c_int, [_P, POINTER(c_void_p), POINTER(c_int64)]),

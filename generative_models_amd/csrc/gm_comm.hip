@@ -25,8 +25,10 @@
 // so a lost peer shows up as a Python exception at the next read-back, never as a hung GPU.
 #include "gm_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 
 namespace {
 
@@ -515,4 +517,74 @@ extern "C" int gm_allreduce_scalars(void* comm, void* stream, float* vals, int k
     GM_CHECK_ARG(cm && vals && k > 0 && k <= 16);
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params_of(cm), vals, k);
     GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL collectives INSIDE the iteration's hipGraph (round 5): the fallback when peer mappings are refused on a node
+// (GM_DP_COMM=rccl).  Round 1 launched torch.distributed all-reduces from the host between three segment graphs:
+// 114 us per iteration on ONE rank against 71 us for the single graph.  RCCL supports stream capture, so the
+// all-reduce of a gradient bucket becomes a node of the same one graph per iteration the single-GPU and the peer
+// paths replay.  The library does NOT link RCCL: the symbols are resolved at first use from whatever librccl the
+// process already carries (torch's bundled one -- two copies of RCCL in one process is what linking /opt/rocm's would
+// risk), so the C-ABI library still loads where there is no RCCL at all.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct NcclUid { char b[128]; };                       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef int (*nccl_get_uid_t)(NcclUid*);
+typedef int (*nccl_init_rank_t)(void**, int, NcclUid, int);
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_destroy_t)(void*);
+typedef const char* (*nccl_errstr_t)(int);
+
+void* nccl_sym(const char* name) {
+    void* f = dlsym(RTLD_DEFAULT, name);
+    if (!f) {
+        static void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) f = dlsym(h, name);
+    }
+    return f;
+}
+int nccl_fail(int rc, const char* what) {
+    nccl_errstr_t es = reinterpret_cast<nccl_errstr_t>(nccl_sym("ncclGetErrorString"));
+    static thread_local char msg[256];
+    snprintf(msg, sizeof(msg), "%s: %s", what, es ? es(rc) : "RCCL error");
+    gm_set_error(msg);
+    return GM_EINVAL - 100 - rc;
+}
+}  // namespace
+
+extern "C" int gm_rccl_unique_id(void* uid128_out) {
+    GM_CHECK_ARG(uid128_out);
+    nccl_get_uid_t f = reinterpret_cast<nccl_get_uid_t>(nccl_sym("ncclGetUniqueId"));
+    if (!f) { gm_set_error("RCCL is not loaded in this process (ncclGetUniqueId not found)"); return GM_EINVAL; }
+    const int rc = f(static_cast<NcclUid*>(uid128_out));
+    return rc ? nccl_fail(rc, "ncclGetUniqueId") : 0;
+}
+
+extern "C" int gm_rccl_comm_create(int rank, int world, const void* uid128, void** comm_out) {
+    GM_CHECK_ARG(uid128 && comm_out && world >= 1 && rank >= 0 && rank < world);
+    nccl_init_rank_t f = reinterpret_cast<nccl_init_rank_t>(nccl_sym("ncclCommInitRank"));
+    if (!f) { gm_set_error("RCCL is not loaded in this process (ncclCommInitRank not found)"); return GM_EINVAL; }
+    NcclUid id;
+    std::memcpy(&id, uid128, sizeof(id));
+    void* c = nullptr;
+    const int rc = f(&c, world, id, rank);
+    if (rc) return nccl_fail(rc, "ncclCommInitRank");
+    *comm_out = c;
+    return 0;
+}
+
+extern "C" int gm_rccl_allreduce_f32(void* rccl_comm, void* stream, float* buf, int64_t n) {
+    GM_CHECK_ARG(rccl_comm && buf && n > 0);
+    static nccl_allreduce_t f = reinterpret_cast<nccl_allreduce_t>(nccl_sym("ncclAllReduce"));
+    if (!f) { gm_set_error("RCCL is not loaded in this process (ncclAllReduce not found)"); return GM_EINVAL; }
+    const int rc = f(buf, buf, (size_t)n, /* ncclFloat32 */ 7, /* ncclSum */ 0, rccl_comm, (hipStream_t)stream);
+    return rc ? nccl_fail(rc, "ncclAllReduce") : 0;
+}
+
+extern "C" int gm_rccl_comm_destroy(void* rccl_comm) {
+    if (!rccl_comm) return 0;
+    nccl_destroy_t f = reinterpret_cast<nccl_destroy_t>(nccl_sym("ncclCommDestroy"));
+    if (f) (void)f(rccl_comm);
+    return 0;
 }

@@ -731,10 +731,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     operations; the lane then holds output index SIGMA(lane & 15) = 4 (lane & 3) + ((lane >> 2) & 3) of its
 //     16-wide sub-tile instead of lane & 15 -- a fixed permutation of the tile's rows / columns that the epilogue
 //     undoes when it writes the accumulators out (XMAP below).
-#ifndef GM_COALESCED_LOADS
-#define GM_COALESCED_LOADS 1
+#ifndef GM_COALESCED_X
+#define GM_COALESCED_X 1
 #endif
-constexpr bool COALESCED = GM_COALESCED_LOADS != 0;
+#ifndef GM_COALESCED_K
+#define GM_COALESCED_K 0
+#endif
+#ifndef GM_PREFETCH_ALL
+#define GM_PREFETCH_ALL 1
+#endif
+constexpr bool COALESCED = GM_COALESCED_X != 0;       // x-contiguous operands
+constexpr bool COALESCED_K = GM_COALESCED_K != 0;     // k-contiguous operands (ds_bpermute)
+constexpr bool PREFETCH_ALL = GM_PREFETCH_ALL != 0;   // a wave issues the loads of ALL its chunks before the first MFMA
 
 __device__ __forceinline__ int sigma16(int i) { return ((i & 3) << 2) | ((i >> 2) & 3); }
 
@@ -1051,7 +1059,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     const int xq_ld = COALESCED ? lane & 3 : (lane >> 2) & 3, xe_ld = COALESCED ? (lane >> 2) & 3 : lane & 3;
     // ... and which output index of the 16-wide sub-tile it then HOLDS (XMAP: sigma16 when coalesced)
     constexpr bool XMAP_A = COALESCED && MODE == MODE_DW && XV, XMAP_B = COALESCED && MODE != MODE_FWD && XV;
-    constexpr bool KCO = COALESCED && VEC;                    // k-contiguous operands by coalesced quads + bpermute
+    constexpr bool KCO = COALESCED_K && VEC;                  // k-contiguous operands by coalesced quads + bpermute
     const int ia = XMAP_A ? sigma16(i16) : i16, ib = XMAP_B ? sigma16(i16) : i16;
     if constexpr (FOLD == 1) {
 #pragma unroll
@@ -1129,23 +1137,10 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         if constexpr (FOLD == 2) return *reinterpret_cast<const float4*>(p.fold_w2 + min(16 * cc + 4 * g4, p.K - 4));
         return make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    int q_first = 0;
-    if constexpr (FOLD != 0) {
-        // Folded head: the workgroup's dS rows are rebuilt from the forward's partial dots BEHIND the
-        // first chunk's operand loads -- both trips to the fabric are in flight together (the prologue
-        // in front of the loop cost a second, serial round trip per launch: in the real step, where
-        // every kernel's inputs are fresh from other XCDs, the folded step was only 1.2 us faster than
-        // the unfolded one although two launches were gone).  Waves without a chunk still take the barrier.
-        float4 ra[MI], rb[NI];
-        float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool have = nq > 0;
-        if (have) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
-            wk = load_wk(w);
-        }
+    // The folded head's prologue (LDS fill of dS, one barrier) runs BEHIND the first operand loads: both trips to the
+    // fabric are in flight together (in front of the loop it cost a second, serial round trip per launch).  Waves
+    // without a chunk still take the barrier.
+    auto fold_prologue = [&]() {
         if constexpr (FOLD == 1) {
             if constexpr (TP) {                               // (the uniform results are head workgroup 0's business)
                 FoldTP tp_unused;
@@ -1153,7 +1148,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             } else {
                 fold_fill_lds(*fold, sds, fold->R);           // every reduction row (ends with the barrier)
             }
-        } else {
+        } else if constexpr (FOLD == 2) {
             if (t < 16 * MI) {                                // the tile's own rows
                 float s_, ds_, l_;
                 fold_row(*fold, min(m0 + t, fold->R - 1), s_, ds_, l_);
@@ -1163,18 +1158,61 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fds[mi] = sds[16 * mi + i16];     // dS of this lane's A rows
         }
-        if (have) consume(ra, rb, wk, 0);
-        q_first = 1;
+    };
+    // PREFETCH_ALL (round 5): a wave has at most a handful of chunks (K = 784: 3 or 4; 512 rows: 2) -- it requests ALL
+    // of them before the first MFMA and consumes them in order (hipcc counts the vmcnt).  One dependent round trip per
+    // wave instead of one per chunk; (MI + NI) float4 of registers per chunk in flight.  QW = chunks held at once.
+    // (the folded-head kernels sit at the 128-register cap of a 1024-thread workgroup already: two chunks there)
+    constexpr int QW = !PREFETCH_ALL ? 0 : ((MI + NI <= 4 && FOLD == 0) ? 4 : 2);
+    bool done = false;
+    if constexpr (QW > 0) {
+        if (nq <= QW) {                                       // wave-uniform
+            float4 ra[QW][MI], rb[QW][NI], wk[QW];
+#pragma unroll
+            for (int q = 0; q < QW; ++q) {
+                if (q < nq) {
+                    const int cc = w + q * WAVES;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) ra[q][mi] = load_a(cc, mi);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) rb[q][ni] = load_b(cc, ni);
+                    wk[q] = load_wk(cc);
+                }
+            }
+            fold_prologue();
+#pragma unroll
+            for (int q = 0; q < QW; ++q)
+                if (q < nq) consume(ra[q], rb[q], wk[q], q);
+            done = true;
+        }
     }
-    for (int q = q_first; q < nq; ++q) {
-        float4 ra[MI], rb[NI];
-        const int cc = w + q * WAVES;
+    if (!done) {
+        int q_first = 0;
+        if constexpr (FOLD != 0) {
+            float4 ra[MI], rb[NI];
+            float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool have = nq > 0;
+            if (have) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+                for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
-        const float4 wk = load_wk(cc);
-        consume(ra, rb, wk, q);
+                for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
+                wk = load_wk(w);
+            }
+            fold_prologue();
+            if (have) consume(ra, rb, wk, 0);
+            q_first = 1;
+        }
+        for (int q = q_first; q < nq; ++q) {
+            float4 ra[MI], rb[NI];
+            const int cc = w + q * WAVES;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+            const float4 wk = load_wk(cc);
+            consume(ra, rb, wk, q);
+        }
     }
     if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
         if (p.vec_epi) {                                     // kernel-argument uniform

@@ -2,7 +2,7 @@
 //
 // Used by the weight gradients over >= 768 rows (gm_gemm.hip gemm16_dw_dma: autograd of ns_gan.py:138-139,155-156 at
 // the bs=1024 shapes).  The stand-alone "slab" GEMM family these helpers were written for lives in tools/gm_slab.h
-// (a measured negative result, profiles/history/r04_experiments.md; the product never launched it).
+// (a measured negative result, profiles/r04_experiments.md; the product never launched it).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -94,7 +94,7 @@ __device__ __forceinline__ void stage_gate_wait(const int64_t* gate, int64_t nee
 // extra workgroups that bring iteration i + 1's draws into the device rings while the GEMM tiles run: a graph of ANY
 // number of iterations then needs only its FIRST iteration staged before it starts, so a run is no longer cut into
 // small first pieces that each wait for all of their draws (the 21 - 33 us piece boundaries and the ~60 us until the
-// first kernel of a cold 20-step run, profiles/history/r04_experiments.md section 7).
+// first kernel of a cold 20-step run, profiles/r04_experiments.md section 7).
 //   gate[0] = iterations the host has WRITTEN, gate[1] = time-out flag, gate[2] = iterations whose draws the host has
 //   SUBMITTED: the rider of a graph's last iteration (may_skip) skips an iteration that was not submitted -- the next
 //   graph's first node stages it then; inner riders always deliver (the host submits a graph's draws right behind its

@@ -226,3 +226,45 @@ class PeerComm:
         if getattr(self, "h", None):
             _lib.load().gm_comm_destroy(self.h)
             self.h = None
+
+
+class RcclGraphComm:
+    """RCCL communicator of the library's own (csrc/gm_comm.hip gm_rccl_*): its all-reduce is issued on the stream it
+    is given, so it can be CAPTURED into the iteration's hipGraph -- the fallback exchange (GM_DP_COMM=rccl) keeps the
+    one-graph-per-iteration structure instead of round 1's host-launched collectives between segment graphs.  The
+    128-byte unique id travels from rank 0 over whatever torch.distributed group is up."""
+
+    def __init__(self, world, rank, group=None):
+        import ctypes
+
+        from . import _lib
+        self.world, self.rank = world, rank
+        uid = ctypes.create_string_buffer(128)
+        err = None
+        if rank == 0:
+            try:
+                _lib.call("gm_rccl_unique_id", uid)
+            except Exception as e:                   # noqa: BLE001
+                err = e
+        if world > 1:
+            import torch.distributed as dist
+            box = [None if err is not None else bytes(uid.raw)] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise _lib.GMError("RCCL graph communicator: rank 0 could not make a unique id%s"
+                                   % ((": %s" % err) if err is not None else ""))
+            uid = ctypes.create_string_buffer(box[0], 128)
+        elif err is not None:
+            raise err
+        self.h = ctypes.c_void_p()
+        _lib.call("gm_rccl_comm_create", rank, world, uid, ctypes.byref(self.h))
+
+    def allreduce(self, buf, stream=None):
+        from . import _lib, ops
+        _lib.call("gm_rccl_allreduce_f32", self.h, stream or ops.stream_ptr(), buf.data_ptr(), buf.numel())
+
+    def close(self):
+        from . import _lib
+        if getattr(self, "h", None):
+            _lib.load().gm_rccl_comm_destroy(self.h)
+            self.h = None

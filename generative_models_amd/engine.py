@@ -424,6 +424,12 @@ class GANEngine:
             if variant == "info":                    # third optimizer: G u Q (info_gan.py:146-148)
                 sizes["Q"] = sum(_align4(p.numel()) for p in model.Q.parameters())
             self._setup_peer_comm(sizes)
+        # the fallback exchange: RCCL all-reduces CAPTURED into the iteration's graph (round 5; GM_RCCL_IN_GRAPH=0 keeps
+        # round 1's host-launched collectives between segment graphs)
+        self._rccl = None
+        if (world_size > 1 or force_dp) and self.comm_mode == "rccl" and use_graph and \
+                os.environ.get("GM_RCCL_IN_GRAPH", "1") != "0":
+            self._setup_rccl_graph_comm()
         alloc = (lambda net: (lambda n: self._comms[net].grad_buffer()[:n])) if self._comms else \
             (lambda net: None)
         self.fG = FlatParams(G.parameters(), device, grad_alloc=alloc("G"))
@@ -563,8 +569,11 @@ class GANEngine:
         the all-gather kernel)."""
         return not self._single() and self.comm_mode == "peer"
 
+    def _rccl_in_graph(self):
+        return not self._single() and self.comm_mode == "rccl" and self._rccl is not None
+
     def _one_graph(self):
-        return self._single() or self._peer()
+        return self._single() or self._peer() or self._rccl_in_graph()
 
     def _tick_in_head(self):
         """The per-graph tick rides in the generator step's head_bwd kernel."""
@@ -693,6 +702,9 @@ class GANEngine:
                 sched, scale = self.schedG, self._lr_scale("G")
             self._comms[net].allreduce_adam(fp.grad, fp.flat, fp.m, fp.v, sched, slot, clamp=clamp,
                                             lr_scale=scale, stream=st)
+            return
+        if self._rccl_in_graph():
+            self._rccl.allreduce(fp.grad, stream=st)  # a node of the iteration's graph; Adam follows in _issue_*_post
             return
         from . import dp
         dp.allreduce_sum_(fp.grad, self.pg)
@@ -1592,13 +1604,36 @@ class GANEngine:
             warnings.warn("generative_models_amd: in-graph peer gradient exchange unavailable (%s); "
                           "falling back to host-launched RCCL all-reduces" % self.comm_fallback)
 
+    def _setup_rccl_graph_comm(self):
+        """A communicator of the library's own whose all-reduce can be captured; any failure (no RCCL in the process,
+        a rank that cannot initialise) leaves every rank on the host-launched path -- agreed on collectively."""
+        from . import dp
+        ok, why = True, None
+        try:
+            self._rccl = dp.RcclGraphComm(self.world, self.rank, self.pg)
+        except Exception as e:                       # noqa: BLE001
+            ok, why, self._rccl = False, "%s: %s" % (type(e).__name__, e), None
+        if self.world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if dist.get_backend(self.pg) == "nccl":
+                flag = flag.to(self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            if not bool(flag.item()) and self._rccl is not None:
+                self._rccl.close()
+                self._rccl = None
+        if self._rccl is None and why:
+            import warnings
+            warnings.warn("generative_models_amd: RCCL all-reduce inside the graph unavailable (%s); host-launched "
+                          "collectives between segment graphs" % why)
+
     def exchange_form(self):
         """Which gradient exchange a step takes: 'none' (one rank), 'one_kernel' / 'two_kernels' (in-graph peer
         exchange, csrc/gm_comm.hip) or 'rccl' (host-launched fallback)."""
         if not self._dp():
             return "none"
         if not self._peer():
-            return "rccl"
+            return "rccl_in_graph" if self._rccl_in_graph() else "rccl"
         comms = getattr(self, "_comms", None) or {}
         return "two_kernels" if any(c.two_kernels for c in comms.values()) else "one_kernel"
 

@@ -577,6 +577,15 @@ int gm_allreduce_adam_f32(void* comm, void* stream, float* grad, int64_t n, floa
                           double beta2, double eps, double weight_decay, float clamp,
                           const float* lr_scale_or_null);
 int gm_allreduce_scalars(void* comm, void* stream, float* vals, int k);
+/* The same SUM as an RCCL collective that can be CAPTURED into the iteration's hipGraph (the fallback when peer
+ * mappings are not available: GM_DP_COMM=rccl; round 1 launched torch.distributed all-reduces from the host between
+ * segment graphs).  RCCL is not linked: its symbols are resolved at first use from the librccl the process already
+ * carries (torch's).  uid128: 128 bytes (ncclUniqueId) made on rank 0 by gm_rccl_unique_id and handed to every rank
+ * by the host; gm_rccl_comm_create is collective.  In place, fp32. */
+int gm_rccl_unique_id(void* uid128_out);
+int gm_rccl_comm_create(int rank, int world, const void* uid128, void** rccl_comm_out);
+int gm_rccl_allreduce_f32(void* rccl_comm, void* stream, float* buf, int64_t n);
+int gm_rccl_comm_destroy(void* rccl_comm);
 
 /* ---- HOST helper (no device work): first B entries of torch.randperm(n, generator=
  * Generator().manual_seed(seed)) in O(B): RandomSampler.__iter__ (torch/utils/data/sampler.py:160-185)

@@ -232,13 +232,16 @@ def test_two_rank_engine_equals_one_rank(variant, kw):
 
 
 @needs_2_gpus
-@pytest.mark.parametrize("variant,kw", [("ns", dict(num_epochs=2))], ids=["ns"])
-def test_two_gpu_engine_equals_one_rank(variant, kw):
-    """The same comparison with ONE GPU PER RANK and RCCL as control plane (skipped on 1-GPU boxes):
-    either exchange mode is acceptable here (peer mappings, or the RCCL fallback if the self-check
-    refused them)."""
+@pytest.mark.parametrize("comm", ["peer", "rccl"])
+@pytest.mark.parametrize("variant,kw", [("ns", dict(num_epochs=2)), ("wgp", dict(num_epochs=1, D_steps=2))], ids=["ns", "wgp"])
+def test_two_gpu_engine_equals_one_rank(variant, kw, comm):
+    """The same comparison with ONE GPU PER RANK and RCCL as control plane (skipped on 1-GPU boxes).  comm = peer:
+    either exchange mode is acceptable (peer mappings, or the RCCL fallback if the self-check refused them);
+    comm = rccl (GM_DP_COMM=rccl): the fallback itself -- RCCL all-reduces captured inside the iteration's graph."""
     one = _run_world(1, variant, kw)[0]
-    two = _run_world(2, variant, kw, real=True)
+    two = _run_world(2, variant, kw, real=True, env={"GM_DP_COMM": comm})
+    if comm == "rccl":
+        assert all(o["xchg"] in ("rccl_in_graph", "rccl") for o in two), [o["xchg"] for o in two]
     for o in two:
         assert o["world"] == 2 and o["rng"] == one["rng"]
         g, d = np.array(o["G"]), np.array(o["D"])

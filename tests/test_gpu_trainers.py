@@ -837,18 +837,23 @@ def test_vae_ae_checkpoint_resume_is_bitwise_uninterrupted(kind, tmp_path):
         assert torch.equal(a, b), k
 
 
-def test_dp_launch_structure_single_rank_rccl():
-    """The data-parallel launch structure (one hipGraph per segment, RCCL all-reduce of the flat
-    gradient buckets in between) on a 1-rank RCCL group: must equal the single-graph run
-    (an all-reduce over one rank is the identity)."""
+@pytest.mark.parametrize("in_graph", [True, False], ids=["rccl_in_graph", "host_launched"])
+def test_dp_launch_structure_single_rank_rccl(in_graph, monkeypatch):
+    """The RCCL fallback of the data-parallel step on a 1-rank group: must equal the single-graph run (an all-reduce
+    over one rank is the identity).  in_graph (round 5): the all-reduces are nodes of the iteration's ONE hipGraph
+    (gm_rccl_allreduce_f32 on the library's own communicator); host_launched (GM_RCCL_IN_GRAPH=0): round 1's hipGraph
+    per segment with torch.distributed all-reduces between them."""
     import socket
     import torch.distributed as dist
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port_no = s.getsockname()[1]; s.close()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_no)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    os.environ["GM_DP_COMM"] = "rccl"
+    monkeypatch.setenv("GM_DP_COMM", "rccl")
+    monkeypatch.setenv("GM_RCCL_IN_GRAPH", "1" if in_graph else "0")
     try:
+        monkeypatch.delenv("GM_DP_COMM")
         ref = run_product("ls", SMALL, 16, dict(num_epochs=2))
+        monkeypatch.setenv("GM_DP_COMM", "rccl")
         tr, model = build_product("ls", SMALL, 16)
         tr.force_dp = True
         eng = tr._get_engine()
@@ -857,7 +862,10 @@ def test_dp_launch_structure_single_rank_rccl():
         with contextlib.redirect_stdout(io.StringIO()):
             tr.train(num_epochs=2)
         torch.cuda.synchronize()
-        assert eng.seg_graphs is not None and len(eng.seg_graphs) == 3
+        if in_graph:
+            assert eng.exchange_form() == "rccl_in_graph" and eng.seg_graphs is None and eng._one_graph()
+        else:
+            assert eng.exchange_form() == "rccl" and eng.seg_graphs is not None and len(eng.seg_graphs) == 3
         # same kernels except Adam (separate launch here, gradient-epilogue fusion in the
         # single-graph run): identical up to fp32 contraction differences
         lclose(tr.Glosses, ref[0].Glosses, "dp-structure Glosses", tol=1e-6)
@@ -865,7 +873,6 @@ def test_dp_launch_structure_single_rank_rccl():
         for (k, a), (_, b) in zip(model.state_dict().items(), ref[1].state_dict().items()):
             assert (a - b).abs().max().item() <= 1e-6, k
     finally:
-        os.environ.pop("GM_DP_COMM", None)
         dist.destroy_process_group()
 
 
