@@ -496,9 +496,6 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
                               world_size=world, rank=rank, force_dp=force_dp)
     eng.configure(W + reps * K + long_steps + (SUSTAINED_MAX_STEPS if sustained_s else 0), lrs[0], lrs[1], D_steps)
     eng.run(W, it_start=0)
-    # graphs of the exact lengths the timed runs launch exist before the clock starts (a trainer captures them during
-    # its first epoch; the other launch paths captured theirs in configure already: no-op there)
-    eng.prepare(K)
     marks = []
 
     def rep(r):
@@ -516,7 +513,6 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
     if long_steps:
         # one long region right behind the timed ones: the steady-state step, so that the fixed cost
         # of a K-step run() (cold start of the host draws, graph boundaries, final sync) can be reported
-        eng.prepare(long_steps)
         ls = timed_reps(lambda r: eng.run(long_steps, it_start=W + reps * K), 1, long_steps,
                         1 if solo else world, dev)
         eng.steady_us_per_step = ls[0] / long_steps * 1e6
@@ -526,7 +522,6 @@ def bench_gan(variant, B_global, W, K, reps, dev, world=1, rank=0, use_graph=Tru
         # ONE uninterrupted window of >= sustained_s seconds of the same step (host draws inside, as everywhere): long
         # enough for an outside observer sampling GPU activity every few seconds (the driver's gpu_busy) to see it
         n_sus = int(min(SUSTAINED_MAX_STEPS, sustained_s * 1e6 / eng.steady_us_per_step + 1))
-        eng.prepare(n_sus)
         su = timed_reps(lambda r: eng.run(n_sus, it_start=W + reps * K + long_steps), 1, n_sus,
                         1 if solo else world, dev)
         eng.sustained = {"seconds": su[0], "steps": n_sus, "us_per_step": su[0] / n_sus * 1e6,

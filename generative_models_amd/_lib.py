@@ -82,13 +82,6 @@ class StageSeg(ctypes.Structure):
                 ("src_block_stride", c_int64), ("dst_block_stride", c_int64)]
 
 
-class StageAheadArgs(ctypes.Structure):
-    """gm_stage_ahead_args (include/gm_hip.h): the next iteration's draws riding in the generator's last launch."""
-    _fields_ = [("segs", ctypes.POINTER(StageSeg)), ("n_segs", c_int), ("parts", c_int),
-                ("ring_slot", Slot), ("it_slot", Slot), ("gate", c_void_p), ("timeout_s", ctypes.c_double),
-                ("range", c_void_p), ("arrive", c_void_p), ("may_skip", c_int)]
-
-
 DRAW_SAMPLER, DRAW_NORMAL, DRAW_UNIFORM, DRAW_INFO = 0, 1, 2, 3
 GM_EUNSUPPORTED = -10002
 
@@ -160,8 +153,6 @@ _SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
                                                 POINTER(HeadBwdArgs), POINTER(HeadFoldArgs)]),
     "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),
-    "gm_stage_ahead_pack": (c_int, [POINTER(StageAheadArgs), _P, c_int64]),
-    "gm_linear_bwd_dw_adam_pair_stage": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs), _P, c_int]),
     "gm_linear_bwd_dw_adam_pair_finalize": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs),
                                                     POINTER(Finalize2Args)]),
     "gm_linear_bwd_dw_adam_head": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,

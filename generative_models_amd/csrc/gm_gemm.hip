@@ -12,12 +12,13 @@
 //     dimension is split ACROSS THE 16 WAVES of the workgroup in round-robin 16-deep chunks, no two waves touch the
 //     same k, so operands are NOT shared through LDS: each wave loads its chunks straight into
 //     v_mfma_f32_16x16x4_f32 fragment registers, with no barrier inside the reduction loop;
-//   * every operand load is 16 bytes per lane: one CU retires about one wave-wide vector-memory instruction per
-//     40 cycles whatever it carries (round 4, tools/slab_probe: 8 B per lane 22-24 GB/s per CU, 12 B 32-34, 16 B
-//     43-45, global_load_lds_dwordx4 53-55).  k-contiguous operands: lane (i = lane & 15, g = lane >> 4) loads the 4
+//   * every operand load is 16 bytes per lane (what an instruction costs the vector cache depends on which lanes read
+//     adjacent bytes: tools/fill_probe, profiles/r05_fill_law.md -- round 4's "40 cycles whatever it carries" was
+//     the uncoalesced fragment pattern).  k-contiguous operands: lane (i = lane & 15, g = lane >> 4) loads the 4
 //     consecutive k = 16c + 4g .. of row i and MFMA j consumes element j (an identical k-permutation for A and B:
-//     legal because a sum does not care); x-contiguous operands: one 16-byte load of 4 consecutive x at one k plus a
-//     4x4 transpose inside each lane quad (two DPP quad_perm steps, no LDS); weight gradients over >= 768 rows:
+//     legal because a sum does not care); x-contiguous operands: one 16-byte load of 4 consecutive x at one k, a quad
+//     reading 64 contiguous bytes of one k-row (round 5: coalesced), plus a 4x4 transpose over lanes l, l^4, l^8, l^12
+//     (DPP, no LDS) and a fixed output permutation undone in the epilogue; weight gradients over >= 768 rows:
 //     whole chunks by LDS-DMA into wave-private buffers and interleaved fragments (gemm16_dw_dma);
 //   * loads are branch-free (clamped addresses, zeroing selects deferred to the consume stage);
 //   * the partial tiles are combined through LDS in wave order, then bias / activation / activation-gradient /
@@ -33,7 +34,6 @@
 #include "gm_head.h"
 #include "gm_gather.h"
 #include "gm_ldsdma.h"
-#include "gm_stage.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -127,24 +127,6 @@ __device__ __forceinline__ float4 raw_xc(const float* __restrict__ P, int64_t ld
     return make_float4(col[(int64_t)min(kb + 0, K - 1) * ld], col[(int64_t)min(kb + 1, K - 1) * ld],
                        col[(int64_t)min(kb + 2, K - 1) * ld], col[(int64_t)min(kb + 3, K - 1) * ld]);
 }
-__device__ __forceinline__ float dpp_xor2(float v) {   // lane ^ 2 within the quad
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_xor1(float v) {   // lane ^ 1 within the quad
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-// new[lane e][reg j] = old[lane j][reg e] over the 4 lanes of a quad
-__device__ __forceinline__ float4 quad_transpose(float4 v, int lane) {
-    const bool b1 = lane & 2, b0 = lane & 1;
-    // step 1: exchange 2x2 blocks with lane^2
-    const float s0 = dpp_xor2(b1 ? v.x : v.z), s1 = dpp_xor2(b1 ? v.y : v.w);
-    if (b1) { v.x = s0; v.y = s1; } else { v.z = s0; v.w = s1; }
-    // step 2: exchange inside the 2x2 blocks with lane^1
-    const float t0 = dpp_xor1(b0 ? v.x : v.y), t1 = dpp_xor1(b0 ? v.z : v.w);
-    if (b0) { v.x = t0; v.z = t1; } else { v.y = t0; v.w = t1; }
-    return v;
-}
-
 __device__ __forceinline__ float4 fix_xc(float4 v, int x, int X, int kb, int K, int ones_col,
                                          int ones_from = 0) {
     const bool okx = x < X, oc = (x == ones_col);
@@ -713,61 +695,34 @@ int launch_lds(hipStream_t s, const GemmP& p, int cfg) {
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- coalesced fragment loads (round 5) -------------------------------------------------------------------------
+// ---- coalesced x-contiguous fragment loads (round 5) ------------------------------------------------------------
 // What a wave-wide 16-byte load costs the CU's vector cache depends on WHICH LANES read adjacent bytes
 // (tools/fill_probe, profiles/r05_fill_law.md; 16 waves x 4 loads in flight, L2-resident operands):
 //     1 KB contiguous                                   21 cycles per instruction, 16 cache accesses
 //     16 rows x 64 B, the four lanes of a QUAD adjacent   30 cycles, 16 accesses
-//     16 rows x 64 B, adjacent bytes 16 LANES APART       44 cycles, 64 accesses + tag-conflict stalls   <- rounds 1-4
-// The MFMA 16x16x4 fragment wants lane (i = lane & 15, g = lane >> 4) to hold row i, k-group g, so a load straight into
-// fragment layout puts a row's four 16-byte pieces 16 lanes apart: every lane is its own cache access.  Rounds 1-4
-// loaded that way (and round 4 read its 44 cycles as a law of the machine).  Now the four lanes of a quad read one
-// row's 64 contiguous bytes and the fragment layout is restored in registers:
-//   k-contiguous operands (X / W in the forward, dA in the input gradient): lane -> row lane >> 2, k-quad lane & 3;
-//     four ds_bpermute_b32 (the LDS crossbar, no LDS memory) bring row i, k-quad g to lane 16 g + i;
-//   x-contiguous operands (both operands of the weight gradient, W in the input gradient): lane -> k-row
-//     4 (lane >> 4) + ((lane >> 2) & 3), x-quad lane & 3; the 4x4 transpose that turns "four x at one k" into "four k
-//     at one x" runs over lane bits 3:2 (lanes l, l^4, l^8, l^12) instead of the quad, for the same number of VALU
-//     operations; the lane then holds output index SIGMA(lane & 15) = 4 (lane & 3) + ((lane >> 2) & 3) of its
-//     16-wide sub-tile instead of lane & 15 -- a fixed permutation of the tile's rows / columns that the epilogue
-//     undoes when it writes the accumulators out (XMAP below).
-#ifndef GM_COALESCED_X
-#define GM_COALESCED_X 1
-#endif
-#ifndef GM_COALESCED_K
-#define GM_COALESCED_K 0
-#endif
-#ifndef GM_PREFETCH_ALL
-#define GM_PREFETCH_ALL 1
-#endif
-constexpr bool COALESCED = GM_COALESCED_X != 0;       // x-contiguous operands
-constexpr bool COALESCED_K = GM_COALESCED_K != 0;     // k-contiguous operands (ds_bpermute)
-constexpr bool PREFETCH_ALL = GM_PREFETCH_ALL != 0;   // a wave issues the loads of ALL its chunks before the first MFMA
-
+//     16 rows x 64 B, adjacent bytes 16 LANES APART       44 cycles, 64 accesses + tag-conflict stalls
+// (round 4 read the 44 cycles of its own loads as a law of the machine).  For the x-contiguous operands -- both operands
+// of the weight gradient, W in the input gradient -- the coalesced form is free: lane -> k-row 4 (lane >> 4) +
+// ((lane >> 2) & 3), x-quad lane & 3 (a quad reads 64 contiguous bytes of one k-row); the 4x4 transpose that turns
+// "four x at one k" into "four k at one x" then runs over lane bits 3:2 (lanes l, l^4, l^8, l^12) instead of the quad,
+// same number of VALU operations; and the lane ends up holding output index SIGMA(lane & 15) = 4 (lane & 3) +
+// ((lane >> 2) & 3) of its 16-wide sub-tile instead of lane & 15 -- a fixed permutation of the tile's rows / columns
+// that the epilogue undoes where it writes the accumulators out (XMAP).  Bit-identical results (same k per MFMA step
+// and lane group).  Measured (profiles/r05_experiments.md section 2, same-call alternation): layer-1 weight gradient +
+// head 12.4 -> 12.2 us, NSGAN bs=256 step 69.0 -> 68.7 us.
+// The k-contiguous operands (X / W in the forward, dA in the input gradient) stay in fragment layout: their coalesced
+// form needs a lane exchange (four ds_bpermute_b32 per fragment) and measured SLOWER inside the step (69.1 -> 70.9 us);
+// so did requesting all of a wave's chunks before the first MFMA (69.0 -> 76.5 us) -- these launches are chains of
+// dependent round trips, not vector-cache-throughput bound (same log).
 __device__ __forceinline__ int sigma16(int i) { return ((i & 3) << 2) | ((i >> 2) & 3); }
 
 __device__ __forceinline__ float4 raw_xc4_16(const float* __restrict__ P, int64_t ld, int x0, int X,
                                              int c, int K, int lane) {
     // e: which of the 4 k-rows of lane-group g; q: which x-quad of the 16-wide sub-tile
-    const int e = COALESCED ? (lane >> 2) & 3 : lane & 3, q = COALESCED ? lane & 3 : (lane >> 2) & 3, g = lane >> 4;
+    const int e = (lane >> 2) & 3, q = lane & 3, g = lane >> 4;
     const int k = min(16 * c + 4 * g + e, K - 1);
     const int x = min(x0 + 4 * q, X - 4);
     return *reinterpret_cast<const float4*>(P + (int64_t)k * ld + x);
-}
-
-// k-contiguous, coalesced: the 4 values k = 16 c + 4 (lane & 3) .. of row x0 + (lane >> 2)
-__device__ __forceinline__ float4 raw_kc_co(const float* __restrict__ P, int64_t ld, int x0, int X, int c, int K,
-                                            int lane) {
-    const float* row = P + (int64_t)min(x0 + (lane >> 2), X - 1) * ld;
-    return *reinterpret_cast<const float4*>(row + min(16 * c + 4 * (lane & 3), K - 4));
-}
-// ... and into fragment layout: lane 16 g + i takes what lane 4 i + g loaded (row i, k-quad g)
-__device__ __forceinline__ float4 kc_to_fragment(float4 v, int lane) {
-    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;          // byte address of the source lane's dword
-    return make_float4(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x))),
-                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y))),
-                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.z))),
-                       __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.w))));
 }
 
 // lane ^ 8 and lane ^ 4 inside a row of 16 lanes, from direction-free DPP controls only (a rotation by half a row;
@@ -1056,10 +1011,9 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     float4 fw[FOLD == 1 ? MI : 1];
     float fds[FOLD == 2 ? MI : 1];
     // x-contiguous 16-byte operands: which x-quad / which of its lane-group's four k-rows this lane LOADS
-    const int xq_ld = COALESCED ? lane & 3 : (lane >> 2) & 3, xe_ld = COALESCED ? (lane >> 2) & 3 : lane & 3;
-    // ... and which output index of the 16-wide sub-tile it then HOLDS (XMAP: sigma16 when coalesced)
-    constexpr bool XMAP_A = COALESCED && MODE == MODE_DW && XV, XMAP_B = COALESCED && MODE != MODE_FWD && XV;
-    constexpr bool KCO = COALESCED_K && VEC;                  // k-contiguous operands by coalesced quads + bpermute
+    const int xq_ld = lane & 3, xe_ld = (lane >> 2) & 3;
+    // ... and which output index of the 16-wide sub-tile it then HOLDS (XMAP: sigma16)
+    constexpr bool XMAP_A = MODE == MODE_DW && XV, XMAP_B = MODE != MODE_FWD && XV;
     const int ia = XMAP_A ? sigma16(i16) : i16, ib = XMAP_B ? sigma16(i16) : i16;
     if constexpr (FOLD == 1) {
 #pragma unroll
@@ -1073,15 +1027,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             if (XV) return raw_xc4_16(A, p.lda, x0, p.M, c, p.K, lane);
             return raw_xc(A, p.lda, x0 + i16, p.M, kb, p.K);
         }
-        if constexpr (KCO) return raw_kc_co(A, p.lda, x0, p.M, c, p.K, lane);
         return raw_kc<VEC>(A, p.lda, x0 + i16, p.M, kb, p.K);
     };
     auto load_b = [&](int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x0 = n0 + 16 * ni;
-        if (MODE == MODE_FWD) {
-            if constexpr (KCO) return raw_kc_co(B, p.ldb, x0, p.N, c, p.K, lane);
-            return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
-        }
+        if (MODE == MODE_FWD) return raw_kc<VEC>(B, p.ldb, x0 + i16, p.N, kb, p.K);
         if (XV) return raw_xc4_16(B, p.ldb, x0, b_cols, c, p.K, lane);
         return raw_xc(B, p.ldb, x0 + i16, b_cols, kb, p.K);
     };
@@ -1089,17 +1039,15 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         const int kb = 16 * c + 4 * g4, x = m0 + 16 * mi + ia;
         if constexpr (FOLD == 1)                              // the loaded row is k = 16c + 4g + e (clamped)
             v = fold_dh4(v, sds[min(16 * c + 4 * g4 + xe_ld, p.K - 1)], fw[mi]);
-        if constexpr (MODE != MODE_DW && KCO) v = kc_to_fragment(v, lane);
         if constexpr (FOLD == 2) v = fold_dh4(v, fds[mi], wk);
         if (MODE == MODE_DW)
-            return fix_xc(XV ? (COALESCED ? lane48_transpose(v, lane) : quad_transpose(v, lane)) : v, x, p.M, kb, p.K, -1);
+            return fix_xc(XV ? lane48_transpose(v, lane) : v, x, p.M, kb, p.K, -1);
         return fix_kc(v, x, p.M, kb, p.K);
     };
     auto fix_b = [&](float4 v, int c, int ni) -> float4 {
         const int kb = 16 * c + 4 * g4, x = n0 + 16 * ni + ib;
-        if (MODE == MODE_FWD) return fix_kc(KCO ? kc_to_fragment(v, lane) : v, x, p.N, kb, p.K);
-        return fix_xc(XV ? (COALESCED ? lane48_transpose(v, lane) : quad_transpose(v, lane)) : v, x, b_cols, kb, p.K,
-                      ones_col, OF ? p.ones_from : 0);
+        if (MODE == MODE_FWD) return fix_kc(v, x, p.N, kb, p.K);
+        return fix_xc(XV ? lane48_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
     };
 
     f32x4 acc[MI][NI];
@@ -1159,60 +1107,31 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             for (int mi = 0; mi < MI; ++mi) fds[mi] = sds[16 * mi + i16];     // dS of this lane's A rows
         }
     };
-    // PREFETCH_ALL (round 5): a wave has at most a handful of chunks (K = 784: 3 or 4; 512 rows: 2) -- it requests ALL
-    // of them before the first MFMA and consumes them in order (hipcc counts the vmcnt).  One dependent round trip per
-    // wave instead of one per chunk; (MI + NI) float4 of registers per chunk in flight.  QW = chunks held at once.
-    // (the folded-head kernels sit at the 128-register cap of a 1024-thread workgroup already: two chunks there)
-    constexpr int QW = !PREFETCH_ALL ? 0 : ((MI + NI <= 4 && FOLD == 0) ? 4 : 2);
-    bool done = false;
-    if constexpr (QW > 0) {
-        if (nq <= QW) {                                       // wave-uniform
-            float4 ra[QW][MI], rb[QW][NI], wk[QW];
+    int q_first = 0;
+    if constexpr (FOLD != 0) {
+        float4 ra[MI], rb[NI];
+        float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool have = nq > 0;
+        if (have) {
 #pragma unroll
-            for (int q = 0; q < QW; ++q) {
-                if (q < nq) {
-                    const int cc = w + q * WAVES;
+            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) ra[q][mi] = load_a(cc, mi);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) rb[q][ni] = load_b(cc, ni);
-                    wk[q] = load_wk(cc);
-                }
-            }
-            fold_prologue();
-#pragma unroll
-            for (int q = 0; q < QW; ++q)
-                if (q < nq) consume(ra[q], rb[q], wk[q], q);
-            done = true;
+            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
+            wk = load_wk(w);
         }
+        fold_prologue();
+        if (have) consume(ra, rb, wk, 0);
+        q_first = 1;
     }
-    if (!done) {
-        int q_first = 0;
-        if constexpr (FOLD != 0) {
-            float4 ra[MI], rb[NI];
-            float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool have = nq > 0;
-            if (have) {
+    for (int q = q_first; q < nq; ++q) {
+        float4 ra[MI], rb[NI];
+        const int cc = w + q * WAVES;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
-                wk = load_wk(w);
-            }
-            fold_prologue();
-            if (have) consume(ra, rb, wk, 0);
-            q_first = 1;
-        }
-        for (int q = q_first; q < nq; ++q) {
-            float4 ra[MI], rb[NI];
-            const int cc = w + q * WAVES;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(cc, mi);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
-            const float4 wk = load_wk(cc);
-            consume(ra, rb, wk, q);
-        }
+        for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
+        const float4 wk = load_wk(cc);
+        consume(ra, rb, wk, q);
     }
     if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
         if (p.vec_epi) {                                     // kernel-argument uniform
@@ -1319,17 +1238,12 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
-// Round 5: workgroups [0, nstage) in front of the tiles are the stage-AHEAD rider (gm_stage.h): they bring the NEXT
-// iteration's draws into the device rings while the tiles run (nstage == 0: none, `sa` unused).  `sa` lives in DEVICE
-// memory (gm_stage_ahead_pack): its segment table is indexed by the rider's workgroup id, and a by-value kernel
-// argument indexed dynamically is copied to scratch by the compiler (392 bytes per lane of EVERY workgroup of the pair).
 template <int G, bool XV, int MI, int NI, bool DMA = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
-                                                              int tnb, const StageAheadP* sa, int nstage) {
+                                                              int tnb) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, DMA, MI, NI>::value];
-    const int id = (int)blockIdx.x - nstage;
-    if (id < 0) stage_ahead_body(*sa, (int)blockIdx.x, reinterpret_cast<int*>(red));
-    else if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
+    const int id = blockIdx.x;
+    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
     else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
@@ -1382,8 +1296,6 @@ struct Rider {
     const GemmP* pair = nullptr;         // MODE_DW: a second weight-gradient GEMM
     bool pair_xvec = false;
     const gm_fin2* fin = nullptr;        // MODE_DW pair: the VAE batch's two loss sums + counter tick
-    const StageAheadP* stage = nullptr;  // MODE_DW pair: the next iteration's draws, host ring -> device ring (DEVICE memory)
-    int stage_blocks = 0;                //               its workgroups (n_segs * parts)
 };
 
 // Tile shapes of the 16-wave kernels, as sub-tiles (16 x 16) per wave: MI x NI
@@ -1548,29 +1460,21 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 p.dma = pb.dma = dma;
                 const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                 const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
-                const StageAheadP* sa = rider.stage;
-                const int nstage = rider.stage ? rider.stage_blocks : 0;
-                const dim3 pgrid(na + tnb * tmb + nstage);
-#define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb, sa, nstage)
-#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(na + tnb * tmb + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
+                const dim3 pgrid(na + tnb * tmb);
+#define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb)
+#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(pgrid.x + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
                 if (rider.fin) GM_TILE_SWITCH(tile, dma, GM_LPF);
                 else GM_TILE_SWITCH(tile, dma, GM_LP);
 #undef GM_LPF
 #undef GM_LP
                 GM_LAUNCH_RET();
             }
-            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums / the
-            // stage-ahead rider theirs)
+            // not pairable in this configuration: the second GEMM gets its own launch afterwards (and the sums theirs)
             Rider none;
             int rc = launch<MODE_DW>(s, p_in, vec, xvec, none);
             if (rc) return rc;
             rc = launch<MODE_DW>(s, pb, false, rider.pair_xvec, none);
-            if (rc) return rc;
-            if (rider.stage) {                       // the rider as its own launch: the caller relies on it
-                hipLaunchKernelGGL(stage_ahead_kernel, dim3(rider.stage_blocks), dim3(1024), 0, s, rider.stage);
-                GM_LAUNCH_RET();
-            }
-            if (!rider.fin) return rc;
+            if (rc || !rider.fin) return rc;
             const gm_fin2& f = *rider.fin;
             return gm_sum_finalize2_tick(s, f.pa, f.na, f.sa, f.oa, f.slot_a, f.pb, f.nb, f.sb, f.ob, f.slot_b, f.tick);
         }
@@ -1910,54 +1814,6 @@ extern "C" int gm_linear_bwd_dw_adam_pair(void* stream, const gm_dw_adam_args* f
     Rider r;
     r.pair = &pb;
     r.pair_xvec = xb;
-    return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
-}
-
-extern "C" int gm_stage_ahead_pack(const gm_stage_ahead_args* st, void* dev_buf, int64_t dev_buf_bytes) {
-    GM_CHECK_ARG(st && dev_buf && dev_buf_bytes >= (int64_t)sizeof(StageAheadP));
-    GM_CHECK_ARG(st->segs && st->n_segs > 0 && st->n_segs <= GM_STAGE_MAX_SEGS && st->parts >= 1 && st->parts <= 8);
-    GM_CHECK_ARG(st->gate && st->range && st->arrive && st->timeout_s > 0.0 && st->timeout_s < 3600.0);
-    StageAheadP sa{};
-    for (int i = 0; i < st->n_segs; ++i) {
-        const gm_stage_seg& g = st->segs[i];
-        const int m = g.blocks > 1 ? g.blocks : 1;
-        GM_CHECK_ARG(g.src && g.dst && g.bytes_per_iter > 0 && g.blocks >= 0 && g.bytes_per_iter % (4 * m) == 0);
-        GM_CHECK_ARG(g.src_block_stride >= 0 && g.dst_block_stride >= 0 && g.src_block_stride % 4 == 0 &&
-                     g.dst_block_stride % 4 == 0);
-        GM_CHECK_ARG(!g.src_block_stride || g.src_block_stride >= g.bytes_per_iter / m);
-        GM_CHECK_ARG(!g.dst_block_stride || g.dst_block_stride >= g.bytes_per_iter / m);
-        sa.seg[i] = g;
-    }
-    sa.n_segs = st->n_segs; sa.parts = st->parts; sa.ring_slot = st->ring_slot; sa.it_slot = st->it_slot;
-    sa.gate = st->gate; sa.timeout = (uint64_t)(st->timeout_s * 1e8);           // wall_clock64(): 100 MHz
-    sa.range = reinterpret_cast<unsigned long long*>(st->range); sa.arrive = st->arrive;
-    sa.may_skip = st->may_skip ? 1 : 0;
-    const hipError_t e = hipMemcpy(dev_buf, &sa, sizeof(sa), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        gm_set_error(hipGetErrorString(e));
-        return -(int)e;
-    }
-    return 0;
-}
-
-extern "C" int gm_linear_bwd_dw_adam_pair_stage(void* stream, const gm_dw_adam_args* first,
-                                                const gm_dw_adam_args* second, const void* packed, int n_blocks) {
-    GM_CHECK_ARG(first && second && packed && n_blocks >= 1 && n_blocks <= 8 * GM_STAGE_MAX_SEGS);
-    GM_CHECK_ARG(first->dW != second->dW && (first->pW != second->pW || !first->pW));
-    GM_CHECK_ARG(!first->pW || ((const float*)first->pW != second->dA && (const float*)first->pW != second->X));
-    GM_CHECK_ARG(!second->pW || ((const float*)second->pW != first->dA && (const float*)second->pW != first->X));
-    GM_CHECK_ARG(first->dW != second->dA && first->dW != second->X && second->dW != first->dA && second->dW != first->X);
-    GemmP pa{}, pb{};
-    bool xa = false, xb = false;
-    int rc = dw_adam_fill(*first, &pa, &xa);
-    if (rc) return rc;
-    rc = dw_adam_fill(*second, &pb, &xb);
-    if (rc) return rc;
-    Rider r;
-    r.pair = &pb;
-    r.pair_xvec = xb;
-    r.stage = static_cast<const StageAheadP*>(packed);
-    r.stage_blocks = n_blocks;
     return launch<MODE_DW>((hipStream_t)stream, pa, false, xa, r);
 }
 

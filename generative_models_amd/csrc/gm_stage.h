@@ -1,6 +1,8 @@
 // gm_stage.h -- host ring -> device ring copies of the per-iteration draws (index batches, noise, eps: what
-// ns_gan.py:218-226 / compute_noise produce on the host one step at a time), shared by the stage-in launches of
-// gm_ops.hip and by the "stage the NEXT iteration" rider of the generator's weight-gradient pair (gm_gemm.hip).
+// ns_gan.py:218-226 / compute_noise produce on the host one step at a time): the stage-in launches of gm_ops.hip.
+// (Round 5 also tried a "stage the NEXT iteration" rider inside the generator's last launch so that a run could be
+// ONE graph of exact length -- measured no better over 20 steps and 4 us per iteration worse in steady state, removed:
+// profiles/r05_experiments.md section 3.)
 #pragma once
 #include "gm_common.h"
 
@@ -87,86 +89,4 @@ __device__ __forceinline__ void stage_gate_wait(const int64_t* gate, int64_t nee
             break;
         }
     }
-}
-
-// ---- stage-AHEAD rider (round 5) -----------------------------------------------------------------------------------
-// The last launch of iteration i (the generator's weight-gradient pair, gm_linear_bwd_dw_adam_pair_stage) carries a few
-// extra workgroups that bring iteration i + 1's draws into the device rings while the GEMM tiles run: a graph of ANY
-// number of iterations then needs only its FIRST iteration staged before it starts, so a run is no longer cut into
-// small first pieces that each wait for all of their draws (the 21 - 33 us piece boundaries and the ~60 us until the
-// first kernel of a cold 20-step run, profiles/r04_experiments.md section 7).
-//   gate[0] = iterations the host has WRITTEN, gate[1] = time-out flag, gate[2] = iterations whose draws the host has
-//   SUBMITTED: the rider of a graph's last iteration (may_skip) skips an iteration that was not submitted -- the next
-//   graph's first node stages it then; inner riders always deliver (the host submits a graph's draws right behind its
-//   launch).
-//   range = (lo << 32) | hi: iterations in the device rings (the word gm_stage_in_prestaged checks).
-// The struct lives in DEVICE memory (gm_stage_ahead_pack): the segment table is indexed by the rider's workgroup id.
-struct StageAheadP {
-    gm_stage_seg seg[GM_STAGE_MAX_SEGS];
-    int n_segs;
-    int parts;                 // workgroups per segment
-    gm_slot ring_slot;         // ring slot of the NEXT iteration
-    gm_slot it_slot;           // its absolute index
-    const int64_t* gate;
-    uint64_t timeout;
-    unsigned long long* range;
-    unsigned int* arrive;      // low 16 bits: rider workgroups that are through; high bits: those that copied
-    int may_skip;              // 1: the rider of a graph's LAST iteration -- the next iteration belongs to another graph,
-                               //    which stages it itself if the host had not even submitted its draws when this ran
-                               // 0: an inner iteration of a graph: the draws WILL be written (bounded gate wait)
-};
-
-// rid: rider workgroup 0 .. n_segs * parts - 1; scratch: >= 1 int of the workgroup's LDS
-//
-// Every PCIe round trip of the rider (~3 us) sits inside the launch it rides in, so it makes as few as it can: the two
-// gate words it may need are requested TOGETHER (one round trip), the copy is the second.  (Measured, round 5: three
-// sequential round trips made the pair launch 4 us longer; riders that instead polled a range pre-staged by the host on
-// a side stream were free in steady state and lost 24 us per iteration whenever the host was late -- removed.)
-__device__ __forceinline__ void stage_ahead_body(const StageAheadP& sa, int rid, int* scratch) {
-    const int64_t next = gm_slot_index(sa.it_slot);
-    if (threadIdx.x == 0) {
-        int go = 0;
-        const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool in = (int64_t)(r >> 32) <= next && next < (int64_t)(r & 0xffffffffull);     // already on the device
-        if (!in) {
-            // both loads are in flight before either is used
-            const int64_t filled = __hip_atomic_load(sa.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const int64_t submitted = __hip_atomic_load(sa.gate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (!sa.may_skip || next < submitted) {
-                go = 1;
-                if (filled < next + 1) stage_gate_wait(sa.gate, next + 1, sa.timeout);
-            }
-        }
-        scratch[0] = go;
-    }
-    __syncthreads();
-    const int go = scratch[0];
-    if (go) {
-        const int si = rid / sa.parts, part = rid - si * sa.parts;
-        stage_copy_seg(sa.seg[si], gm_slot_index(sa.ring_slot), 1, (int64_t)part * blockDim.x + threadIdx.x,
-                       (int64_t)sa.parts * blockDim.x);
-        __threadfence();                                  // this workgroup's ring writes: device-visible
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int total = (unsigned int)(sa.n_segs * sa.parts);
-        const unsigned int old = __hip_atomic_fetch_add(sa.arrive, 1u + ((unsigned int)go << 16), __ATOMIC_ACQ_REL,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-        if ((old & 0xffffu) == total - 1) {               // last rider workgroup of this launch
-            __hip_atomic_store(sa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((old >> 16) + (unsigned int)go == total) {    // every segment part was copied HERE
-                const unsigned long long r = __hip_atomic_load(sa.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long it0 = (unsigned long long)next;
-                const unsigned long long lo = ((r & 0xffffffffull) == it0) ? (r >> 32) : it0;
-                __hip_atomic_store(sa.range, (lo << 32) | (it0 + 1ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-// the rider as a launch of its own (the pair it should ride in could not share a tile shape); static: the header is
-// included by two translation units
-static __global__ __launch_bounds__(1024) void stage_ahead_kernel(const StageAheadP* sa) {
-    __shared__ int scratch[1];
-    stage_ahead_body(*sa, (int)blockIdx.x, scratch);
 }

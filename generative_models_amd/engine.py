@@ -466,15 +466,7 @@ class GANEngine:
         self.prestage = os.environ.get("GM_PRESTAGE", "1") != "0"
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
-        self._ride_arrive = torch.zeros(1, dtype=torch.int32, device=device)   # the stage-ahead riders' own counter
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
-        # stage-ahead (round 5, gm_linear_bwd_dw_adam_pair_stage): the generator's last launch of iteration i brings
-        # iteration i + 1's draws into the device rings, a graph only stages its FIRST iteration itself, and a run is
-        # [32, 32, ..., remainder] graphs of exact length -- no small first pieces, no pre-staging side stream
-        self.stage_ahead = os.environ.get("GM_STAGE_AHEAD", "1") != "0"
-        self.STAGE_PARTS = max(1, min(8, int(os.environ.get("GM_STAGE_PARTS", "2"))))
-        self._last_of_graph = True
-        self._graphs_exact = {}
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1047,13 +1039,10 @@ class GANEngine:
             adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
             zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
             zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
-            # (the rider of a graph's last iteration may find the next iteration not even submitted: _issue_iteration
-            # says which one is being captured)
-            stage = (self._stage_pack[1 if self._last_of_graph else 0] if self._stage_ahead() else None)
             ops.linear_bwd_dw_adam_pair(
                 dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
                 dict(dA=self.dHg, X=zbase, lin=self.G1, adam=adam, M=self.Bl, x_slot=zG_slot),
-                stream=st, stage=stage)
+                stream=st)
             return
         self._G_dw2(st, it)
         self._G_dw1(st, it)
@@ -1235,8 +1224,7 @@ class GANEngine:
             # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
             # configure(), [1] = raised by a stage-in kernel whose wait timed out.  Allocated once per
             # engine: captured graphs hold its address.
-            # [2] = iterations whose draws have been SUBMITTED (stage-ahead rider: _pump)
-            self._gate = torch.zeros(4, dtype=torch.int64).pin_memory()
+            self._gate = torch.zeros(2, dtype=torch.int64).pin_memory()
             self._gate_np = self._gate.numpy()
             gp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", self._gate.data_ptr(), ctypes.byref(gp))
@@ -1314,12 +1302,7 @@ class GANEngine:
         """Stage-in of iterations [it, it+k): host ring -> device ring (first launch of a graph)."""
         from . import _lib
         ring_slot, it_slot = self._slot(it, 1, 0, self.R, 1), self._slot(it, 1, 0, 0, 1)
-        if self._stage_ahead():
-            # only the graph's FIRST iteration: the others arrive with the iteration in front of them, and this one too
-            # when the graph in front was launched after its draws were submitted (then this launch just returns)
-            _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, 1, self._gate_dev,
-                      it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
-        elif self.gated and self._prestaging():
+        if self.gated and self._prestaging():
             _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
                       it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
         elif self.gated:
@@ -1328,17 +1311,9 @@ class GANEngine:
         else:
             _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
 
-    def _stage_ahead(self):
-        """The next iteration's draws ride in the generator's weight-gradient pair (the iteration's last launch on
-        one GPU with Adam in the epilogues).  Not: DRAGAN (its uniforms go through the copy engine a piece at a time),
-        BEGAN / InfoGAN (launches behind the pair), data parallel (the exchange follows the pair), eager mode."""
-        return (self.stage_ahead and self.gated and self.use_graph and self._one_graph() and self._single()
-                and self.pair_dw and self._adam_in_epilogue("G") and not getattr(self, "_u_copy", False)
-                and self.variant not in ("be", "info") and not self._standalone_G)
-
     def _prestaging(self):
         """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
-        return self.prestage and self.gated and self.use_graph and self._one_graph() and not self._stage_ahead()
+        return self.prestage and self.gated and self.use_graph and self._one_graph()
 
     def _prestage(self, it, k):
         """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
@@ -1517,7 +1492,7 @@ class GANEngine:
         if self._gate is not None:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
-        self._pre_range.zero_(); self._pre_arrive.zero_(); self._ride_arrive.zero_()   # iterations restart at 0: nothing is pre-staged
+        self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1667,32 +1642,17 @@ class GANEngine:
             def body(k):
                 def fn(st):
                     self._issue_stage_in(st, 0, k)
-                    for i in range(k):
-                        self._last_of_graph = (i == k - 1)
+                    for _ in range(k):
                         self._issue_iteration(st, 0)
                 return fn
-            self._graph_body = body
-            self._graphs_exact = {}
-            self._stage_pack = None
-            if self._stage_ahead():
-                # (graph mode: the slots are resolved on the device from the step counter, which the generator step's
-                # head has already advanced when the pair runs); [0]: inner iterations of a graph, [1]: its last one
-                self._stage_pack = [ops.stage_ahead_pack(
-                    self._segs, len(self._segs), self._slot(0, 1, 1, self.R, 1, post=True),
-                    self._slot(0, 1, 1, 0, 1, post=True), self._gate_dev, self.GATE_TIMEOUT_S, self._pre_range,
-                    self._ride_arrive, parts=self.STAGE_PARTS, may_skip=bool(last))
-                    for last in (0, 1)]
             self.graph = ops.Graph().capture(body(1))
             self.graphs_by_size = [(1, self.graph)]
-            self._graphs_exact[1] = self.graph
             k = 2
-            while k <= self.graph_iters and not self._stage_ahead():
+            while k <= self.graph_iters:
                 self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
                 k *= 2
             if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
                 self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
-            for k_, g_ in self.graphs_by_size:
-                self._graphs_exact[k_] = g_
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
@@ -1702,22 +1662,6 @@ class GANEngine:
             self.seg_graphs = [(ops.Graph().capture(lambda st, run=run: run(st, 0)), ar)
                                for run, ar in segs]
         self._graph_key = self._key
-
-    def _graph_of(self, k):
-        """The graph of exactly k iterations (stage-ahead: captured on first use and kept; prepare() does it ahead)."""
-        g = self._graphs_exact.get(k)
-        if g is None:
-            torch.cuda.synchronize()
-            g = self._graphs_exact[k] = ops.Graph().capture(self._graph_body(k))
-        return g
-
-    def prepare(self, n_iters):
-        """Capture the graphs a run(n_iters) will launch (stage-ahead: [graph_iters] * q + [remainder]) so that the
-        first such run does not pay for the capture.  A no-op on the other paths (their graphs exist already)."""
-        self._ensure_graph()
-        if self.use_graph and self._one_graph() and self._stage_ahead():
-            for k in set(self._plan(self._next_it, n_iters, False)):
-                self._graph_of(k)
 
     def _drain(self):
         """Wait for host fills still in flight (configure / error paths)."""
@@ -1763,8 +1707,6 @@ class GANEngine:
             self._fills.append((it, n, fut))
             self._cursor += n
             unfinished += n
-        if self._gate is not None:
-            self._gate_np[2] = self._cursor           # (pinned: the stage-ahead rider reads it)
 
     def _slots_free_now(self, c0, n, wait):
         """True when the ring slots of [c0, c0+n) can be rewritten (the launch that last staged them in has completed); wait=True blocks for it."""
@@ -1822,12 +1764,6 @@ class GANEngine:
         while cap * 2 <= min(self.graph_iters, self.R):
             cap *= 2
         out, done = [], 0
-        if self._stage_ahead():
-            # graphs of EXACT length: whole `cap`s and one remainder; a graph needs only its first
-            # iteration's draws before it starts (the others ride in), so nothing is cut small for a cold start
-            # (they may cross the end of the ring: every in-graph copy is one iteration's slot)
-            q, r = divmod(n, cap)
-            return [cap] * q + ([r] if r else [])
         while n > 0:
             seg = min(n, self.R - it % self.R)
             q, r = divmod(seg, cap)
@@ -1875,9 +1811,7 @@ class GANEngine:
 
     def _launch(self, it, k):
         """Enqueue iterations [it, it+k) (their ring slots are uploaded)."""
-        if self.use_graph and self._one_graph() and self._stage_ahead():
-            self._graph_of(k).launch()
-        elif self.use_graph and self._one_graph():
+        if self.use_graph and self._one_graph():
             for size, g in self.graphs_by_size:           # largest first: 32, 16, ..., 1 iterations
                 while k >= size:
                     g.launch()
@@ -1939,17 +1873,12 @@ class GANEngine:
                 self._reap()
                 if trace is not None:
                     trace.append(("reaped", it, time.perf_counter()))
-                sa = self._stage_ahead()
-                # stage-ahead: only the piece's FIRST iteration has to be submitted before its graph is enqueued (its
-                # first node waits for that one); the rest are submitted right behind the launch and arrive with the
-                # riders
-                need = it + 1 if sa else it + k
-                self._pump(limit, upto=need)
+                self._pump(limit, upto=it + k)
                 if trace is not None:
                     trace.append(("pumped", it, time.perf_counter()))
-                while self._cursor < need:
+                while self._cursor < it + k:
                     self._reap(block=True)
-                    self._pump(limit, upto=need)
+                    self._pump(limit, upto=it + k)
                 if not gated:
                     self._reap(upto=it + k)
                     self._pump(limit)                 # further draws overlap the launch below
@@ -1958,20 +1887,21 @@ class GANEngine:
                     self._copy_U(it + k)
                 if trace is not None:
                     trace.append(("got", it, time.perf_counter()))
-                if self._prestaging() and not sa:
+                if self._prestaging():
                     self._prestage(it, k)
                 self._launch(it, k)
                 if trace is not None:
                     trace.append(("graph", it, time.perf_counter()))
+                # the piece's event must also cover the side stream's pre-stage of its slots: the host
+                # refills a pinned slot for iteration j + R once the event of the piece that holds j has fired, and a late
+                # pre-stage would otherwise still be reading it.  (The pre-stage was issued before the graph and is done
+                # long before the graph is: the wait never stalls the launch stream.)
+                self._join_prestage()
                 ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
                 ev.record()
                 self._launched.append((it + k, ev))
                 if gated:
                     self._pump(limit)                 # (gated: the launch itself overlaps this piece's draws)
-                if sa:
-                    while self._cursor < it + k:      # every iteration of a launched graph WILL be drawn
-                        self._reap(block=True)
-                        self._pump(limit, upto=it + k)
                 if trace is not None:
                     trace.append(("pump2", it, time.perf_counter()))
                 if trace is not None:

@@ -135,42 +135,14 @@ def _dw_adam_args(dA, X, lin, adam, M, x_slot, betas, eps, weight_decay):
 
 
 def linear_bwd_dw_adam_pair(first, second, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                            stream=None, stage=None):
+                            stream=None):
     """Two linear_bwd_dw_adam calls over the same batch rows as ONE launch.  first / second:
-    dict(dA, X, lin, adam, M=None, x_slot=NO_SLOT).
-    stage: what stage_ahead_pack returned -- the launch also carries the stage-ahead rider that brings the NEXT
-    iteration's draws into the device rings (gm_linear_bwd_dw_adam_pair_stage)."""
+    dict(dA, X, lin, adam, M=None, x_slot=NO_SLOT)."""
     import ctypes
     mk = lambda d: _dw_adam_args(d["dA"], d["X"], d["lin"], d.get("adam"), d.get("M"),
                                  d.get("x_slot", NO_SLOT), betas, eps, weight_decay)
     a, b = mk(first), mk(second)
-    if stage is None:
-        _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
-        return
-    packed, n_blocks = stage
-    _lib.call("gm_linear_bwd_dw_adam_pair_stage", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b),
-              packed.data_ptr(), n_blocks)
-
-
-STAGE_AHEAD_BYTES = 512
-
-
-def stage_ahead_pack(segs, n_segs, ring_slot, it_slot, gate, timeout_s, range_, arrive, parts=2, may_skip=True):
-    """(device buffer, workgroups) naming the stage-ahead rider of linear_bwd_dw_adam_pair(stage=...): segs (ctypes array
-    of StageSeg), the NEXT iteration's ring slot / absolute index, gate (device-visible address of the pinned fill
-    gate, 4 int64), range / arrive (device tensors).  Synchronous; not inside a capture."""
-    import ctypes
-    from ._lib import StageAheadArgs, StageSeg
-    sa = StageAheadArgs()
-    sa.segs, sa.n_segs, sa.parts = ctypes.cast(segs, ctypes.POINTER(StageSeg)), n_segs, parts
-    sa.ring_slot, sa.it_slot = ring_slot, it_slot
-    sa.gate, sa.timeout_s = gate, timeout_s
-    assert range_.dtype == torch.int64 and arrive.dtype == torch.int32
-    sa.range, sa.arrive = range_.data_ptr(), arrive.data_ptr()
-    sa.may_skip = 1 if may_skip else 0
-    buf = torch.zeros(STAGE_AHEAD_BYTES, dtype=torch.uint8, device=range_.device)
-    _lib.call("gm_stage_ahead_pack", ctypes.byref(sa), buf.data_ptr(), buf.numel())
-    return buf, n_segs * parts
+    _lib.call("gm_linear_bwd_dw_adam_pair", stream or stream_ptr(), ctypes.byref(a), ctypes.byref(b))
 
 
 def linear_bwd_dw_adam_pair_finalize(first, second, fin, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

@@ -514,30 +514,6 @@ int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slo
 int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                           const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish, int max_blocks,
                           uint64_t* range, unsigned int* arrive, int mark);
-/* gm_linear_bwd_dw_adam_pair with a STAGE-AHEAD rider (round 5; replaces, per iteration, what ns_gan.py:218-226 and
- * compute_noise do on the host at the top of the NEXT step): a few extra workgroups of the generator's last launch copy
- * the next iteration's ring slots host -> device while the GEMM tiles run, so that a graph of any length needs only
- * its first iteration staged before it starts.
- *   gate (device-visible pinned host memory, FOUR int64): [0] iterations written by the host, [1] time-out flag,
- *   [2] iterations whose draws have been SUBMITTED (a may_skip rider skips an iteration that was not: the next graph's
- *   gm_stage_in_prestaged(mark = 0) stages it then); ring_slot / it_slot: the NEXT iteration's ring slot and absolute
- *   index (resolved from the step counter where the launch runs); range / arrive: the words of gm_stage_in_prestaged
- *   (arrive: one zeroed unsigned int owned by these launches); parts: workgroups per segment (1..8).
- * When the pair cannot share a tile shape the two GEMMs and the rider are three launches. */
-typedef struct gm_stage_ahead_args {
-    const gm_stage_seg* segs; int n_segs; int parts;
-    gm_slot ring_slot, it_slot;
-    const int64_t* gate; double timeout_s;
-    uint64_t* range; unsigned int* arrive;
-    int may_skip;               /* 1: rider of a graph's LAST iteration (skips an iteration whose draws were not submitted:
-                                 * gate[2]); 0: inner iteration (waits for the draws, bounded by timeout_s) */
-} gm_stage_ahead_args;
-/* The rider's description is packed ONCE into caller-owned device memory (>= GM_STAGE_AHEAD_BYTES; synchronous copy,
- * not inside a stream capture) and named by every launch: n_blocks = n_segs * parts. */
-#define GM_STAGE_AHEAD_BYTES 512
-int gm_stage_ahead_pack(const gm_stage_ahead_args* st, void* dev_buf, int64_t dev_buf_bytes);
-int gm_linear_bwd_dw_adam_pair_stage(void* stream, const gm_dw_adam_args* first, const gm_dw_adam_args* second,
-                                     const void* packed, int n_blocks);
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 

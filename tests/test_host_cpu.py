@@ -331,7 +331,6 @@ def test_launch_planner_invariants(R, graph_iters):
         pass
     e = E()
     e.graph_iters, e.R, e.FIRST_PIECE = graph_iters, R, 2
-    e._stage_ahead = lambda: False             # the pre-round-5 planner (data parallel, DRAGAN, BEGAN, InfoGAN)
     plan = lambda it, n, cold: engine.GANEngine._plan(e, it, n, cold)
     cap = min(graph_iters, R)
     for it in (0, 5, R - 1, R, 3 * R + 2):
@@ -348,29 +347,6 @@ def test_launch_planner_invariants(R, graph_iters):
                     done += x
     if R >= 32 and graph_iters >= 16:
         assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
-
-
-@pytest.mark.parametrize("R,graph_iters", [(128, 32), (25, 32), (7, 8), (16, 32)])
-def test_launch_planner_stage_ahead(R, graph_iters):
-    """Stage-ahead planner (round 5): graphs of exact length -- whole caps and ONE remainder -- that cover the run and do
-    not depend on whether the run starts cold or where in the ring it starts (every in-graph copy is one iteration's
-    slot, so a graph may cross the end of the ring)."""
-    class E:
-        pass
-    e = E()
-    e.graph_iters, e.R, e.FIRST_PIECE = graph_iters, R, 2
-    e._stage_ahead = lambda: True
-    cap = 1
-    while cap * 2 <= min(graph_iters, R):
-        cap *= 2
-    for it in (0, 5, R - 1, R, 3 * R + 2):
-        for n in (0, 1, 2, 3, 20, 25, 64, 200, 2000):
-            p = engine.GANEngine._plan(e, it, n, True)
-            assert p == engine.GANEngine._plan(e, it, n, False) == engine.GANEngine._plan(e, 0, n, True)
-            assert sum(p) == n and all(1 <= x <= cap for x in p) and sum(1 for x in p if x != cap) <= 1, (it, n, p)
-    if R >= 32 and graph_iters >= 32:
-        assert engine.GANEngine._plan(e, 125, 20, True) == [20]        # the driver's 20-step run: ONE graph, anywhere
-        assert engine.GANEngine._plan(e, 0, 200, True) == [32] * 6 + [8]
 
 
 @pytest.mark.parametrize("record", ["r02_bench_default.json", "r02_bench_steps20_warmup5.json"])
