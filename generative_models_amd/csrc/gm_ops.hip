@@ -628,6 +628,13 @@ extern "C" int gm_event_sync(void* ev) {
     GM_HIP(hipEventSynchronize((hipEvent_t)ev));
     return 0;
 }
+extern "C" int gm_event_query(void* ev, int* done_out) {
+    GM_CHECK_ARG(ev && done_out);
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e != hipSuccess && e != hipErrorNotReady) { gm_set_error(hipGetErrorString(e)); return -(int)e; }
+    *done_out = (e == hipSuccess) ? 1 : 0;
+    return 0;
+}
 extern "C" int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
     GM_CHECK_ARG(ms_out);
     GM_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));

@@ -20,6 +20,8 @@ step, D gradients during the G step); every observable -- parameters, loss lists
 position -- matches the reference."""
 import math
 
+import collections
+
 import numpy as np
 import torch
 
@@ -467,6 +469,7 @@ class GANEngine:
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
+        self._pre_events, self._pre_event_pool = collections.deque(), []
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -777,27 +780,44 @@ class GANEngine:
         # (the DAG experiment runs the gather on a side stream, concurrently with this launch)
         return self.variant == "wgp" and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
 
+    # ---- the critic step behind the generator's forward: three builders, one per launch structure -------------------
+    #   folded     separable losses (+ RaGAN / Fisher on one GPU): hidden layer forward with the head's partial dots,
+    #              then ONE launch for the layer-1 weight gradient + head backward + both Adam steps
+    #   fused head penalty variants (WGAN-GP, DRAGAN) and anything the fold does not take (many-row launches, data
+    #              parallel): head_fwd_loss + a grouped / stacked weight-gradient launch
+    #   unfused    N = 1 GEMV + loss kernel (+ the scalar exchanges of RaGAN / Fisher under data parallelism) + separate
+    #              gradient launches
     def _D_rest(self, st, it, j):
+        if self._fold_head():
+            return self._critic_folded(st, it, j)
+        if self.fuse_head and self.variant not in ("ra", "fisher"):
+            return self._critic_fused_head(st, it, j)
+        return self._critic_unfused(st, it, j)
+
+    def _critic_folded(self, st, it, j):
         Bl, d = self.Bl, self.D_steps
         D1, D2 = self.D1, self.D2
-        X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
+        X2, Hd, S2, dS = self.X2, self.Hd, self.S2, self.dS
         loss_slot = self._slot(it, d, j, 0, 1)
-        grouped = False
-        if self._fold_head():
-            # 2 launches instead of 3: hidden layer forward (+ partial dots of the head), then the
-            # layer-1 weight gradient (+Adam) with the head's backward workgroups riding -- scores,
-            # row losses and dS are rebuilt from the partial dots in that launch's prologue
-            ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st)
-            adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss,
-                                pen=self.aux if self.variant == "fisher" else None)   # Fisher: lambda lives in aux
-            head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
-                        adam=adam)
-            ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
-            if self.variant == "fisher":
-                from . import ops_fused as of
-                of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)
-            return
+        # 2 launches instead of 3: hidden layer forward (+ partial dots of the head), then the
+        # layer-1 weight gradient (+Adam) with the head's backward workgroups riding -- scores,
+        # row losses and dS are rebuilt from the partial dots in that launch's prologue
+        ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st)
+        adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
+        fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss,
+                            pen=self.aux if self.variant == "fisher" else None)   # Fisher: lambda lives in aux
+        head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
+                    adam=adam)
+        ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
+        if self.variant == "fisher":
+            from . import ops_fused as of
+            of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)
+
+    def _critic_forward(self, st, it, j):
+        """D's hidden layer on [x ; G(z)] (WGAN-GP / DRAGAN: on [x_hat ; x ; G(z)] as one 3B-row launch) and the
+        penalty's forward pieces; returns (aux, hyper) of the loss."""
+        Bl = self.Bl
+        D1 = self.D1
         merged = self.variant in ("wgp", "dra") and self.merge_fwd3
         if merged:
             if self.variant == "wgp":
@@ -806,7 +826,7 @@ class GANEngine:
                 self._dra_prepare(st, it, j)
             ops.linear_fwd(self.XX4[:3 * Bl], D1.W, D1.b, self.HH3, "relu", M=3 * Bl, stream=st)
         else:
-            ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)
+            ops.linear_fwd(self.X2, D1.W, D1.b, self.Hd, "relu", M=2 * Bl, stream=st)
         aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
         if self.variant == "wgp":
             self._issue_gp_forward(st, it, j, fwd_done=merged)
@@ -814,72 +834,93 @@ class GANEngine:
         if self.variant == "dra":
             self._issue_dra_forward(st, it, j, fwd_done=merged)
             aux, hyper = self.pen, tuple(self.hyper) + (0.0,) * (7 - len(self.hyper)) + (self.gp_lambda,)
-        if self.fuse_head and self.variant not in ("ra", "fisher"):
-            from . import ops_fused as of
-            of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
-                             self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
-            adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-            if self.group_head:
-                # head backward + first-layer weight gradient (+ both Adam steps when they are
-                # fused: one GPU, nothing accumulates into these gradients later): ONE launch
-                head = dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
-                            loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam)
-                if self._wgp_stacked():
-                    # dW1 = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows (the penalty rows do not reach
-                    # db1), gw2 += the penalty's share (computed by _issue_gp_forward)
-                    if self.pen_in_head:
-                        head["pen"] = dict(s=self.Sh, h=self.Hh, t=self.T)    # summed by the head workgroups
-                    else:
-                        head["gw2_add"] = self.gw2_pen
-                    ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
-                                                stream=st)
-                elif self._dra_stacked():
-                    # the penalty's second backward first (it reads W1 and w2, which this launch steps): t = dv W1^T,
-                    # then dA1 and the sigma'' path's share of (gw2, gb2) on their own; then ONE launch:
-                    # dW1 over 4B rows (+ db1 from the last 3B), the head's backward with both shares added, Adam x 2
-                    self._issue_dra_backward(st, stacked=True)
-                    head["gw2_add"], head["gb2_add"] = self.gw2_pen, self.gb2_pen
-                    ops.linear_bwd_dw_adam_head(self.DU4, self.XX5, D1, adam, head, M=4 * Bl, ones_from=Bl,
-                                                stream=st)
-                else:
-                    ops.linear_bwd_dw_adam_head(dHd, X2, D1, adam, head, M=2 * Bl, stream=st)
-                grouped = True
-            else:
-                of.head_bwd(Hd, dS, D2.W, self.rowloss, None, D2.gW, D2.gb, self.lossD, loss_slot,
-                            self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
-        else:
-            ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
-            loss = lambda **kw: ops.gan_loss(
-                self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD, dS[:Bl], dS[Bl:],
-                hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot, aux=aux, db=D2.gb, stream=st, **kw)
-            if self._dp() and self.variant == "ra":
-                # mean(D(G(z))) and sum(du) span the GLOBAL batch (ra_gan.py:204)
-                loss(phase=1, pre=self.pre)
-                self._exchange_scalars(st, self.pre, 1)
-                loss(phase=2, pre=self.pre)
-                self._exchange_scalars(st, self.pre[1:], 1)
-                loss(phase=3, pre=self.pre)
-            elif self._dp() and self.variant == "fisher":
-                # the four moments span the GLOBAL batch; lambda's ascent is then identical on every
-                # rank (fisher_gan.py:214-223,155-156); rank 0 reports the (global) loss
-                loss(phase=1, pre=self.pre)
-                self._exchange_scalars(st, self.pre, 4)
-                loss(phase=2, pre=self.pre, loss_scale=1.0 if self.rank == 0 else 0.0)
-            else:
-                loss()
-            ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
-            ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        if grouped:
-            pass
-        elif self._adam_in_epilogue("D"):
-            ops.linear_bwd_dw_adam(dHd, X2, D1, self._adam_args("D", self._slot(it, d, j, 0, 1)),
+        return aux, hyper
+
+    def _critic_dw1(self, st, it, j):
+        """Layer-1 weight gradient on its own (+ Adam in its epilogue on one GPU), then what is left of the penalty."""
+        Bl, d = self.Bl, self.D_steps
+        if self._adam_in_epilogue("D"):
+            ops.linear_bwd_dw_adam(self.dHd, self.X2, self.D1, self._adam_args("D", self._slot(it, d, j, 0, 1)),
                                    M=2 * Bl, stream=st)
         else:
-            ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
+            ops.linear_bwd_dw(self.dHd, self.X2, self.D1.gW, self.D1.gb, M=2 * Bl, stream=st)
+
+    def _critic_penalty_backward(self, st):
         if self.variant == "wgp" and not self._wgp_stacked():
             self._issue_gp_backward(st)
         if self.variant == "dra" and not self._dra_stacked():
             self._issue_dra_backward(st)
+
+    def _critic_fused_head(self, st, it, j):
+        from . import ops_fused as of
+        Bl, d = self.Bl, self.D_steps
+        D1, D2 = self.D1, self.D2
+        X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
+        loss_slot = self._slot(it, d, j, 0, 1)
+        aux, hyper = self._critic_forward(st, it, j)
+        of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
+                         self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
+        adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
+        if not self.group_head:
+            of.head_bwd(Hd, dS, D2.W, self.rowloss, None, D2.gW, D2.gb, self.lossD, loss_slot,
+                        self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
+            self._critic_dw1(st, it, j)
+            self._critic_penalty_backward(st)
+            return
+        # head backward + first-layer weight gradient (+ both Adam steps when they are
+        # fused: one GPU, nothing accumulates into these gradients later): ONE launch
+        head = dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
+                    loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam)
+        if self._wgp_stacked():
+            # dW1 = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows (the penalty rows do not reach
+            # db1), gw2 += the penalty's share (computed by _issue_gp_forward)
+            if self.pen_in_head:
+                head["pen"] = dict(s=self.Sh, h=self.Hh, t=self.T)    # summed by the head workgroups
+            else:
+                head["gw2_add"] = self.gw2_pen
+            ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
+                                        stream=st)
+        elif self._dra_stacked():
+            # the penalty's second backward first (it reads W1 and w2, which this launch steps): t = dv W1^T,
+            # then dA1 and the sigma'' path's share of (gw2, gb2) on their own; then ONE launch:
+            # dW1 over 4B rows (+ db1 from the last 3B), the head's backward with both shares added, Adam x 2
+            self._issue_dra_backward(st, stacked=True)
+            head["gw2_add"], head["gb2_add"] = self.gw2_pen, self.gb2_pen
+            ops.linear_bwd_dw_adam_head(self.DU4, self.XX5, D1, adam, head, M=4 * Bl, ones_from=Bl,
+                                        stream=st)
+        else:
+            ops.linear_bwd_dw_adam_head(dHd, X2, D1, adam, head, M=2 * Bl, stream=st)
+        self._critic_penalty_backward(st)
+
+    def _critic_unfused(self, st, it, j):
+        Bl, d = self.Bl, self.D_steps
+        D2 = self.D2
+        Hd, S2, dS, dHd = self.Hd, self.S2, self.dS, self.dHd
+        loss_slot = self._slot(it, d, j, 0, 1)
+        aux, hyper = self._critic_forward(st, it, j)
+        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
+        loss = lambda **kw: ops.gan_loss(
+            self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD, dS[:Bl], dS[Bl:],
+            hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot, aux=aux, db=D2.gb, stream=st, **kw)
+        if self._dp() and self.variant == "ra":
+            # mean(D(G(z))) and sum(du) span the GLOBAL batch (ra_gan.py:204)
+            loss(phase=1, pre=self.pre)
+            self._exchange_scalars(st, self.pre, 1)
+            loss(phase=2, pre=self.pre)
+            self._exchange_scalars(st, self.pre[1:], 1)
+            loss(phase=3, pre=self.pre)
+        elif self._dp() and self.variant == "fisher":
+            # the four moments span the GLOBAL batch; lambda's ascent is then identical on every
+            # rank (fisher_gan.py:214-223,155-156); rank 0 reports the (global) loss
+            loss(phase=1, pre=self.pre)
+            self._exchange_scalars(st, self.pre, 4)
+            loss(phase=2, pre=self.pre, loss_scale=1.0 if self.rank == 0 else 0.0)
+        else:
+            loss()
+        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
+        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
+        self._critic_dw1(st, it, j)
+        self._critic_penalty_backward(st)
 
     def _issue_D_pre(self, st, it, j):
         self._D_gather(st, it, j)
@@ -1332,6 +1373,13 @@ class GANEngine:
                   self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
                   self._pre_arrive.data_ptr(), 1)
         self._pre_dirty = True
+        # The host refills a pinned slot for iteration j + R once the launch that holds j has completed
+        # (_slots_free_now); a pre-stage that is LATE would still be reading it, so its completion is tracked too --
+        # on the host (an event per pre-stage, queried there), not as a cross-stream wait in front of the next graph
+        # (measured: +1 - 2 us per step over 20 steps, round 5 call G).
+        ev = self._pre_event_pool.pop() if self._pre_event_pool else ops.Event()
+        ev.record(self._pre_stream)
+        self._pre_events.append((it, ev))        # (first iteration whose host slots it reads)
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
@@ -1493,6 +1541,8 @@ class GANEngine:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
         self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
+        while self._pre_events:                               # (everything on the device has been synchronized above)
+            self._pre_event_pool.append(self._pre_events.popleft()[1])
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1713,6 +1763,14 @@ class GANEngine:
         need = c0 + n - self.R
         if need <= 0:
             return True
+        # side-stream pre-stages that read the host slots of iterations < need must be through as well (oldest first)
+        while self._pre_events and self._pre_events[0][0] < need:
+            pe = self._pre_events[0][1]
+            if not pe.query():
+                if not wait:
+                    return False
+                pe.sync()
+            self._pre_event_pool.append(self._pre_events.popleft()[1])
         for it_end, e in self._launched:
             if it_end >= need:
                 if not e.query():
@@ -1892,11 +1950,6 @@ class GANEngine:
                 self._launch(it, k)
                 if trace is not None:
                     trace.append(("graph", it, time.perf_counter()))
-                # the piece's event must also cover the side stream's pre-stage of its slots: the host
-                # refills a pinned slot for iteration j + R once the event of the piece that holds j has fired, and a late
-                # pre-stage would otherwise still be reading it.  (The pre-stage was issued before the graph and is done
-                # long before the graph is: the wait never stalls the launch stream.)
-                self._join_prestage()
                 ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
                 ev.record()
                 self._launched.append((it + k, ev))

@@ -646,6 +646,7 @@ int gm_clock_probe(void* stream, int iters, unsigned long long* out2, float* sin
 int gm_event_create(void** ev_out);
 int gm_event_record(void* ev, void* stream);
 int gm_event_sync(void* ev);
+int gm_event_query(void* ev, int* done_out);       /* 1: everything recorded in front of it has completed */
 int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
 int gm_event_destroy(void* ev);
 
