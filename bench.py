@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
 LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip try_launch_lds
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
-PROFILE_ROUND = "r04"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
+PROFILE_ROUND = "r05"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
 FOLD_HEAD_DEFAULT = os.environ.get("GM_FOLD_HEAD", "1") != "0"   # engine default (folded critic head)
 
 

@@ -470,6 +470,7 @@ class GANEngine:
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
         self._pre_events, self._pre_event_pool = collections.deque(), []
+        self._track_pre = os.environ.get("GM_TRACK_PRESTAGE", "1") != "0"
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1377,9 +1378,10 @@ class GANEngine:
         # (_slots_free_now); a pre-stage that is LATE would still be reading it, so its completion is tracked too --
         # on the host (an event per pre-stage, queried there), not as a cross-stream wait in front of the next graph
         # (measured: +1 - 2 us per step over 20 steps, round 5 call G).
-        ev = self._pre_event_pool.pop() if self._pre_event_pool else ops.Event()
-        ev.record(self._pre_stream)
-        self._pre_events.append((it, ev))        # (first iteration whose host slots it reads)
+        if self._track_pre:
+            ev = self._pre_event_pool.pop() if self._pre_event_pool else ops.Event()
+            ev.record(self._pre_stream)
+            self._pre_events.append((it, ev))    # (first iteration whose host slots it reads)
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
