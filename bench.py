@@ -935,10 +935,12 @@ def main():
                        # steady-state step of the same engine (the 512-step region) and what a K-step run() costs on
                        # top of K of those: cold start of the host draws, graph boundaries, final synchronize
                        "steady_us_per_step": eng.steady_us_per_step,
-                       "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if eng.steady_us_per_step else None},
+                       # (meaningful for short runs: at thousands of steps it is the noise of two measurements)
+                       "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step)
+                       if (eng.steady_us_per_step and K <= 200) else None},
             # (top-level copies of config.steady_us_per_step / run_fixed_cost_us / roofline.step_frac: tools read them)
             "steady_us_per_step": eng.steady_us_per_step,
-            "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if eng.steady_us_per_step else None,
+            "run_fixed_cost_us": (dt * 1e6 - K * eng.steady_us_per_step) if (eng.steady_us_per_step and K <= 200) else None,
             "step_mfma_frac": img_s / world * FLOP_PER_IMAGE / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -470,7 +470,6 @@ class GANEngine:
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
         self._pre_events, self._pre_event_pool = collections.deque(), []
-        self._track_pre = os.environ.get("GM_TRACK_PRESTAGE", "1") != "0"
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1182,6 +1181,7 @@ class GANEngine:
         ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
+    PRE_EVENTS = 16     # completion events of side-stream pre-stages in flight (_slots_free_now)
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
     PRE_BLOCKS = 32     # workgroups per segment of a pre-staging launch (it runs beside the iteration kernels)
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
@@ -1369,6 +1369,7 @@ class GANEngine:
             h = ctypes.c_void_p()
             _lib.call("gm_stream_create", ctypes.byref(h))
             self._pre_stream, self._pre_event = h, ops.Event()
+            self._pre_event_pool = [ops.Event() for _ in range(self.PRE_EVENTS)]
         _lib.call("gm_stage_in_prestaged", self._pre_stream, self._segs, len(self._segs),
                   ops.slot(0, 0, it % self.R, self.R, 1), k, self._gate_dev, ops.slot(0, 0, it, 0, 1),
                   self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
@@ -1378,10 +1379,14 @@ class GANEngine:
         # (_slots_free_now); a pre-stage that is LATE would still be reading it, so its completion is tracked too --
         # on the host (an event per pre-stage, queried there), not as a cross-stream wait in front of the next graph
         # (measured: +1 - 2 us per step over 20 steps, round 5 call G).
-        if self._track_pre:
-            ev = self._pre_event_pool.pop() if self._pre_event_pool else ops.Event()
-            ev.record(self._pre_stream)
-            self._pre_events.append((it, ev))    # (first iteration whose host slots it reads)
+        # (events come from a pool made with the side stream: creating one per pre-stage cost ~10 us each, measured)
+        while len(self._pre_events) >= self.PRE_EVENTS:          # oldest pre-stage: many pieces ago, long done
+            old = self._pre_events.popleft()[1]
+            old.sync()
+            self._pre_event_pool.append(old)
+        ev = self._pre_event_pool.pop()
+        ev.record(self._pre_stream)
+        self._pre_events.append((it, ev))        # (first iteration whose host slots it reads)
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
