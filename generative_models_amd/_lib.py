@@ -241,7 +241,6 @@ _SIGNATURES = {
     "gm_event_create": (c_int, [POINTER(c_void_p)]),
     "gm_event_record": (c_int, [_P, _P]),
     "gm_event_sync": (c_int, [_P]),
-    "gm_event_query": (c_int, [_P, POINTER(c_int)]),
     "gm_event_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
     "gm_event_destroy": (c_int, [_P]),
 }

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
                 const unsigned long long lo = ((r & 0xffffffffull) == it0) ? (r >> 32) : it0;
                 __hip_atomic_store(p.range, (lo << 32) | (it0 + (unsigned long long)p.n_iters), __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_AGENT);
+                if (p.done_host)                              // every workgroup's host reads are behind its arrival
+                    __hip_atomic_store(p.done_host, (int64_t)(it0 + (unsigned long long)p.n_iters), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -106,6 +109,7 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
     if (mark && gate) {                                   // pre-staging: one wave waits, then the copy runs ungated
         hipLaunchKernelGGL(stage_gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gate, it_slot, n_iters,
                            p.timeout);
+        p.done_host = const_cast<int64_t*>(gate) + 3;
         p.gate = nullptr;
     }
     hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0,
@@ -626,13 +630,6 @@ extern "C" int gm_event_record(void* ev, void* stream) {
 }
 extern "C" int gm_event_sync(void* ev) {
     GM_HIP(hipEventSynchronize((hipEvent_t)ev));
-    return 0;
-}
-extern "C" int gm_event_query(void* ev, int* done_out) {
-    GM_CHECK_ARG(ev && done_out);
-    const hipError_t e = hipEventQuery((hipEvent_t)ev);
-    if (e != hipSuccess && e != hipErrorNotReady) { gm_set_error(hipGetErrorString(e)); return -(int)e; }
-    *done_out = (e == hipSuccess) ? 1 : 0;
     return 0;
 }
 extern "C" int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {

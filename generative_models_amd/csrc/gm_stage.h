@@ -28,6 +28,10 @@ struct StageP {
     unsigned long long* range;
     unsigned int* arrive;
     int mark;
+    // mark == 1: gate[3] (pinned host memory) <- it + n_iters once the copy is complete: the host may refill the pinned
+    // slots these iterations were read from only after that (it reads the word for free; a completion EVENT per
+    // pre-stage cost 1 - 2 us per step over 20 steps, round 5 call I)
+    int64_t* done_host;
 };
 
 // thread t of `stride` copies its share of iterations [first, first + n_iters) of one segment

@@ -469,7 +469,7 @@ class GANEngine:
         self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
         self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
         self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
-        self._pre_events, self._pre_event_pool = collections.deque(), []
+        self._pre_issued = collections.deque()           # (first, end) of the pre-stages issued, oldest first
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1181,7 +1181,6 @@ class GANEngine:
         ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
-    PRE_EVENTS = 16     # completion events of side-stream pre-stages in flight (_slots_free_now)
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
     PRE_BLOCKS = 32     # workgroups per segment of a pre-staging launch (it runs beside the iteration kernels)
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
@@ -1266,7 +1265,8 @@ class GANEngine:
             # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
             # configure(), [1] = raised by a stage-in kernel whose wait timed out.  Allocated once per
             # engine: captured graphs hold its address.
-            self._gate = torch.zeros(2, dtype=torch.int64).pin_memory()
+            # [3] = iterations the side stream's pre-stages have finished copying (gm_stage_in_prestaged, mark = 1)
+            self._gate = torch.zeros(4, dtype=torch.int64).pin_memory()
             self._gate_np = self._gate.numpy()
             gp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", self._gate.data_ptr(), ctypes.byref(gp))
@@ -1369,24 +1369,15 @@ class GANEngine:
             h = ctypes.c_void_p()
             _lib.call("gm_stream_create", ctypes.byref(h))
             self._pre_stream, self._pre_event = h, ops.Event()
-            self._pre_event_pool = [ops.Event() for _ in range(self.PRE_EVENTS)]
         _lib.call("gm_stage_in_prestaged", self._pre_stream, self._segs, len(self._segs),
                   ops.slot(0, 0, it % self.R, self.R, 1), k, self._gate_dev, ops.slot(0, 0, it, 0, 1),
                   self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
                   self._pre_arrive.data_ptr(), 1)
         self._pre_dirty = True
         # The host refills a pinned slot for iteration j + R once the launch that holds j has completed
-        # (_slots_free_now); a pre-stage that is LATE would still be reading it, so its completion is tracked too --
-        # on the host (an event per pre-stage, queried there), not as a cross-stream wait in front of the next graph
-        # (measured: +1 - 2 us per step over 20 steps, round 5 call G).
-        # (events come from a pool made with the side stream: creating one per pre-stage cost ~10 us each, measured)
-        while len(self._pre_events) >= self.PRE_EVENTS:          # oldest pre-stage: many pieces ago, long done
-            old = self._pre_events.popleft()[1]
-            old.sync()
-            self._pre_event_pool.append(old)
-        ev = self._pre_event_pool.pop()
-        ev.record(self._pre_stream)
-        self._pre_events.append((it, ev))        # (first iteration whose host slots it reads)
+        # (_slots_free_now); a pre-stage that is LATE would still be reading it.  Its last workgroup therefore stores
+        # "pre-staged up to" into gate[3] (pinned: the host reads it for free) and _slots_free_now waits for that too.
+        self._pre_issued.append((it, it + k))
 
     def __del__(self):
         # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
@@ -1548,8 +1539,7 @@ class GANEngine:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
         self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
-        while self._pre_events:                               # (everything on the device has been synchronized above)
-            self._pre_event_pool.append(self._pre_events.popleft()[1])
+        self._pre_issued.clear()                              # (everything on the device has been synchronized above)
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1770,14 +1760,18 @@ class GANEngine:
         need = c0 + n - self.R
         if need <= 0:
             return True
-        # side-stream pre-stages that read the host slots of iterations < need must be through as well (oldest first)
-        while self._pre_events and self._pre_events[0][0] < need:
-            pe = self._pre_events[0][1]
-            if not pe.query():
+        # side-stream pre-stages that read the host slots of iterations < need must be through as well (oldest first;
+        # they complete in order, each leaving "pre-staged up to" in gate[3])
+        while self._pre_issued and self._pre_issued[0][0] < need:
+            if self._gate_np[3] < self._pre_issued[0][1]:
                 if not wait:
                     return False
-                pe.sync()
-            self._pre_event_pool.append(self._pre_events.popleft()[1])
+                import time
+                t0 = time.perf_counter()
+                while self._gate_np[3] < self._pre_issued[0][1]:
+                    if time.perf_counter() - t0 > self.GATE_TIMEOUT_S:
+                        raise GMError("a pre-stage of iterations [%d, %d) did not complete" % self._pre_issued[0])
+            self._pre_issued.popleft()
         for it_end, e in self._launched:
             if it_end >= need:
                 if not e.query():

@@ -517,11 +517,6 @@ class Event:
     def sync(self):
         _lib.call("gm_event_sync", self.h)
 
-    def query(self):
-        done = ctypes.c_int(0)
-        _lib.call("gm_event_query", self.h, ctypes.byref(done))
-        return bool(done.value)
-
     def elapsed_ms(self, stop):
         ms = ctypes.c_float()
         _lib.call("gm_event_elapsed_ms", self.h, stop.h, ctypes.byref(ms))

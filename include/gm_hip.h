@@ -507,7 +507,9 @@ int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slo
  *             that consumes them -- its gate wait and its PCIe reads overlap the kernels of the graph in front;
  *             it_slot must name the absolute iteration without the step counter (it belongs to the other stream);
  *             the last workgroup to finish (arrive: one zeroed unsigned int) extends the range, or restarts it at
- *             [it, it + n_iters) when they do not continue it;
+ *             [it, it + n_iters) when they do not continue it, and then stores it + n_iters to gate[3] (the gate is
+ *             FOUR int64 for these launches: [0] filled, [1] time-out flag, [2] unused, [3] pre-staged up to) -- the
+ *             host may overwrite the pinned slots of these iterations only after that;
  *   mark = 0: the in-graph launch -- returns at once when [it, it + n_iters) lies inside the range and is
  *             gm_stage_in_gated otherwise (a pre-stage that is late only costs the copy being made twice, with
  *             the same bytes). */
@@ -646,7 +648,6 @@ int gm_clock_probe(void* stream, int iters, unsigned long long* out2, float* sin
 int gm_event_create(void** ev_out);
 int gm_event_record(void* ev, void* stream);
 int gm_event_sync(void* ev);
-int gm_event_query(void* ev, int* done_out);       /* 1: everything recorded in front of it has completed */
 int gm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
 int gm_event_destroy(void* ev);
 
