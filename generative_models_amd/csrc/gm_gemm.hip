@@ -637,7 +637,9 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
 
 // Tile shape of the LDS kernel for an M x N output: the fewest workgroup rounds on 256 CUs weighted
 // by tile area (time per round), the larger tile on ties.  1: 64x64, 2: 32x64.  Measured on MI355X
-// (profiles/r02_experiments.md): 128x64 tiles lose to two rounds of 64x64 on the 2048x784 output.
+// (profiles/r02_experiments.md): 128x64 tiles lose to two rounds of 64x64 on the 2048x784 output; round 5 (call M):
+// forcing 32x64 tiles so that TWO workgroups share a CU is no faster anywhere (fwd 2048x784->400 19.7 -> 20.0 us,
+// 2048x400->784 20.6 -> 23.0, dX 1024 rows 12.1 -> 13.2): this rule stays.
 inline int lds_pick_cfg(int M, int N) {
     const int bm[2] = {64, 32}, bn[2] = {64, 64}, id[2] = {1, 2};
     long best = -1; int pick = 0;
