@@ -38,7 +38,7 @@ constexpr int64_t SCAL_FLOATS = 64;              // scalar exchange: 2 parities 
 constexpr unsigned long long WAIT_TICKS = 10ull * 100000000ull;   // bounded waits: 10 s of the 100 MHz wall clock
 
 struct Region {            // layout of one rank's exchange region (byte offsets)
-    int64_t flags, scal, in, out, total;
+    int64_t flags, scal, in, out, stage, stage_stride, total;     // stage: [source rank][slice] of the push exchange
 };
 Region layout(int64_t n_floats) {
     Region r;
@@ -48,7 +48,13 @@ Region layout(int64_t n_floats) {
     r.in = r.scal + 2 * SCAL_FLOATS * 4 * MAXW;   // [parity][rank][16 floats]
     r.in = ((r.in + 255) / 256) * 256;
     r.out = r.in + nb;
-    r.total = r.out + nb;
+    // push exchange: every peer deposits ITS contribution to my slice here (a slice is at most ceil(n4 / W) float4 for
+    // any W <= MAXW: W = 1 needs none, W = 2 the largest -- half the bucket per source, MAXW sources: sized for the
+    // worst case of every world size, 4 * nb bytes would be wasteful: the stride is fixed at nb / 2 rounded up, and
+    // only `world` sources exist: total <= MAXW * nb / 2)
+    r.stage = r.out + nb;
+    r.stage_stride = ((nb / 2 + 16 + 255) / 256) * 256;
+    r.total = r.stage + MAXW * r.stage_stride;
     return r;
 }
 
@@ -62,7 +68,8 @@ struct Comm {
     unsigned long long* sseq;  // device: number of completed scalar exchanges
     int* err;                  // device: set when a bounded wait expired
     unsigned* arrive;          // device: workgroups of the one-kernel exchange that have written their part of `out`
-    int two_kernels;           // 1: reduce and gather as two launches (ranks sharing ONE device: see gm_comm_set_exchange)
+    int two_kernels;           // exchange form: 0 one kernel (pull), 1 reduce + gather launches (pull; ranks sharing ONE
+                               // device), 2 one kernel, PUSH (posted remote writes only): gm_comm_set_exchange
     int coarse;                // 1: the region is plain hipMalloc memory (fine-grained allocation refused)
     int max_blocks;            // workgroups of an exchange launch: what can be co-resident on THIS device (or less)
 };
@@ -290,6 +297,101 @@ __global__ __launch_bounds__(256) void xchg_kernel(CommP c, float* __restrict__ 
     }
 }
 
+// PUSH exchange (round 5): the same sum, moved by posted remote WRITES only.  The pull forms above
+// READ the peers' `in` (reduce-scatter) and `out` (all-gather) over xGMI -- every cache line a full round trip with a
+// bounded number outstanding.  Here rank r
+//   A  writes its contribution to every other rank's slice into THAT rank's stage[r] (remote stores), and -- once all
+//      its workgroups have done so (arrival counter 1, release) -- raises flag phase 2 at every peer;
+//   B  waits for the peers' phase-2 flags, sums ITS slice over ranks 0..W-1 in rank order (its own part straight from
+//      `in`, the others from its local stage: the same values in the same order as the pull forms -- bit-identical),
+//      writes the result into its own `out` AND into every peer's `out` at the slice's place (remote stores); after
+//      arrival counter 2, flag phase 3;
+//   C  waits for the peers' phase-3 flags and reads the whole reduced bucket from its LOCAL `out` (+ Adam).
+// Every element of `in` / `out` / stage is touched by one thread of one rank per step (the grid-stride index sets of
+// A, B and C coincide per slice), so single buffers are safe by the same argument as above: a peer overwrites my
+// stage (exchange s + 1, step A) only after its step C of s, which waited for my phase-3 flag, which follows my step
+// B -- the only reader of my stage.  Needs all workgroups of a launch co-resident, like xchg_kernel.
+__device__ __forceinline__ void arrive_then_flag(const CommP& c, unsigned* counter, int phase, unsigned long long s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's (remote) stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);                  // system scope
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {                               // last workgroup of this rank: tell the peers, re-arm
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (phase == 3) c.seq[0] = s;                         // (every workgroup has read it: it arrived twice)
+            for (int peer = 0; peer < c.world; ++peer)
+                if (peer != c.rank)
+                    __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        wait_peers(c, phase, s);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);                  // system scope: see what the peers deposited
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void push_kernel(CommP c, float* __restrict__ g, int64_t n, AdamP ad) {
+    const unsigned long long s = c.seq[0] + 1;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4* in = reinterpret_cast<const float4*>(c.base[c.rank] + c.lay.in);
+    float4* out = reinterpret_cast<float4*>(c.base[c.rank] + c.lay.out);
+    if (c.world > 1) {
+        // A: my contributions to the peers' slices
+        for (int o = 0; o < c.world; ++o) {
+            if (o == c.rank) continue;
+            int64_t lo, hi;
+            slice_of(n4, c.world, o, &lo, &hi);
+            float4* dst = reinterpret_cast<float4*>(c.base[o] + c.lay.stage + (int64_t)c.rank * c.lay.stage_stride);
+            for (int64_t i = lo + first; i < hi; i += stride) dst[i - lo] = in[i];
+        }
+        arrive_then_flag(c, c.arrive + 1, 2, s);
+        // B: my slice, summed in rank order, to everybody's `out`
+        int64_t lo, hi;
+        slice_of(n4, c.world, c.rank, &lo, &hi);
+        for (int64_t i = lo + first; i < hi; i += stride) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < c.world; ++r) {
+                const float4 v = (r == c.rank) ? in[i]
+                    : reinterpret_cast<const float4*>(c.base[c.rank] + c.lay.stage + (int64_t)r * c.lay.stage_stride)[i - lo];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            out[i] = a;
+            for (int peer = 0; peer < c.world; ++peer)
+                if (peer != c.rank) reinterpret_cast<float4*>(c.base[peer] + c.lay.out)[i] = a;
+        }
+        arrive_then_flag(c, c.arrive + 2, 3, s);
+    }
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (ad.enabled) {
+        const int64_t si = gm_slot_index(ad.sched_slot);
+        step_size = ad.sched[2 * si] * (ad.lr_scale ? ad.lr_scale[0] : 1.0f);
+        bc2_sqrt = ad.sched[2 * si + 1];
+    }
+    // C: the whole reduced bucket is local now (per slice: the same indices this thread touched in A / B)
+    for (int r = 0; r < c.world; ++r) {
+        int64_t lo, hi;
+        slice_of(n4, c.world, r, &lo, &hi);
+        const float4* src = (c.world > 1) ? out : in;
+        for (int64_t i = lo + first; i < hi; i += stride) {
+            const float4 G = src[i];
+            if (c.world > 1 || reinterpret_cast<const float4*>(g) != src) reinterpret_cast<float4*>(g)[i] = G;
+            if (ad.enabled) {
+                float4 P = reinterpret_cast<float4*>(ad.p)[i];
+                float4 M = reinterpret_cast<float4*>(ad.m)[i];
+                float4 V = reinterpret_cast<float4*>(ad.v)[i];
+                adam_update(P.x, G.x, M.x, V.x, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.y, G.y, M.y, V.y, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.z, G.z, M.z, V.z, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                adam_update(P.w, G.w, M.w, V.w, step_size, bc2_sqrt, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.wd, ad.clamp);
+                reinterpret_cast<float4*>(ad.p)[i] = P;
+                reinterpret_cast<float4*>(ad.m)[i] = M;
+                reinterpret_cast<float4*>(ad.v)[i] = V;
+            }
+        }
+    }
+}
+
 // Scalar exchange: vals[0..k) <- sum over ranks (rank order) of every rank's vals[0..k), k <= 16.
 // One workgroup: write mine into every peer's slot array (remote stores), signal, wait, sum locally.
 __global__ __launch_bounds__(64) void scalars_kernel(CommP c, float* __restrict__ vals, int k) {
@@ -432,7 +534,7 @@ extern "C" int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out)
 // reduce + gather pair, whose first wait is a 77-workgroup, 18-register kernel.
 extern "C" int gm_comm_set_exchange(void* comm, int two_kernels) {
     Comm* cm = static_cast<Comm*>(comm);
-    GM_CHECK_ARG(cm && (two_kernels == 0 || two_kernels == 1));
+    GM_CHECK_ARG(cm && two_kernels >= 0 && two_kernels <= 2);
     cm->two_kernels = two_kernels;
     return 0;
 }
@@ -483,7 +585,9 @@ static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const 
         hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
     static int two = -1;                              // GM_DP_TWO_KERNELS=1: round 3's reduce + gather pair everywhere (A/B)
     if (two < 0) { const char* e = getenv("GM_DP_TWO_KERNELS"); two = e ? atoi(e) : 0; }
-    if (two || cm->two_kernels) {
+    if (cm->two_kernels == 2) {
+        hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
+    } else if (two || cm->two_kernels) {
         hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
         hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
     } else {

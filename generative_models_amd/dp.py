@@ -103,6 +103,7 @@ class PeerComm:
         self.fine_grained = True
         self.shared_device = False
         self.two_kernels = False                     # which exchange form the launches take (gm_comm_set_exchange)
+        self.push = False
         if err is None:
             fg = ctypes.c_int(1)
             _lib.call("gm_comm_info", self.h, ctypes.byref(fg))
@@ -134,13 +135,19 @@ class PeerComm:
             # one-kernel form's spinning workgroups would starve the co-located peers' GEMM kernels of registers
             # (gm_comm_set_exchange).  GM_DP_ONE_KERNEL=1 keeps the one-kernel form (the direct exchange tests).
             self.shared_device = len({g[2] for g in got}) < world
-            if err is None and self.shared_device and os.environ.get("GM_DP_ONE_KERNEL") != "1":
+            push = os.environ.get("GM_DP_PUSH") == "1"           # posted remote writes instead of remote reads
+            one_kernel = push or os.environ.get("GM_DP_ONE_KERNEL") == "1"
+            if err is None and self.shared_device and not one_kernel:
                 _lib.call("gm_comm_set_exchange", self.h, 1)
                 self.two_kernels = True
-            elif err is None and self.shared_device:
-                # the one-kernel form between ranks on ONE device (tests): few spinning workgroups per rank, so that
-                # the co-located ranks' GEMM workgroups still find room on every CU
-                _lib.call("gm_comm_set_max_blocks", self.h, int(os.environ.get("GM_DP_XCHG_BLOCKS", "32")))
+            elif err is None:
+                if push:
+                    _lib.call("gm_comm_set_exchange", self.h, 2)
+                    self.push = True
+                if self.shared_device:
+                    # a one-kernel form between ranks on ONE device (tests): few spinning workgroups per rank, so
+                    # that the co-located ranks' GEMM workgroups still find room on every CU
+                    _lib.call("gm_comm_set_max_blocks", self.h, int(os.environ.get("GM_DP_XCHG_BLOCKS", "32")))
             oks = [None] * world
             dist.all_gather_object(oks, err is None, group=group)      # also: every rank has mapped every region
             if not all(oks):

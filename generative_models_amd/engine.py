@@ -1650,14 +1650,16 @@ class GANEngine:
                           "collectives between segment graphs" % why)
 
     def exchange_form(self):
-        """Which gradient exchange a step takes: 'none' (one rank), 'one_kernel' / 'two_kernels' (in-graph peer
-        exchange, csrc/gm_comm.hip) or 'rccl' (host-launched fallback)."""
+        """Which gradient exchange a step takes: 'none' (one rank), 'one_kernel' / 'one_kernel_push' / 'two_kernels'
+        (in-graph peer exchange, csrc/gm_comm.hip), 'rccl_in_graph' or 'rccl' (host-launched) for the fallback."""
         if not self._dp():
             return "none"
         if not self._peer():
             return "rccl_in_graph" if self._rccl_in_graph() else "rccl"
         comms = getattr(self, "_comms", None) or {}
-        return "two_kernels" if any(c.two_kernels for c in comms.values()) else "one_kernel"
+        if any(c.two_kernels for c in comms.values()):
+            return "two_kernels"
+        return "one_kernel_push" if any(getattr(c, "push", False) for c in comms.values()) else "one_kernel"
 
     def optim_state(self):
         """Everything the optimizers and controllers carry across steps, after the train() call that

@@ -537,11 +537,14 @@ int gm_comm_error(void* comm, int* flag_out);
  * may store into it while a kernel polls it), 0 when the runtime refused that allocation and the
  * region is plain device memory: valid only when every rank shares one device. */
 int gm_comm_info(void* comm, int* fine_grained_out);
-/* two_kernels = 0 (default): an all-reduce is ONE kernel (reduce-scatter, arrival counter, all-gather + Adam);
- * 1: two launches (reduce, gather).  Ranks that share one device must use 1: the one-kernel form keeps every
- * rank's ~300 workgroups spinning on peer flags, which starves the peers' GEMM workgroups of registers when they
- * run on the same CUs (dp.PeerComm sets it from the ranks' device identities). */
-int gm_comm_set_exchange(void* comm, int two_kernels);
+/* Exchange form.  0 (default): an all-reduce is ONE kernel (reduce-scatter, arrival counter, all-gather + Adam) that
+ * READS the peers' buckets over the peer mappings; 1: the same as two launches (reduce, gather) -- ranks that share
+ * one device must use 1 unless they also lower gm_comm_set_max_blocks: the one-kernel forms keep every rank's
+ * workgroups spinning on peer flags, which starves the peers' GEMM workgroups when they run on the same CUs
+ * (dp.PeerComm sets it from the ranks' device identities); 2: ONE kernel that moves the data by posted remote
+ * WRITES only (every rank deposits its contributions in the slice owners' staging areas, owners write the reduced
+ * slices into every rank's `out`): no xGMI read round trips.  All three give bit-identical sums (rank order). */
+int gm_comm_set_exchange(void* comm, int form);
 /* Upper bound on the workgroups of one exchange launch.  The one-kernel form needs ALL its workgroups co-resident
  * (each spins until every peer's last workgroup has arrived): the default (max_blocks = 0) is what the occupancy API
  * reports for this device or partition (CPX mode, HSA_CU_MASK), at most 320; ranks that share one device pass less. */

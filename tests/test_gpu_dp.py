@@ -94,19 +94,22 @@ def _comm_worker(rank, world, port, q, real=False):
 
 
 def _comm_case(world, real, one_kernel=False):
+    """one_kernel: False (two launches), True (one kernel, remote reads) or "push" (one kernel, posted remote writes)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, real)) for r in range(world)]
     # ranks sharing one device default to the two-launch exchange (dp.PeerComm); GM_DP_ONE_KERNEL=1 keeps the
-    # one-kernel form, whose cross-rank protocol (arrival counter, last arriver signals) is what this case covers
+    # one-kernel form, whose cross-rank protocol (arrival counter, last arriver signals) is what this case covers;
+    # GM_DP_PUSH=1 the push form (two arrival counters, flag phases 2 / 3, staging areas)
+    key = "GM_DP_PUSH" if one_kernel == "push" else "GM_DP_ONE_KERNEL"
     if one_kernel:
-        os.environ["GM_DP_ONE_KERNEL"] = "1"
+        os.environ[key] = "1"
     try:
         for p in procs:
             p.start()
     finally:
-        os.environ.pop("GM_DP_ONE_KERNEL", None)
+        os.environ.pop(key, None)
     out = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
@@ -117,15 +120,16 @@ def _comm_case(world, real, one_kernel=False):
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
-@pytest.mark.parametrize("one_kernel", [False, True], ids=["two_launches", "one_kernel"])
+@pytest.mark.parametrize("one_kernel", [False, True, "push"], ids=["two_launches", "one_kernel", "push"])
 def test_peer_allreduce_between_processes(world, one_kernel):
     _comm_case(world, real=False, one_kernel=one_kernel)
 
 
 @needs_2_gpus
-def test_peer_allreduce_between_gpus():
+@pytest.mark.parametrize("form", [True, "push"], ids=["one_kernel", "push"])
+def test_peer_allreduce_between_gpus(form):
     """One rank per GPU, up to 8: the exchange crosses the xGMI links (skipped on 1-GPU boxes)."""
-    _comm_case(min(torch.cuda.device_count(), 8), real=True)
+    _comm_case(min(torch.cuda.device_count(), 8), real=True, one_kernel=form)
 
 
 SMALL = dict(image_size=64, hidden_dim=48, z_dim=8, batch=16, n_train=160, n_val=48, n_test=48,
@@ -404,6 +408,13 @@ def test_n_rank_training_with_the_one_kernel_exchange(variant, batch, world, kw)
     assert all(o["xchg"] == "two_kernels" for o in two_launch)
     for k, v in many[0]["params"].items():
         assert np.array_equal(v, two_launch[0]["params"][k]), "one-kernel vs two-launch exchange: %s" % k
+    # ... and the PUSH form (posted remote writes only: round 5) gives the same bits again
+    pushed = _run_world(world, variant, kw, cfg=_full_cfg(batch), env={"GM_DP_PUSH": "1"})
+    assert all(o["xchg"] == "one_kernel_push" for o in pushed), [o["xchg"] for o in pushed]
+    for o in pushed:
+        assert o["rng"] == one["rng"] and o["G"] == many[0]["G"] and o["D"] == many[0]["D"]
+        for k, v in o["params"].items():
+            assert np.array_equal(v, many[0]["params"][k]), "push vs pull exchange: %s" % k
 
 
 def test_two_rank_vae_equals_one_rank_full_size():
