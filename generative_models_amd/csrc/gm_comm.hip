@@ -33,7 +33,9 @@
 namespace {
 
 constexpr int MAXW = 8;
-constexpr int64_t FLAG_BYTES = 4096;             // [phase 0..3][source rank] u64, padded
+constexpr int64_t FLAG_BYTES = 4096;             // [phase 0..7][source rank] u64, one 64-byte line each: 0 / 1 the pull
+                                                 // exchange's two phases, 2 the scalar exchange, 4 / 5 the push exchange
+constexpr int PUSH_PHASE_A = 4, PUSH_PHASE_B = 5;
 constexpr int64_t SCAL_FLOATS = 64;              // scalar exchange: 2 parities x up to 16 values (+pad)
 constexpr unsigned long long WAIT_TICKS = 10ull * 100000000ull;   // bounded waits: 10 s of the 100 MHz wall clock
 
@@ -301,15 +303,15 @@ __global__ __launch_bounds__(256) void xchg_kernel(CommP c, float* __restrict__ 
 // READ the peers' `in` (reduce-scatter) and `out` (all-gather) over xGMI -- every cache line a full round trip with a
 // bounded number outstanding.  Here rank r
 //   A  writes its contribution to every other rank's slice into THAT rank's stage[r] (remote stores), and -- once all
-//      its workgroups have done so (arrival counter 1, release) -- raises flag phase 2 at every peer;
-//   B  waits for the peers' phase-2 flags, sums ITS slice over ranks 0..W-1 in rank order (its own part straight from
+//      its workgroups have done so (arrival counter 1, release) -- raises flag phase 4 at every peer;
+//   B  waits for the peers' phase-4 flags, sums ITS slice over ranks 0..W-1 in rank order (its own part straight from
 //      `in`, the others from its local stage: the same values in the same order as the pull forms -- bit-identical),
 //      writes the result into its own `out` AND into every peer's `out` at the slice's place (remote stores); after
-//      arrival counter 2, flag phase 3;
-//   C  waits for the peers' phase-3 flags and reads the whole reduced bucket from its LOCAL `out` (+ Adam).
+//      arrival counter 2, flag phase 5;
+//   C  waits for the peers' phase-5 flags and reads the whole reduced bucket from its LOCAL `out` (+ Adam).
 // Every element of `in` / `out` / stage is touched by one thread of one rank per step (the grid-stride index sets of
 // A, B and C coincide per slice), so single buffers are safe by the same argument as above: a peer overwrites my
-// stage (exchange s + 1, step A) only after its step C of s, which waited for my phase-3 flag, which follows my step
+// stage (exchange s + 1, step A) only after its step C of s, which waited for my phase-5 flag, which follows my step
 // B -- the only reader of my stage.  Needs all workgroups of a launch co-resident, like xchg_kernel.
 __device__ __forceinline__ void arrive_then_flag(const CommP& c, unsigned* counter, int phase, unsigned long long s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's (remote) stores have left
@@ -319,7 +321,7 @@ __device__ __forceinline__ void arrive_then_flag(const CommP& c, unsigned* count
         const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == gridDim.x - 1) {                               // last workgroup of this rank: tell the peers, re-arm
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (phase == 3) c.seq[0] = s;                         // (every workgroup has read it: it arrived twice)
+            if (phase == PUSH_PHASE_B) c.seq[0] = s;              // (every workgroup has read it: it arrived twice)
             for (int peer = 0; peer < c.world; ++peer)
                 if (peer != c.rank)
                     __hip_atomic_store(flag_ptr(c, peer, phase, c.rank), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void push_kernel(CommP c, float* __restrict__ 
             float4* dst = reinterpret_cast<float4*>(c.base[o] + c.lay.stage + (int64_t)c.rank * c.lay.stage_stride);
             for (int64_t i = lo + first; i < hi; i += stride) dst[i - lo] = in[i];
         }
-        arrive_then_flag(c, c.arrive + 1, 2, s);
+        arrive_then_flag(c, c.arrive + 1, PUSH_PHASE_A, s);
         // B: my slice, summed in rank order, to everybody's `out`
         int64_t lo, hi;
         slice_of(n4, c.world, c.rank, &lo, &hi);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void push_kernel(CommP c, float* __restrict__ 
             for (int peer = 0; peer < c.world; ++peer)
                 if (peer != c.rank) reinterpret_cast<float4*>(c.base[peer] + c.lay.out)[i] = a;
         }
-        arrive_then_flag(c, c.arrive + 2, 3, s);
+        arrive_then_flag(c, c.arrive + 2, PUSH_PHASE_B, s);
     }
     float step_size = 0.f, bc2_sqrt = 1.f;
     if (ad.enabled) {
