@@ -152,6 +152,15 @@ _SIGNATURES = {
                                                 c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
                                                 POINTER(HeadBwdArgs), POINTER(HeadFoldArgs)]),
+    "gm_gather_rows_bits_packed": (c_int, [_P, _P, c_int, c_int64, _P, Slot, _P, c_int]),
+    "gm_linear_fwd_gather_bits_packed": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
+                                                 c_int, _P, c_int, c_int64, _P, Slot, _P, c_int]),
+    "gm_linear_fwd_headpart_bits": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int,
+                                            _P, _P, _P, c_int64, _P, _P, c_int, c_int]),
+    "gm_linear_bwd_dw_adam_head_fold_bits": (c_int, [_P, _P, c_int64, _P, c_int64, Slot, _P, _P, c_int, c_int,
+                                                     c_int, _P, _P, _P, _P, _P, _P, _P, Slot, ctypes.c_double,
+                                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, c_float,
+                                                     POINTER(HeadBwdArgs), POINTER(HeadFoldArgs), _P, c_int, c_int]),
     "gm_linear_bwd_dw_adam_pair": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs)]),
     "gm_linear_bwd_dw_adam_pair_finalize": (c_int, [_P, POINTER(DwAdamArgs), POINTER(DwAdamArgs),
                                                     POINTER(Finalize2Args)]),

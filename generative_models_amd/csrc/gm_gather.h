@@ -15,6 +15,10 @@ struct GatherP {
     // of 3136 B: the one batch-proportional HBM read stream of the step shrinks 32x; the gather
     // expands to the fp32 rows the GEMMs consume.
     const uint32_t* bits; int wpr;
+    // ... and, instead of expanding, the selected rows copied AS WORDS: out_bits[b * wpr ..) =
+    // the dataset row's wpr words; the consumers (gm_linear_fwd_headpart_bits, gm_linear_bwd_dw_adam_head_fold_bits)
+    // expand in registers.  100 B written per row instead of 3136.
+    uint32_t* out_bits;
 };
 
 // bid: index among the gather workgroups; every workgroup has blockDim.x / 64 waves = rows.
@@ -29,6 +33,10 @@ static __device__ __forceinline__ void gather_body(const GatherP& p, int bid) {
     float* dst = p.out + (int64_t)b * p.ld_out;
     if (p.bits) {
         const uint32_t* w = p.bits + r * (int64_t)p.wpr;
+        if (p.out_bits) {
+            for (int i = lane; i < p.wpr; i += 64) p.out_bits[(int64_t)b * p.wpr + i] = w[i];
+            return;
+        }
         if (p.vec) {                        // 4 pixels = 4 bits of one word (row_elems % 4 == 0)
             float4* d4 = reinterpret_cast<float4*>(dst);
             for (int q = lane; q < (p.row_elems >> 2); q += 64) {
@@ -69,7 +77,7 @@ static inline int gm_gather_fill(const float* data, int64_t n_rows, const int64_
     g->vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) &&
              ((reinterpret_cast<uintptr_t>(data) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    g->bits = nullptr; g->wpr = 0;
+    g->bits = nullptr; g->wpr = 0; g->out_bits = nullptr;
     return 0;
 }
 
@@ -82,6 +90,17 @@ static inline int gm_gather_fill_bits(const uint32_t* bits, int words_per_row, i
     g->data = nullptr; g->n_rows = n_rows; g->idx = idx; g->idx_slot = idx_slot; g->out = out;
     g->ld_out = ld_out; g->B = B; g->row_elems = row_elems;
     g->vec = (row_elems % 4 == 0) && (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    g->bits = bits; g->wpr = words_per_row;
+    g->bits = bits; g->wpr = words_per_row; g->out_bits = nullptr;
+    return 0;
+}
+
+// bit-packed dataset, rows copied as words (GatherP::out_bits)
+static inline int gm_gather_fill_bits_packed(const uint32_t* bits, int words_per_row, int64_t n_rows,
+                                             const int64_t* idx, gm_slot idx_slot, uint32_t* out_bits, int B,
+                                             GatherP* g) {
+    GM_CHECK_ARG(bits && idx && out_bits && B > 0 && words_per_row > 0 && n_rows > 0 && out_bits != bits);
+    g->data = nullptr; g->n_rows = n_rows; g->idx = idx; g->idx_slot = idx_slot; g->out = nullptr;
+    g->ld_out = 0; g->B = B; g->row_elems = 32 * words_per_row; g->vec = 0;
+    g->bits = bits; g->wpr = words_per_row; g->out_bits = out_bits;
     return 0;
 }

@@ -90,7 +90,19 @@ struct GemmP {
     const float* add;         // dx: v += add_scale * add[m,n] before the activation gradient
     int64_t ldadd;
     float add_scale;
+    // bit-packed operand rows (PK kernels): rows [0, pk_rows) of the batch-row operand -- A in the
+    // forward, B = X in the weight gradient -- are read from pk_bits (GatherP's layout: element e of row r = bit e & 31 of
+    // word r * pk_wpr + (e >> 5)) and expanded to 0.0f / 1.0f in registers; the fp32 rows behind them are never touched.
+    // pk_rows % 32 == 0: a forward tile / a 16-row reduction chunk is packed or fp32 as a whole, and each kind gets its own
+    // branch-free loop (selecting per fragment inside one loop made hipcc serialise the loads behind s_waitcnt vmcnt(0)).
+    const uint32_t* pk_bits; int pk_wpr; int pk_rows;
 };
+
+// elements e .. e+3 (e % 4 == 0) of a packed row from the word that holds them; expanded where the fragment is consumed
+__device__ __forceinline__ float4 pk_expand(uint32_t word, int e) {
+    const uint32_t v = word >> (e & 31);
+    return make_float4((float)(v & 1u), (float)((v >> 1) & 1u), (float)((v >> 2) & 1u), (float)((v >> 3) & 1u));
+}
 
 // Operand loads are BRANCH-FREE: out-of-range rows / k are clamped to a valid address and the
 // value is zeroed by a select afterwards.  (With `if (in range) load` hipcc branches around every
@@ -985,13 +997,15 @@ template <int MODE, bool DMA, int MI, int NI> struct RedSize {
 // formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
 // TP (with FOLD == 1): the rows' dS come from the two-phase prologue (RaGAN / Fisher critic steps, gm_head.h).
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool DMA = false,
-          bool TP = false>
+          bool TP = false, bool PK = false>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
     static_assert(!TP || (FOLD == 1 && !DMA), "two-phase losses: folded weight gradient, operands through registers");
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
     static_assert(G == 1, "per-chunk schedule (G stays in the kernel names so that they keep their shape across rounds)");
+    static_assert(!PK || (WAVES == 16 && !DMA && ((MODE == MODE_FWD && VEC) || (MODE == MODE_DW && XV))),
+                  "bit-packed operand rows: 16-byte operand paths through registers only");
     // DMA: the launch chose the LDS-DMA weight gradient (its own kernel instantiations: as a run-time branch inside the
     // shared kernels a second body cost the bs=256 step 1.5 us in registers and code it never runs)
     if constexpr (DMA && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
@@ -1109,6 +1123,61 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             for (int mi = 0; mi < MI; ++mi) fds[mi] = sds[16 * mi + i16];     // dS of this lane's A rows
         }
     };
+    if constexpr (PK) {
+        // Bit-packed batch rows (GemmP::pk_bits): the forward's A rows of a tile below pk_rows, the weight gradient's
+        // B (= X) rows of a reduction chunk below pk_rows.  One 4-byte load per fragment instead of a 16-byte one --
+        // the word that holds this lane's four elements -- expanded to 0.0f / 1.0f where the fp32 fragment would be
+        // fixed up; from there on the same instructions on the same values.  Packed and fp32 chunks run in SEPARATE
+        // loops (a wave's chunks w, w + 16, ... are packed up to q_pk).
+        constexpr int PN = MODE == MODE_FWD ? MI : NI;
+        auto pk_elem = [&](int c, int j) -> int {             // first of the four elements this lane takes from its word
+            return MODE == MODE_FWD ? min(16 * c + 4 * g4, p.K - 4) : min(n0 + 16 * j + 4 * xq_ld, b_cols - 4);
+        };
+        auto load_pk = [&](int c, int j) -> uint32_t {
+            const int row = MODE == MODE_FWD ? m0 + 16 * j + i16 : 16 * c + 4 * g4 + xe_ld;
+            return p.pk_bits[(int64_t)row * p.pk_wpr + (pk_elem(c, j) >> 5)];
+        };
+        const int nq_s = __builtin_amdgcn_readfirstlane(nq);
+        int q_pk;
+        if (MODE == MODE_FWD) q_pk = (m0 < p.pk_rows) ? nq_s : 0;
+        else q_pk = min(nq_s, max(0, ((p.pk_rows >> 4) - __builtin_amdgcn_readfirstlane(w) + WAVES - 1) / WAVES));
+        auto do_chunk = [&](auto is_pk, auto with_prologue, int q) {
+            constexpr bool P = decltype(is_pk)::value;
+            float4 ra[MI], rb[NI];
+            uint32_t pw[PN];
+            const int cc = w + q * WAVES;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                if constexpr (P && MODE == MODE_FWD) pw[mi] = load_pk(cc, mi);
+                else ra[mi] = load_a(cc, mi);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                if constexpr (P && MODE == MODE_DW) pw[ni] = load_pk(cc, ni);
+                else rb[ni] = load_b(cc, ni);
+            }
+            const float4 wk = load_wk(cc);
+            if constexpr (decltype(with_prologue)::value) fold_prologue();
+            if constexpr (P) {
+#pragma unroll
+                for (int j = 0; j < PN; ++j) {
+                    const float4 x = pk_expand(pw[j], pk_elem(cc, j));
+                    if constexpr (MODE == MODE_FWD) ra[j] = x; else rb[j] = x;
+                }
+            }
+            consume(ra, rb, wk, q);
+        };
+        constexpr std::true_type yes{};
+        constexpr std::false_type no{};
+        int q0 = 0;
+        if constexpr (FOLD != 0) {
+            if (nq_s > 0) { if (q_pk > 0) do_chunk(yes, yes, 0); else do_chunk(no, yes, 0); }
+            else fold_prologue();
+            q0 = 1;
+        }
+        for (int q = q0; q < q_pk; ++q) do_chunk(yes, no, q);
+        for (int q = max(q0, q_pk); q < nq_s; ++q) do_chunk(no, no, q);
+    } else {
     int q_first = 0;
     if constexpr (FOLD != 0) {
         float4 ra[MI], rb[NI];
@@ -1134,6 +1203,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(cc, ni);
         const float4 wk = load_wk(cc);
         consume(ra, rb, wk, q);
+    }
     }
     if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
         if (p.vec_epi) {                                     // kernel-argument uniform
@@ -1183,7 +1253,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
 // two touch disjoint outputs and neither reads what the other writes (gm_hip.h), so the launch
 // boundary -- and its ~2 us of idle machine inside a graph -- between them disappears.
 template <int MODE, bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false,
-          bool TP = false>
+          bool TP = false, bool PK = false>
 __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP& hp, int hrows,
                                                  int hblocks) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE, DMA, MI, NI>::value];
@@ -1195,13 +1265,23 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body<TP>(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP, PK>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
 template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false>
 __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP hp, int hrows,
                                                               int hblocks) {
     gemm16_with_head<MODE_DW, VEC, G, XV, MI, NI, OF, FOLDED, DMA>(p, hp, hrows, hblocks);
+}
+
+// The folded critic step's two launches reading the real rows of [x ; G(z)] as BITS (GemmP::pk_bits): one tile shape
+// each -- the shapes pick_tile gives the MNIST critic (32x32 forward tiles, 32x48 weight-gradient tiles).
+__global__ __launch_bounds__(1024) void gemm16_fwd_bits_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_FWD, false, 2, 2>::value];
+    gemm16_body<MODE_FWD, true, 16, 1, false, 2, 2, false, 0, false, false, true>(p, red, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(1024) void gemm16_dw_head_bits_kernel(GemmP p, HeadBwdP hp, int hrows, int hblocks) {
+    gemm16_with_head<MODE_DW, false, 1, true, 2, 3, false, true, false, false, true>(p, hp, hrows, hblocks);
 }
 
 // The same launch for the critic steps whose loss is not a mean of per-row terms (RaGAN, Fisher): folded head with
@@ -1362,6 +1442,35 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                ((int64_t)q.K + 64) * (q.lda > q.ldb ? q.lda : q.ldb) < (1ll << 31);
     };
     p.dma = dma_ok(p, xv);
+    // bit-packed operand rows: the two launches of the folded critic step only, one tile shape each (every other
+    // configuration is refused -- there is no fp32 copy of those rows to fall back to)
+    if (p.pk_bits) {
+        if constexpr (MODE == MODE_FWD) {
+            if (!vec || !p.hd_part || rider.gather || p.ip_out) {
+                gm_set_error("bit-packed rows: the forward needs 16-byte aligned operands and the folded head's partial dots");
+                return GM_EINVAL;
+            }
+            const dim3 bgrid((p.N + 31) / 32, (p.M + 31) / 32);
+            hipLaunchKernelGGL(gemm16_fwd_bits_kernel, bgrid, dim3(1024), 0, s, p);
+            GM_LAUNCH_RET();
+        } else if constexpr (MODE == MODE_DW) {
+            if (!head || !folded || head->fold.enabled != 1 || !xv || p.ones_from > 0 || rider.pair) {
+                gm_set_error("bit-packed rows: the weight gradient needs the folded head of a separable loss and "
+                             "16-byte aligned operands");
+                return GM_EINVAL;
+            }
+            p.dma = false;                                   // operands through registers (the expansion lives there)
+            const dim3 bgrid((p.N + 47) / 48, (p.M + 31) / 32);
+            const int hblocks = gm_head_bwd_blocks(*head);
+            const int hrows = (hblocks + (int)bgrid.x - 1) / (int)bgrid.x;
+            hipLaunchKernelGGL(gemm16_dw_head_bits_kernel, dim3(bgrid.x, bgrid.y + hrows), dim3(1024), 0, s, p, *head,
+                               hrows, hblocks);
+            GM_LAUNCH_RET();
+        } else {
+            gm_set_error("bit-packed rows: forward and weight gradient only");
+            return GM_EINVAL;
+        }
+    }
     // many-row forward / input-gradient launches: LDS-staged macro tiles.  Riders get their own launch first (a head /
     // gather workgroup set is microseconds next to a >= 1024-row GEMM).
     if constexpr (MODE != MODE_DW) {
@@ -1552,6 +1661,29 @@ extern "C" int gm_linear_fwd_headpart(void* stream, const float* X, int64_t ldx,
     return launch<MODE_FWD>((hipStream_t)stream, p, vec);
 }
 
+// gm_linear_fwd_headpart whose first `rows` rows of X are read from the packed copy (gm_gather_rows_bits_packed)
+extern "C" int gm_linear_fwd_headpart_bits(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                           const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                           int K, int N, int act, const float* w2, const float* b2,
+                                           float* part, int64_t ldp, float* snap, const uint32_t* xbits,
+                                           int words_per_row, int rows) {
+    GM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+    GM_CHECK_ARG(act >= GM_ACT_ID && act <= GM_ACT_SIGMOID);
+    GM_CHECK_ARG(w2 && b2 && part && snap && ldp >= (N + 31) / 32 && ldp % 4 == 0);
+    GM_CHECK_ARG(part != Y && snap != Y && (const float*)part != X && (const float*)snap != X);
+    GM_CHECK_ARG(xbits && rows > 0 && rows <= M && rows % 32 == 0 && words_per_row * 32 >= K && K % 4 == 0);
+    GM_CHECK_ARG((const void*)xbits != (const void*)Y && (const void*)xbits != (const void*)part);
+    GemmP p{};
+    p.A = X; p.B = W; p.C = Y; p.M = M; p.N = N; p.K = K;
+    p.lda = ldx; p.ldb = K; p.ldc = ldy; p.bias = bias; p.epi = act;
+    p.a_slot = x_slot; p.b_slot = no_slot();
+    p.hd_w2 = w2; p.hd_b2 = b2; p.hd_part = part; p.hd_ldp = ldp; p.hd_snap = snap;
+    p.pk_bits = xbits; p.pk_wpr = words_per_row; p.pk_rows = rows;
+    const bool vec = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (K % 4 == 0) &&
+                     (x_slot.stride % 4 == 0);
+    return launch<MODE_FWD>((hipStream_t)stream, p, vec);
+}
+
 extern "C" int gm_linear_fwd_sqerr(void* stream, const float* X, int64_t ldx, const float* W,
                                   const float* bias, float* Y, int64_t ldy, int M, int K, int N,
                                   const float* target, int64_t ld_target, float* dA, int64_t lda,
@@ -1593,6 +1725,17 @@ extern "C" int gm_linear_fwd_gather_bits(void* stream, const float* X, int64_t l
     const int rc = gm_gather_fill_bits(bits, words_per_row, n_rows, idx, idx_slot, out, ld_out, B, row_elems, &g);
     if (rc) return rc;
     return fwd_gather_impl(stream, X, ldx, x_slot, W, bias, Y, ldy, M, K, N, act, g, out);
+}
+
+extern "C" int gm_linear_fwd_gather_bits_packed(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
+                                                const float* W, const float* bias, float* Y, int64_t ldy, int M,
+                                                int K, int N, int act, const uint32_t* bits, int words_per_row,
+                                                int64_t n_rows, const int64_t* idx, gm_slot idx_slot,
+                                                uint32_t* out_bits, int B) {
+    GatherP g{};
+    const int rc = gm_gather_fill_bits_packed(bits, words_per_row, n_rows, idx, idx_slot, out_bits, B, &g);
+    if (rc) return rc;
+    return fwd_gather_impl(stream, X, ldx, x_slot, W, bias, Y, ldy, M, K, N, act, g, reinterpret_cast<float*>(out_bits));
 }
 
 static int fwd_gather_impl(void* stream, const float* X, int64_t ldx, gm_slot x_slot,
@@ -1785,6 +1928,44 @@ extern "C" int gm_linear_bwd_dw_adam_head_fold(void* stream, const float* H, int
         a.enabled = 1;
     }
     return dw_impl(stream, H, ldh, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &hp, 0, fold->snap);
+}
+
+// gm_linear_bwd_dw_adam_head_fold whose first `rows` rows of X are read from the packed copy
+extern "C" int gm_linear_bwd_dw_adam_head_fold_bits(void* stream, const float* H, int64_t ldh,
+                                                    const float* X, int64_t ldx, gm_slot x_slot, float* dW,
+                                                    float* db, int M, int K, int N, float* pW, float* mW,
+                                                    float* vW, float* pb, float* mb, float* vb,
+                                                    const float* sched, gm_slot sched_slot, double beta1,
+                                                    double beta2, double eps, double weight_decay, float clamp,
+                                                    const gm_head_bwd_args* head, const gm_head_fold_args* fold,
+                                                    const uint32_t* xbits, int words_per_row, int rows) {
+    GM_CHECK_ARG(head && fold && !head->gen_mode && head->H == H && 2 * head->B == M && head->Hd == N);
+    GM_CHECK_ARG(!sched || (db && pW && mW && vW && pb && mb && vb));
+    GM_CHECK_ARG((const float*)head->w2 != pW || !pW);
+    GM_CHECK_ARG(head->gw2 != dW && (const float*)dW != H);
+    GM_CHECK_ARG(fold->snap != (const float*)head->w2 && fold->snap != (const float*)head->b2);
+    GM_CHECK_ARG(xbits && rows > 0 && rows <= M && rows % 32 == 0 && words_per_row * 32 >= K && K % 4 == 0);
+    GM_CHECK_ARG((const void*)xbits != (const void*)dW && (const void*)xbits != (const void*)pW);
+    HeadBwdP hp{};
+    const int rc = gm_head_from_args(*head, &hp, fold);
+    if (rc) return rc;
+    gm_adam_epi a{};
+    if (sched) {
+        a.pW = pW; a.mW = mW; a.vW = vW; a.pb = pb; a.mb = mb; a.vb = vb; a.sched = sched;
+        a.sched_slot = sched_slot; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2;
+        a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay; a.clamp = clamp;
+        a.enabled = 1;
+    }
+    GemmP p{};
+    bool xvec = false;
+    const int rf = dw_fill(H, ldh, X, ldx, x_slot, dW, db, M, K, N, 0, sched ? &a : nullptr, &p, &xvec);
+    if (rf) return rf;
+    p.fold_w2 = fold->snap;
+    if (!aligned16(fold->snap)) xvec = false;
+    p.pk_bits = xbits; p.pk_wpr = words_per_row; p.pk_rows = rows;
+    Rider r;
+    r.head = &hp;
+    return launch<MODE_DW>((hipStream_t)stream, p, false, xvec, r);
 }
 
 static int dw_adam_fill(const gm_dw_adam_args& a, GemmP* p, bool* xvec) {

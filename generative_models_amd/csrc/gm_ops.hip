@@ -173,6 +173,16 @@ extern "C" int gm_gather_rows_bits(void* stream, const uint32_t* bits, int words
     GM_LAUNCH_RET();
 }
 
+extern "C" int gm_gather_rows_bits_packed(void* stream, const uint32_t* bits, int words_per_row, int64_t n_rows,
+                                          const int64_t* idx, gm_slot idx_slot, uint32_t* out_bits, int B) {
+    GatherP g{};
+    const int rc = gm_gather_fill_bits_packed(bits, words_per_row, n_rows, idx, idx_slot, out_bits, B, &g);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(g, 4)), dim3(256), 0,
+                       (hipStream_t)stream, g);
+    GM_LAUNCH_RET();
+}
+
 // ------------------------------------------------------------------------------------------
 // K4 adversarial losses.  One 256-thread workgroup: the score vectors are [B] (B <= a few
 // thousand), so a single workgroup with wave64 shuffle + LDS reductions is both the fastest

@@ -730,10 +730,33 @@ class GANEngine:
         """The batch gather rides in the grid of the generator's first forward launch."""
         return self.ride_gather
 
+    def _packed_operand(self):
+        """The critic step reads its real rows as BITS: the gather copies the selected rows of the
+        1-bit resident dataset as words (100 B per MNIST row instead of 3136 B of fp32) and the folded step's two
+        launches -- hidden layer forward, layer-1 weight gradient -- expand them in registers
+        (gm_linear_fwd_headpart_bits, gm_linear_bwd_dw_adam_head_fold_bits).  Bit-identical losses and parameters
+        (tests/test_gpu_trainers.py); GM_PACKED_OPERAND=1 turns it on -- measured neither faster nor slower than the
+        fp32 rows on one MI355X (profiles/r05_experiments.md section 9), so the default stays the path every other
+        variant shares.  Needs the folded step of a separable loss and a batch of whole 32-row tiles."""
+        import os
+        if os.environ.get("GM_PACKED_OPERAND", "0") != "1":
+            return False
+        return isinstance(self.data, ops.PackedData) and self._fold_head() and \
+            self.variant not in ("ra", "fisher") and self.Bl % 32 == 0 and self.I % 4 == 0
+
+    def _xbits(self):
+        """(words, words per row, rows) of the packed real rows, or None."""
+        if not self._packed_operand():
+            return None
+        if getattr(self, "Xbits", None) is None:
+            self.Xbits = torch.zeros(self.Bl, self.data.wpr, dtype=torch.int32, device=self.device)
+        return (self.Xbits, self.data.wpr, self.Bl)
+
     def _gather_args(self, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
         r0 = self.ring_r0                         # this rank's rows of the (device) index ring
-        return dict(data=self.data, idx=self.idx_ring.view(-1)[r0:], out=self.X2, B=Bl,
+        xb = self._xbits()
+        return dict(data=self.data, idx=self.idx_ring.view(-1)[r0:], out=self.X2 if xb is None else xb[0], B=Bl,
                     idx_slot=self._slot(it, d, j, R * d, self.ring_B))
 
     def _D_gather(self, st, it, j):
@@ -802,13 +825,14 @@ class GANEngine:
         # 2 launches instead of 3: hidden layer forward (+ partial dots of the head), then the
         # layer-1 weight gradient (+Adam) with the head's backward workgroups riding -- scores,
         # row losses and dS are rebuilt from the partial dots in that launch's prologue
-        ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st)
+        xb = self._xbits()                                # real rows as bits: X2[:Bl] is never written or read
+        ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st, xbits=xb)
         adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
         fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss,
                             pen=self.aux if self.variant == "fisher" else None)   # Fisher: lambda lives in aux
         head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
                     adam=adam)
-        ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st)
+        ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st, xbits=xb)
         if self.variant == "fisher":
             from . import ops_fused as of
             of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)

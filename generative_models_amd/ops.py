@@ -106,6 +106,13 @@ def linear_fwd_gather(x, W, b, y, act, data, idx, out, M=None, B=None, x_slot=NO
     M = x.shape[0] if M is None else M
     n_rows, row = data.shape
     B = out.shape[0] if B is None else B
+    if isinstance(data, PackedData) and out.dtype == torch.int32:     # ... and the rows stay packed (out: [B, wpr] words)
+        assert out.is_contiguous() and out.shape[1] == data.wpr
+        _lib.call("gm_linear_fwd_gather_bits_packed", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
+                  x_slot, _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
+                  _chk(y, "y").data_ptr(), _ld(y), M, K, N, ACT[act], data.data_ptr(), data.wpr,
+                  n_rows, idx.data_ptr(), idx_slot, out.data_ptr(), B)
+        return y
     if isinstance(data, PackedData):                 # 1 bit / pixel resident dataset
         _lib.call("gm_linear_fwd_gather_bits", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x),
                   x_slot, _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None,
@@ -268,12 +275,20 @@ def _al4(n):
     return (n + 3) // 4 * 4
 
 
-def linear_fwd_headpart(x, W, b, y, act, head_lin, fold, M=None, x_slot=NO_SLOT, stream=None):
+def linear_fwd_headpart(x, W, b, y, act, head_lin, fold, M=None, x_slot=NO_SLOT, stream=None, xbits=None):
     """linear_fwd of the critic's hidden layer that also leaves the folded head's partial dots and
-    the (w2, b2) snapshot in `fold` (HeadFold)."""
+    the (w2, b2) snapshot in `fold` (HeadFold).  xbits = (words, words_per_row, rows): the first `rows` rows of x
+    are read from the packed copy (gather_rows_packed) instead."""
     N, K = W.shape
     M = x.shape[0] if M is None else M
     assert fold.hidden == N and fold.part.shape[0] >= M
+    if xbits is not None:
+        _lib.call("gm_linear_fwd_headpart_bits", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x), x_slot,
+                  _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None, _chk(y, "y").data_ptr(),
+                  _ld(y), M, K, N, ACT[act] if not isinstance(act, int) else act, head_lin.W.data_ptr(),
+                  head_lin.b.data_ptr(), fold.part.data_ptr(), fold.part.shape[1], fold.snap.data_ptr(),
+                  xbits[0].data_ptr(), xbits[1], xbits[2])
+        return y
     _lib.call("gm_linear_fwd_headpart", stream or stream_ptr(), _chk(x, "x").data_ptr(), _ld(x), x_slot,
               _chk(W, "W").data_ptr(), b.data_ptr() if b is not None else None, _chk(y, "y").data_ptr(),
               _ld(y), M, K, N, ACT[act] if not isinstance(act, int) else act, head_lin.W.data_ptr(),
@@ -296,24 +311,26 @@ def linear_bwd_dx_head_fold(H, W, dX, head, fold_args, below=None, epi="id", M=N
 
 
 def linear_bwd_dw_adam_head_fold(H, X, lin, adam, head, fold_args, M=None, x_slot=NO_SLOT,
-                                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, stream=None):
-    """linear_bwd_dw_adam_head in the folded form (see linear_bwd_dx_head_fold)."""
+                                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, stream=None, xbits=None):
+    """linear_bwd_dw_adam_head in the folded form (see linear_bwd_dx_head_fold).  xbits: as linear_fwd_headpart."""
     import ctypes
     N, K = lin.gW.shape
     M = H.shape[0] if M is None else M
     a = _head_args(head, betas, eps)
+    name = "gm_linear_bwd_dw_adam_head_fold" + ("_bits" if xbits is not None else "")
+    tail = (xbits[0].data_ptr(), xbits[1], xbits[2]) if xbits is not None else ()
     if adam is None:
-        _lib.call("gm_linear_bwd_dw_adam_head_fold", stream or stream_ptr(), _chk(H, "H").data_ptr(),
+        _lib.call(name, stream or stream_ptr(), _chk(H, "H").data_ptr(),
                   _ld(H), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
                   lin.gb.data_ptr(), M, K, N, None, None, None, None, None, None, None, NO_SLOT,
-                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a), ctypes.byref(fold_args))
+                  betas[0], betas[1], eps, weight_decay, 0.0, ctypes.byref(a), ctypes.byref(fold_args), *tail)
         return
-    _lib.call("gm_linear_bwd_dw_adam_head_fold", stream or stream_ptr(), _chk(H, "H").data_ptr(),
+    _lib.call(name, stream or stream_ptr(), _chk(H, "H").data_ptr(),
               _ld(H), _chk(X, "X").data_ptr(), _ld(X), x_slot, lin.gW.data_ptr(),
               lin.gb.data_ptr(), M, K, N, lin.W.data_ptr(), lin.mW.data_ptr(), lin.vW.data_ptr(),
               lin.b.data_ptr(), lin.mb.data_ptr(), lin.vb.data_ptr(), adam["sched"].data_ptr(),
               adam["sched_slot"], betas[0], betas[1], eps, weight_decay, adam.get("clamp", 0.0),
-              ctypes.byref(a), ctypes.byref(fold_args))
+              ctypes.byref(a), ctypes.byref(fold_args), *tail)
 
 
 def linear_bwd_dx_head(dA, W, dX, head, below=None, epi="id", M=None, stream=None):
@@ -391,6 +408,11 @@ def gather_rows(data, idx, out, B=None, idx_slot=NO_SLOT, stream=None):
     n_rows, row = data.shape
     B = out.shape[0] if B is None else B
     assert idx.dtype == torch.int64 and idx.is_cuda
+    if isinstance(data, PackedData) and out.dtype == torch.int32:     # rows copied as words: out [B, wpr]
+        assert out.is_contiguous() and out.shape[1] == data.wpr
+        _lib.call("gm_gather_rows_bits_packed", stream or stream_ptr(), data.data_ptr(), data.wpr, n_rows,
+                  idx.data_ptr(), idx_slot, out.data_ptr(), B)
+        return out
     if isinstance(data, PackedData):
         _lib.call("gm_gather_rows_bits", stream or stream_ptr(), data.data_ptr(), data.wpr, n_rows,
                   idx.data_ptr(), idx_slot, out.data_ptr(), _ld(out), B, row)

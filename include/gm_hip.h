@@ -388,6 +388,30 @@ int gm_linear_fwd_gather_bits(void* stream, const float* X, int64_t ldx, gm_slot
 int gm_gather_rows_bits(void* stream, const uint32_t* bits, int words_per_row, int64_t n_rows,
                         const int64_t* idx, gm_slot idx_slot, float* out, int64_t ld_out, int B,
                         int row_elems);
+/* Bit-packed rows AS A GEMM OPERAND (the data is process_batch's, ns_gan.py:222-226, binarised by
+ * utils.py:31): the gather copies the selected rows as WORDS (out_bits[b * words_per_row ..), 100 B per MNIST row
+ * instead of 3136), and the folded critic step's two launches read rows [0, rows) of X from that copy, expanding to
+ * 0.0f / 1.0f in registers -- the fp32 rows X[0 .. rows) are neither written nor read.  Same MFMA sequence on the same
+ * values: results are bit-identical to the fp32-operand entry points.  rows % 32 == 0, K % 4 == 0 (a forward tile /
+ * reduction chunk is packed as a whole); one tile shape per launch (32x32 forward, 32x48 weight gradient, operands
+ * through registers); anything else returns GM_EINVAL -- there is no fp32 copy to fall back to. */
+int gm_gather_rows_bits_packed(void* stream, const uint32_t* bits, int words_per_row, int64_t n_rows,
+                               const int64_t* idx, gm_slot idx_slot, uint32_t* out_bits, int B);
+int gm_linear_fwd_gather_bits_packed(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                                     const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                                     const uint32_t* bits, int words_per_row, int64_t n_rows, const int64_t* idx,
+                                     gm_slot idx_slot, uint32_t* out_bits, int B);
+int gm_linear_fwd_headpart_bits(void* stream, const float* X, int64_t ldx, gm_slot x_slot, const float* W,
+                                const float* bias, float* Y, int64_t ldy, int M, int K, int N, int act,
+                                const float* w2, const float* b2, float* part, int64_t ldp, float* snap,
+                                const uint32_t* xbits, int words_per_row, int rows);
+int gm_linear_bwd_dw_adam_head_fold_bits(void* stream, const float* H, int64_t ldh, const float* X,
+                                         int64_t ldx, gm_slot x_slot, float* dW, float* db, int M, int K, int N,
+                                         float* pW, float* mW, float* vW, float* pb, float* mb, float* vb,
+                                         const float* sched, gm_slot sched_slot, double beta1, double beta2,
+                                         double eps, double weight_decay, float clamp,
+                                         const gm_head_bwd_args* head, const gm_head_fold_args* fold,
+                                         const uint32_t* xbits, int words_per_row, int rows);
 /* Two gm_linear_bwd_dw_adam calls over the same batch rows as ONE launch (the generator step's two
  * weight gradients are independent once d loss / d hidden is known).  Falls back to two launches
  * when the pair cannot share a tile configuration.  sched == NULL in an argument block: plain

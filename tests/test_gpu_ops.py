@@ -818,6 +818,88 @@ def test_packed_dataset_gather_equals_fp32_gather(N, I, B):
     assert not ops.PackedData.is_binary(torch.rand(4, 4))
 
 
+# ---------------------------------------------------------------------------------------------
+# Bit-packed rows as a GEMM operand: the gather copies words, the folded critic step's two
+# launches expand them in registers -- every output bit equal to the fp32-row launches'
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,I,B", [(500, 784, 256), (77, 64, 16), (40, 100, 24), (300, 2100, 9)])
+def test_packed_gather_copies_the_rows_as_words(N, I, B):
+    torch.manual_seed(N + I)
+    data = torch.bernoulli(torch.full((N, I), 0.3)).cuda()
+    packed = ops.PackedData(data)
+    idx = torch.randint(0, N, (B,), device="cuda")
+    out = torch.full((B, packed.wpr), -1, dtype=torch.int32, device="cuda")
+    ops.gather_rows(packed, idx, out)
+    assert torch.equal(out, packed.bits[idx])
+    x, W, bias = torch.randn(2 * B, 20, device="cuda"), torch.randn(48, 20, device="cuda"), torch.zeros(48, device="cuda")
+    y1, y2 = torch.empty(2 * B, 48, device="cuda"), torch.empty(2 * B, 48, device="cuda")
+    out2 = torch.full((B, packed.wpr), -1, dtype=torch.int32, device="cuda")
+    ops.linear_fwd(x, W, bias, y1, "relu")
+    ops.linear_fwd_gather(x, W, bias, y2, "relu", packed, idx, out2)
+    assert torch.equal(y1, y2) and torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("variant,out_act", [("ns", "sigmoid"), ("w", "id")])
+@pytest.mark.parametrize("B,I,Hd,rows", [(256, 784, 400, 256), (64, 784, 400, 64), (64, 36, 20, 64), (32, 64, 48, 32),
+                                         (352, 784, 400, 352), (96, 100, 72, 32), (256, 784, 400, 128)])
+def test_folded_critic_step_reads_packed_rows_bit_identically(variant, out_act, B, I, Hd, rows):
+    """gm_linear_fwd_headpart_bits / gm_linear_bwd_dw_adam_head_fold_bits: the first `rows` rows of [x ; G(z)] come
+    from the packed copy, the fp32 rows behind them hold garbage -- hidden layer, partial dots, gradients, Adam'd
+    parameters, moments and loss must equal the fp32-row launches bit for bit (same MFMA sequence on the same values)."""
+    import torch.nn as nn
+    from generative_models_amd.engine import FlatParams, _Linear
+    hyper = [0.0, 1.0, 1.0]
+    torch.manual_seed(B + I)
+    data = torch.bernoulli(torch.full((rows, I), 0.3))
+    fake = torch.rand(2 * B - rows, I)
+
+    def run(bits):
+        torch.manual_seed(11)
+        net = nn.Sequential(nn.Linear(I, Hd), nn.Linear(Hd, 1))
+        fp = FlatParams(net.parameters(), DEV)
+        fp.m.normal_().mul_(1e-3); fp.v.uniform_(0.0, 1e-4)
+        L1, L2 = _Linear(fp, net[0]), _Linear(fp, net[1])
+        X2 = torch.cat([data, fake]).to(DEV)
+        xb = None
+        if bits:
+            pk = ops.PackedData(data.to(DEV))
+            X2[:rows] = float("nan")                      # never read
+            xb = (pk.bits, pk.wpr, rows)
+        H = torch.empty(2 * B, Hd, device=DEV)
+        S = torch.zeros(2 * B, device=DEV); dS = torch.zeros_like(S); rl = torch.zeros_like(S)
+        loss = torch.zeros(1, device=DEV)
+        sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(DEV)
+        adam = dict(sched=sched, sched_slot=ops.slot(0, 0, 2, 0, 1), clamp=0.0)
+        head = dict(H=H, lin=L2, loss_out=loss, loss_slot=ops.NO_SLOT, inv_b=1.0 / B, B=B, adam=adam)
+        fold = ops.HeadFold(2 * B, Hd, DEV)
+        ops.linear_fwd_headpart(X2, L1.W, L1.b, H, "relu", L2, fold, xbits=xb)
+        fa = fold.args(variant, out_act, hyper, S=S, dS=dS, rowloss=rl)
+        ops.linear_bwd_dw_adam_head_fold(H, X2, L1, adam, head, fa, xbits=xb)
+        torch.cuda.synchronize()
+        return dict(H=H, part=fold.part.clone(), flat=fp.flat.clone(), grad=fp.grad.clone(), m=fp.m.clone(),
+                    v=fp.v.clone(), loss=loss.clone(), S=S, dS=dS, rl=rl)
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert not torch.isnan(b[k]).any(), k
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_packed_operand_refuses_what_it_cannot_carry():
+    """No fp32 copy exists behind packed rows: a row count that is not whole 32-row tiles is an error, never a
+    silent read of the unwritten rows."""
+    from types import SimpleNamespace
+    B, I, Hd = 24, 64, 48
+    pk = ops.PackedData(torch.bernoulli(torch.full((B, I), 0.5)).to(DEV))
+    X2 = torch.zeros(2 * B, I, device=DEV); H = torch.zeros(2 * B, Hd, device=DEV)
+    W1 = torch.zeros(Hd, I, device=DEV); b1 = torch.zeros(Hd, device=DEV)
+    L2 = SimpleNamespace(W=torch.zeros(1, Hd, device=DEV), b=torch.zeros(1, device=DEV))
+    fold = ops.HeadFold(2 * B, Hd, DEV)
+    from generative_models_amd._lib import GMError
+    with pytest.raises(GMError):
+        ops.linear_fwd_headpart(X2, W1, b1, H, "relu", L2, fold, xbits=(pk.bits, pk.wpr, B))
+
+
 def test_stage_in_gate_waits_for_the_host_and_times_out_without_hanging():
     """gm_stage_in_gated: the kernel copies only after the fill counter in pinned host memory covers
     its iterations; a counter that never advances ends in a bounded wait + the time-out flag (the GPU

@@ -195,6 +195,39 @@ def test_fp32_resident_dataset_equals_bit_packed(monkeypatch):
         assert torch.equal(x, y), k
 
 
+PK_CFG = dict(image_size=784, hidden_dim=400, z_dim=20, n_train=2048, n_val=256, n_test=256, image_shape=(1, 28, 28))
+PK_CASES = [("ns", PK_CFG, 256, {}), ("ns", PK_CFG, 64, {}), ("ls", PK_CFG, 256, {}), ("w", PK_CFG, 256, dict(D_steps=2)),
+            ("mm", PK_CFG, 128, dict(G_init=1)), ("info", PK_CFG, 256, {}), ("f", PK_CFG, 256, dict(method="pearson")),
+            ("ns", SMALL, 32, {}), ("ls", SMALL, 64, {})]
+
+
+@pytest.mark.parametrize("variant,cfg,batch,kw", PK_CASES,
+                         ids=["%s_b%d_%d" % (v, b, c["image_size"]) for v, c, b, _ in PK_CASES])
+def test_packed_operand_rows_equal_fp32_rows(variant, cfg, batch, kw, monkeypatch):
+    """GM_PACKED_OPERAND=1: the critic step reads its real rows as bits -- the gather writes
+    100 B per row instead of 3136, the fp32 rows of X2 are never written -- and the run is bitwise the run on fp32 rows."""
+    a = run_product(variant, cfg, batch, dict(num_epochs=2, **kw), capped=6)
+    assert not a[0]._engine._packed_operand()
+    assert float(a[0]._engine.X2[:batch].abs().max()) > 0.0
+    monkeypatch.setenv("GM_PACKED_OPERAND", "1")
+    b = run_product(variant, cfg, batch, dict(num_epochs=2, **kw), capped=6)
+    eng = b[0]._engine
+    assert eng._packed_operand() and bool(eng.Xbits.any())
+    assert float(eng.X2[:batch].abs().max()) == 0.0          # the fp32 real rows were never written
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
+
+
+def test_packed_operand_is_not_taken_where_the_step_cannot_carry_it(monkeypatch):
+    """Ragged batches (24 rows: not whole 32-row tiles) and the penalty variants keep the fp32 rows."""
+    monkeypatch.setenv("GM_PACKED_OPERAND", "1")
+    a = run_product("ns", RAGGED, 24, dict(num_epochs=1))
+    assert not a[0]._engine._packed_operand() and float(a[0]._engine.X2[:24].abs().max()) > 0.0
+    b = run_product("wgp", SMALL, 16, dict(num_epochs=1, D_steps=1))
+    assert not b[0]._engine._packed_operand()
+
+
 @pytest.mark.parametrize("variant,env", [("wgp", "GM_WGP_PEN_IN_HEAD"), ("wgp", "GM_WGP_STACK"), ("ns", "GM_FOLD_HEAD"),
                                          ("wgp", "GM_FOLD_HEAD"), ("dra", "GM_DRA_STACK"), ("ra", "GM_FOLD_HEAD_TP"),
                                          ("fisher", "GM_FOLD_HEAD_TP")])
