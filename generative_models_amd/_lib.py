@@ -232,8 +232,6 @@ _SIGNATURES = {
     "gm_stage_in": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int]),
     "gm_stage_in_gated": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int, _P, Slot, ctypes.c_double, _P,
                                   c_int]),
-    "gm_stage_in_prestaged": (c_int, [_P, POINTER(StageSeg), c_int, Slot, c_int, _P, Slot, ctypes.c_double, _P,
-                                      c_int, _P, _P, c_int]),
     "gm_host_device_ptr": (c_int, [_P, POINTER(c_void_p)]),
     "gm_host_replay": (c_int, [_P, c_int64, POINTER(DrawOp), c_int, c_int]),
     "gm_host_replay_threads": (c_int, [c_int]),

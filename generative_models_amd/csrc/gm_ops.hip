@@ -36,45 +36,14 @@ extern "C" int gm_tick(void* stream, int64_t* ctr, int64_t inc) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stage_in_kernel(StageP p) {
     if (p.publish && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.publish = gm_slot_index(p.it_slot);
-    if (p.range && !p.mark) {
-        // already in the device rings?  (agent-scope load by every lane: one transaction; the kernels behind this
-        // one acquire at their own start)
-        const unsigned long long r = __hip_atomic_load(p.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t it0 = gm_slot_index(p.it_slot);
-        if ((int64_t)(r >> 32) <= it0 && it0 + p.n_iters <= (int64_t)(r & 0xffffffffull)) return;
-    }
-    if (p.gate) {
-        if (threadIdx.x == 0) {
-            stage_gate_wait(p.gate, gm_slot_index(p.it_slot) + p.n_iters, p.timeout);
-        }
-        __syncthreads();
-    }
     stage_copy(p);
-    if (p.range && p.mark) {
-        __threadfence();                                      // this workgroup's ring writes: device-visible
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int total = gridDim.x * gridDim.y;
-            if (__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-                __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long r = __hip_atomic_load(p.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long it0 = (unsigned long long)gm_slot_index(p.it_slot);
-                const unsigned long long lo = ((r & 0xffffffffull) == it0) ? (r >> 32) : it0;
-                __hip_atomic_store(p.range, (lo << 32) | (it0 + (unsigned long long)p.n_iters), __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                if (p.done_host)                              // every workgroup's host reads are behind its arrival
-                    __hip_atomic_store(p.done_host, (int64_t)(it0 + (unsigned long long)p.n_iters), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
 }
 
-// The gate wait of a pre-staging launch as its own one-wave kernel in front of the copy (same stream): ONE wave polls
-// the host's fill counter, not one per workgroup of the copy.  Measured with the wait inside the copy kernel: the
-// bs=1024 step went 145 -> 163 us -- its ~100 workgroups sat on ~100 CUs for as long as the host took to draw a
-// 32-iteration piece (1.6 ms), and a CU whose registers are committed to two 512-thread GEMM workgroups cannot take
-// the second one while a waiting workgroup holds its share.
+// The fill gate of a stage-in (gm_stage_in_gated): ONE wave, its own launch in front of the copy on the same stream,
+// polls the host's fill counter -- one word of pinned host memory.  Polled from every workgroup of the copy it cost a
+// serialized PCIe read per workgroup: ~1 us per iteration staged (tools/piece_cost_probe.py, round 5: a graph launch of
+// k iterations 25 + 68.7 k us with the poll inside the copy, 22 + 67.5 k us with this kernel); and workgroups that
+// wait inside the copy sit on CUs for as long as the host takes to draw (round 4: bs=1024 step 145 -> 163 us).
 __global__ __launch_bounds__(64) void stage_gate_wait_kernel(const int64_t* gate, gm_slot it_slot, int n_iters,
                                                              uint64_t timeout) {
     if (threadIdx.x != 0) return;
@@ -83,8 +52,7 @@ __global__ __launch_bounds__(64) void stage_gate_wait_kernel(const int64_t* gate
 
 static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                          const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish = nullptr,
-                         int max_blocks = 256, unsigned long long* range = nullptr, unsigned int* arrive = nullptr,
-                         int mark = 0) {
+                         int max_blocks = 256) {
     GM_CHECK_ARG(segs && n_segs > 0 && n_segs <= GM_STAGE_MAX_SEGS && n_iters > 0);
     StageP p{};
     int64_t most = 0;
@@ -100,18 +68,13 @@ static int stage_in_impl(void* stream, const gm_stage_seg* segs, int n_segs, gm_
         if (segs[i].bytes_per_iter > most) most = segs[i].bytes_per_iter;
     }
     p.n_segs = n_segs; p.slot = slot; p.n_iters = n_iters;
-    p.gate = gate; p.it_slot = it_slot; p.publish = publish;
-    p.range = range; p.arrive = arrive; p.mark = mark;
-    p.timeout = (uint64_t)(timeout_s * 1e8);          // wall_clock64(): 100 MHz
+    p.it_slot = it_slot; p.publish = publish;
     int64_t blocks = (most * n_iters / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > max_blocks) blocks = max_blocks;
-    if (mark && gate) {                                   // pre-staging: one wave waits, then the copy runs ungated
+    if (gate)                                             // wall_clock64(): 100 MHz
         hipLaunchKernelGGL(stage_gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gate, it_slot, n_iters,
-                           p.timeout);
-        p.done_host = const_cast<int64_t*>(gate) + 3;
-        p.gate = nullptr;
-    }
+                           (uint64_t)(timeout_s * 1e8));
     hipLaunchKernelGGL(stage_in_kernel, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0,
                        (hipStream_t)stream, p);
     GM_LAUNCH_RET();
@@ -127,15 +90,6 @@ extern "C" int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_s
     GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0 && max_blocks >= 1);
     return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s, publish,
                          max_blocks > 256 ? 256 : max_blocks);
-}
-
-extern "C" int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
-                                     const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish,
-                                     int max_blocks, uint64_t* range, unsigned int* arrive, int mark) {
-    GM_CHECK_ARG(gate && timeout_s > 0.0 && timeout_s < 3600.0 && max_blocks >= 1 && range && (mark == 0 || mark == 1));
-    GM_CHECK_ARG(!mark || arrive);
-    return stage_in_impl(stream, segs, n_segs, slot, n_iters, gate, it_slot, timeout_s, publish,
-                         max_blocks > 256 ? 256 : max_blocks, reinterpret_cast<unsigned long long*>(range), arrive, mark);
 }
 
 // Device-side address of pinned host memory (hipHostMalloc / torch pin_memory()).

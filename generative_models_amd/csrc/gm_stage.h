@@ -11,27 +11,11 @@ struct StageP {
     int n_segs;
     gm_slot slot;
     int n_iters;
-    // fill gate (gm_stage_in_gated): the graph may be launched BEFORE the host has finished writing
-    // its iterations' ring slots; every workgroup waits until *gate (pinned host memory, advanced by
-    // the host after each sub-chunk of draws) covers them.  Bounded: after `timeout` ticks of the
-    // 100 MHz wall clock the kernel raises gate[1] and copies what is there (the host checks it).
-    const int64_t* gate;
+    // (fill gate, gm_stage_in_gated: a one-wave launch in front of this one waits for the host's draws -- stage_gate_wait)
     gm_slot it_slot;
-    uint64_t timeout;
     int64_t* publish;       // optional: workgroup (0,0) stores the absolute iteration of it_slot here (a
                             // stable base for a second stage-in that runs concurrently with iterations
                             // that advance the step counter)
-    // pre-staging (gm_stage_in_prestaged): *range = (lo << 32) | hi, the iterations [lo, hi) an EARLIER launch on
-    // another stream has already brought into the device rings.  mark == 0: this launch returns at once when its
-    // own iterations are inside the range; mark == 1: this launch is such an earlier one -- its last workgroup to
-    // finish (arrive) extends the range (or restarts it at its own iterations when they do not continue it).
-    unsigned long long* range;
-    unsigned int* arrive;
-    int mark;
-    // mark == 1: gate[3] (pinned host memory) <- it + n_iters once the copy is complete: the host may refill the pinned
-    // slots these iterations were read from only after that (it reads the word for free; a completion EVENT per
-    // pre-stage cost 1 - 2 us per step over 20 steps, round 5 call I)
-    int64_t* done_host;
 };
 
 // thread t of `stride` copies its share of iterations [first, first + n_iters) of one segment

@@ -20,7 +20,6 @@ step, D gradients during the G step); every observable -- parameters, loss lists
 position -- matches the reference."""
 import math
 
-import collections
 
 import numpy as np
 import torch
@@ -463,13 +462,9 @@ class GANEngine:
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
         self.gated = os.environ.get("GM_GATED", "1") != "0"
-        # pre-staging (gm_stage_in_prestaged): the host issues every piece's stage-in on a side stream as soon as its
-        # draws are submitted; the graph's own stage-in then finds its iterations inside _pre_range and returns
-        self.prestage = os.environ.get("GM_PRESTAGE", "1") != "0"
-        self._pre_range = torch.zeros(1, dtype=torch.int64, device=device)
-        self._pre_arrive = torch.zeros(1, dtype=torch.int32, device=device)
-        self._pre_stream, self._pre_event, self._pre_dirty = None, None, False
-        self._pre_issued = collections.deque()           # (first, end) of the pre-stages issued, oldest first
+        # (rounds 4 - 5 also issued every piece's stage-in on a side stream ahead of its graph: with the gate wait as its
+        # own one-wave kernel in front of an ungated copy the in-graph stage-in is the faster form everywhere -- a launch
+        # of k iterations 22 + 67.5 k us against 31 + 67.5 k us, profiles/r05_experiments.md section 10 -- removed)
         if os.environ.get("GM_RAMP"):
             self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
         if os.environ.get("GM_FIRST_PIECE"):
@@ -1206,7 +1201,6 @@ class GANEngine:
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
-    PRE_BLOCKS = 32     # workgroups per segment of a pre-staging launch (it runs beside the iteration kernels)
     RAMP = (1, 1, 2, 4, 8, 16)   # sub-chunk sizes of the first fills of a cold run
     FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
     GATE_TIMEOUT_S = 20.0
@@ -1289,8 +1283,7 @@ class GANEngine:
             # fill gate (gm_stage_in_gated): [0] = iterations written into the host rings since
             # configure(), [1] = raised by a stage-in kernel whose wait timed out.  Allocated once per
             # engine: captured graphs hold its address.
-            # [3] = iterations the side stream's pre-stages have finished copying (gm_stage_in_prestaged, mark = 1)
-            self._gate = torch.zeros(4, dtype=torch.int64).pin_memory()
+            self._gate = torch.zeros(2, dtype=torch.int64).pin_memory()
             self._gate_np = self._gate.numpy()
             gp = ctypes.c_void_p()
             _lib.call("gm_host_device_ptr", self._gate.data_ptr(), ctypes.byref(gp))
@@ -1368,59 +1361,11 @@ class GANEngine:
         """Stage-in of iterations [it, it+k): host ring -> device ring (first launch of a graph)."""
         from . import _lib
         ring_slot, it_slot = self._slot(it, 1, 0, self.R, 1), self._slot(it, 1, 0, 0, 1)
-        if self.gated and self._prestaging():
-            _lib.call("gm_stage_in_prestaged", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
-                      it_slot, self.GATE_TIMEOUT_S, None, max_blocks, self._pre_range.data_ptr(), None, 0)
-        elif self.gated:
+        if self.gated:
             _lib.call("gm_stage_in_gated", st, self._segs, len(self._segs), ring_slot, k, self._gate_dev,
                       it_slot, self.GATE_TIMEOUT_S, None, max_blocks)
         else:
             _lib.call("gm_stage_in", st, self._segs, len(self._segs), ring_slot, k)
-
-    def _prestaging(self):
-        """Pieces are staged in ahead of their graphs (single-graph iterations with the fill gate)."""
-        return self.prestage and self.gated and self.use_graph and self._one_graph()
-
-    def _prestage(self, it, k):
-        """Stage-in of iterations [it, it+k) on the side stream, NOW: their draws are submitted (the kernel waits
-        on the fill gate for them), their device ring slots are free (a fill is only submitted once the launch
-        that last read its slots has completed), and the graph that consumes them is still to be enqueued behind
-        whatever the launch stream is running -- the gate wait and the PCIe reads (12 us for one iteration, 99 us
-        for 32) leave the critical path.  Few workgroups: it shares the CUs with the iteration kernels."""
-        from . import _lib
-        if self._pre_stream is None:
-            import ctypes
-            h = ctypes.c_void_p()
-            _lib.call("gm_stream_create", ctypes.byref(h))
-            self._pre_stream, self._pre_event = h, ops.Event()
-        _lib.call("gm_stage_in_prestaged", self._pre_stream, self._segs, len(self._segs),
-                  ops.slot(0, 0, it % self.R, self.R, 1), k, self._gate_dev, ops.slot(0, 0, it, 0, 1),
-                  self.GATE_TIMEOUT_S, None, self.PRE_BLOCKS, self._pre_range.data_ptr(),
-                  self._pre_arrive.data_ptr(), 1)
-        self._pre_dirty = True
-        # The host refills a pinned slot for iteration j + R once the launch that holds j has completed
-        # (_slots_free_now); a pre-stage that is LATE would still be reading it.  Its last workgroup therefore stores
-        # "pre-staged up to" into gate[3] (pinned: the host reads it for free) and _slots_free_now waits for that too.
-        self._pre_issued.append((it, it + k))
-
-    def __del__(self):
-        # the pre-staging side stream is this engine's own (pending work on a destroyed stream still completes)
-        try:
-            if getattr(self, "_pre_stream", None) is not None:
-                from . import _lib
-                _lib.load().gm_stream_destroy(self._pre_stream)
-                self._pre_stream = None
-        except Exception:                             # noqa: BLE001  (interpreter teardown)
-            pass
-
-    def _join_prestage(self):
-        """The launch stream waits for the side stream's last pre-stage (end of run(): whoever synchronizes with the
-        launch stream afterwards has then synchronized with every kernel run() issued)."""
-        if self._pre_dirty:
-            from . import _lib
-            self._pre_event.record(self._pre_stream)
-            _lib.call("gm_stream_wait_event", ops.stream_ptr(), self._pre_event.h)
-            self._pre_dirty = False
 
     def _draw_info_noise(self, dst):
         """info_gan.py:306-325: [randn(B,z) | one_hot(randint(0,nd,(B,))) | randn(B,nc)].  The
@@ -1562,8 +1507,6 @@ class GANEngine:
         if self._gate is not None:
             torch.cuda.synchronize(self.device)      # no stage-in of an earlier run may still be waiting
             self._gate_np[:] = 0
-        self._pre_range.zero_(); self._pre_arrive.zero_()    # iterations restart at 0: nothing is pre-staged
-        self._pre_issued.clear()                              # (everything on the device has been synchronized above)
         torch.cuda.synchronize(self.device)
         import os
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
@@ -1708,7 +1651,7 @@ class GANEngine:
         if self._one_graph():
             # graphs of graph_iters, ..., 4, 2, 1 iterations (the device counter advances inside every
             # iteration): any run length is a handful of launches.  Each starts with the stage-in of its own
-            # iterations (round 4: normally a check that the side stream's pre-stage has been there).  Two forms
+            # iterations (a one-wave wait on the fill gate + the copy: gm_stage_in_gated).  Two forms
             # that were measured and removed in round 4's clean-up: the iteration as a multi-stream DAG inside the
             # graph (-35 %, profiles/r01_experiments.md) and the stage-in's tail on a forked branch of a long graph
             # (72.4 -> 81.7 us per iteration, r02) -- any parallel branch leaves the runtime's linear-chain path.
@@ -1786,18 +1729,6 @@ class GANEngine:
         need = c0 + n - self.R
         if need <= 0:
             return True
-        # side-stream pre-stages that read the host slots of iterations < need must be through as well (oldest first;
-        # they complete in order, each leaving "pre-staged up to" in gate[3])
-        while self._pre_issued and self._pre_issued[0][0] < need:
-            if self._gate_np[3] < self._pre_issued[0][1]:
-                if not wait:
-                    return False
-                import time
-                t0 = time.perf_counter()
-                while self._gate_np[3] < self._pre_issued[0][1]:
-                    if time.perf_counter() - t0 > self.GATE_TIMEOUT_S:
-                        raise GMError("a pre-stage of iterations [%d, %d) did not complete" % self._pre_issued[0])
-            self._pre_issued.popleft()
         for it_end, e in self._launched:
             if it_end >= need:
                 if not e.query():
@@ -1972,8 +1903,6 @@ class GANEngine:
                     self._copy_U(it + k)
                 if trace is not None:
                     trace.append(("got", it, time.perf_counter()))
-                if self._prestaging():
-                    self._prestage(it, k)
                 self._launch(it, k)
                 if trace is not None:
                     trace.append(("graph", it, time.perf_counter()))
@@ -1992,7 +1921,6 @@ class GANEngine:
                 if trace is not None:
                     trace.append(("launched", it + k, time.perf_counter()))
                 it += k
-            self._join_prestage()
             self._reap(upto=end)                      # a failed draw surfaces here, not as a GPU time-out
             self._pump(limit)
             self._reap()
@@ -2028,11 +1956,46 @@ class GANEngine:
         self.use_graph, self.g_off = saved_graph, saved_off
         self._standalone_G = False
 
-    def losses(self, it0, it1):
-        """Per-iteration (G loss, mean D loss over D_steps) like ns_gan.py:142-154."""
+    def mark(self):
+        """An event behind everything run() has enqueued so far: losses(after=mark) waits for THAT point only, so a
+        caller may enqueue the next epoch before it reads the previous epoch's losses (trainers._train)."""
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def _read_back(self, tensors, after):
+        """Device loss slices -> numpy, on a side stream behind `after` (the launch stream is not synchronised: whatever
+        was enqueued after the mark keeps running)."""
+        if getattr(self, "_rb_stream", None) is None:
+            self._rb_stream = torch.cuda.Stream(device=self.device)
+            self._rb_event = torch.cuda.Event()
+            self._rb_pinned = {}
+        out = []
+        with torch.cuda.stream(self._rb_stream):
+            self._rb_stream.wait_event(after)
+            for i, t in enumerate(tensors):
+                buf = self._rb_pinned.get(i)
+                if buf is None or buf.numel() < t.numel():
+                    buf = self._rb_pinned[i] = torch.empty(max(t.numel(), 1024), dtype=t.dtype).pin_memory()
+                buf[:t.numel()].copy_(t.reshape(-1), non_blocking=True)
+                out.append((buf, t.numel()))
+            self._rb_event.record(self._rb_stream)
+        self._rb_event.synchronize()
+        return [b[:n].numpy().copy() for b, n in out]
+
+    def losses(self, it0, it1, after=None):
+        """Per-iteration (G loss, mean D loss over D_steps) like ns_gan.py:142-154.  after: an event from mark() --
+        wait for that point instead of synchronising the launch stream (one GPU only)."""
         d = self.D_steps
         lg_t = self.lossG[self.g_off + it0:self.g_off + it1]
         ld_t = self.lossD[it0 * d:it1 * d]
+        if after is not None and self.world == 1:
+            lg, ld = self._read_back([lg_t, ld_t], after)
+            ld = ld.reshape(-1, d)
+            self._check_gate()
+            G = lg.astype(np.float64).tolist()
+            D = ld.astype(np.float64).mean(axis=1).tolist() if d > 1 else ld.astype(np.float64)[:, 0].tolist()
+            return G, D
         if self.world > 1:       # per-rank partial means (1/B_global scaling) -> global means
             import torch.distributed as dist
             from . import dp
@@ -2052,8 +2015,10 @@ class GANEngine:
         D = ld.astype(np.float64).mean(axis=1).tolist() if d > 1 else ld.astype(np.float64)[:, 0].tolist()
         return G, D
 
-    def mi_losses(self, it0, it1):
+    def mi_losses(self, it0, it1, after=None):
         t = self.lossMI[it0:it1]
+        if after is not None and self.world == 1:
+            return [float(x) for x in self._read_back([t], after)[0]]
         if self.world > 1:                           # per-rank partial means -> global
             import torch.distributed as dist
             from . import dp

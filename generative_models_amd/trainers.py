@@ -366,18 +366,45 @@ class GANTrainer:
                           g_init=G_init, resume=self.__dict__.pop("_resume_optim", None))
             if G_init > 0:
                 eng.g_init_steps(G_init)
+            # One GPU, no viz: epoch e+1 is ENQUEUED before epoch e's losses are read back (on a side stream, behind an
+            # event at epoch e's end), so the GPU does not idle through the read-back, the progress line and the next
+            # run()'s start -- ~0.5 ms per epoch, 3.5 % of a 196-step NSGAN epoch at bs=256.  Same values, same order of
+            # the progress lines; nothing between the reference's epochs reads the model (ns_gan.py:158-170 with
+            # viz=False).  GM_PIPELINE_EPOCHS=0: read back before the next epoch is enqueued.
+            import os
+            pipelined = (not self.viz) and eng.world == 1 and os.environ.get("GM_PIPELINE_EPOCHS", "1") != "0"
+
+            def finish(epoch, it0, mark):
+                G_losses, D_losses = eng.losses(it0, it0 + epoch_steps, after=mark)     # one sync per epoch
+                if self.variant == "info":
+                    self.MIlosses.extend(eng.mi_losses(it0, it0 + epoch_steps, after=mark))
+                self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+                self._viz_epoch(epoch)
+
+            pending = None
             for epoch in range(1, num_epochs + 1):
                 self.model.train()
                 it0 = (epoch - 1) * epoch_steps
                 # viz draws from the global generator at every epoch end (ns_gan.py:168,234): the host
                 # replay must then not run ahead into the next epoch's draws
-                eng.run(epoch_steps, it_start=it0,
-                        horizon=None if self.viz else num_epochs * epoch_steps)
-                G_losses, D_losses = eng.losses(it0, it0 + epoch_steps)     # one sync per epoch
-                if self.variant == "info":
-                    self.MIlosses.extend(eng.mi_losses(it0, it0 + epoch_steps))
-                self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
-                self._viz_epoch(epoch)
+                try:
+                    eng.run(epoch_steps, it_start=it0,
+                            horizon=None if self.viz else num_epochs * epoch_steps)
+                except BaseException:
+                    if pending is not None:                # the finished epoch's losses are recorded before the error surfaces
+                        try:
+                            finish(*pending)
+                        except Exception:                  # noqa: BLE001
+                            pass
+                    raise
+                mark = eng.mark() if pipelined else None
+                if pending is not None:
+                    finish(*pending)
+                    pending = None
+                if pipelined and epoch < num_epochs:
+                    pending = (epoch, it0, mark)
+                else:
+                    finish(epoch, it0, mark)
             return
         # GENERAL path: user-overridden hooks, same loop as the reference
         if self.__dict__.get("_resume_optim") is not None:

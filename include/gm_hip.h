@@ -514,9 +514,11 @@ int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot
 /* The same with a FILL GATE: the launch may be enqueued before the host has finished writing the
  * iterations' slots (ns_gan.py:218-226 draws them on the host one step at a time; here the host
  * writes a sub-chunk and then advances gate[0] = number of iterations written since configure).
- * Every workgroup waits (system-scope acquire loads of pinned host memory) until
- * gate[0] >= it + n_iters, it = index of `it_slot` (the absolute iteration); after timeout_s seconds
- * it raises gate[1] = 1 and proceeds -- the host must check gate[1] before trusting results.
+ * ONE wave -- its own one-wave launch in front of the copy, same stream -- waits (system-scope loads of pinned
+ * host memory) until gate[0] >= it + n_iters, it = index of `it_slot` (the absolute iteration); after
+ * timeout_s seconds it raises gate[1] = 1 and the copy proceeds -- the host must check gate[1] before
+ * trusting results.  (Polled from every workgroup of the copy the gate cost a serialized PCIe read per
+ * workgroup, ~1 us per iteration staged: round 5.)
  * gate: device-visible address (gm_host_device_ptr) of two int64 in pinned host memory.
  * publish (optional, device memory): workgroup (0,0) stores `it` there -- a second stage-in that runs
  * on a forked branch of the graph, concurrently with iterations that advance the step counter, resolves
@@ -525,21 +527,6 @@ int gm_stage_in(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot
 int gm_stage_in_gated(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
                       const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish,
                       int max_blocks);
-/* gm_stage_in_gated with PRE-STAGING (round 4).  *range (device memory, zero-initialised) = (lo << 32) | hi: the
- * iterations [lo, hi) that launches with mark = 1 have already brought into the device rings.
- *   mark = 1: issued by the host on a SIDE stream as soon as the iterations' draws are submitted, ahead of the graph
- *             that consumes them -- its gate wait and its PCIe reads overlap the kernels of the graph in front;
- *             it_slot must name the absolute iteration without the step counter (it belongs to the other stream);
- *             the last workgroup to finish (arrive: one zeroed unsigned int) extends the range, or restarts it at
- *             [it, it + n_iters) when they do not continue it, and then stores it + n_iters to gate[3] (the gate is
- *             FOUR int64 for these launches: [0] filled, [1] time-out flag, [2] unused, [3] pre-staged up to) -- the
- *             host may overwrite the pinned slots of these iterations only after that;
- *   mark = 0: the in-graph launch -- returns at once when [it, it + n_iters) lies inside the range and is
- *             gm_stage_in_gated otherwise (a pre-stage that is late only costs the copy being made twice, with
- *             the same bytes). */
-int gm_stage_in_prestaged(void* stream, const gm_stage_seg* segs, int n_segs, gm_slot slot, int n_iters,
-                          const int64_t* gate, gm_slot it_slot, double timeout_s, int64_t* publish, int max_blocks,
-                          uint64_t* range, unsigned int* arrive, int mark);
 /* Device-side address of a pinned host allocation (hipHostGetDevicePointer). */
 int gm_host_device_ptr(void* host_ptr, void** dev_ptr_out);
 

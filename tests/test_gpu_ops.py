@@ -946,61 +946,6 @@ def test_stage_in_gate_waits_for_the_host_and_times_out_without_hanging():
     assert float(x.sum()) == 8.0
 
 
-def test_stage_in_prestaged_skips_what_a_side_stream_brought_in_and_copies_the_rest():
-    """gm_stage_in_prestaged: a mark = 1 launch on a side stream copies its iterations and records them in the range
-    word (extending a range it continues, restarting one it does not); the in-graph form (mark = 0) returns without
-    touching the rings when its iterations are inside the range and is the gated copy otherwise.  Whether the in-graph
-    launch copied is observed by changing the HOST ring between the two launches."""
-    import ctypes
-    from generative_models_amd import _lib
-    R, n = 16, 1024
-    host = torch.zeros(R, n).pin_memory()
-    dev = torch.full((R, n), -1.0, device="cuda")
-    gate = torch.zeros(2, dtype=torch.int64).pin_memory()
-    hp, gp, side = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-    _lib.call("gm_host_device_ptr", host.data_ptr(), ctypes.byref(hp))
-    _lib.call("gm_host_device_ptr", gate.data_ptr(), ctypes.byref(gp))
-    _lib.call("gm_stream_create", ctypes.byref(side))
-    segs = (_lib.StageSeg * 1)(_lib.StageSeg(hp.value, dev.data_ptr(), n * 4))
-    rng = torch.zeros(1, dtype=torch.int64, device="cuda")
-    arrive = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
-    gate.numpy()[0] = 1 << 40                           # every draw "written"
-
-    def pre(it, k):
-        _lib.call("gm_stage_in_prestaged", side, segs, 1, ops.slot(0, 0, it % R, R, 1), k, gp.value,
-                  ops.slot(0, 0, it, 0, 1), 5.0, None, 4, rng.data_ptr(), arrive.data_ptr(), 1)
-        torch.cuda.synchronize()                         # (device-wide: the side stream too)
-
-    def in_graph(it, k):                                 # slots through the device step counter, as in a graph
-        ctr.fill_(it)
-        _lib.call("gm_stage_in_prestaged", ops.stream_ptr(), segs, 1, ops.slot(ctr.data_ptr(), 1, 0, R, 1), k, gp.value,
-                  ops.slot(ctr.data_ptr(), 1, 0, 0, 1), 5.0, None, 256, rng.data_ptr(), None, 0)
-        torch.cuda.synchronize()
-
-    unpack = lambda: (int(rng) >> 32, int(rng) & 0xffffffff)
-    host[:] = 1.0
-    pre(0, 2)
-    assert unpack() == (0, 2) and int(arrive) == 0 and bool((dev[:2] == 1).all()) and bool((dev[2:] == -1).all())
-    pre(2, 4)                                            # continues the range
-    assert unpack() == (0, 6) and bool((dev[:6] == 1).all())
-    host[:] = 2.0
-    in_graph(2, 4)                                       # inside the range: no copy
-    assert bool((dev[:6] == 1).all())
-    in_graph(4, 4)                                       # [4, 8) is not: the gated copy
-    assert bool((dev[4:8] == 2).all()) and bool((dev[:4] == 1).all()) and unpack() == (0, 6)
-    pre(12, 2)                                           # does not continue [0, 6): the range restarts
-    assert unpack() == (12, 14) and bool((dev[12:14] == 2).all())
-    host[:] = 3.0
-    in_graph(0, 2)                                       # no longer covered
-    assert bool((dev[:2] == 3).all())
-    in_graph(12, 2)
-    assert bool((dev[12:14] == 2).all())
-    pre(14, 2); pre(16, 4)                               # across the end of the ring: slots 14, 15 then 0..3
-    assert unpack() == (12, 20) and bool((dev[14:16] == 3).all()) and bool((dev[:4] == 3).all())
-    _lib.call("gm_stream_destroy", side)
-
-
 @pytest.mark.parametrize("B,Bl,w,dtype", [(64, 16, 20, torch.float32), (24, 8, 1, torch.int64), (12, 3, 5, torch.float32)])
 def test_stage_in_strided_pieces_copy_only_the_ranks_rows(B, Bl, w, dtype):
     """gm_stage_seg with blocks / block strides: a data-parallel rank stages ITS rows of every [B, w] draw

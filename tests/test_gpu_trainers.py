@@ -254,6 +254,30 @@ def test_summation_order_switches_agree_within_rounding(variant, env, monkeypatc
         assert float((x - y).abs().mean()) <= 2e-5, (env, k)
 
 
+@pytest.mark.parametrize("variant,kw", [("ns", dict(num_epochs=4)), ("w", dict(num_epochs=3, D_steps=2)),
+                                        ("info", dict(num_epochs=3)), ("fisher", dict(num_epochs=3))])
+def test_epochs_enqueued_ahead_of_the_loss_read_back_change_nothing(variant, kw, monkeypatch, capsys):
+    """trainers._train enqueues epoch e+1 before it reads epoch e's losses back (side stream, behind an event at the
+    epoch's end): loss histories, progress lines, parameters and the generator state must equal the run that reads
+    back before enqueueing (GM_PIPELINE_EPOCHS=0)."""
+    def go():
+        tr, model = build_product(variant, SMALL, 16)
+        tr.train(**kw)
+        torch.cuda.synchronize()
+        return tr, model, torch.get_rng_state(), capsys.readouterr().out
+    a = go()
+    monkeypatch.setenv("GM_PIPELINE_EPOCHS", "0")
+    b = go()
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses and a[0].num_epochs == b[0].num_epochs
+    assert len(a[0].Glosses) == kw["num_epochs"] * int(np.ceil(10 / kw.get("D_steps", 1)))
+    if variant == "info":
+        assert a[0].MIlosses == b[0].MIlosses
+    assert a[3] == b[3] and a[3].count("Epoch[") == kw["num_epochs"]
+    assert torch.equal(a[2], b[2])
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
+
+
 def test_run_to_run_determinism():
     a = run_product("ls", SMALL, 16, dict(num_epochs=1))
     b = run_product("ls", SMALL, 16, dict(num_epochs=1))
