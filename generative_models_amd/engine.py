@@ -456,9 +456,10 @@ class GANEngine:
         # layer's forward epilogue, scores / losses / dS rebuilt in the consumers' prologues, dH formed
         # in registers (csrc/gm_head.h).  "2": also where the forward would take the LDS macro-tile kernel
         self.fold_env = os.environ.get("GM_FOLD_HEAD", "1")
-        # iterations per graph (largest captured size; powers of two below it are captured too).  A
-        # graph boundary costs ~14 us of idle GPU plus the ~9 us stage-in of its draws (measured,
-        # profiles/r02_experiments.md): 32 iterations per graph amortise that to < 1 us / iteration
+        # iterations per graph (largest captured size; powers of two below it are captured too).  A graph launch costs
+        # 22 us of GPU time beyond its iterations (hand-off between graphs + the stage-in of its draws:
+        # tools/piece_cost_probe.py, profiles/r05_experiments.md section 10).  GM_GRAPH_ITERS fixes it; otherwise
+        # configure() picks 128 / 64 / 32 with the ring the draws of this variant afford (_ring_and_graph_size)
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
         self.gated = os.environ.get("GM_GATED", "1") != "0"
@@ -1205,13 +1206,46 @@ class GANEngine:
     FIRST_PIECE = 2     # iterations in the first graph of a cold run (see _plan)
     GATE_TIMEOUT_S = 20.0
 
+    def _ring_and_graph_size(self, D_steps):
+        """(ring slots, iterations of the largest graph).  Longer graphs amortise the 22 us a graph launch costs beyond
+        its iterations (NSGAN bs=256, 4096 steps x 3, same-call alternation: 32 per graph / 128 slots 68.0 us per step,
+        64 / 256 67.5 - 67.8, 128 / 512 67.4 - 67.6; profiles/r05_experiments.md section 10); the ring holds four of
+        the largest graphs so that the host draws, the copy and the GPU never wait for one another's slots.  But a
+        graph waits for ALL its iterations' draws, and the host draws only as fast as the batch is small: at bs=1024
+        (172 KB of draws per iteration, 60 us of host time against 143 us on the GPU) 128-iteration graphs made a
+        cold 600-step run 2 % SLOWER (147 against 144.4 us per step).  So: 128 per graph up to 64 KB of draws per
+        iteration (the GLOBAL batch's indices and noise; NSGAN bs=256: 42 KB), 64 up to 128 KB, else 32.
+        GM_RING / GM_GRAPH_ITERS fix either.
+        DRAGAN stages 0.8 MB per critic step at B = 256 and keeps <= 64 slots (16 slots, round 1's choice, serialised
+        host fills and GPU graphs: a 16-iteration graph had to FINISH before its slots could be refilled)."""
+        import os
+        B, Z, d = self.B, self.Z, D_steps
+        per_it = d * B * (8 + 4 * Z) + B * 4 * Z                      # indices + zD per critic step, zG
+        if self.variant == "wgp":
+            per_it += d * B * 4
+        if self.variant == "info":
+            per_it += B * 4 * Z
+        if self.variant == "dra":
+            per_it += d * B * 4 * (1 + self.I)
+        env_ring, env_gi = os.environ.get("GM_RING"), os.environ.get("GM_GRAPH_ITERS")
+        if env_ring:
+            ring = int(env_ring)
+        else:
+            ring = 512 if per_it <= (64 << 10) else 256 if per_it <= (128 << 10) else GAN_RING
+        R = max(1, min(ring, 64) if self.variant == "dra" else ring)
+        gi = max(1, int(env_gi)) if env_gi else max(32, min(128, R // 4))
+        return R, gi
+
     def _alloc_rings(self, R):
         """Device rings of R iterations and PINNED host rings of the same layout.  The host replay
         writes sub-chunks straight into the host rings; the first kernel of every graph
         (gm_stage_in) pulls its own iterations' slots into the device rings."""
         d, B, Z, dev = self.D_steps, self.B, self.Z, self.device
         self.R = R
-        self.SUB = max(1, min(self.graph_iters, R))
+        # iterations per fill job: the fill gate advances per JOB, so this is the granularity at which graphs see their
+        # draws arrive -- independent of the graph size (as one 128-iteration job a 4-iteration graph at an epoch's start
+        # waited 1.9 ms for draws it did not need: Trainer.train() 69.5 -> 75.3 us per step)
+        self.SUB = max(1, min(32, self.graph_iters, R))
         self.z_joint = self._batch_gen()
         # (leading dims per ring, pieces per iteration, trailing dims): every ring is a sequence of
         # [B, *tail] draws, `pieces` of them per iteration
@@ -1512,15 +1546,15 @@ class GANEngine:
         self._trace = [] if os.environ.get("GM_TRACE_RUN") == "1" else None
         self._event_pool = []
         import os
-        ring = int(os.environ.get("GM_RING", GAN_RING))
-        # (not shrunk to short runs: a later, longer train() on this engine then keeps rings AND graphs)
-        # DRAGAN stages a B x 784 uniform tensor per critic step (0.8 MB at B = 256): 64 slots = 51 MB of
-        # pinned + device ring.  (16 slots, round 1's choice, serialised host fills and GPU graphs: a
-        # 16-iteration graph had to FINISH before its slots could be refilled -- 236 us per iteration.)
-        R = max(1, min(ring, 64) if self.variant == "dra" else ring)
-        key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
-               self.fuse_head, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated)
         self.D_steps = D_steps
+        R, self.graph_iters = self._ring_and_graph_size(D_steps)
+        # graphs larger than the run are never launched: not captured either (a later, longer train() recaptures)
+        gmax = 1
+        while gmax * 2 <= min(self.graph_iters, max(1, n_iters)):
+            gmax *= 2
+        self._graph_max = self.graph_iters if self.graph_iters <= n_iters else gmax
+        key = (D_steps, R, self.clip, self.hyper, g_init, self.gp_lambda, self.use_graph,
+               self.fuse_head, self.fuse_adam, self.fold_tick, self._batch_gen(), self.gated, self._graph_max)
         if getattr(self, "_ring_key", None) != (D_steps, R, self._batch_gen()):
             self._alloc_rings(R)
             self._ring_key = (D_steps, R, self._batch_gen())
@@ -1664,11 +1698,11 @@ class GANEngine:
             self.graph = ops.Graph().capture(body(1))
             self.graphs_by_size = [(1, self.graph)]
             k = 2
-            while k <= self.graph_iters:
+            while k <= self._graph_max:
                 self.graphs_by_size.insert(0, (k, ops.Graph().capture(body(k))))
                 k *= 2
-            if self.graphs_by_size[0][0] != self.graph_iters and self.graph_iters > 1:
-                self.graphs_by_size.insert(0, (self.graph_iters, ops.Graph().capture(body(self.graph_iters))))
+            if self.graphs_by_size[0][0] != self._graph_max and self._graph_max > 1:
+                self.graphs_by_size.insert(0, (self._graph_max, ops.Graph().capture(body(self._graph_max))))
             self.seg_graphs = None
         else:
             # data parallel: one hipGraph per segment, RCCL all-reduces launched between them
@@ -1926,9 +1960,13 @@ class GANEngine:
             self._reap()
             self._release_rng()                       # (draws still ahead of `end`: the state stays with them)
             if trace is not None:
-                tev[-1].synchronize()
-                trace.append(("gpu_piece_ends_us", [round(tev[0].elapsed_time(e) * 1e3, 1) for e in tev[1:]],
-                              time.perf_counter()))
+                import os
+                if os.environ.get("GM_TRACE_NOSYNC") == "1":      # the caller evaluates the events once the GPU is through
+                    trace.append(("gpu_piece_events", tev, time.perf_counter()))
+                else:
+                    tev[-1].synchronize()
+                    trace.append(("gpu_piece_ends_us", [round(tev[0].elapsed_time(e) * 1e3, 1) for e in tev[1:]],
+                                  time.perf_counter()))
         except BaseException:
             if self._gate is not None:
                 self._gate_np[0] = 1 << 62            # open every gate: nothing on the GPU waits for draws that will not come
@@ -1971,8 +2009,12 @@ class GANEngine:
             self._rb_event = torch.cuda.Event()
             self._rb_pinned = {}
         out = []
+        # The HOST waits for the mark; only then is anything enqueued on the side stream.  (A stream-side wait on an event
+        # that is an epoch away sat in the second hardware queue as a pending barrier, and while it did EVERY kernel of
+        # the launch stream took ~1 us longer: 128-iteration graphs 8 620 -> 9 670 us, Trainer.train() 68.9 -> 75.7 us
+        # per step -- tools/trainer_pipeline_probe.py, profiles/r05_experiments.md section 10.)
+        after.synchronize()
         with torch.cuda.stream(self._rb_stream):
-            self._rb_stream.wait_event(after)
             for i, t in enumerate(tensors):
                 buf = self._rb_pinned.get(i)
                 if buf is None or buf.numel() < t.numel():

@@ -349,6 +349,26 @@ def test_launch_planner_invariants(R, graph_iters):
         assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
 
 
+@pytest.mark.parametrize("variant,B,Z,d,expect", [("ns", 256, 20, 1, (512, 128)), ("wgp", 256, 20, 1, (512, 128)),
+                                                   ("ns", 512, 20, 1, (256, 64)), ("ns", 1024, 20, 1, (128, 32)),
+                                                   ("wgp", 256, 20, 5, (128, 32)), ("dra", 256, 20, 1, (64, 32)),
+                                                   ("info", 256, 40, 1, (256, 64))])
+def test_ring_and_graph_size_follow_the_bytes_of_draws_per_iteration(variant, B, Z, d, expect, monkeypatch):
+    """GANEngine._ring_and_graph_size: 128 iterations per graph on a 512-slot ring up to 64 KB of host draws per
+    iteration, 64 / 256 up to 128 KB, else 32 / 128; DRAGAN keeps <= 64 slots; GM_RING / GM_GRAPH_ITERS fix either."""
+    class E:
+        pass
+    e = E()
+    e.variant, e.B, e.Z, e.I = variant, B, Z, 784
+    monkeypatch.delenv("GM_RING", raising=False)
+    monkeypatch.delenv("GM_GRAPH_ITERS", raising=False)
+    assert engine.GANEngine._ring_and_graph_size(e, d) == expect
+    monkeypatch.setenv("GM_RING", "96")
+    assert engine.GANEngine._ring_and_graph_size(e, d) == (min(96, 64) if variant == "dra" else 96, 32)
+    monkeypatch.setenv("GM_GRAPH_ITERS", "8")
+    assert engine.GANEngine._ring_and_graph_size(e, d)[1] == 8
+
+
 @pytest.mark.parametrize("record", ["r02_bench_default.json", "r02_bench_steps20_warmup5.json"])
 def test_committed_bench_records_follow_the_contract(record):
     """The bench lines committed under profiles/ carry every key of the driver's contract with the
