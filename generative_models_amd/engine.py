@@ -8,8 +8,8 @@ two `.item()` syncs.  Here, per iteration:
            (csrc/gm_hostrng.cpp: mt19937 + ATen's normal_/uniform_/random_/randint restated bit
            for bit, O(B) randperm prefix for the sampler) on a native worker thread, straight into
            PINNED host rings that mirror the device rings; graphs are enqueued ahead of their draws;
-  device : hipGraphs of 1..32 iterations (each: D_steps critic steps + 1 generator step): a stage-in
-           kernel that waits on the fill gate and pulls its iterations' ring slots over PCIe, then
+  device : hipGraphs of 1..128 iterations (each: D_steps critic steps + 1 generator step): a one-wave wait
+           on the fill gate and a stage-in kernel that pulls the iterations' ring slots over PCIe, then
            MFMA GEMMs with fused bias/activation/activation-gradient epilogues (gather, critic head,
            Adam riding in their launches).  A device counter advanced by the graph itself selects
            the ring slot / Adam-schedule row / loss slot, so replays need no host-side arguments;
@@ -17,15 +17,17 @@ two `.item()` syncs.  Here, per iteration:
 
 Only the wasted work of the reference is skipped (G gradients during the D
 step, D gradients during the G step); every observable -- parameters, loss lists, RNG stream
-position -- matches the reference."""
-import math
+position -- matches the reference.
 
-
+This module: the shared pieces (FlatParams, host RNG replay) and the GAN engine's CORE; what a GAN iteration launches is
+gan_steps.py (mix-ins), BEGAN's overrides began_engine.py, the VAE / AE / BIR-VAE engines vae_engine.py (all re-exported
+here)."""
 import numpy as np
 import torch
 
 from . import ops
 from ._lib import GMError
+from .gan_steps import CriticStep, GeneratorStep, InfoQStep, PenaltySteps
 
 CHUNK = 64          # iterations prefetched per host->device upload (VAE / AE passes)
 GAN_RING = 128      # iterations of draws the GAN engines' host / device rings hold
@@ -381,9 +383,10 @@ class NumpyReplay:
             return False
 
 
-class GANEngine:
+class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
     """Graph-captured D_steps x train_D + train_G iteration for the score-based GAN variants
-    (ns, mm, w, ls, ra, f, fisher, wgp)."""
+    (ns, mm, w, ls, ra, f, fisher, wgp, info, dra; BEGAN: began_engine.BEGANEngine).  This class is the CORE: buffers and
+    switches, rings and host draws, graph capture, run(); what an iteration launches lives in gan_steps.py."""
 
     SUPPORTED = ("ns", "mm", "w", "ls", "ra", "f", "fisher", "wgp", "info", "be", "dra")
 
@@ -720,485 +723,6 @@ class GANEngine:
         self._issue_G_pre(st, it)
         self._allreduce(("G", 0), st, it)
         self._issue_G_post(st, it)
-
-    # ---- pieces of one critic step (composed sequentially, or as parallel graph branches) -----
-    def _gather_rides(self):
-        """The batch gather rides in the grid of the generator's first forward launch."""
-        return self.ride_gather
-
-    def _packed_operand(self):
-        """The critic step reads its real rows as BITS: the gather copies the selected rows of the
-        1-bit resident dataset as words (100 B per MNIST row instead of 3136 B of fp32) and the folded step's two
-        launches -- hidden layer forward, layer-1 weight gradient -- expand them in registers
-        (gm_linear_fwd_headpart_bits, gm_linear_bwd_dw_adam_head_fold_bits).  Bit-identical losses and parameters
-        (tests/test_gpu_trainers.py); GM_PACKED_OPERAND=1 turns it on -- measured neither faster nor slower than the
-        fp32 rows on one MI355X (profiles/r05_experiments.md section 9), so the default stays the path every other
-        variant shares.  Needs the folded step of a separable loss and a batch of whole 32-row tiles."""
-        import os
-        if os.environ.get("GM_PACKED_OPERAND", "0") != "1":
-            return False
-        return isinstance(self.data, ops.PackedData) and self._fold_head() and \
-            self.variant not in ("ra", "fisher") and self.Bl % 32 == 0 and self.I % 4 == 0
-
-    def _xbits(self):
-        """(words, words per row, rows) of the packed real rows, or None."""
-        if not self._packed_operand():
-            return None
-        if getattr(self, "Xbits", None) is None:
-            self.Xbits = torch.zeros(self.Bl, self.data.wpr, dtype=torch.int32, device=self.device)
-        return (self.Xbits, self.data.wpr, self.Bl)
-
-    def _gather_args(self, it, j):
-        Bl, d, R = self.Bl, self.D_steps, self.R
-        r0 = self.ring_r0                         # this rank's rows of the (device) index ring
-        xb = self._xbits()
-        return dict(data=self.data, idx=self.idx_ring.view(-1)[r0:], out=self.X2 if xb is None else xb[0], B=Bl,
-                    idx_slot=self._slot(it, d, j, R * d, self.ring_B))
-
-    def _D_gather(self, st, it, j):
-        if self._gather_rides():
-            return                                  # done by _D_gen's first launch
-        ops.gather_rows(stream=st, **self._gather_args(it, j))
-
-    def _batch_gen(self):
-        """Both generator forwards of an iteration (critic step's G(zD), generator step's G(zG))
-        read the same G parameters: with D_steps == 1 they run as ONE launch pair on 2B rows (the
-        noise ring stores [zD; zG] back to back -- on a data-parallel rank that needs the rank-local
-        device rings, where the rank's zD rows and zG rows of an iteration are adjacent)."""
-        return self.batch_gen_env and self.D_steps == 1 and \
-            (self.world == 1 or self._local_rings())
-
-    def _local_rings(self):
-        """Data parallel: device rings hold only this rank's rows of every draw (see _alloc_rings)."""
-        import os
-        return self.world > 1 and self.variant != "dra" and os.environ.get("GM_LOCAL_RINGS", "1") != "0"
-
-    def _D_gen(self, st, it, j):
-        Bl, d, R = self.Bl, self.D_steps, self.R
-        G1, G2 = self.G1, self.G2
-        zD_slot = self._slot(it, d, j, R * d, self.zD_stride)
-        zbase = self.zD_base[self.ring_r0 * self.Z:].view(-1, self.Z)
-        rows = 2 * Bl if (self._batch_gen() and not self._standalone_G) else Bl
-        if self._gather_rides():
-            ops.linear_fwd_gather(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot,
-                                  stream=st, **self._gather_args(it, j))
-        else:
-            ops.linear_fwd(zbase, G1.W, G1.b, self.HG, "relu", M=rows, x_slot=zD_slot, stream=st)
-        if self._interp_in_gen():
-            # WGAN-GP: x_hat = eps*x + (1-eps)*G(zD) written by this launch's epilogue for its first
-            # Bl rows (the real rows were gathered by the previous launch's rider)
-            r0 = self.ring_r0
-            ops.linear_fwd_interp(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", self.eps_ring.view(-1)[r0:],
-                                  self._slot(it, d, j, R * d, self.ring_B), self.XX[:Bl], self.Xh, Bl, M=rows,
-                                  stream=st)
-        else:
-            ops.linear_fwd(self.HG, G2.W, G2.b, self.XX[Bl:], "sigmoid", M=rows, stream=st)
-
-    def _interp_in_gen(self):
-        import os
-        # (the DAG experiment runs the gather on a side stream, concurrently with this launch)
-        return self.variant == "wgp" and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
-
-    # ---- the critic step behind the generator's forward: three builders, one per launch structure -------------------
-    #   folded     separable losses (+ RaGAN / Fisher on one GPU): hidden layer forward with the head's partial dots,
-    #              then ONE launch for the layer-1 weight gradient + head backward + both Adam steps
-    #   fused head penalty variants (WGAN-GP, DRAGAN) and anything the fold does not take (many-row launches, data
-    #              parallel): head_fwd_loss + a grouped / stacked weight-gradient launch
-    #   unfused    N = 1 GEMV + loss kernel (+ the scalar exchanges of RaGAN / Fisher under data parallelism) + separate
-    #              gradient launches
-    def _D_rest(self, st, it, j):
-        if self._fold_head():
-            return self._critic_folded(st, it, j)
-        if self.fuse_head and self.variant not in ("ra", "fisher"):
-            return self._critic_fused_head(st, it, j)
-        return self._critic_unfused(st, it, j)
-
-    def _critic_folded(self, st, it, j):
-        Bl, d = self.Bl, self.D_steps
-        D1, D2 = self.D1, self.D2
-        X2, Hd, S2, dS = self.X2, self.Hd, self.S2, self.dS
-        loss_slot = self._slot(it, d, j, 0, 1)
-        # 2 launches instead of 3: hidden layer forward (+ partial dots of the head), then the
-        # layer-1 weight gradient (+Adam) with the head's backward workgroups riding -- scores,
-        # row losses and dS are rebuilt from the partial dots in that launch's prologue
-        xb = self._xbits()                                # real rows as bits: X2[:Bl] is never written or read
-        ops.linear_fwd_headpart(X2, D1.W, D1.b, Hd, "relu", D2, self.fold, M=2 * Bl, stream=st, xbits=xb)
-        adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-        fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss,
-                            pen=self.aux if self.variant == "fisher" else None)   # Fisher: lambda lives in aux
-        head = dict(H=Hd, lin=D2, loss_out=self.lossD, loss_slot=loss_slot, inv_b=self.inv_b, B=Bl,
-                    adam=adam)
-        ops.linear_bwd_dw_adam_head_fold(Hd, X2, D1, adam, head, fa, M=2 * Bl, stream=st, xbits=xb)
-        if self.variant == "fisher":
-            from . import ops_fused as of
-            of.fisher_commit(self.aux, stream=st)        # lambda <- its successor (fisher_gan.py:155-156)
-
-    def _critic_forward(self, st, it, j):
-        """D's hidden layer on [x ; G(z)] (WGAN-GP / DRAGAN: on [x_hat ; x ; G(z)] as one 3B-row launch) and the
-        penalty's forward pieces; returns (aux, hyper) of the loss."""
-        Bl = self.Bl
-        D1 = self.D1
-        merged = self.variant in ("wgp", "dra") and self.merge_fwd3
-        if merged:
-            if self.variant == "wgp":
-                self._gp_prepare(st, it, j)
-            else:
-                self._dra_prepare(st, it, j)
-            ops.linear_fwd(self.XX4[:3 * Bl], D1.W, D1.b, self.HH3, "relu", M=3 * Bl, stream=st)
-        else:
-            ops.linear_fwd(self.X2, D1.W, D1.b, self.Hd, "relu", M=2 * Bl, stream=st)
-        aux, hyper = (self.aux if self.variant == "fisher" else None), self.hyper
-        if self.variant == "wgp":
-            self._issue_gp_forward(st, it, j, fwd_done=merged)
-            aux, hyper = self.pen, (0.0,) * 7 + (self.gp_lambda,)
-        if self.variant == "dra":
-            self._issue_dra_forward(st, it, j, fwd_done=merged)
-            aux, hyper = self.pen, tuple(self.hyper) + (0.0,) * (7 - len(self.hyper)) + (self.gp_lambda,)
-        return aux, hyper
-
-    def _critic_dw1(self, st, it, j):
-        """Layer-1 weight gradient on its own (+ Adam in its epilogue on one GPU), then what is left of the penalty."""
-        Bl, d = self.Bl, self.D_steps
-        if self._adam_in_epilogue("D"):
-            ops.linear_bwd_dw_adam(self.dHd, self.X2, self.D1, self._adam_args("D", self._slot(it, d, j, 0, 1)),
-                                   M=2 * Bl, stream=st)
-        else:
-            ops.linear_bwd_dw(self.dHd, self.X2, self.D1.gW, self.D1.gb, M=2 * Bl, stream=st)
-
-    def _critic_penalty_backward(self, st):
-        if self.variant == "wgp" and not self._wgp_stacked():
-            self._issue_gp_backward(st)
-        if self.variant == "dra" and not self._dra_stacked():
-            self._issue_dra_backward(st)
-
-    def _critic_fused_head(self, st, it, j):
-        from . import ops_fused as of
-        Bl, d = self.Bl, self.D_steps
-        D1, D2 = self.D1, self.D2
-        X2, Hd, S2, dS, dHd = self.X2, self.Hd, self.S2, self.dS, self.dHd
-        loss_slot = self._slot(it, d, j, 0, 1)
-        aux, hyper = self._critic_forward(st, it, j)
-        of.head_fwd_loss(self.loss_key, False, Hd, D2.W, D2.b, self.out_act, Bl, hyper,
-                         self.inv_b, aux, S2, dS, self.rowloss, dH=dHd, stream=st)
-        adam = self._adam_args("D", self._slot(it, d, j, 0, 1)) if self._adam_in_epilogue("D") else None
-        if not self.group_head:
-            of.head_bwd(Hd, dS, D2.W, self.rowloss, None, D2.gW, D2.gb, self.lossD, loss_slot,
-                        self.inv_b, False, Bl, lin=D2, adam=adam, stream=st)
-            self._critic_dw1(st, it, j)
-            self._critic_penalty_backward(st)
-            return
-        # head backward + first-layer weight gradient (+ both Adam steps when they are
-        # fused: one GPU, nothing accumulates into these gradients later): ONE launch
-        head = dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossD,
-                    loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, adam=adam)
-        if self._wgp_stacked():
-            # dW1 = [u ; dH]^T [gamma ; x ; G(z)] over 3B rows (the penalty rows do not reach
-            # db1), gw2 += the penalty's share (computed by _issue_gp_forward)
-            if self.pen_in_head:
-                head["pen"] = dict(s=self.Sh, h=self.Hh, t=self.T)    # summed by the head workgroups
-            else:
-                head["gw2_add"] = self.gw2_pen
-            ops.linear_bwd_dw_adam_head(self.DU, self.XX4, D1, adam, head, M=3 * Bl, ones_from=Bl,
-                                        stream=st)
-        elif self._dra_stacked():
-            # the penalty's second backward first (it reads W1 and w2, which this launch steps): t = dv W1^T,
-            # then dA1 and the sigma'' path's share of (gw2, gb2) on their own; then ONE launch:
-            # dW1 over 4B rows (+ db1 from the last 3B), the head's backward with both shares added, Adam x 2
-            self._issue_dra_backward(st, stacked=True)
-            head["gw2_add"], head["gb2_add"] = self.gw2_pen, self.gb2_pen
-            ops.linear_bwd_dw_adam_head(self.DU4, self.XX5, D1, adam, head, M=4 * Bl, ones_from=Bl,
-                                        stream=st)
-        else:
-            ops.linear_bwd_dw_adam_head(dHd, X2, D1, adam, head, M=2 * Bl, stream=st)
-        self._critic_penalty_backward(st)
-
-    def _critic_unfused(self, st, it, j):
-        Bl, d = self.Bl, self.D_steps
-        D2 = self.D2
-        Hd, S2, dS, dHd = self.Hd, self.S2, self.dS, self.dHd
-        loss_slot = self._slot(it, d, j, 0, 1)
-        aux, hyper = self._critic_forward(st, it, j)
-        ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=2 * Bl, stream=st)
-        loss = lambda **kw: ops.gan_loss(
-            self.loss_key, False, S2[:Bl], S2[Bl:], Bl, self.out_act, self.lossD, dS[:Bl], dS[Bl:],
-            hyper=hyper, inv_b=self.inv_b, loss_slot=loss_slot, aux=aux, db=D2.gb, stream=st, **kw)
-        if self._dp() and self.variant == "ra":
-            # mean(D(G(z))) and sum(du) span the GLOBAL batch (ra_gan.py:204)
-            loss(phase=1, pre=self.pre)
-            self._exchange_scalars(st, self.pre, 1)
-            loss(phase=2, pre=self.pre)
-            self._exchange_scalars(st, self.pre[1:], 1)
-            loss(phase=3, pre=self.pre)
-        elif self._dp() and self.variant == "fisher":
-            # the four moments span the GLOBAL batch; lambda's ascent is then identical on every
-            # rank (fisher_gan.py:214-223,155-156); rank 0 reports the (global) loss
-            loss(phase=1, pre=self.pre)
-            self._exchange_scalars(st, self.pre, 4)
-            loss(phase=2, pre=self.pre, loss_scale=1.0 if self.rank == 0 else 0.0)
-        else:
-            loss()
-        ops.linear_bwd_dw(dS.view(-1, 1), Hd, D2.gW, None, M=2 * Bl, stream=st)
-        ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        self._critic_dw1(st, it, j)
-        self._critic_penalty_backward(st)
-
-    def _issue_D_pre(self, st, it, j):
-        self._D_gather(st, it, j)
-        self._D_gen(st, it, j)
-        self._D_rest(st, it, j)
-
-    def _adam_args(self, net, sched_slot):
-        sched = {"D": self.schedD, "G": self.schedG}.get(net)
-        if net == "MI":
-            sched = self.schedMI
-        return dict(sched=sched, sched_slot=sched_slot, clamp=self.clip if net == "D" else 0.0)
-
-    # ---- InfoGAN train_Q (info_gan.py:269-304) + MI_optimizer.step: runs after the generator
-    # step, i.e. after the folded tick -> every slot is addressed with post=True ---------------
-    def _issue_Q(self, st, it):
-        from . import ops_fused as of
-        Bl, R = self.Bl, self.R
-        G1, G2, Q1, Q2 = self.G1, self.G2, self.Q1, self.Q2
-        Hg, Xg = self.Hg2, self.Xg2                   # free again: the generator step is done
-        zbase = self.zQ_ring.view(-1)[self.ring_r0 * self.Z:].view(-1, self.Z)
-        z_slot = self._slot(it, 1, 0, R, self.ring_B * self.Z, post=True)
-        s_slot = self._slot(it, 1, 0, 0, 1, post=True)
-        ops.linear_fwd(zbase, G1.W, G1.b, Hg, "relu", M=Bl, x_slot=z_slot, stream=st)
-        ops.linear_fwd(Hg, G2.W, G2.b, Xg, "sigmoid", M=Bl, stream=st)
-        ops.linear_fwd(Xg, Q1.W, Q1.b, self.Hq, "relu", M=Bl, stream=st)
-        ops.linear_fwd(self.Hq, Q2.W, Q2.b, self.Qo, "id", M=Bl, stream=st)
-        of.info_q_loss(self.Qo, zbase, z_slot, Bl, self.zd, self.nd, self.nc, self.dQo, self.lossMI,
-                       s_slot, B_global=self.B, stream=st)
-        fused = self.fuse_adam and self._single()
-        if fused:
-            adam = self._adam_args("MI", s_slot)
-            dw = lambda dA, X, lin, **kw: ops.linear_bwd_dw_adam(dA, X, lin, adam, M=Bl, stream=st, **kw)
-            g1, g2 = self.G1mi, self.G2mi
-        else:
-            dw = lambda dA, X, lin, **kw: ops.linear_bwd_dw(dA, X, lin.gW, lin.gb, M=Bl, stream=st, **kw)
-            g1, g2 = G1, G2
-        # every dX reads a layer's weights before that layer's dW(+Adam) launch
-        ops.linear_bwd_dx(self.dQo, Q2.W, self.dHq, below=self.Hq, epi="relu", M=Bl, stream=st)
-        ops.linear_bwd_dx(self.dHq, Q1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
-        ops.linear_bwd_dx(self.dXg, G2.W, self.dHg, below=Hg, epi="relu", M=Bl, stream=st)
-        if self.pair_dw and fused:
-            # the four weight gradients as two paired launches (round 4; the big GEMM first: its tile serves both)
-            ops.linear_bwd_dw_adam_pair(dict(dA=self.dHq, X=Xg, lin=Q1, adam=adam, M=Bl),
-                                        dict(dA=self.dQo, X=self.Hq, lin=Q2, adam=adam, M=Bl), stream=st)
-            ops.linear_bwd_dw_adam_pair(dict(dA=self.dXg, X=Hg, lin=g2, adam=adam, M=Bl),
-                                        dict(dA=self.dHg, X=zbase, lin=g1, adam=adam, M=Bl, x_slot=z_slot), stream=st)
-        else:
-            dw(self.dQo, self.Hq, Q2)
-            dw(self.dHq, Xg, Q1)
-            dw(self.dXg, Hg, g2)
-            dw(self.dHg, zbase, g1, x_slot=z_slot)
-        if self._peer():
-            # MI_optimizer.step (info_gan.py:148,207): G's gradient bucket with the MI optimizer's OWN
-            # moments, and Q's bucket -- all-reduce + Adam in the gather kernels
-            self._comms["G"].allreduce_adam(self.fG.grad, self.fG.flat, self.mi_m, self.mi_v, self.schedMI,
-                                            s_slot, stream=st)
-            self._comms["Q"].allreduce_adam(self.fQ.grad, self.fQ.flat, self.fQ.m, self.fQ.v, self.schedMI,
-                                            s_slot, stream=st)
-        elif not fused:
-            ops.adam(self.fG.flat, self.fG.grad, self.mi_m, self.mi_v, self.schedMI, s_slot, stream=st)
-            ops.adam(self.fQ.flat, self.fQ.grad, self.fQ.m, self.fQ.v, self.schedMI, s_slot, stream=st)
-
-    def _issue_D_post(self, st, it, j):
-        if self._adam_in_epilogue("D") or self._peer():
-            return                  # already applied by the gradient epilogues / the all-gather kernel
-        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
-                 self._slot(it, self.D_steps, j, 0, 1), clamp=self.clip, stream=st)
-
-    # ---- pieces of the generator step (own Hg2/Xg2 buffers: its generator forward only needs G's
-    # parameters, so it can run as a parallel branch of the critic step) ----------------------
-    def _G_zslot(self, it):
-        zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
-        return zbase, self._slot(it, 1, 0, self.R, self.zG_stride)
-
-    def _G_gen(self, st, it):
-        if self._batch_gen() and not self._standalone_G:
-            return                                  # done together with the critic step's G(z)
-        G1, G2 = self.G1, self.G2
-        zbase, zG_slot = self._G_zslot(it)
-        ops.linear_fwd(zbase, G1.W, G1.b, self.Hg2, "relu", M=self.Bl, x_slot=zG_slot, stream=st)
-        ops.linear_fwd(self.Hg2, G2.W, G2.b, self.Xg2, "sigmoid", M=self.Bl, stream=st)
-
-    def _G_critic(self, st, it):
-        """D(G(z)) forward, loss, and the backward through D down to d loss / d (pre-sigmoid G)."""
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        Hd, S2, dS, dHd, Xg = self.Hd, self.S2, self.dS, self.dHd, self.Xg2
-        loss_slot = self._slot(it, 1, self.g_off, 0, 1)
-        if self._fold_head_G():
-            tick = self.ctr if self._tick_in_head() else None
-            ops.linear_fwd_headpart(Xg, D1.W, D1.b, Hd, "relu", D2, self.fold, M=Bl, stream=st)
-            fa = self.fold.args(self.loss_key, self.out_act, self.hyper, S=S2, dS=dS, rowloss=self.rowloss)
-            ops.linear_bwd_dx_head_fold(
-                Hd, D1.W, self.dXg, dict(H=Hd, lin=D2, loss_out=self.lossG, loss_slot=loss_slot,
-                                         inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
-                fa, below=Xg, epi="sigmoid", M=Bl, stream=st)
-            return
-        ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
-        if self.fuse_head:
-            from . import ops_fused as of
-            tick = self.ctr if self._tick_in_head() else None
-            of.head_fwd_loss(self.loss_key, True, Hd, D2.W, D2.b, self.out_act, Bl, self.hyper,
-                             self.inv_b, None, S2, dS, self.rowloss, dH=dHd, stream=st)
-            if self.ride_head_dx:
-                # the head's one scalar workgroup (loss + tick) rides in the dX launch
-                ops.linear_bwd_dx_head(
-                    dHd, D1.W, self.dXg,
-                    dict(H=Hd, dS=dS, lin=D2, rowloss=self.rowloss, loss_out=self.lossG,
-                         loss_slot=loss_slot, inv_b=self.inv_b, B=Bl, gen_mode=True, tick=tick),
-                    below=Xg, epi="sigmoid", M=Bl, stream=st)
-                return
-            of.head_bwd(Hd, dS, D2.W, self.rowloss, None, None, None, self.lossG, loss_slot,
-                        self.inv_b, True, Bl, tick=tick, stream=st)
-        else:
-            ops.linear_fwd(Hd, D2.W, D2.b, S2.view(-1, 1), self.out_act, M=Bl, stream=st)
-            ops.gan_loss(self.loss_key, True, None, S2, Bl, self.out_act, self.lossG, None, dS,
-                         hyper=self.hyper, inv_b=self.inv_b, loss_slot=loss_slot, stream=st)
-            ops.linear_bwd_dx(dS.view(-1, 1), D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
-        ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, stream=st)
-
-    # everything below runs AFTER the generator step's head kernel, i.e. after the folded tick
-    def _G_sched_slot(self, it):
-        return self._slot(it, 1, self.g_off, 0, 1, post=True)
-
-    def _G_dh(self, st, it):
-        ops.linear_bwd_dx(self.dXg, self.G2.W, self.dHg, below=self.Hg2, epi="relu", M=self.Bl,
-                          stream=st)
-
-    def _G_dw2(self, st, it):
-        if self._adam_in_epilogue("G"):             # updates G2.W: must come after _G_dh read it
-            ops.linear_bwd_dw_adam(self.dXg, self.Hg2, self.G2,
-                                   self._adam_args("G", self._G_sched_slot(it)), M=self.Bl, stream=st)
-        else:
-            ops.linear_bwd_dw(self.dXg, self.Hg2, self.G2.gW, self.G2.gb, M=self.Bl, stream=st)
-
-    def _G_dw1(self, st, it):
-        zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
-        zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
-        if self._adam_in_epilogue("G"):
-            ops.linear_bwd_dw_adam(self.dHg, zbase, self.G1,
-                                   self._adam_args("G", self._G_sched_slot(it)), M=self.Bl,
-                                   x_slot=zG_slot, stream=st)
-        else:
-            ops.linear_bwd_dw(self.dHg, zbase, self.G1.gW, self.G1.gb, M=self.Bl, x_slot=zG_slot,
-                              stream=st)
-
-    def _G_dh_dw1(self, st, it):
-        self._G_dh(st, it)
-        self._G_dw1(st, it)
-
-    def _issue_G_pre(self, st, it):
-        self._G_gen(st, it)
-        self._G_critic(st, it)
-        self._G_dh(st, it)                          # reads G2.W before _G_dw2 may update it
-        if self.pair_dw:
-            # both weight gradients of the generator (+ their Adam steps on one GPU): ONE launch
-            adam = self._adam_args("G", self._G_sched_slot(it)) if self._adam_in_epilogue("G") else None
-            zbase = self.zG_base[self.ring_r0 * self.Z:].view(-1, self.Z)
-            zG_slot = self._slot(it, 1, 0, self.R, self.zG_stride, post=True)
-            ops.linear_bwd_dw_adam_pair(
-                dict(dA=self.dXg, X=self.Hg2, lin=self.G2, adam=adam, M=self.Bl),
-                dict(dA=self.dHg, X=zbase, lin=self.G1, adam=adam, M=self.Bl, x_slot=zG_slot),
-                stream=st)
-            return
-        self._G_dw2(st, it)
-        self._G_dw1(st, it)
-
-    def _issue_G_post(self, st, it):
-        if self._adam_in_epilogue("G") or self._peer():
-            return
-        ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
-                 self._G_sched_slot(it), stream=st)
-
-    # ---- the same iteration as a DAG: independent pieces become parallel hipGraph branches ----
-    # -- WGAN-GP penalty: w_gp_gan.py:195-218, hand-derived second backward (SURVEY.md A.3) -----
-    def _gp_prepare(self, st, it, j):
-        """x_hat, unless the generator's last launch already wrote it."""
-        from . import ops_fused as ops_gp
-        Bl, d, R = self.Bl, self.D_steps, self.R
-        if not self._interp_in_gen():
-            eps_slot = self._slot(it, d, j, R * d, self.ring_B)
-            ops_gp.interp(self.eps_ring.view(-1)[self.ring_r0:], eps_slot, self.X2[:Bl], self.X2[Bl:], self.Xh,
-                          stream=st)
-
-    def _issue_gp_forward(self, st, it, j, fwd_done=False):
-        from . import ops_fused as ops_gp
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        if not fwd_done:
-            self._gp_prepare(st, it, j)
-            ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
-        if self._wgp_stacked():
-            ops_gp.head_gp(self.Hh, D2.W, D2.b, self.Sh, self.U, stream=st)     # D(x_hat), u: one launch
-        else:
-            ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "relu", M=Bl, stream=st)
-            ops_gp.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)              # u = m2*(m1.w2)
-        ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                # g = u W1
-        ops_gp.gp_norm(self.Gr, self.Gam, self.pen, self.gp_lambda, self.inv_b, stream=st)
-        if self._wgp_stacked():
-            # second backward, w2's share, BEFORE the stacked dW1 launch steps W1:
-            # t = gamma W1^T, gw2_pen = sum_b m2 m1 . t   (w_gp_gan.py:215; SURVEY.md A.3)
-            ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)
-            if not self.pen_in_head:
-                ops_gp.gp_dw2_store(self.Sh, self.Hh, self.T, self.gw2_pen, stream=st)
-
-    # -- DRAGAN penalty: dra_gan.py:198-223; sigmoid critic => second-order terms (SURVEY.md A.3) --
-    def _dra_prepare(self, st, it, j):
-        """x_hat = x + (1 - delta) * C * std(x) * U  (dra_gan.py:200-205)."""
-        from . import ops_fused as of
-        Bl, d, R = self.Bl, self.D_steps, self.R
-        x = self.X2[:Bl]
-        if self._dp():
-            # images.data.std() is over the GLOBAL batch (dra_gan.py:204): (sum x, sum x^2) of my rows,
-            # summed over ranks, then the unbiased std of B*I elements
-            of.std_sums(x, Bl, self.pre[8:], ws=self.std_ws, stream=st)
-            self._exchange_scalars(st, self.pre[8:], 2)
-            of.std_from_sums(self.pre[8:], self.B * self.I, self.stdv, stream=st)
-        else:
-            of.std_all(x, Bl, self.stdv, ws=self.std_ws, stream=st)       # images.data.std()
-        r0 = self.ring_r0                                                          # my rows of the draws
-        of.dragan_xhat(x, self.delta_ring.view(-1)[r0:], self._slot(it, d, j, R * d, self.ring_B),
-                       self.U_ring.view(-1)[r0 * self.I:], self._slot(it, d, j, R * d, self.ring_B * self.I),
-                       self.stdv, self.Xh, Bl, stream=st)
-
-    def _issue_dra_forward(self, st, it, j, fwd_done=False):
-        from . import ops_fused as of
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        if not fwd_done:
-            self._dra_prepare(st, it, j)
-            ops.linear_fwd(self.Xh, D1.W, D1.b, self.Hh, "relu", M=Bl, stream=st)
-        ops.linear_fwd(self.Hh, D2.W, D2.b, self.Sh.view(-1, 1), "sigmoid", M=Bl, stream=st)
-        of.gp_u(self.Sh, self.Hh, D2.W, self.U, stream=st)                          # m1 . w2 (sigma > 0)
-        ops.linear_bwd_dx(self.U, D1.W, self.Gr, M=Bl, stream=st)                   # v = (m1.w2) W1
-        of.dragan_rows(self.Sh, self.Gr, self.Gam, self.da2, self.pen, self.gp_lambda, self.inv_b,
-                       Bl, stream=st)                                               # Gam = dv
-
-    def _issue_dra_backward(self, st, stacked=False):
-        from . import ops_fused as of
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        if stacked:
-            ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)      # T = dv W1^T
-            of.dragan_head_bwd(self.Hh, self.T, self.da2, D2.W, self.gw2_pen, self.gb2_pen, self.dA1, Bl,
-                               store=True, stream=st)
-            return
-        ops.linear_bwd_dw(self.U, self.Gam, D1.gW, None, M=Bl, accumulate=True, stream=st)
-        ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)          # T = dv W1^T
-        of.dragan_head_bwd(self.Hh, self.T, self.da2, D2.W, D2.gW, D2.gb, self.dA1, Bl, stream=st)
-        ops.linear_bwd_dw(self.dA1, self.Xh, D1.gW, D1.gb, M=Bl, accumulate=True, stream=st)
-
-    def _issue_gp_backward(self, st):
-        from . import ops_fused as ops_gp
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        ops.linear_bwd_dw(self.U, self.Gam, D1.gW, None, M=Bl, accumulate=True, stream=st)
-        ops.linear_fwd(self.Gam, D1.W, None, self.T, "id", M=Bl, stream=st)      # gamma W1^T
-        ops_gp.gp_dw2(self.Sh, self.Hh, self.T, D2.gW, stream=st)
 
     # -- host prefetch of one chunk of iterations ---------------------------------------------
     AHEAD = 3           # x SUB iterations of host draws may be submitted and unfinished
@@ -2069,680 +1593,6 @@ class GANEngine:
         return [float(x) for x in t.cpu().numpy()]
 
 
-class VAEEngine:
-    """vae.py:144-167 (train loop) + :214-223 (evaluate) as hipGraphs: one graph per distinct
-    batch size (full batches and the ragged last one, 50 000 mod 512 = 336), a device step counter
-    selecting index rows / eps rows / Adam-schedule rows / loss slots."""
-
-    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
-                 force_dp=False):
-        self.model, self.device, self.use_graph = model, device, use_graph
-        enc, dec = model.encoder, model.decoder
-        plist = [enc.linear.weight, enc.linear.bias,
-                 (enc.mu.weight, enc.log_var.weight), (enc.mu.bias, enc.log_var.bias),
-                 dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias]
-        self._dp_init(plist, world_size, rank, process_group, force_dp)
-        self.fp = FlatParams(plist, device, grad_alloc=self._grad_alloc)
-        fp = self.fp
-        self.E1, self.D1, self.D2 = _Linear(fp, enc.linear), _Linear(fp, dec.linear), \
-            _Linear(fp, dec.recon)
-        Z, H = enc.mu.weight.shape
-        self.Z, self.H, self.I = Z, H, enc.linear.weight.shape[1]
-        i_w = [i for i, p in enumerate(fp.params) if p is enc.mu.weight][0]
-        i_b = [i for i, p in enumerate(fp.params) if p is enc.mu.bias][0]
-        o_w, o_b = fp.offsets[i_w], fp.offsets[i_b]
-
-        class _Packed:          # [mu ; log_var] as one 2Z x H layer
-            W = fp.flat[o_w:o_w + 2 * Z * H].view(2 * Z, H)
-            b = fp.flat[o_b:o_b + 2 * Z]
-            gW = fp.grad[o_w:o_w + 2 * Z * H].view(2 * Z, H)
-            gb = fp.grad[o_b:o_b + 2 * Z]
-            mW, vW = fp.m[o_w:o_w + 2 * Z * H], fp.v[o_w:o_w + 2 * Z * H]
-            mb, vb = fp.m[o_b:o_b + 2 * Z], fp.v[o_b:o_b + 2 * Z]
-        self.ML = _Packed
-        self._common_init(device)
-
-    has_eps = True              # the VAE draws eps per batch (vae.py:104); the plain AE does not
-
-    # ---- data parallel (SURVEY.md 8e): every batch's rows are split over the ranks; the losses are
-    # SUMS (vae.py:203,212), so the gradient all-reduce is a plain sum with no 1/N and the per-rank
-    # loss slots add up to the reference's values -------------------------------------------------
-    def _dp_init(self, plist, world, rank, pg, force_dp):
-        import os
-        self.world, self.rank, self.pg, self.force_dp = world, rank, pg, bool(force_dp)
-        self.comm, self._grad_alloc = None, None
-        if world > 1 or force_dp:
-            if os.environ.get("GM_DP_COMM", "peer") != "peer":
-                raise GMError("data-parallel VAE / AE exchange gradients with the in-graph peer "
-                              "communicator (GM_DP_COMM=peer)")
-            from . import dp
-            n = 0
-            for item in plist:
-                for q in (item if isinstance(item, (tuple, list)) else (item,)):
-                    n += q.numel()
-                n = _align4(n)
-            self.comm = dp.PeerComm(n, world, rank, pg)
-            ok = self.comm.selfcheck(self.device)
-            if world > 1:
-                import torch.distributed as dist
-                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-                if dist.get_backend(pg) == "nccl":
-                    flag = flag.to(self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
-                ok = bool(flag.item())
-            if not ok:
-                raise GMError("peer exchange self-check failed: data-parallel VAE / AE needs hipIpc peer "
-                              "mappings between the ranks' GPUs")
-            self._grad_alloc = lambda k: self.comm.grad_buffer()[:k]
-
-    def _dp(self):
-        return self.world > 1 or self.force_dp
-
-    def _rows(self, b):
-        """Rows [lo, hi) of a batch of b rows owned by this rank (ragged batches split as evenly as
-        integer division allows)."""
-        return b * self.rank // self.world, b * (self.rank + 1) // self.world
-
-    def read_losses(self, buf, lo, n):
-        """Loss slots [lo, lo+n) summed over ranks (each rank holds its rows' partial sums)."""
-        t = buf[lo:lo + n]
-        if self.world > 1:
-            import torch.distributed as dist
-            from . import dp
-            self.comm.check()
-            t = t.cpu() if dist.get_backend(self.pg) != "nccl" else t.clone()
-            dp.allreduce_sum_(t, self.pg)
-        return t.cpu().numpy()
-
-    def _common_init(self, device):
-        from . import _respect_cpu_quota
-        _respect_cpu_quota(force=False)             # once per process, when the first engine is built
-        self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
-        self.graphs = {}
-        self._bufB = None
-        import os
-        self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
-        self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
-        self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))   # batches per graph
-        self.prefetch_gather = os.environ.get("GM_VAE_PREFETCH_GATHER", "1") != "0"
-        # launch fusions of round 3 (each replaces a ~5 us latency-bound launch by an epilogue)
-        self.fuse_sqerr = os.environ.get("GM_VAE_FUSE_SQERR", "1") != "0"
-        self.fuse_reparam_bwd = os.environ.get("GM_VAE_FUSE_REPARAM_BWD", "1") != "0"
-        self.fuse_reparam_fwd = os.environ.get("GM_VAE_FUSE_REPARAM_FWD", "1") != "0"
-        self.fuse_bwd_mid = os.environ.get("GM_VAE_BWD_MID", "1") != "0"
-        self.fin_in_dw = os.environ.get("GM_VAE_FINALIZE_IN_DW", "1") != "0"
-        self.fin_done = torch.zeros(1, dtype=torch.int32, device=device)
-
-    def _alloc(self, B):
-        if self._bufB == B:
-            return
-        dev, I, H, Z = self.device, self.I, self.H, self.Z
-        z = lambda *s: torch.zeros(*s, device=dev)
-        self.X, self.He, self.ml, self.Zs = z(B, I), z(B, H), z(B, 2 * Z), z(B, Z)
-        self.Xb = (self.X, z(B, I))                 # batch i of a multi-batch graph reads Xb[i % 2]
-        self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
-        self.dHdec, self.dZ, self.dml, self.dHe = z(B, H), z(B, Z), z(B, 2 * Z), z(B, H)
-        self.part = z(B)
-        self._sq_alloc(B)
-        self.part_kl = z((B * Z + 255) // 256)
-        self._bufB = B
-        self.graphs = {}
-
-    def _slot(self, t, mul, add, ring, stride):
-        if self.use_graph:
-            return ops.slot(self.ctr.data_ptr(), mul, add, ring, stride)
-        i = t * mul + add
-        if ring > 0:
-            i %= ring
-        return ops.slot(0, 0, i, 0, stride)
-
-    # -- reconstruction loss in the decoder's last forward (ops.linear_fwd_sqerr; GM_VAE_FUSE_SQERR=0: the
-    # separate gm_sqerr_sigmoid_bwd launch) -- per (row, 32-column tile) partials, rows ldp floats apart
-    def _sq_alloc(self, B):
-        ldp = _align4((self.I + 31) // 32)
-        self.part2 = torch.zeros(B, ldp, device=self.device)
-
-    def _recon_fwd(self, st, x_in, lin, X, b):
-        """x_hat = sigmoid(lin(x_in)), dA = d sum((X - x_hat)^2) / d (pre-sigmoid), and the loss partials.
-        Returns (partials tensor, number of floats to sum)."""
-        from . import ops_fused as of_
-        if self.fuse_sqerr:
-            ops.linear_fwd_sqerr(x_in, lin.W, lin.b, self.Xr, X, self.dA, self.part2, M=b, stream=st)
-            return self.part2, b * self.part2.shape[1]
-        ops.linear_fwd(x_in, lin.W, lin.b, self.Xr, "sigmoid", M=b, stream=st)
-        of_.sqerr_sigmoid_bwd(X, self.Xr, self.dA, self.part, b, stream=st)
-        return self.part, b
-
-    def _gather_plan(self, pos, of):
-        """Batch `pos` of a graph of `of` equal-size batches: (its image buffer, whether it gathers its
-        own rows, the buffer the NEXT batch's rows are prefetched into or None).  Inside a multi-batch
-        graph the gather of batch i+1 rides in a small forward GEMM of batch i (gm_linear_fwd_gather:
-        extra workgroups of that launch), so only the graph's first batch pays a gather launch."""
-        X = self.Xb[pos % 2]
-        nxt = self.Xb[(pos + 1) % 2] if (self.prefetch_gather and pos + 1 < of) else None
-        return X, (pos == 0 or not self.prefetch_gather), nxt
-
-    def _fwd_with_prefetch(self, st, t, lo, b, x, lin, y, act, nxt):
-        """linear_fwd, carrying the gather of the next batch's rows (ring slot t + 1) when asked to."""
-        if nxt is None:
-            ops.linear_fwd(x, lin.W, lin.b, y, act, M=b, stream=st)
-        else:
-            ops.linear_fwd_gather(x, lin.W, lin.b, y, act, self.data, self.idx_ring.view(-1)[lo:], nxt, M=b,
-                                  B=b, idx_slot=self._slot(t, 1, 1, self.R, self.B), stream=st)
-
-    def _issue(self, st, t, b, train, pos=0, of=1):
-        """One batch of size b: forward + losses (+ backward + Adam when train)."""
-        from . import ops_fused as of_
-        of = max(1, of)
-        R, B, Z = self.R, self.B, self.Z
-        E1, ML, D1, D2 = self.E1, self.ML, self.D1, self.D2
-        idx_slot = self._slot(t, 1, 0, R, B)
-        eps_slot = self._slot(t, 1, 0, R, B * Z)
-        loss_slot = self._slot(t, 1, 0, 0, 1)
-        recon_out, kl_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
-        lo, hi = self._rows(b)                       # this rank's rows of the batch
-        b = hi - lo
-        X, own, nxt = self._gather_plan(pos, of)
-        if own:
-            ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], X, B=b, idx_slot=idx_slot, stream=st)
-        ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
-        self._fwd_with_prefetch(st, t, lo, b, self.He, ML, self.ml, "id", nxt)
-        eps_base = self.eps_ring.view(-1)[lo * Z:]
-        if self.fuse_reparam_fwd and Z <= 32 and Z % 4 == 0:
-            # reparameterisation + the decoder's first layer: ONE launch (the GEMM workgroups form z from
-            # (mu, log_var, eps) themselves; bit-identical to the two launches)
-            n_kl = of_.vae_reparam_fwd(self.ml, eps_base, self.Zs, self.part_kl, b, Z, D1.W, D1.b, self.Hdec, "relu",
-                                       eps_slot=eps_slot, stream=st)
-        else:
-            n_kl = of_.vae_reparam_wide(self.ml, eps_base, self.Zs, self.part_kl, b, Z, eps_slot=eps_slot, stream=st)
-            ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
-        part, n_part = self._recon_fwd(st, self.Hdec, D2, X, b)
-        if train:
-            sched_slot = self._slot(t, 1, 0, 0, 1)
-            if self.fuse_adam and not self._dp():
-                # Adam (weight_decay 1e-5, vae.py:139-142) folded into every dW epilogue; each dX
-                # GEMM reads a layer's weights BEFORE that layer's dW launch updates them
-                adam = dict(sched=self.sched, sched_slot=sched_slot)
-                dw = lambda dA, X, lin: ops.linear_bwd_dw_adam(dA, X, lin, adam, M=b,
-                                                               weight_decay=self.wd, stream=st)
-            else:
-                adam = None
-                dw = lambda dA, X, lin: ops.linear_bwd_dw(dA, X, lin.gW, lin.gb, M=b, stream=st)
-            if self.pair_dw:
-                # weight gradients of two layers as ONE launch once both their inputs exist (the dX
-                # GEMMs that still read those weights are issued first)
-                dw2 = lambda a1, a2: ops.linear_bwd_dw_adam_pair(
-                    dict(dA=a1[0], X=a1[1], lin=a1[2], adam=adam, M=b),
-                    dict(dA=a2[0], X=a2[1], lin=a2[2], adam=adam, M=b),
-                    weight_decay=self.wd if adam is not None else 0.0, stream=st)
-            else:
-                dw2 = lambda a1, a2: (dw(*a1), dw(*a2))
-            ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            # gm_vae_bwd_mid keeps ONE hidden width (decoder's = encoder's) of at most 512 in its workgroup; other
-            # models (hidden_dim 800 / 1024, unequal widths) take the two generic dX launches below
-            mid = (self.fuse_bwd_mid and self.fuse_reparam_bwd and Z <= 32 and self.H % 4 == 0 and self.H <= 512
-                   and D1.W.shape[0] == self.H and ML.W.shape[1] == self.H)
-            if mid:
-                # dz, d loss / d [mu | log_var] and dHe: the two narrow GEMMs between the decoder's and the encoder's
-                # wide ones as ONE launch, 16 rows per workgroup (reads D1.W and ML.W before the pairs step them)
-                of_.vae_bwd_mid(self.dHdec, D1.W, self.ml, eps_base, self.dml, ML.W, self.He, self.dHe, b,
-                                eps_slot=eps_slot, stream=st)
-            elif self.fuse_reparam_bwd:
-                # dz and, in the same launch's epilogue, d loss / d [mu | log_var] (vae.py:100-106,210-212)
-                ops.linear_bwd_dx_reparam(self.dHdec, D1.W, self.dZ, self.ml, eps_base, self.dml, M=b,
-                                          eps_slot=eps_slot, stream=st)
-            else:
-                ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, stream=st)
-            dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
-            if not self.fuse_reparam_bwd:
-                of_.vae_reparam_bwd(self.ml, eps_base, self.dZ, self.dml, b, Z,
-                                   eps_slot=eps_slot, stream=st)
-            if not mid:
-                ops.linear_bwd_dx(self.dml, ML.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            if self.fin_in_dw and self.pair_dw and adam is not None and not self._dp():
-                # the batch's LAST launch: the encoder's two weight gradients + Adam, both loss sums (vae.py:203, :212)
-                # in one more workgroup of the same grid, the counter tick by the last workgroup to finish
-                ops.linear_bwd_dw_adam_pair_finalize(
-                    dict(dA=self.dHe, X=X, lin=E1, adam=adam, M=b), dict(dA=self.dml, X=self.He, lin=ML, adam=adam, M=b),
-                    dict(pa=part, na=n_part, out_a=recon_out, slot_a=loss_slot, pb=self.part_kl, nb=n_kl, out_b=kl_out,
-                         slot_b=loss_slot, done=self.fin_done, tick=self.ctr if self.use_graph else None),
-                    weight_decay=self.wd, stream=st)
-                return
-            dw2((self.dHe, X, E1), (self.dml, self.He, ML))    # (the big GEMM first: its tile shape serves both)
-            self._optimizer_step(st, sched_slot)
-        # both loss sums (vae.py:203, :212) are the step's LAST launch, which also carries the counter tick
-        of_.sum_finalize2(part, n_part, recon_out, loss_slot, self.part_kl, n_kl, kl_out, loss_slot,
-                          tick=self.ctr if self.use_graph else None, stream=st)
-
-    def _optimizer_step(self, st, sched_slot):
-        """optimizer.step() (vae.py:162) when it is not fused into the dW epilogues: data parallel ->
-        gradient SUM over ranks + Adam in the exchange's gather kernel."""
-        if self._dp():
-            self.comm.allreduce_adam(self.fp.grad, self.fp.flat, self.fp.m, self.fp.v, self.sched, sched_slot,
-                                     weight_decay=self.wd, stream=st)
-        elif not self.fuse_adam:
-            ops.adam(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sched, sched_slot,
-                     weight_decay=self.wd, stream=st)
-
-    def configure(self, B, n_train_steps, lr, weight_decay, resume=None):
-        dev = self.device
-        self._alloc(B)
-        self.B, self.wd = B, float(weight_decay)
-        self.fp.rebind()
-        self.fp.reset_state()
-        self.fp.grad.zero_()
-        self.step0 = 0
-        self.run_config = {"B": int(B), "lr": float(lr), "weight_decay": float(weight_decay)}
-        if resume is not None:                       # see GANEngine.configure
-            saved = resume.get("config")
-            if saved is not None and not resume.get("lenient", False):
-                diff = {k: (saved[k], self.run_config[k]) for k in self.run_config
-                        if k in saved and saved[k] != self.run_config[k]}
-                if diff:
-                    raise GMError("checkpoint was written by a run with different settings (saved, now): "
-                                  "%s; load_checkpoint(path, strict=False) overrides" % diff)
-            if resume["m"].numel() != self.fp.m.numel():
-                raise GMError("checkpoint optimizer state does not match this model")
-            self.fp.m.copy_(resume["m"]); self.fp.v.copy_(resume["v"])
-            self.step0 = int(resume["step"])
-        self.steps_planned = n_train_steps
-        # buffers whose addresses the captured graphs hold are kept across train() calls (grow-only),
-        # so a second train() with the same batch size / weight decay replays instead of re-capturing
-        self._moved = False
-        self.sched = GANEngine._pbuf(self, "sched", ops.adam_schedule(lr, max(1, n_train_steps),
-                                                                      start=self.step0 + 1))
-        self.recon = GANEngine._pbuf(self, "recon", max(1, n_train_steps))
-        self.kl = GANEngine._pbuf(self, "kl", max(1, n_train_steps))
-        self.R = CHUNK
-        if getattr(self, "_ring_B", None) != B:
-            self.idx_ring = torch.zeros(self.R, B, dtype=torch.int64, device=dev)
-            self.eps_ring = torch.zeros(self.R, B, self.Z, device=dev)
-            self.stage = [dict(idx=torch.zeros(self.R, B, dtype=torch.int64).pin_memory(),
-                               eps=torch.zeros(self.R, B, self.Z).pin_memory(), event=None)
-                          for _ in range(2)]
-            self._ring_B = B
-            self._moved = True
-        vkey = (B, self.wd, self.use_graph, self.fuse_adam, self.pair_dw, self.prefetch_gather)
-        if self._moved or getattr(self, "_vkey", None) != vkey:
-            self.graphs = {}
-        self._vkey = vkey
-        self.t_train = 0
-
-    def optim_state(self):
-        torch.cuda.synchronize()
-        return {"m": self.fp.m.detach().cpu().clone(), "v": self.fp.v.detach().cpu().clone(),
-                "step": self.step0 + self.steps_planned, "config": dict(self.run_config)}
-
-    def _graph(self, b, train, k=1):
-        """hipGraph of k consecutive batches of size b (the device counter advances per batch)."""
-        key = (b, train, self.data.data_ptr(), k)
-        if key not in self.graphs:
-            torch.cuda.synchronize()
-            # full batches: every power-of-two size at once (an epoch's chunking asks for different
-            # sizes from pass to pass; capturing them one by one would land inside later passes)
-            sizes = [k]
-            if b == self.B and self.use_graph:
-                sizes, n = [], 1
-                while n <= self.graph_iters:
-                    sizes.append(n)
-                    n *= 2
-                if k not in sizes:
-                    sizes.append(k)
-            for n in sizes:
-                kk = (b, train, self.data.data_ptr(), n)
-                if kk not in self.graphs:
-                    self.graphs[kk] = ops.Graph().capture(
-                        lambda st, n=n: [self._issue(st, 0, b, train, pos=i, of=n) for i in range(n)])
-        return self.graphs[key]
-
-    def run_pass(self, data, perm, train, t0):
-        """One pass over `data` in the order `perm` (host int64 tensor): batches of B rows, last
-        one ragged.  Global eps draws (vae.py:104) happen here, batch by batch, in order.
-        t0: first loss/schedule slot.  Returns number of batches."""
-        self.data = data
-        B, R, Z = self.B, self.R, self.Z
-        n = perm.numel()
-        nb = (n + B - 1) // B
-        self.ctr.fill_(t0)
-        done, which = 0, 0
-        while done < nb:
-            t = t0 + done
-            cnt = min(R - (t % R), nb - done)
-            s = self.stage[which]
-            which ^= 1
-            if s["event"] is not None:
-                s["event"].synchronize()
-            sizes = [min(B, n - (done + k) * B) for k in range(cnt)]
-            lo = done * B
-            hi = min(n, lo + cnt * B)
-            s["idx"].view(-1)[:hi - lo].copy_(perm[lo:hi])    # rows of B indices, last one ragged
-            self._draw_chunk(s, sizes)
-            r = t % R
-            self.idx_ring[r:r + cnt].copy_(s["idx"][:cnt], non_blocking=True)
-            self._upload_chunk(s, r, cnt)
-            ev = torch.cuda.Event()
-            ev.record()
-            s["event"] = ev
-            k = 0
-            while k < len(sizes):
-                b = sizes[k]
-                if not self.use_graph:
-                    self._issue(ops.stream_ptr(), t + k, b, train)
-                    k += 1
-                    continue
-                run = 1
-                while k + run < len(sizes) and sizes[k + run] == b:
-                    run += 1
-                # the run of equal-size batches as power-of-two graphs, largest first (each size is
-                # captured once, on first use): only a graph's FIRST batch pays its own gather launch
-                piece = 1
-                while piece * 2 <= min(run, self.graph_iters):
-                    piece *= 2
-                self._graph(b, train, piece).launch()
-                k += piece
-            done += cnt
-        return nb
-
-    def _torch_normal_rows(self, dst, sizes):
-        """torch.randn(b, Z) per batch of the chunk (global CPU generator, in order) into dst[k]: the
-        full batches in one C call (HostReplay), a ragged last batch on its own."""
-        B, Z = self.B, self.Z
-        nfull = sum(1 for b in sizes if b == B)
-        from ._lib import DRAW_NORMAL
-        replay = HostReplay.available() and B * Z >= 16
-        if replay and nfull:
-            replay = HostReplay.run([HostReplay.op(DRAW_NORMAL, B * Z, dst, B * Z * 4)], nfull)
-        for k, b in enumerate(sizes):
-            if replay and b == B:
-                continue
-            if replay and b * Z >= 16 and HostReplay.run([HostReplay.op(DRAW_NORMAL, b * Z, dst[k], 0)], 1):
-                continue
-            dst[k].view(-1)[:b * Z].normal_()
-
-    def _draw_chunk(self, s, sizes):
-        """HOST draws of the chunk's batches, in the reference's order (vae.py:104)."""
-        if self.has_eps:
-            self._torch_normal_rows(s["eps"], sizes)
-
-    def _upload_chunk(self, s, r, cnt):
-        if self.has_eps:
-            self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
-
-    def alloc_val(self, n):
-        if getattr(self, "vrecon", None) is None or self.vrecon.numel() < n:
-            self.vrecon = torch.zeros(n, device=self.device)
-            self.vkl = torch.zeros(n, device=self.device)
-            self.graphs = {k: g for k, g in self.graphs.items() if k[1]}   # drop eval graphs
-
-
-class AEEngine(VAEEngine):
-    """ae.py:104-164 on the VAE engine's machinery: encoder layer (relu),
-    decoder layer (sigmoid), squared-error loss; no sampling, so no eps ring and no KL term."""
-
-    has_eps = False
-
-    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
-                 force_dp=False):
-        self.model, self.device, self.use_graph = model, device, use_graph
-        enc, dec = model.encoder, model.decoder
-        plist = [enc.linear.weight, enc.linear.bias, dec.linear.weight, dec.linear.bias]
-        self._dp_init(plist, world_size, rank, process_group, force_dp)
-        self.fp = FlatParams(plist, device, grad_alloc=self._grad_alloc)
-        self.E1, self.D2 = _Linear(self.fp, enc.linear), _Linear(self.fp, dec.linear)
-        self.H, self.I = enc.linear.weight.shape
-        self.Z = 1                                   # dummy width of the (unused) eps ring
-        self._common_init(device)
-
-    def _alloc(self, B):
-        if self._bufB == B:
-            return
-        z = lambda *s: torch.zeros(*s, device=self.device)
-        self.X, self.He, self.Xr, self.dA = z(B, self.I), z(B, self.H), z(B, self.I), z(B, self.I)
-        self.Xb = (self.X, z(B, self.I))
-        self.dHe, self.part = z(B, self.H), z(B)
-        self._sq_alloc(B)
-        self._bufB = B
-        self.graphs = {}
-
-    def _issue(self, st, t, b, train, pos=0, of=1):
-        """One batch of size b: ae.py:147-160 (+ backward and Adam when train)."""
-        from . import ops_fused as of_
-        E1, D2 = self.E1, self.D2
-        idx_slot = self._slot(t, 1, 0, self.R, self.B)
-        loss_slot = self._slot(t, 1, 0, 0, 1)
-        lo, hi = self._rows(b)                       # this rank's rows of the batch
-        b = hi - lo
-        X, own, nxt = self._gather_plan(pos, of)
-        if own:
-            ops.gather_rows(self.data, self.idx_ring.view(-1)[lo:], X, B=b, idx_slot=idx_slot, stream=st)
-        self._fwd_with_prefetch(st, t, lo, b, X, E1, self.He, "relu", nxt)
-        part, n_part = self._recon_fwd(st, self.He, D2, X, b)
-        if train:
-            sched_slot = self._slot(t, 1, 0, 0, 1)
-            adam = dict(sched=self.sched, sched_slot=sched_slot) if (self.fuse_adam and not self._dp()) else None
-            # dH reads the decoder weights before the paired dW launch updates them
-            ops.linear_bwd_dx(self.dA, D2.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            ops.linear_bwd_dw_adam_pair(dict(dA=self.dA, X=self.He, lin=D2, adam=adam, M=b),
-                                        dict(dA=self.dHe, X=X, lin=E1, adam=adam, M=b),
-                                        weight_decay=self.wd if adam is not None else 0.0, stream=st)
-            self._optimizer_step(st, sched_slot)
-        of_.sum_finalize(part, n_part, self.recon if train else self.vrecon, out_slot=loss_slot,
-                        tick=self.ctr if self.use_graph else None, stream=st)
-
-
-class BIRVAEEngine(VAEEngine):
-    """bir_vae.py:119-232: encoder 784->400->mu, z = mu + eps with eps ~
-    N(0, set_var) from NUMPY's global RNG (drawn on the host exactly as the reference does,
-    bir_vae.py:92-94 -- a variance used as a standard deviation is part of the contract), decoder,
-    loss = sum (x - x_hat)^2 + 1000 * MMD(z) with the Gaussian-kernel MMD against
-    x = torch.randn(z.shape) (:203, global torch CPU generator).  `kl` / `vkl` hold the MMD terms."""
-
-    LAMBDA = 1000.0
-
-    def __init__(self, model, device, use_graph=True, world_size=1, rank=0, process_group=None,
-                 force_dp=False):
-        if world_size > 1 or force_dp:
-            raise GMError("BIR-VAE's MMD couples every pair of rows of the batch: it does not shard on "
-                          "the batch axis (run it on one GPU)")
-        self.model, self.device, self.use_graph = model, device, use_graph
-        enc, dec = model.encoder, model.decoder
-        plist = [enc.linear.weight, enc.linear.bias, enc.mu.weight, enc.mu.bias,
-                 dec.linear.weight, dec.linear.bias, dec.recon.weight, dec.recon.bias]
-        self._dp_init(plist, 1, 0, None, False)
-        self.fp = FlatParams(plist, device)
-        fp = self.fp
-        self.E1, self.MU = _Linear(fp, enc.linear), _Linear(fp, enc.mu)
-        self.D1, self.D2 = _Linear(fp, dec.linear), _Linear(fp, dec.recon)
-        self.Z, self.H = enc.mu.weight.shape
-        self.I = enc.linear.weight.shape[1]
-        self.set_var = float(model.set_var)
-        self._common_init(device)
-
-    def _alloc(self, B):
-        if self._bufB == B:
-            return
-        dev, I, H, Z = self.device, self.I, self.H, self.Z
-        z = lambda *s: torch.zeros(*s, device=dev)
-        self.X, self.He, self.Mu, self.Zs = z(B, I), z(B, H), z(B, Z), z(B, Z)
-        self.Xb = (self.X, z(B, I))
-        self.Hdec, self.Xr, self.dA = z(B, H), z(B, I), z(B, I)
-        self.dHdec, self.dZ, self.dZm, self.dHe = z(B, H), z(B, Z), z(B, Z), z(B, H)
-        self.part, self.partm = z(B), z(B)
-        self._sq_alloc(B)
-        self._bufB = B
-        self.graphs = {}
-
-    def configure(self, B, n_train_steps, lr, weight_decay, resume=None):
-        super().configure(B, n_train_steps, lr, weight_decay, resume=resume)
-        if getattr(self, "_prior_B", None) != B or "prior" not in self.stage[0]:
-            self.prior_ring = torch.zeros(self.R, B, self.Z, device=self.device)
-            for s in self.stage:
-                s["prior"] = torch.zeros(self.R, B, self.Z).pin_memory()
-            self._prior_B = B
-            self.graphs = {}
-
-    def _draw_chunk(self, s, sizes):
-        import numpy as np
-        Z = self.Z
-        # model(images) -> reparameterize: np.random.normal(0, set_var, mu.shape).float(), batch after batch on
-        # numpy's global generator: replayed in C for the whole chunk (NumpyReplay), else through numpy itself
-        if not (NumpyReplay.available() and NumpyReplay.fill(self.set_var, s["eps"], self.B, Z, sizes)):
-            for k, b in enumerate(sizes):
-                e = np.random.normal(loc=0.0, scale=self.set_var, size=(b, Z))
-                s["eps"][k].view(-1)[:b * Z].copy_(torch.from_numpy(e).float().view(-1))
-        # maximum_mean_discrepancy: torch.randn(z.shape) -- a different generator, order-independent
-        self._torch_normal_rows(s["prior"], sizes)
-
-    def _upload_chunk(self, s, r, cnt):
-        self.eps_ring[r:r + cnt].copy_(s["eps"][:cnt], non_blocking=True)
-        self.prior_ring[r:r + cnt].copy_(s["prior"][:cnt], non_blocking=True)
-
-    def _issue(self, st, t, b, train, pos=0, of=1):
-        from . import ops_fused as of_
-        R, B, Z = self.R, self.B, self.Z
-        E1, MU, D1, D2 = self.E1, self.MU, self.D1, self.D2
-        idx_slot = self._slot(t, 1, 0, R, B)
-        eps_slot = self._slot(t, 1, 0, R, B * Z)
-        loss_slot = self._slot(t, 1, 0, 0, 1)
-        recon_out, mmd_out = (self.recon, self.kl) if train else (self.vrecon, self.vkl)
-        X, own, nxt = self._gather_plan(pos, of)
-        if own:
-            ops.gather_rows(self.data, self.idx_ring.view(-1), X, B=b, idx_slot=idx_slot, stream=st)
-        ops.linear_fwd(X, E1.W, E1.b, self.He, "relu", M=b, stream=st)
-        self._fwd_with_prefetch(st, t, 0, b, self.He, MU, self.Mu, "id", nxt)
-        of_.bir_reparam(self.Mu, self.eps_ring.view(-1), self.Zs, b, Z, eps_slot=eps_slot, stream=st)
-        ops.linear_fwd(self.Zs, D1.W, D1.b, self.Hdec, "relu", M=b, stream=st)
-        part, n_part = self._recon_fwd(st, self.Hdec, D2, X, b)
-        of_.bir_mmd(self.Zs, self.prior_ring.view(-1), self.partm, self.dZm if train else None, b, Z,
-                   self.LAMBDA, prior_slot=eps_slot, stream=st)
-        if train:
-            sched_slot = self._slot(t, 1, 0, 0, 1)
-            adam = dict(sched=self.sched, sched_slot=sched_slot) if self.fuse_adam else None
-            dw2 = lambda a1, a2: ops.linear_bwd_dw_adam_pair(
-                dict(dA=a1[0], X=a1[1], lin=a1[2], adam=adam, M=b),
-                dict(dA=a2[0], X=a2[1], lin=a2[2], adam=adam, M=b),
-                weight_decay=self.wd if adam is not None else 0.0, stream=st)
-            # every dX reads a layer's weights BEFORE that layer's dW(+Adam) launch updates them
-            ops.linear_bwd_dx(self.dA, D2.W, self.dHdec, below=self.Hdec, epi="relu", M=b, stream=st)
-            # d loss / d z = decoder path + d(1000 * mmd)/dz ; z = mu + eps -> d/d mu is the same
-            ops.linear_bwd_dx(self.dHdec, D1.W, self.dZ, M=b, add=self.dZm, add_scale=1.0, stream=st)
-            dw2((self.dA, self.Hdec, D2), (self.dHdec, self.Zs, D1))
-            ops.linear_bwd_dx(self.dZ, MU.W, self.dHe, below=self.He, epi="relu", M=b, stream=st)
-            dw2((self.dZ, self.He, MU), (self.dHe, X, E1))
-            self._optimizer_step(st, sched_slot)
-        # reconstruction sum and 1000 * MMD in the step's last launch, which also carries the tick
-        of_.sum_finalize2(part, n_part, recon_out, loss_slot, self.partm, b, mmd_out, loss_slot,
-                          scale_b=self.LAMBDA, tick=self.ctr if self.use_graph else None, stream=st)
-
-
-class BEGANEngine(GANEngine):
-    """be_gan.py:109-258 as a hipGraph: autoencoder critic (784->400->784), per-row L1 losses, the
-    proportional controller K and both ReduceLROnPlateau schedulers kept in device memory and
-    advanced by a one-thread kernel at the end of every iteration (which also carries the tick) --
-    the reference's four `.item()` syncs per step disappear."""
-
-    def __init__(self, model, data, B, device, use_graph=True, world_size=1, rank=0,
-                 process_group=None, force_dp=False):
-        super().__init__("be", model, data, B, device, use_graph=use_graph, world_size=world_size,
-                         rank=rank, process_group=process_group, force_dp=force_dp)
-        Bl, I = self.Bl, self.I
-        z = lambda *s, **k: torch.zeros(*s, device=device, **k)
-        self.Yd, self.dY, self.rows = z(2 * Bl, I), z(2 * Bl, I), z(2 * Bl)
-        self.st, self.dst, self.ist = z(8), z(8, dtype=torch.float64), z(2, dtype=torch.int64)
-
-    # fusions that do not apply here
-    def _tick_in_head(self):
-        return False
-
-    def _adam_in_epilogue(self, net):
-        return False                      # Adam needs the device-side lr scale: separate launch
-
-    def configure(self, n_iters, G_lr, D_lr, D_steps, GAMMA=0.5, LAMBDA=1e-3, K=0.0, patience=0,
-                  **kw):
-        resume = kw.get("resume")
-        self.gamma, self.lam, self.patience = float(GAMMA), float(LAMBDA), int(patience)
-        super().configure(n_iters, G_lr, D_lr, D_steps, resume=resume,
-                          extra_config=dict(GAMMA=self.gamma, LAMBDA=self.lam, patience=self.patience))
-        self.st.zero_()
-        self.st[0] = float(K)
-        self.st[4] = 1.0
-        self.st[5] = 1.0
-        self.dst.zero_()
-        self.dst[0] = float("inf")                 # ReduceLROnPlateau.best (mode='min')
-        self.dst[1], self.dst[2], self.dst[3], self.dst[4] = D_lr, G_lr, D_lr, G_lr
-        self.ist.zero_()
-        if resume is not None:
-            # the controller K (be_gan.py:189-191) and both ReduceLROnPlateau schedulers (:133-136,
-            # :194-195: best, bad-epoch counts, current lr scales) continue where the run stopped;
-            # the K argument of this train() call is superseded by the saved K
-            be = resume["began"]
-            self.st.copy_(be["st"]); self.dst.copy_(be["dst"]); self.ist.copy_(be["ist"])
-
-    def optim_state(self):
-        st = super().optim_state()
-        cpu = lambda t: t.detach().cpu().clone()
-        st["began"] = {"st": cpu(self.st), "dst": cpu(self.dst), "ist": cpu(self.ist)}
-        st["config"] = dict(self.run_config)
-        return st
-
-    def _D_rest(self, st, it, j):
-        from . import ops_fused as of
-        Bl, d = self.Bl, self.D_steps
-        D1, D2 = self.D1, self.D2
-        X2, Hd, Yd, dY, dHd = self.X2, self.Hd, self.Yd, self.dY, self.dHd
-        ops.linear_fwd(X2, D1.W, D1.b, Hd, "relu", M=2 * Bl, stream=st)            # encoder
-        ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=2 * Bl, stream=st)              # decoder
-        of.l1_rows(Yd, X2, 2 * Bl, Bl, self.st, dY, self.rows, B_global=self.B, stream=st)   # K = st[0]
-        of.began_dloss(self.rows, Bl, self.st, self.lossD, self._slot(it, d, j, 0, 1), B_global=self.B,
-                       stream=st)
-        if self._dp():
-            # DX, DG are means over the GLOBAL batch (be_gan.py:189-195): the per-rank partial means
-            # in st[1:3] are summed over ranks before the K controller / plateau schedulers read them
-            self._exchange_scalars(st, self.st[1:], 2)
-        ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=2 * Bl, stream=st)
-        if self.pair_dw:
-            # both weight gradients of the autoencoder critic as one launch (plain gradients: Adam needs the
-            # device-side lr scale and stays a launch of its own)
-            ops.linear_bwd_dw_adam_pair(dict(dA=dY, X=Hd, lin=D2, adam=None, M=2 * Bl),
-                                        dict(dA=dHd, X=X2, lin=D1, adam=None, M=2 * Bl), stream=st)
-        else:
-            ops.linear_bwd_dw(dY, Hd, D2.gW, D2.gb, M=2 * Bl, stream=st)
-            ops.linear_bwd_dw(dHd, X2, D1.gW, D1.gb, M=2 * Bl, stream=st)
-
-    def _lr_scale(self, net):
-        return self.st[4:5] if net == "D" else self.st[5:6]
-
-    def _issue_D_post(self, st, it, j):
-        if self._peer():
-            return
-        ops.adam(self.fD.flat, self.fD.grad, self.fD.m, self.fD.v, self.schedD,
-                 self._slot(it, self.D_steps, j, 0, 1), lr_scale=self.st[4:5], stream=st)
-
-    def _G_critic(self, st, it):
-        from . import ops_fused as of
-        Bl = self.Bl
-        D1, D2 = self.D1, self.D2
-        Hd, Yd, dY, dHd, Xg = self.Hd, self.Yd, self.dY, self.dHd, self.Xg2
-        ops.linear_fwd(Xg, D1.W, D1.b, Hd, "relu", M=Bl, stream=st)
-        ops.linear_fwd(Hd, D2.W, D2.b, Yd, "id", M=Bl, stream=st)
-        of.l1_rows(Yd, Xg, Bl, Bl, None, dY, self.rows, B_global=self.B, stream=st)
-        of.sum_finalize(self.rows, Bl, self.lossG, scale=self.inv_b,
-                        out_slot=self._slot(it, 1, self.g_off, 0, 1), stream=st)
-        ops.linear_bwd_dx(dY, D2.W, dHd, below=Hd, epi="relu", M=Bl, stream=st)
-        # G(z) enters |D(G(z)) - G(z)| twice: through D and directly (-sign/B = -dY)
-        ops.linear_bwd_dx(dHd, D1.W, self.dXg, below=Xg, epi="sigmoid", M=Bl, add=dY, add_scale=-1.0,
-                          stream=st)
-
-    def _issue_G_post(self, st, it):
-        if self._peer():
-            return
-        ops.adam(self.fG.flat, self.fG.grad, self.fG.m, self.fG.v, self.schedG,
-                 self._G_sched_slot(it), lr_scale=self.st[5:6], stream=st)
-
-    def _issue_end(self, st, it):
-        from . import ops_fused as of
-        of.began_update(self.st, self.dst, self.ist, self.gamma, self.lam, self.patience,
-                        self.ctr if self.use_graph else None, stream=st)
-
-    def K_value(self):
-        return float(self.st[0].item())
+# the engines built on this module's pieces (imported last: they import FlatParams / GANEngine ... from here)
+from .vae_engine import AEEngine, BIRVAEEngine, VAEEngine      # noqa: E402,F401
+from .began_engine import BEGANEngine                          # noqa: E402,F401

@@ -349,6 +349,19 @@ def test_launch_planner_invariants(R, graph_iters):
         assert plan(5, 20, True) == [2, 2, 16]        # the driver's 20-step run
 
 
+def test_no_function_of_the_package_reads_a_name_its_module_does_not_define():
+    """tools/undefined_names.py over every module of the package: a method moved between modules (engine.py ->
+    gan_steps.py / vae_engine.py / began_engine.py) must not leave a global behind that only a rarely run path reads."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    mods = ["generative_models_amd." + m for m in ("engine", "gan_steps", "vae_engine", "began_engine", "trainers", "ops",
+                                                   "ops_fused", "dp", "viz", "_lib", "_build")]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "undefined_names.py")] + mods,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("variant,B,Z,d,expect", [("ns", 256, 20, 1, (512, 128)), ("wgp", 256, 20, 1, (512, 128)),
                                                    ("ns", 512, 20, 1, (256, 64)), ("ns", 1024, 20, 1, (128, 32)),
                                                    ("wgp", 256, 20, 5, (128, 32)), ("dra", 256, 20, 1, (64, 32)),
