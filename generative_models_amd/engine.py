@@ -466,6 +466,7 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
         self.gated = os.environ.get("GM_GATED", "1") != "0"
+        self._early_submit = os.environ.get("GM_EARLY_SUBMIT", "1") != "0"
         # (rounds 4 - 5 also issued every piece's stage-in on a side stream ahead of its graph: with the gate wait as its
         # own one-wave kernel in front of an ungated copy the in-graph stage-in is the faster form everywhere -- a launch
         # of k iterations 22 + 67.5 k us against 31 + 67.5 k us, profiles/r05_experiments.md section 10 -- removed)
@@ -1429,6 +1430,10 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         gated = self.gated
         if cold:
             self._ramp = list(self.RAMP)
+            # the first piece's draws go to the fill worker before anything else happens here: the GPU's first gate opens
+            # ~30 us after THIS point, everything below (gate check, plan, first launch: ~50 us) runs beside the draws
+            if gated and self._native_fill and self._early_submit:
+                self._pump(limit, upto=it_start + min(self.FIRST_PIECE, n_iters))
         trace = self._trace
         if trace is not None:
             import time
