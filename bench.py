@@ -915,8 +915,11 @@ def main():
                                    "784-400-20 MLPs, N=50000 synthetic Bernoulli images, parity-mode "
                                    "RNG protocol, Adam 2e-4, D_steps=1",
                        "global_batch": B_global,
-                       "launch": ("hipGraph/iteration" if (world == 1 and not force_dp) else
-                                  ("hipGraph/iteration incl. 2 in-graph peer all-reduces (+Adam) over hipIpc/xGMI mappings"
+                       "launch": (("hipGraphs of up to %d iterations (8 launches each), draws staged in from a %d-slot "
+                                   "pinned ring by the graph's first two nodes" % (eng.graph_iters, eng.R))
+                                  if (world == 1 and not force_dp) else
+                                  (("hipGraphs of up to %d iterations incl. 2 in-graph peer all-reduces (+Adam) per "
+                                    "iteration over hipIpc/xGMI mappings" % eng.graph_iters)
                                    if eng._peer() else "hipGraph per segment + 2 RCCL all-reduces/iteration"))
                        if eng.use_graph else "eager",
                        "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
