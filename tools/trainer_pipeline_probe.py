@@ -38,13 +38,8 @@ li = 0
 for n, r in enumerate(runs):
     tev = r[1]
     ts = [base.elapsed_time(e) * 1e3 for e in tev]       # us since the first run's entry event
-    its = []
-    for _ in tev[1:]:
-        its.append(launched[li][1]); li += 1
-    prev_it = its[0] - 0
-    out = []
-    for j in range(1, len(ts)):
-        k = its[j - 1] - (its[j - 2] if j > 1 else (runs and (its[0] - (its[0] - 0))))
-        out.append((round(ts[j] - ts[j - 1], 1)))
+    its = [launched[li + j][1] for j in range(len(tev) - 1)]     # iteration each piece ends at
+    li += len(tev) - 1
+    durations = [round(ts[j] - ts[j - 1], 1) for j in range(1, len(ts))]
     print("run %d: entry event at %.0f us, piece ends at %s, piece durations %s, iterations up to %s"
-          % (n, ts[0], [round(x) for x in ts[1:]], out, its))
+          % (n, ts[0], [round(x) for x in ts[1:]], durations, its))
