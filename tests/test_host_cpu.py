@@ -107,6 +107,64 @@ def test_dropin_surface_and_state_dict_keys():
         f_gan.Divergence("not-a-divergence")
 
 
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_epoch_loop_enqueues_the_next_epoch_before_it_reads_the_previous_one_back(pipelined, monkeypatch, capsys):
+    """trainers._train on a stand-in engine (no GPU): with one rank and no viz, epoch e+1's run() comes BEFORE epoch e's
+    losses(after=mark of epoch e); histories and progress lines come out in epoch order either way; an error in a later
+    run() still records the finished epoch; GM_PIPELINE_EPOCHS=0 reads back before the next epoch is enqueued."""
+    import ns_gan
+    from oracle import port
+    loaders = port.synthetic_loaders(16, n_train=160, n_val=48, n_test=48, image_shape=(1, 8, 8))
+    tr = ns_gan.NSGANTrainer(ns_gan.NSGAN(64, 48, 8), *loaders)
+    calls = []
+
+    class Engine:
+        world = 1
+        fail_at = None
+
+        def configure(self, n, *a, **k):
+            calls.append(("configure", n))
+
+        def run(self, n, it_start=0, horizon=None):
+            if self.fail_at == it_start:
+                raise RuntimeError("boom")
+            calls.append(("run", it_start, n, horizon))
+
+        def mark(self):
+            calls.append(("mark",))
+            return "mark%d" % sum(1 for c in calls if c[0] == "mark")
+
+        def losses(self, it0, it1, after=None):
+            calls.append(("losses", it0, it1, after))
+            return [float(it0)] * (it1 - it0), [float(it0) + 0.5] * (it1 - it0)
+
+    eng = Engine()
+    monkeypatch.setattr(tr, "_get_engine", lambda: eng)
+    if not pipelined:
+        monkeypatch.setenv("GM_PIPELINE_EPOCHS", "0")
+    tr.train(3)
+    names = [(c[0],) + ((c[1],) if c[0] in ("run", "losses") else ()) for c in calls]
+    if pipelined:
+        assert names == [("configure",), ("run", 0), ("mark",), ("run", 10), ("mark",), ("losses", 0), ("run", 20), ("mark",),
+                         ("losses", 10), ("losses", 20)]
+        assert [c[3] for c in calls if c[0] == "losses"] == ["mark1", "mark2", "mark3"]
+    else:
+        assert names == [("configure",), ("run", 0), ("losses", 0), ("run", 10), ("losses", 10), ("run", 20), ("losses", 20)]
+        assert all(c[3] is None for c in calls if c[0] == "losses")
+    assert all(c[3] == 30 for c in calls if c[0] == "run")               # horizon: the whole train() call
+    assert tr.Glosses == [0.0] * 10 + [10.0] * 10 + [20.0] * 10 and tr.Dlosses[10] == 10.5 and tr.num_epochs == 3
+    out = capsys.readouterr().out
+    assert [ln[:10] for ln in out.strip().splitlines()] == ["Epoch[1/3]", "Epoch[2/3]", "Epoch[3/3]"]
+    # an error in epoch 3's run(): epochs 1 and 2 are on record when it surfaces
+    tr2 = ns_gan.NSGANTrainer(ns_gan.NSGAN(64, 48, 8), *loaders)
+    eng2 = Engine()
+    eng2.fail_at = 20
+    monkeypatch.setattr(tr2, "_get_engine", lambda: eng2)
+    with pytest.raises(RuntimeError):
+        tr2.train(3)
+    assert tr2.num_epochs == 2 and len(tr2.Glosses) == 20
+
+
 def test_same_seed_gives_reference_initial_weights():
     """nn.Linear construction order == the reference's (G.linear, G.generate, D.linear, D...)."""
     import ns_gan
