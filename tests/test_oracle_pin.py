@@ -104,7 +104,13 @@ def _assert_gan_bit_exact(variant, kw, dims):
 FULL_PIN_CASES = [("ns", 256, dict(num_epochs=1)), ("ns", 100, dict(num_epochs=1)), ("ns", 64, dict(num_epochs=1)),
                   ("wgp", 256, dict(num_epochs=1, D_steps=1)), ("wgp", 100, dict(num_epochs=3, D_steps=5)),
                   ("ls", 1024, dict(num_epochs=1)), ("f", 256, dict(num_epochs=1, method="hellinger")),
-                  ("f", 256, dict(num_epochs=1, method="pearson"))]
+                  ("f", 256, dict(num_epochs=1, method="pearson")),
+                  # round 5: every other variant at the real widths too (the GPU parity tests compare against the port at
+                  # these shapes: tests/test_gpu_trainers.py FULL_CASES)
+                  ("dra", 256, dict(num_epochs=1, D_steps=1)), ("be", 256, dict(num_epochs=1)),
+                  ("info", 256, dict(num_epochs=1)), ("ra", 256, dict(num_epochs=1)),
+                  ("fisher", 256, dict(num_epochs=1)), ("mm", 256, dict(num_epochs=1, G_init=2)),
+                  ("w", 256, dict(num_epochs=2, D_steps=2))]
 
 
 @needs_ref
