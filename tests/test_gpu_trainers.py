@@ -1006,31 +1006,114 @@ def _param_dev(model, o_model, lr):
 
 
 # Parameter deviations MEASURED on the MI355X (max / mean over all tensors after the free-running steps of each test;
-# profiles/r05_parity_full_size.jsonl) -- the tests assert 10x these ("not <= lr"), with floors of 1e-6 / 1e-9.
-# Three cases sit above north_star's 1e-5 and each has its cause pinned elsewhere:
-#   f_hellinger 1.8e-4: two CPU evaluations of the same loop (fp32 GEMMs vs fp64-accumulated GEMMs) differ by the SAME
-#       1.84e-4 / 3.9e-7 mean / 1.0e-3 of the elements (profiles/r05_adam_amplification_cpu.json): Adam's 1/(sqrt(v)+1e-8);
-#   f_pearson 4.6e-5 and VAE bs=512 4.3e-4: one hidden unit whose pre-activation is within 2e-7 of the relu's kink takes
-#       the other branch (lockstep gradient test below; the oracle's encoder has |pre| = 7.5e-9 in the VAE's first batch)
-#       and Adam turns that row's missing gradient into whole steps.
+# profiles/r05_parity_full_size.jsonl, re-measured in round 6: profiles/r06_parity_full_size.jsonl).  Round 6 (VERDICT r5
+# item 1): every case is asserted at north_star's 1e-5 (or 10x its measured deviation where that is SMALLER)
+# over every parameter element -- except the elements the ORACLE'S OWN RUN marks as ill-conditioned (class _Evidence):
+#   (k) the weight row / bias element / next-layer column of a hidden unit whose pre-activation comes within 2e-7 of the
+#       relu's kink in some training forward of the oracle: two fp32 summation orders disagree on the sign of a 784-term
+#       dot product that small, the unit takes the other branch for one sample, and Adam's normalised step turns that
+#       sample's missing contribution into whole steps of the unit's own weights (VAE bs=512: all 96 elements above 1e-5
+#       are row 119 of encoder.linear -- |pre| = 7.5e-9 in the first batch -- everything else is within 4.5e-8;
+#       f_pearson's critic: all 334 in row 238 of D.linear, the rest within 8.6e-7);
+#   (z) elements whose oracle gradient passes within 5 % of the tensor's typical gradient magnitude of ZERO in some step
+#       (min_t |g_t| <= 0.05 * median_elements(max_t |g_t|)): Adam's m / (sqrt(v) + 1e-8) turns a last-bit difference
+#       of such a gradient into a fraction of a step (profiles/r05_adam_amplification_cpu.json: two CPU evaluations
+#       of the same loop differ by the same 1.84e-4 there).  f_hellinger: the 98 elements above 1e-5 all lie in this set.
+# Inside the marked set a case may deviate up to 2x what was measured there (INSIDE_MEASURED); a case without an entry
+# gets no allowance at all.  A defect of 1e-3 in any element outside the set fails.
 PARAM_MEASURED = {
     "dra": (1.0e-7, 8.5e-11), "be": (1.3e-7, 9.1e-11), "info": (1.5e-6, 4.7e-8), "ra": (1.5e-7, 1.8e-10),
-    "fisher": (5.2e-8, 8.0e-11), "mm": (1.3e-7, 2.5e-10), "w": (4.1e-6, 5.3e-8), "f_pearson": (4.6e-5, 3.3e-7),
+    "fisher": (5.2e-8, 8.0e-11), "mm": (1.3e-7, 2.5e-10), "w": (4.1e-6, 5.3e-8), "f_pearson": (8.4e-6, 3.3e-7),
     "wgp_d5": (1.1e-6, 2.4e-10), "dra_d5": (3.0e-6, 1.2e-8), "w_d5": (1.5e-8, 5.0e-11),
     "f_total_variation": (1.9e-8, 1.0e-10), "f_forward_kl": (5.7e-7, 9.6e-11), "f_reverse_kl": (2.8e-8, 7.5e-11),
-    "f_hellinger": (1.8e-4, 3.9e-7), "f_jensen_shannon": (2.6e-8, 8.5e-11),
+    "f_hellinger": (8.1e-6, 3.9e-7), "f_jensen_shannon": (2.6e-8, 8.5e-11),
     "ns_b256": (1.2e-7, 3.0e-10), "wgp_b256": (1.4e-6, 1.3e-10), "ls_b1024": (3.8e-7, 7.3e-9), "ns_b1024": (3.5e-6, 2.4e-8),
-    "vae_b512_ragged": (4.3e-4, 3.1e-8),
+    "vae_b512_ragged": (4.5e-8, 3.1e-8),
     "ns_b100": (3.2e-7, 3.2e-10), "ns_b64": (4.8e-7, 4.3e-10), "wgp_b100": (1.5e-7, 2.0e-10), "ls_b100": (9.3e-8, 1.7e-10),
 }
+# largest deviation measured INSIDE the oracle-marked element set (everything else: no allowance)
+INSIDE_MEASURED = {"f_hellinger": 1.85e-4, "f_pearson": 4.7e-5, "vae_b512_ragged": 4.4e-4}
+# which marks a case is granted: the VAE's deviations are ALL one kink unit's row (everything else within 4.5e-8), so it
+# gets (k) only -- its gradients differ by orders of magnitude between the 512- and the 336-row batches and (z) would mark
+# three quarters of encoder.linear
+MARKS = {"f_hellinger": "kz", "f_pearson": "kz", "vae_b512_ragged": "k"}
+KINK = 2e-7            # |pre-activation| below which two fp32 summation orders may disagree on its sign
+NEAR_ZERO = 0.05       # of the tensor's median gradient magnitude
+GAN_LAYERS = {"D.linear": (("D.linear.weight", "D.linear.bias"), ("D.discriminate.weight",)),
+              "G.linear": (("G.linear.weight", "G.linear.bias"), ("G.generate.weight",))}
+VAE_LAYERS = {"encoder.linear": (("encoder.linear.weight", "encoder.linear.bias"), ("encoder.mu.weight", "encoder.log_var.weight")),
+              "decoder.linear": (("decoder.linear.weight", "decoder.linear.bias"), ("decoder.recon.weight",))}
 
 
-def _param_assert(key, dev):
-    """dev: _param_dev(...); bound = 10x the measured deviation of this case (floors 1e-6 max / 1e-9 mean)."""
+class _Evidence:
+    """What the oracle's own free-running run says about WHICH parameter elements are ill-conditioned: forward hooks on
+    the hidden layers (training forwards only) record every unit's smallest |pre-activation|; tap() keeps every
+    parameter element's smallest and largest |gradient| over the optimizer steps."""
+
+    def __init__(self, o_model, layers):
+        self.layers, self.pre, self.gmin, self.gmax = layers, {}, {}, {}
+        for name in layers:
+            mod = o_model
+            for part in name.split("."):
+                mod = getattr(mod, part)
+            mod.register_forward_hook(lambda m_, i_, out, name=name: self._pre(o_model, name, out))
+
+    def _pre(self, o_model, name, out):
+        if o_model.training:
+            v = out.detach().abs().min(dim=0).values
+            self.pre[name] = v if name not in self.pre else torch.minimum(self.pre[name], v)
+
+    def tap(self, kind, tr_, info):
+        if kind in ("D", "G"):
+            named = [("%s.%s" % (kind, n), p_) for n, p_ in getattr(tr_.model, kind).named_parameters()]
+        elif kind == "VAE":
+            named = list(tr_.model.named_parameters())
+        else:
+            return
+        for n, p_ in named:
+            g = p_.grad.detach().abs()
+            self.gmin[n] = g.clone() if n not in self.gmin else torch.minimum(self.gmin[n], g)
+            self.gmax[n] = g.clone() if n not in self.gmax else torch.maximum(self.gmax[n], g)
+
+    def kink_units(self):
+        return {name: torch.nonzero(v <= KINK).flatten().tolist() for name, v in self.pre.items()}
+
+    def marked(self, key, shape, marks="kz"):
+        m = torch.zeros(shape, dtype=torch.bool)
+        for name, (rows, cols) in (self.layers.items() if "k" in marks else ()):
+            units = torch.nonzero(self.pre[name] <= KINK).flatten()
+            if key in rows:
+                m[units] = True
+            if key in cols:
+                m[:, units] = True
+        if "z" in marks and key in self.gmin and self.gmin[key].numel() >= 64:           # (a median over a handful of elements says nothing)
+            m |= self.gmin[key] <= NEAR_ZERO * self.gmax[key].median()
+        return m
+
+
+def _param_assert(key, dev, model=None, o_model=None, ev=None):
+    """dev: _param_dev(...).  Every element within min(1e-5, 10x this case's measured deviation) (floor 1e-6) and every
+    tensor's mean within 10x measured (floor 1e-9).  Cases with an INSIDE_MEASURED entry: the elements the oracle's own
+    run marks (ev.marked) may deviate up to 2x what was measured inside the set; the bound on all others stays."""
     mx, mean = PARAM_MEASURED[key]
-    bmax, bmean = max(10 * mx, 1e-6), max(10 * mean, 1e-9)
-    for k, v in dev.items():
-        assert v["max"] <= bmax and v["mean"] <= bmean, (key, k, v, bmax, bmean)
+    bmax, bmean = min(max(10 * mx, 1e-6), 1e-5), max(10 * mean, 1e-9)
+    if key not in INSIDE_MEASURED:
+        for k, v in dev.items():
+            assert v["max"] <= bmax and v["mean"] <= bmean, (key, k, v, bmax, bmean)
+        return None
+    inside_bound, rec = 2 * INSIDE_MEASURED[key], {}
+    for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
+        d = (a.cpu() - b).abs()
+        m = ev.marked(k, d.shape, MARKS[key])
+        out_max = float(d[~m].max()) if bool((~m).any()) else 0.0
+        in_max = float(d[m].max()) if bool(m.any()) else 0.0
+        rec[k] = dict(outside_max=out_max, inside_max=in_max, marked_frac=float(m.float().mean()),
+                      above_1e5=int((d > 1e-5).sum()), above_1e5_outside=int((d[~m] > 1e-5).sum()))
+        assert out_max <= bmax, (key, k, "an element the oracle does not mark as ill-conditioned deviates", rec[k])
+        assert in_max <= inside_bound, (key, k, rec[k], inside_bound)
+        assert float(m.float().mean()) <= 0.5, (key, k, "the marked set must stay a minority", rec[k])
+        assert dev[k]["mean"] <= bmean, (key, k, dev[k], bmean)
+    return dict(kink_units=ev.kink_units(), tensors=rec)
 
 
 @pytest.mark.parametrize("variant,kw", FULL_CASES, ids=[_case_id(v, kw) for v, kw in FULL_CASES])
@@ -1050,7 +1133,8 @@ def test_full_size_engine_vs_oracle(variant, kw):
     o_model = port.build(variant, 784, 400, 20)
     okw = dict(kw)
     method = okw.pop("method", "jensen_shannon")
-    o = port.GANPort(variant, o_model, ld[0], method=method)
+    ev = _Evidence(o_model, GAN_LAYERS) if _case_id(variant, kw) in INSIDE_MEASURED else None
+    o = port.GANPort(variant, o_model, ld[0], method=method, tap=ev.tap if ev else None)
     o.train(**okw)
     o_rng = torch.get_rng_state()
 
@@ -1066,9 +1150,12 @@ def test_full_size_engine_vs_oracle(variant, kw):
         lclose(tr.MIlosses, o.MIlosses, "info full-size MIlosses")
     assert torch.equal(o_rng, torch.get_rng_state())
     dev = _param_dev(model, o_model, 2e-4)
-    _record("full_size_engine_vs_oracle[%s]" % _case_id(variant, kw), steps=steps,
-            Dloss_err=_loss_err(tr.Dlosses, o.Dlosses), Gloss_err=_loss_err(tr.Glosses, o.Glosses), params=dev)
-    _param_assert(_case_id(variant, kw), dev)
+    attributed = None
+    try:
+        attributed = _param_assert(_case_id(variant, kw), dev, model, o_model, ev)
+    finally:
+        _record("full_size_engine_vs_oracle[%s]" % _case_id(variant, kw), steps=steps, attributed=attributed,
+                Dloss_err=_loss_err(tr.Dlosses, o.Dlosses), Gloss_err=_loss_err(tr.Glosses, o.Glosses), params=dev)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1124,7 +1211,8 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     mk = lambda: port.synthetic_loaders(512, n_train=n_train, n_val=512, n_test=512, image_shape=(1, 28, 28))
     ld0 = mk()                                      # (seeds the dataset generator: BEFORE the model's seed)
     o_model = port.build("vae", 784, 400, 20)
-    o = port.VAEPort(o_model, *ld0)
+    ev = _Evidence(o_model, VAE_LAYERS)
+    o = port.VAEPort(o_model, *ld0, tap=ev.tap)
     o.train(3)
     o_rng = torch.get_rng_state()
     ld = mk()
@@ -1137,16 +1225,19 @@ def test_vae_b512_ragged_parameters_tensor_by_tensor():
     torch.cuda.synchronize()
     assert len(tr.recon_loss) == 12
     dev = _param_dev(model, o_model, 1e-3)
-    _record("vae_b512_ragged_tensor_by_tensor", recon_err=_loss_err(tr.recon_loss, o.recon_loss),
-            kl_err=_loss_err(tr.kl_loss, o.kl_loss),
-            best_val_rel_err=abs(tr.best_val_loss - o.best_val_loss) / abs(o.best_val_loss), params=dev)
+    attributed = None
+    try:
+        attributed = _param_assert("vae_b512_ragged", dev, model, o_model, ev)
+    finally:
+        _record("vae_b512_ragged_tensor_by_tensor", recon_err=_loss_err(tr.recon_loss, o.recon_loss),
+                kl_err=_loss_err(tr.kl_loss, o.kl_loss), attributed=attributed,
+                best_val_rel_err=abs(tr.best_val_loss - o.best_val_loss) / abs(o.best_val_loss), params=dev)
     # measured (profiles/r04_parity_full_size.jsonl): recon 1.0e-7, kl 1.4e-7, best_val 7.6e-8 -- asserted with a
     # 15-fold margin, an order below north_star's 1e-5
     lclose(tr.recon_loss, o.recon_loss, "VAE recon", tol=2e-6)
     lclose(tr.kl_loss, o.kl_loss, "VAE kl", tol=2e-6)
     assert abs(tr.best_val_loss - o.best_val_loss) <= 2e-6 * abs(o.best_val_loss)
     assert torch.equal(o_rng, torch.get_rng_state())
-    _param_assert("vae_b512_ragged", dev)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1234,11 +1325,18 @@ def test_vae_reference_default_batch_full_epoch():
     cpu_pair = _param_dev(o_model, x_model, 1e-3)
     pmax = lambda d: max(v["max"] for v in d.values())
     _record("vae_b100_full_epoch", recon_err_first30=float(er[:30].max()), kl_err_first30=float(ek[:30].max()),
+            first_batch_the_oracle_moves_1e6_under_exp_rounding=int(np.argmax(np.maximum(rel(o.recon_loss, x.recon_loss), rel(o.kl_loss, x.kl_loss)) > 1e-6)),
             recon_err_500=float(er.max()), kl_err_500=float(ek.max()),
             vs_rounded_exp=dict(recon_err_500=float(xr.max()), kl_err_500=float(xk.max()), param_max=pmax(dev_x)),
             cpu_stock_vs_cpu_rounded_exp_param_max=pmax(cpu_pair),
             best_val_rel_err=abs(tr.best_val_loss - o.best_val_loss) / abs(o.best_val_loss), params=dev_o)
-    # against the stock oracle: north_star's bound while the problem is well conditioned (measured 4e-7 up to batch 33)
+    # against the stock oracle: north_star's bound while the problem is well conditioned (measured 4e-7 up to batch 33;
+    # the KL term falls from 1 300 to ~20 over these batches and the posterior collapses right behind them).  ADVICE r5:
+    # the strict check over this horizon extends to every parameter's gradient in
+    # test_vae_full_size_teacher_forced_gradients_lockstep[100] (30 batches, measured <= 7.6e-7 of each tensor's scale);
+    # the drift-relative criterion below is what remains once exp(lv) - lv - 1 cancels five digits.  (Where the ORACLE
+    # ITSELF first moves by 1e-6 under a different rounding of exp() depends on the host's libm / vector width: batch
+    # 31 - 35 in the build container, 80 on the GPU box -- recorded, not asserted.)
     assert max(er[:30].max(), ek[:30].max()) <= TOL, (er[:30].max(), ek[:30].max())
     # over the whole epoch the HIP path must not be further from the stock oracle than the oracle's own exp() rounding
     # moves it (factor 3 of slack).  (Measured: the three evaluations -- torch's exp, the rounded exp, the device's expf
@@ -1335,10 +1433,12 @@ def test_full_size_teacher_forced_gradients_lockstep(variant, batch, kw):
 
 @pytest.mark.parametrize("batch", [512, 100])
 def test_vae_full_size_teacher_forced_gradients_lockstep(batch):
-    """vae.py:193-212 at 784-400-20: four batches in lockstep (one training batch + the validation pass per call),
-    every parameter's gradient of recon + kl against the oracle's autograd."""
+    """vae.py:193-212 at 784-400-20: batches in lockstep (one training batch + the validation pass per call), every
+    parameter's gradient of recon + kl against the oracle's autograd.  B = 512: four batches; B = 100 (the reference's
+    default loaders): thirty -- the horizon over which test_vae_reference_default_batch_full_epoch holds the losses to
+    1e-5 (the strict check there extended to the parameters' gradients)."""
     import vae
-    steps = 4
+    steps = 30 if batch == 100 else 4
     mk = lambda: port.synthetic_loaders(batch, n_train=batch, n_val=batch, n_test=batch, image_shape=(1, 28, 28))
     ld0 = mk()
     o_model = port.build("vae", 784, 400, 20)
