@@ -809,6 +809,62 @@ def bench_trainer(epochs=3):
             "steps": epochs * steps}
 
 
+def bench_general_path(epochs=2):
+    """The README's extension contract (/root/reference/README.md:29-65; loop ns_gan.py:122-156): a user subclass of
+    NSGANTrainer that overrides ONLY train_D / train_G -- the README's own LSGAN edit -- at bs=256.  It cannot run on
+    the fused engine; generative_models_amd/captured.py replays the two hooks as one captured graph per D+G iteration
+    on the device data path.  One warm-up epoch on the same trainer (eager first iteration, capture), then `epochs`
+    timed.  The fully general host loop (DataLoader reshuffle, CPU randn + H2D, .item() per step) is timed beside it
+    on 40 iterations."""
+    import ns_gan
+
+    class ReadmeLS(ns_gan.NSGANTrainer):
+        def train_D(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            G_output = self.model.G(noise)
+            DX_score, DG_score = self.model.D(images), self.model.D(G_output)
+            return (0.50 * torch.mean((DX_score - 1.) ** 2)) + (0.50 * torch.mean((DG_score - 0.) ** 2))
+
+        def train_G(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            DG_score = self.model.D(self.model.G(noise))
+            return 0.50 * torch.mean((DG_score - 1.) ** 2)
+
+    ds = synthetic_dataset()
+
+    def run(n_batches, warm, timed):
+        class Capped(torch.utils.data.DataLoader):
+            def __len__(self):
+                return n_batches
+        torch.manual_seed(1234)
+        model = ns_gan.NSGAN(image_size=IMG, hidden_dim=HID, z_dim=Z)
+        tr = ReadmeLS(model, Capped(ds, batch_size=B_PER_GPU, shuffle=True), None, None, viz=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(warm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.train(timed)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert np.isfinite(tr.Glosses).all()
+        return tr, dt / (timed * n_batches)
+
+    steps = len(torch.utils.data.DataLoader(ds, batch_size=B_PER_GPU))
+    tr, per = run(steps, 1, epochs)
+    cap = getattr(tr, "_captured", None)
+    out = {"what": "README.md:29-65 LSGAN override of ns_gan.NSGANTrainer (train_D / train_G only), bs=256, "
+                   "%d iterations per epoch, %d epochs timed after one warm epoch" % (steps, epochs),
+           "mode": (cap.mode if cap is not None and cap.done else "host loop"),
+           "us_per_step": per * 1e6, "img_s": B_PER_GPU / per, "steps": epochs * steps}
+    os.environ["GM_CAPTURED_GENERAL"] = "0"
+    try:
+        _, per_h = run(40, 1, 1)
+    finally:
+        del os.environ["GM_CAPTURED_GENERAL"]
+    out["host_loop_us_per_step"] = per_h * 1e6
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-run under torch.distributed.run."""
     import socket
@@ -834,6 +890,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--sustained", type=float, default=6.0,
                     help="seconds of ONE uninterrupted window of the headline step behind the timed regions (0: skip)")
+    ap.add_argument("--general-path", action="store_true", help="run only the README-override leg and print its entry")
     ap.add_argument("--only", default=None, help="profiling: run ONE of the extra configs (wgp_b256, ns_b1024, "
                     "ls_b1024, dra_b256, vae_b512) and print its entry instead of the contract line")
     args = ap.parse_args()
@@ -868,6 +925,9 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     W, K, reps = args.warmup, args.steps, max(1, args.reps)
+    if args.general_path:
+        print(json.dumps(bench_general_path()))
+        return
     if args.only:
         print(json.dumps(other_configs(dev, min(K, 400), W, min(reps, 3), cpu=False, only=args.only)))
         return
@@ -974,6 +1034,9 @@ def main():
             if not args.no_configs:
                 # INSIDE `config`: the driver's record keeps the contract keys + config / roofline / cpu_baseline
                 line["config"]["trainer"] = bench_trainer()
+                gp = bench_general_path()
+                gp["over_fast_step"] = gp["us_per_step"] / (dt / K * 1e6)
+                line["config"]["general_path"] = gp
                 # (GPU legs of the configs section first, every CPU baseline after them: see other_configs); each
                 # entry carries its own roofline and cpu_baseline
                 line["config"]["other_configs"] = other_configs(dev, min(K, 400), W, min(reps, 3),

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "gm_arch": (c_char_p, []),
     "gm_last_error": (c_char_p, []),
     "gm_tick": (c_int, [_P, _P, c_int64]),
+    "gm_copy_slot_f32": (c_int, [_P, _P, Slot, _P, Slot, c_int64]),
     "gm_gather_rows": (c_int, [_P, _P, c_int64, _P, Slot, _P, c_int64, c_int, c_int]),
     "gm_linear_fwd": (c_int, [_P, _P, c_int64, Slot, _P, _P, _P, c_int64, c_int, c_int, c_int,
                               c_int]),

@@ -420,6 +420,28 @@ static int adam_impl(void* stream, float* p, const float* g, float* m, float* v,
 }
 
 // ------------------------------------------------------------------------------------------
+// ring slot <-> plain tensor copy (captured general path: a user's train_D / train_G read ordinary tensors,
+// the graph that replays them walks prefetched rings through the device counter)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_slot_kernel(const float* __restrict__ src, gm_slot src_slot,
+                                                       float* __restrict__ dst, gm_slot dst_slot, int64_t n) {
+    const float* s = src + gm_slot_offset(src_slot);
+    float* d = dst + gm_slot_offset(dst_slot);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+
+extern "C" int gm_copy_slot_f32(void* stream, const float* src, gm_slot src_slot, float* dst, gm_slot dst_slot,
+                                int64_t n) {
+    GM_CHECK_ARG(src && dst && n > 0);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(copy_slot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_slot, dst,
+                       dst_slot, n);
+    GM_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------
 // activation backward (general autograd path)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dY,

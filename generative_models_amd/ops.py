@@ -467,6 +467,11 @@ def act_bwd(dY, Y, dA, act, stream=None):
     return dA
 
 
+def copy_slot(src, dst, n, src_slot=NO_SLOT, dst_slot=NO_SLOT, stream=None):
+    """dst[dst_slot + i] = src[src_slot + i] for i < n fp32 words (gm_copy_slot_f32)."""
+    _lib.call("gm_copy_slot_f32", stream or stream_ptr(), src.data_ptr(), src_slot, dst.data_ptr(), dst_slot, n)
+
+
 def tick(ctr, inc=1, stream=None):
     _lib.call("gm_tick", stream or stream_ptr(), ctr.data_ptr(), inc)
 

@@ -337,6 +337,48 @@ class GANTrainer:
               and it.batch_size is not None and it.batch_size <= len(it.dataset))
         return bool(ok)
 
+    def _captured_general_ok(self):
+        """Only train_D / train_G differ from the stock trainer (README.md:29-65): stock process_batch / compute_noise
+        (their draws are what the host replays), stock networks, the reference's loader, one GPU, and a variant whose
+        stock hooks draw nothing but compute_noise's randn (captured.VARIANTS)."""
+        import os
+        from . import captured, dp
+        if os.environ.get("GM_CAPTURED_GENERAL", "1") == "0" or not torch.cuda.is_available():
+            return False
+        if self.variant not in captured.VARIANTS or dp.current()[0] != 1:
+            return False
+        if not (self._hook_is_stock("process_batch") and self._hook_is_stock("compute_noise")
+                and self._hook_is_stock("_after_D_backward")):
+            return False
+        m = self.model
+        if not (_stock_module(getattr(m, "G", None)) and _stock_module(getattr(m, "D", None))):
+            return False
+        from .engine import HostReplay
+        it = self.train_iter
+        if not HostReplay.available() or (it.batch_size or 0) * m.z_dim < 16:
+            return False
+        return bool(isinstance(it, torch.utils.data.DataLoader)
+                    and isinstance(it.dataset, torch.utils.data.TensorDataset)
+                    and isinstance(it.sampler, torch.utils.data.RandomSampler)
+                    and it.sampler.generator is None and it.generator is None
+                    and not it.sampler.replacement and it.num_workers == 0
+                    and it.batch_size is not None and it.batch_size <= len(it.dataset))
+
+    def _get_captured(self):
+        from .captured import CapturedLoop
+        it = self.train_iter
+        key = (id(it.dataset), it.batch_size)
+        if getattr(self, "_captured", None) is None or self._captured_key != key:
+            import os
+            dev = next(self.model.parameters()).device
+            imgs = it.dataset.tensors[0]
+            data = imgs.reshape(imgs.shape[0], -1).to(dev, torch.float32).contiguous()
+            if os.environ.get("GM_PACKED", "1") != "0" and ops.PackedData.is_binary(data):
+                data = ops.PackedData(data)
+            self._captured = CapturedLoop(self, data, it.batch_size, dev)
+            self._captured_key = key
+        return self._captured
+
     def _get_engine(self):
         from .engine import GANEngine
         it = self.train_iter
@@ -415,6 +457,25 @@ class GANTrainer:
         # WGAN's clamp (w_gan.py:158,241-243) is folded into the Adam kernel unless the user
         # overrides clip_D_weights: then theirs is called after every critic step
         user_clip = clip > 0 and hasattr(self, "clip_D_weights") and not self._hook_is_stock("clip_D_weights")
+        # README.md:29-65 -- ONLY train_D / train_G overridden: the stock loop around them keeps the device data path
+        # and the two hooks are replayed as one captured graph per iteration (captured.py)
+        if G_init == 0 and not user_clip and self._captured_general_ok():
+            from .captured import NotCapturable
+            cap = self._get_captured()
+            cap.configure(num_epochs * epoch_steps, G_lr, D_lr, D_steps, clip, train_D_kw or {}, train_G_kw or {})
+            try:
+                for epoch in range(1, num_epochs + 1):
+                    m.train()
+                    it0 = (epoch - 1) * epoch_steps
+                    cap.run(epoch_steps, use_graph=self.use_graph)
+                    G_losses, D_losses = cap.losses(it0, it0 + epoch_steps)
+                    self._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+                    self._viz_epoch(epoch)
+                return
+            except NotCapturable as e:          # raised by the FIRST iteration's transaction only: nothing has changed
+                if cap.done:
+                    raise
+                self._captured_refused = str(e)
         G_opt = FlatAdam(m.G.parameters(), G_lr)
         D_opt = FlatAdam(m.D.parameters(), D_lr, clamp=0.0 if user_clip else clip)
         kwD, kwG = train_D_kw or {}, train_G_kw or {}

@@ -61,6 +61,12 @@ const char* gm_last_error(void);
  * Trainer.train (ns_gan.py:117-126). */
 int gm_tick(void* stream, int64_t* ctr, int64_t inc);
 
+/* ---- dst[dst_slot + i] = src[src_slot + i], i < n (fp32 words).  The README extension contract at speed
+ * (/root/reference/README.md:29-65): a user's train_D / train_G read ordinary tensors -- compute_noise's result
+ * (ns_gan.py:218-220) -- and return a 0-dim loss; the graph that replays them copies the iteration's noise out of
+ * the prefetched ring and its loss into the per-step history (the .item() of ns_gan.py:142,154) with this. */
+int gm_copy_slot_f32(void* stream, const float* src, gm_slot src_slot, float* dst, gm_slot dst_slot, int64_t n);
+
 /* ---- K1: batch gather.  Replaces DataLoader collate in process_batch (ns_gan.py:222-226):
  * out[b,:] = data[idx[b],:].  idx is int64 [B] at slot `idx_slot`. */
 int gm_gather_rows(void* stream, const float* data, int64_t n_rows, const int64_t* idx,

@@ -458,6 +458,152 @@ def test_user_override_takes_general_path():
     lclose(tr.Glosses, o_tr.Glosses, "override Glosses")
     lclose(tr.Dlosses, o_tr.Dlosses, "override Dlosses")
     assert torch.equal(o_rng, torch.get_rng_state())
+    # round 6: only train_D / train_G are overridden -> the hooks were replayed as a captured graph on the device
+    # data path (captured.py), not run through the host DataLoader loop
+    assert tr._captured is not None and tr._captured.mode == "graph" and tr._captured.done == len(tr.Glosses)
+    for (k, a), (_, b) in zip(model.state_dict().items(), o_model.state_dict().items()):
+        assert float((a.cpu() - b).abs().max()) <= 2e-5, k
+
+
+def _readme_ls_trainer(base):
+    """The README's own example (/root/reference/README.md:33-65): NSGAN -> LSGAN by overriding train_D / train_G."""
+    class MyLS(base):
+        def train_D(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            G_output = self.model.G(noise)
+            DX_score, DG_score = self.model.D(images), self.model.D(G_output)
+            return (0.50 * torch.mean((DX_score - 1.) ** 2)) + (0.50 * torch.mean((DG_score - 0.) ** 2))
+
+        def train_G(self, images):
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            DG_score = self.model.D(self.model.G(noise))
+            return 0.50 * torch.mean((DG_score - 1.) ** 2)
+    return MyLS
+
+
+@pytest.mark.parametrize("batch,D_steps", [(256, 1), (100, 2)])
+def test_readme_override_full_size_captured_vs_oracle(batch, D_steps):
+    """README.md:29-65 at 784-400-20: a user subclass that overrides ONLY train_D / train_G (the README's LSGAN edit of
+    NSGANTrainer) runs as a captured graph on the device data path and must reproduce the oracle's LSGAN run (same
+    learning rates as the NSGAN trainer it subclasses): losses 1e-5, parameters 1e-5, generator state bit-exact."""
+    import ns_gan
+    steps = 12
+    kw = dict(num_epochs=2, G_lr=2e-4, D_lr=2e-4, D_steps=D_steps)
+    ld = _capped_loaders(batch, steps // 2 * D_steps)
+    o_model = port.build("ls", 784, 400, 20)
+    o = port.GANPort("ls", o_model, ld[0])
+    o.train(**kw)
+    o_rng = torch.get_rng_state()
+    ld = _capped_loaders(batch, steps // 2 * D_steps)
+    torch.manual_seed(1234)
+    model = ns_gan.NSGAN(784, 400, 20)
+    tr = _readme_ls_trainer(ns_gan.NSGANTrainer)(model, *ld)
+    assert not tr._stock() and tr._captured_general_ok()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(2, D_steps=D_steps)
+    torch.cuda.synchronize()
+    assert tr._captured.mode == "graph" and len(tr.Glosses) == steps and tr.num_epochs == 2
+    lclose(tr.Glosses, o.Glosses, "README override Glosses")
+    lclose(tr.Dlosses, o.Dlosses, "README override Dlosses")
+    assert torch.equal(o_rng, torch.get_rng_state())
+    dev = _param_dev(model, o_model, 2e-4)
+    _record("readme_override_captured[b%d_d%d]" % (batch, D_steps), steps=steps, Dloss_err=_loss_err(tr.Dlosses, o.Dlosses),
+            Gloss_err=_loss_err(tr.Glosses, o.Glosses), params=dev)
+    for k, v in dev.items():
+        assert v["max"] <= 1e-5, (k, v)
+
+
+def test_captured_general_path_equals_the_host_loop(monkeypatch):
+    """The captured loop against the fully general loop (GM_CAPTURED_GENERAL=0: host DataLoader, CPU randn, .item() per
+    step) on the same user subclass: same draws, same kernels for the GEMMs -> the same losses and parameters to
+    rounding (the host loop also back-propagates the gradients the reference throws away; they do not reach a result)."""
+    import ns_gan
+
+    def run():
+        loaders = port.synthetic_loaders(32, n_train=SMALL["n_train"], n_val=48, n_test=48, image_shape=SMALL["image_shape"])
+        torch.manual_seed(1234)
+        model = ns_gan.NSGAN(SMALL["image_size"], SMALL["hidden_dim"], SMALL["z_dim"])
+        tr = _readme_ls_trainer(ns_gan.NSGANTrainer)(model, *loaders)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(3, D_steps=2)
+        torch.cuda.synchronize()
+        return tr, model, torch.get_rng_state()
+    a = run()
+    assert a[0]._captured.mode == "graph"
+    monkeypatch.setenv("GM_CAPTURED_GENERAL", "0")
+    b = run()
+    assert getattr(b[0], "_captured", None) is None
+    lclose(a[0].Glosses, b[0].Glosses, "captured vs host loop G", tol=2e-6)
+    lclose(a[0].Dlosses, b[0].Dlosses, "captured vs host loop D", tol=2e-6)
+    assert torch.equal(a[2], b[2])
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert float((x - y).abs().max()) <= 2e-5, k
+
+
+def test_captured_general_path_refuses_hooks_that_draw_themselves(monkeypatch):
+    """A train_D that consumes the global CPU generator itself (WGAN-GP style torch.rand) cannot be pre-drawn by the host
+    replay: the first iteration's transaction detects it, restores parameters / optimizer / generator state, and the
+    run takes the host loop -- bitwise the run with the captured path switched off."""
+    import ns_gan
+    from generative_models_amd.trainers import to_cuda
+
+    class Noisy(_readme_ls_trainer(ns_gan.NSGANTrainer)):
+        def train_D(self, images):
+            jitter = to_cuda(torch.rand(images.shape[0], 1))             # an extra draw between the stock ones
+            noise = self.compute_noise(images.shape[0], self.model.z_dim)
+            DX, DG = self.model.D(images), self.model.D(self.model.G(noise))
+            return 0.5 * torch.mean((DX - 1 + 0.01 * jitter) ** 2) + 0.5 * torch.mean(DG ** 2)
+
+    def run():
+        loaders = port.synthetic_loaders(16, n_train=SMALL["n_train"], n_val=48, n_test=48, image_shape=SMALL["image_shape"])
+        torch.manual_seed(1234)
+        model = ns_gan.NSGAN(SMALL["image_size"], SMALL["hidden_dim"], SMALL["z_dim"])
+        tr = Noisy(model, *loaders)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(2)
+        torch.cuda.synchronize()
+        return tr, model, torch.get_rng_state()
+    a = run()
+    assert a[0]._captured.done == 0 and "generator" in a[0]._captured_refused
+    monkeypatch.setenv("GM_CAPTURED_GENERAL", "0")
+    b = run()
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses and torch.equal(a[2], b[2])
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
+
+
+def test_captured_general_path_hooks_that_cannot_be_captured_run_eagerly_on_the_device_path():
+    """A hook that reads a value back (.item()) cannot be captured: the iterations then run eagerly, still on the
+    device data path (prefetched rings, device gather, flat Adam) -- same results as the captured replay of the same
+    arithmetic."""
+    import ns_gan
+    LS = _readme_ls_trainer(ns_gan.NSGANTrainer)
+
+    class Peeking(LS):
+        def train_G(self, images):
+            loss = LS.train_G(self, images)
+            self.last_G = loss.item()                                   # a host read: not capturable
+            return loss
+
+    def run(cls):
+        loaders = port.synthetic_loaders(16, n_train=SMALL["n_train"], n_val=48, n_test=48, image_shape=SMALL["image_shape"])
+        torch.manual_seed(1234)
+        model = ns_gan.NSGAN(SMALL["image_size"], SMALL["hidden_dim"], SMALL["z_dim"])
+        tr = cls(model, *loaders)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(2)
+        torch.cuda.synchronize()
+        return tr, model, torch.get_rng_state()
+    a, b = run(Peeking), run(LS)
+    assert a[0]._captured.mode == "eager" and a[0]._captured.done == len(a[0].Glosses) and b[0]._captured.mode == "graph"
+    assert a[0].Glosses == b[0].Glosses and a[0].Dlosses == b[0].Dlosses and torch.equal(a[2], b[2])
+    assert a[0].last_G == a[0].Glosses[-1]
+    for (k, x), (_, y) in zip(a[1].state_dict().items(), b[1].state_dict().items()):
+        assert torch.equal(x, y), k
 
 
 # ---------------------------------------------------------------------------------------------
