@@ -61,5 +61,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_stamps(verbose=False):
+    """libgm_hip_stamps.so: the same library with gm_gemm.hip compiled under -DGM_STAMPS (per-wave timeline probe,
+    tools/wave_timeline.py).  Never loaded by the product: the tool points GM_LIB_PATH at it."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.isfile(hipcc):
+        hipcc = "hipcc"
+    out = os.path.join(HERE, "libgm_hip_stamps.so")
+    obj = os.path.join(CSRC, "gm_gemm_stamps.o")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DGM_STAMPS",
+           "-c", os.path.join(CSRC, "gm_gemm.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    others = [os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o") for s in SOURCES[1:]] + \
+        [os.path.join(CSRC, h.rsplit(".", 1)[0] + ".o") for h in HOST_SOURCES]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj] + others + ["-lpthread", "-o", out],
+                   check=True, cwd=CSRC)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

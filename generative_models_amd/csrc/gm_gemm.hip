@@ -40,6 +40,60 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ------------------------------------------------------------------------------------------
+// Per-wave timeline probe (tools/wave_timeline.py -> profiles/r06_*_wave_timeline.md).  ONLY in a build of the library
+// with -DGM_STAMPS (libgm_hip_stamps.so, never the shipped one: GM_STAMP() compiles to nothing otherwise).  Every GEMM
+// launch gets a slot of a device buffer (the host numbers launches in issue order, so the nodes of a captured graph
+// keep theirs across replays); thread 0 of EVERY workgroup folds its entry / exit time into the slot header (min / max
+// of the 100 MHz wall clock: launch-to-launch gaps), and lane 0 of every wave of ONE workgroup (the probe tile) records
+// (shader cycle counter, wall clock) at the marked points of the kernel body.
+// ------------------------------------------------------------------------------------------
+#ifdef GM_STAMPS
+namespace gm_stamps {
+constexpr int WAVES = 16, IDS = 40, HDR = 8, MAXB = 512, SLOT_WORDS = HDR + 2 * MAXB + WAVES * IDS * 2, SLOTS = 64;
+// host side: where the slots live and which tile stamps; they travel to the kernels INSIDE GemmP (scalar registers: a
+// first version read two device globals per stamp -- a memory round trip in every wave of every workgroup -- and folded
+// the launch's entry / exit times with atomics on one address: the step under the probe took 127 us instead of 68)
+static unsigned long long* host_buf = nullptr;
+static int host_tile = 0, host_next = 0;
+struct Ctx { unsigned long long* slot; int tile; };
+__device__ __forceinline__ void rec(const Ctx& c, int tile, int id) {
+    if (!c.slot || tile != c.tile || (threadIdx.x & 63)) return;
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long* w = c.slot + HDR + 2 * MAXB + ((threadIdx.x >> 6) * IDS + id) * 2;
+    w[0] = clock64(); w[1] = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+}
+// every workgroup: its own entry / exit word (no atomics, nothing waits for the store)
+__device__ __forceinline__ void edge(const Ctx& c, bool exit_, int tile, int M, int N, int K, int mode) {
+    if (!c.slot || threadIdx.x) return;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (blk < MAXB) c.slot[HDR + 2 * blk + (exit_ ? 1 : 0)] = wall_clock64();
+    if (!exit_ && tile == 0) {                                // (a rider launch's workgroup 0 is not a GEMM tile)
+        c.slot[0] = 1; c.slot[2] = (unsigned long long)gridDim.x * gridDim.y; c.slot[3] = M; c.slot[4] = N; c.slot[5] = K;
+        c.slot[6] = mode; c.slot[7] = blockDim.x;
+    }
+}
+}  // namespace gm_stamps
+#define GM_STAMP(ctx, tile, id) gm_stamps::rec((ctx), (tile), (id))
+#define GM_STAMP_EDGE(p, exit_, tile, mode) gm_stamps::edge((p).stamp, (exit_), (tile), (p).M, (p).N, (p).K, (mode))
+// keeps the stamp behind the instructions that produce `v` (the wait for an operand, the last MFMA of a chunk)
+#define GM_STAMP_AFTER(v) asm volatile("" ::"v"(v))
+extern "C" int gm_stamps_set(unsigned long long* dev_buf, int probe_tile) {
+    gm_stamps::host_buf = dev_buf; gm_stamps::host_tile = probe_tile; gm_stamps::host_next = 0;
+    return 0;
+}
+extern "C" int gm_stamps_layout(int* out6) {
+    out6[0] = gm_stamps::WAVES; out6[1] = gm_stamps::IDS; out6[2] = gm_stamps::HDR; out6[3] = gm_stamps::SLOT_WORDS;
+    out6[4] = gm_stamps::SLOTS; out6[5] = gm_stamps::MAXB;
+    return 0;
+}
+#else
+#define GM_STAMP(slot, tile, id) do {} while (0)
+#define GM_STAMP_EDGE(p, exit_, tile, mode) do {} while (0)
+#define GM_STAMP_AFTER(v) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int TM = 32, TN = 32;
@@ -96,6 +150,9 @@ struct GemmP {
     // pk_rows % 32 == 0: a forward tile / a 16-row reduction chunk is packed or fp32 as a whole, and each kind gets its own
     // branch-free loop (selecting per fragment inside one loop made hipcc serialise the loads behind s_waitcnt vmcnt(0)).
     const uint32_t* pk_bits; int pk_wpr; int pk_rows;
+#ifdef GM_STAMPS
+    gm_stamps::Ctx stamp;     // timeline probe build only
+#endif
 };
 
 // elements e .. e+3 (e % 4 == 0) of a packed row from the word that holds them; expanded where the fragment is consumed
@@ -459,6 +516,11 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
+#ifdef GM_STAMPS
+    const gm_stamps::Ctx st_slot = p.stamp; const int st_tile = (int)blockIdx.x;
+#endif
+    GM_STAMP_EDGE(p, false, st_tile, MODE + 10);
+    GM_STAMP(st_slot, st_tile, 0);                            // entry
 
     constexpr int KQ = BK / 4;                                    // 16-byte units per k-contiguous row
     constexpr int XQ = BN / 4;                                    // 16-byte units per x-contiguous row
@@ -579,6 +641,7 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
         __builtin_amdgcn_sched_barrier(0);                                         \
         __syncthreads();                                                           \
         __builtin_amdgcn_sched_barrier(0);                                         \
+        if ((s_) < 30) GM_STAMP(st_slot, st_tile, 3 + (s_));                       \
     }
 
     const int S = (p.K + BK - 1) / BK;
@@ -588,8 +651,11 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
     GM_LDS_LSTORE(1 % PD, 1, 1)
 #pragma unroll
     for (int q = 2; q < PD + 2; ++q) { GM_LDS_GLOAD(q % PD, q) }
+    GM_STAMP(st_slot, st_tile, 1);                            // two stages stored (their loads had landed), PD more requested
     __syncthreads();
     GM_LDS_FRAGS(0, 0)
+    GM_STAMP_AFTER(fa[0][0][0].x);
+    GM_STAMP(st_slot, st_tile, 2);                            // first fragments in registers: the pipeline starts
     if constexpr (NS > 0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) GM_LDS_STAGE(s, s % PD, s & 1)
@@ -623,6 +689,7 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
                 lds[(wk * BM + wm * WTM + ti * 32 + row) * BN + wn * WTN + tj * 32 + r] = v;
             }
     __syncthreads();
+    GM_STAMP(st_slot, st_tile, 36);                           // partial tiles of the WK groups in LDS
     if (p.vec_epi && !(MODE == MODE_DX && p.rp_dml)) {          // kernel-argument uniform: float4 groups (see store4)
         for (int e = t; e < BM * (BN / 4); e += NT) {
             const int row = e / (BN / 4), c4 = e % (BN / 4);
@@ -635,6 +702,8 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
             const int m = m0 + row, n = n0 + 4 * c4;
             if (m < p.M && n < p.N) store_group<MODE>(p, v, m, n, 0x7fffffff);
         }
+        GM_STAMP(st_slot, st_tile, 37);                       // epilogue stores issued
+        GM_STAMP_EDGE(p, true, st_tile, MODE + 10);
         return;
     }
     for (int e = t; e < BM * BN; e += NT) {
@@ -695,6 +764,10 @@ int lds_cfg_for(const GemmP& p, bool vec, bool xv) {
 
 template <int MODE>
 int launch_lds(hipStream_t s, const GemmP& p, int cfg) {
+    // (round 6, profiles/r06_experiments.md section 3: BK = 64 (13 barriers instead of 25), 2 x 2 waves x 2 k-groups (half the
+    // partial tiles in the epilogue) and 2 register stages instead of 4 all measured level or slower than this --
+    // 20.0 / 19.9 / 20.0 against 19.7 us on 2048 x 784 -> 400: the stages run at 1 150 - 1 210 cycles against 1 024 of
+    // MFMA issue, what the launch loses it loses to tile quantisation, profiles/r06_ns_b1024_wave_timeline.md)
     if (cfg == 1) return launch_lds_cfg<MODE, 64, 64, 32, 64, 4, 1, 4>(s, p);
     return launch_lds_cfg<MODE, 32, 64, 32, 32, 4, 1, 4>(s, p);
 }
@@ -808,6 +881,10 @@ __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f3
                 img[row * CT + col] = acc[e][f][r];
             }
     __syncthreads();
+#ifdef GM_STAMPS
+    const int st_tile = (m0 / RT) * (int)gridDim.x + n0 / CT;
+#endif
+    GM_STAMP(p.stamp, st_tile, 10);                      // partial tiles of all waves in LDS
     if (t >= G) return;
     const int row = t / (CT / 2), c2 = t % (CT / 2);
     float2 v = make_float2(0.f, 0.f);
@@ -816,6 +893,8 @@ __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f3
         const float2 x = *reinterpret_cast<const float2*>(&red[ww * IMG + row * CT + 2 * c2]);
         v.x += x.x; v.y += x.y;
     }
+    GM_STAMP_AFTER(v.x);
+    GM_STAMP(p.stamp, st_tile, 11);                      // sixteen images summed; the epilogue's round trips follow
     const int m = m0 + row, n = n0 + 2 * c2;
     if (m >= p.M) return;
     if (n + 1 < p.n_real) { store2_dw(p, v, m, n); return; }
@@ -1016,6 +1095,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     const int lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
     const int m0 = by * (16 * MI), n0 = bx * (16 * NI);
+#ifdef GM_STAMPS
+    const gm_stamps::Ctx st_slot = p.stamp; const int st_tile = by * (int)gridDim.x + bx;
+#endif
+    GM_STAMP_EDGE(p, false, st_tile, MODE);
+    GM_STAMP(st_slot, st_tile, 0);                            // entry
 
     const float* A = p.A + gm_slot_offset(p.a_slot);
     const float* B = p.B + gm_slot_offset(p.b_slot);
@@ -1085,6 +1169,8 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         for (int mi = 0; mi < MI; ++mi) fa[mi] = fix_a(ra[mi], cq, mi, wk);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ni] = fix_b(rb[ni], cq, ni);
+        GM_STAMP_AFTER(fa[MI - 1].x); GM_STAMP_AFTER(fb[NI - 1].x);
+        if (q < 4) GM_STAMP(st_slot, st_tile, 1 + 2 * q);     // chunk q: operands landed and fixed up, MFMAs start
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1096,6 +1182,8 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi].w, fb[ni].w, c4, 0, 0, 0);
                 acc[mi][ni] = c4;
             }
+        GM_STAMP_AFTER(acc[MI - 1][NI - 1][0]);
+        if (q < 4) GM_STAMP(st_slot, st_tile, 2 + 2 * q);     // chunk q: last MFMA retired
     };
     auto load_wk = [&](int cc) -> float4 {                    // FOLD == 2: w2 of the chunk's four reduction columns
         if constexpr (FOLD == 2) return *reinterpret_cast<const float4*>(p.fold_w2 + min(16 * cc + 4 * g4, p.K - 4));
@@ -1191,6 +1279,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             wk = load_wk(w);
         }
         fold_prologue();
+        GM_STAMP(st_slot, st_tile, 13);                       // folded head: dS of every reduction row rebuilt in LDS
         if (have) consume(ra, rb, wk, 0);
         q_first = 1;
     }
@@ -1205,9 +1294,12 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         consume(ra, rb, wk, q);
     }
     }
+    GM_STAMP(st_slot, st_tile, 9);                            // reduction loop done (this wave)
     if constexpr (MODE == MODE_DW && WAVES == 16 && MI * NI > 4) {
         if (p.vec_epi) {                                     // kernel-argument uniform
             dw_reduce_onepass<MI, NI, false, XMAP_A>(p, red, acc, m0, n0, false);
+            GM_STAMP(st_slot, st_tile, 12);                   // epilogue stores issued
+            GM_STAMP_EDGE(p, true, st_tile, MODE);
             return;
         }
     }
@@ -1236,10 +1328,13 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 }
             }
             __syncthreads();
+            if (bm + bn == 0) GM_STAMP(st_slot, st_tile, 10); // partial tiles of all waves in LDS (first block)
             reduce_and_store<MODE, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bn,
                                                               (2 * bn + 1 < NI) ? 0x7fffffff : n0 + 32 * bn + 16,
                                                               (2 * bm + 1 < MI) ? 32 : 16);
         }
+    GM_STAMP(st_slot, st_tile, 12);                           // epilogue stores issued
+    GM_STAMP_EDGE(p, true, st_tile, MODE);
 }
 
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool DMA = false>
@@ -1430,6 +1525,11 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     const bool folded = head && head->fold.enabled;
     GemmP p = p_in;
     p.vec_epi = vec_epi_ok<MODE>(p);
+#ifdef GM_STAMPS
+    p.stamp.slot = gm_stamps::host_buf ? gm_stamps::host_buf + (size_t)(gm_stamps::host_next++ % gm_stamps::SLOTS) * gm_stamps::SLOT_WORDS
+                                       : nullptr;
+    p.stamp.tile = gm_stamps::host_tile;
+#endif
     const bool xv = xvec && MODE != MODE_FWD;
     // weight gradients over >= GM_DW_DMA_MIN_K rows on 16-byte aligned operands: chunks by LDS-DMA (gemm16_dw_dma).
     // Measured (profiles/r04_experiments.md): 2048 rows 26.0 -> 24.2 us, 1024 rows 15.3 -> 15.2, 768 rows 12.2 -> 11.9;

@@ -311,8 +311,43 @@ def gen_round3():
                                        torch=torch.__version__))
 
 
+def gen_round6():
+    """Round-6 fixtures (VERDICT r5 "missing" 3): 50-step FREE-RUNNING curves of the unmodified reference for the
+    BASELINE configs that only had 12 - 16 steps -- WGAN-GP B = 256 D_steps = 1 (w_gp_gan.py:96-175), LSGAN and NSGAN
+    B = 1024 (ls_gan.py:95-171, ns_gan.py:94-170) -- and ONE FULL VAE EPOCH at B = 512 over 50 000 images: 97 full
+    batches + the ragged 336 + the validation pass (vae.py:127-191), the epoch bench.py times."""
+    for variant, batch, kw in (("wgp", 256, dict(num_epochs=1, D_steps=1)), ("ls", 1024, dict(num_epochs=1)),
+                               ("ns", 1024, dict(num_epochs=1))):
+        tr, model = run_reference(variant, FULL, batch, kw, steps_cap=50)
+        arrays = {"Glosses": np.array(tr.Glosses), "Dlosses": np.array(tr.Dlosses)}
+        for k, v in model.state_dict().items():
+            arrays["digest:" + k] = digest(v)
+        save("%s_full_b%d_50steps" % (variant, batch), arrays,
+             dict(variant=variant, cfg=FULL, batch=batch, steps=50, train_kw=kw, rng=rng_digest(),
+                  torch=torch.__version__))
+    mod = ref_harness.load("vae")
+    loaders = ref_harness.synthetic_loaders(512, n_train=50000, n_val=FULL["n_val"], n_test=FULL["n_test"],
+                                            image_shape=FULL["image_shape"])
+    torch.manual_seed(1234)
+    model = mod.VAE(image_size=784, hidden_dim=400, z_dim=20)
+    tr = mod.VAETrainer(model, *loaders, viz=False)
+    with ref_harness.quiet():
+        tr.train(num_epochs=1)
+    assert len(tr.recon_loss) == 98
+    arrays = {"recon_loss": np.array(tr.recon_loss), "kl_loss": np.array(tr.kl_loss),
+              "best_val_loss": np.array(tr.best_val_loss)}
+    for k, v in model.state_dict().items():
+        arrays["digest:" + k] = digest(v)
+    save("vae_full_b512_epoch98", arrays, dict(variant="vae", cfg=FULL, batch=512, steps=98, n_train=50000,
+                                               train_kw=dict(num_epochs=1), rng=rng_digest(),
+                                               torch=torch.__version__))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["round3"]:
+    if sys.argv[1:] == ["round6"]:
+        torch.set_num_threads(1)
+        gen_round6()
+    elif sys.argv[1:] == ["round3"]:
         torch.set_num_threads(1)
         gen_round3()
     elif sys.argv[1:] == ["vae_viz"]:
@@ -329,3 +364,4 @@ if __name__ == "__main__":
         gen_bir()
         gen_round2()
         gen_round3()
+        gen_round6()

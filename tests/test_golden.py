@@ -23,7 +23,8 @@ def load(name):
 
 SMALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_small.npz"))
                if not os.path.basename(p).startswith(("vae", "ae_", "bir_")))
-FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256", "ns_full_b256_50steps", "ns_full_b1024"]
+FULL = ["ns_full_b256", "ls_full_b1024", "wgp_full_b256", "ns_full_b256_50steps", "ns_full_b1024",
+        "wgp_full_b256_50steps", "ls_full_b1024_50steps", "ns_full_b1024_50steps"]
 
 
 def run_port_gan(meta, batch, max_steps=None):
@@ -33,14 +34,22 @@ def run_port_gan(meta, batch, max_steps=None):
     model = port.build(meta["variant"], cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
     kw = dict(meta["train_kw"])
     method = kw.pop("method", "jensen_shannon")
-    tr = port.GANPort(meta["variant"], model, loaders[0], method=method)
+    train_iter = loaders[0]
+    if max_steps is not None and max_steps > len(train_iter):
+        # the fixture was cut with a DataLoader whose __len__ reports `steps` (oracle/gen_golden.py run_reference): more
+        # steps than the real epoch holds (B = 1024: 49) need the same here
+        class Capped(torch.utils.data.DataLoader):
+            def __len__(self):
+                return max_steps
+        train_iter = Capped(train_iter.dataset, batch_size=batch, shuffle=True)
+    tr = port.GANPort(meta["variant"], model, train_iter, method=method)
     tr.train(max_steps=max_steps, **kw)
     return tr, model
 
 
 def test_fixture_inventory():
     assert len(SMALL) == 16, SMALL          # 10 variants + 6 f-divergences
-    for n in FULL + ["vae_small", "vae_full_b512", "vae_full_b512_ragged", "ae_small", "ae_full_b512",
+    for n in FULL + ["vae_small", "vae_full_b512", "vae_full_b512_ragged", "vae_full_b512_epoch98", "ae_small", "ae_full_b512",
                      "bir_small", "bir_full_b256"]:
         assert os.path.isfile(os.path.join(GOLDEN, n + ".npz")), n
 
@@ -63,7 +72,16 @@ def test_gan_small(name):
 @pytest.mark.parametrize("name", FULL)
 def test_gan_full(name):
     z, meta = load(name)
-    tr, model = run_port_gan(meta, meta["batch"], max_steps=meta["steps"])
+    threads = torch.get_num_threads()
+    if meta["steps"] > 24:
+        # 50-step free-running curves: beyond ~24 steps two CPU thread counts of the SAME code drift apart chaotically
+        # (1.6e-5 between 1 and 8 threads of the reference itself); the fixtures were generated
+        # with one thread (oracle/gen_golden.py), so the port is run with one
+        torch.set_num_threads(1)
+    try:
+        tr, model = run_port_gan(meta, meta["batch"], max_steps=meta["steps"])
+    finally:
+        torch.set_num_threads(threads)
     np.testing.assert_allclose(np.array(tr.Glosses), z["Glosses"], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(np.array(tr.Dlosses), z["Dlosses"], rtol=RTOL, atol=ATOL)
     from oracle.gen_golden import digest
@@ -71,7 +89,7 @@ def test_gan_full(name):
         np.testing.assert_allclose(digest(v), z["digest:" + k], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged", "vae_full_b512_epoch98"])
 def test_vae(name):
     z, meta = load(name)
     cfg = meta["cfg"]

@@ -349,6 +349,35 @@ def test_two_train_calls_reset_adam():
     assert tr.num_epochs == 2
 
 
+# largest relative loss deviation over all 50 free-running steps, measured on the MI355X (profiles/r06_parity_50step.json)
+LONG_MEASURED = {"ns_full_b256_50steps": 1.9e-7, "ls_full_b1024_50steps": 3.6e-7, "ns_full_b1024_50steps": 5.2e-6}
+
+
+def _oracle_min_hidden_preact(variant, meta):
+    """Per D+G step of the ORACLE'S free run of a fixture's configuration: the smallest |hidden pre-activation| its
+    critic forms in that step (D on x, G(z), x_hat in the critic step; D on G(z) in the generator step)."""
+    cfg, steps, batch = meta["cfg"], meta["steps"], meta["batch"]
+    rng = torch.get_rng_state()
+
+    class Capped(torch.utils.data.DataLoader):
+        def __len__(self):
+            return steps
+    ld = port.synthetic_loaders(batch, n_train=cfg["n_train"], n_val=cfg["n_val"], n_test=cfg["n_test"],
+                                image_shape=tuple(cfg["image_shape"]))
+    o_model = port.build(variant, cfg["image_size"], cfg["hidden_dim"], cfg["z_dim"])
+    cur, per_step = [], []
+    o_model.D.linear.register_forward_hook(lambda m_, i_, out: cur.append(float(out.detach().abs().min())))
+
+    def tap(kind, tr_, info):
+        if kind == "G":
+            per_step.append(min(cur))
+            cur.clear()
+    o = port.GANPort(variant, o_model, Capped(ld[0].dataset, batch_size=batch, shuffle=True), tap=tap)
+    o.train(**meta["train_kw"])
+    torch.set_rng_state(rng)
+    return per_step
+
+
 @pytest.mark.parametrize("name", sorted(
     os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
     if os.path.basename(p).split("_")[0] in ("ns", "mm", "w", "wgp", "ls", "ra", "fisher", "f",
@@ -380,23 +409,42 @@ def test_engine_vs_reference_golden(name):
     import hashlib
     assert hashlib.sha256(p_rng.numpy().tobytes()).hexdigest() == meta["rng"], "RNG stream position"
     if name.endswith("50steps"):
-        # 50-step FREE-RUNNING NSGAN B=256 curve.  Two fp32 summation orders of the
-        # same math drift apart chaotically on this horizon (survey probe: 1.6e-5 between 1 and 8
-        # CPU threads of the reference itself), so the bound here is stated, not the 1e-5 of the
-        # short horizons on paper; the measured value is written to gpurun_out/parity_50step.json,
-        # quoted in DESIGN.md and asserted below with a 10x margin.
+        # 50-step FREE-RUNNING curves (NSGAN B=256; round 6: WGAN-GP B=256, LSGAN / NSGAN B=1024).  Two
+        # fp32 summation orders of the same math drift apart chaotically on this horizon (survey probe: 1.6e-5 between 1
+        # and 8 CPU threads of the reference itself), so: north_star's 1e-5 over the first 24 steps, and over all 50 the
+        # MEASURED deviation of each fixture with a 10x margin (LONG_MEASURED; floor 2e-6) -- the measured values are
+        # written to gpurun_out/parity_50step.json and quoted in DESIGN.md.
         g, d = np.asarray(p_tr.Glosses), np.asarray(p_tr.Dlosses)
         eg = np.abs(g - z["Glosses"]) / np.maximum(1, np.abs(z["Glosses"]))
         ed = np.abs(d - z["Dlosses"]) / np.maximum(1, np.abs(z["Dlosses"]))
         out = os.path.join(os.path.dirname(HERE), "gpurun_out")
         if os.path.isdir(out):
-            json.dump({"max_rel_err_G_50": float(eg.max()), "max_rel_err_D_50": float(ed.max()),
-                       "max_rel_err_G_24": float(eg[:24].max()), "max_rel_err_D_24": float(ed[:24].max())},
-                      open(os.path.join(out, "parity_50step.json"), "w"))
-        assert max(eg[:24].max(), ed[:24].max()) <= TOL, (eg[:24].max(), ed[:24].max())
-        # the MEASURED margin is asserted, not the loose bound: 1.9e-7 in round 2's kernels; 2e-6 leaves
-        # room for a different summation order (e.g. the folded head's) without hiding a real defect
-        assert max(eg.max(), ed.max()) <= 2e-6, (eg.max(), ed.max())
+            path = os.path.join(out, "parity_50step.json")
+            rec = json.load(open(path)) if os.path.isfile(path) else {}
+            rec[name] = {"max_rel_err_G_50": float(eg.max()), "max_rel_err_D_50": float(ed.max()),
+                         "max_rel_err_G_24": float(eg[:24].max()), "max_rel_err_D_24": float(ed[:24].max()),
+                         "max_rel_err_G_40": float(eg[:40].max()), "max_rel_err_D_40": float(ed[:40].max()),
+                         "rel_err_G": [float("%.3g" % x) for x in eg], "rel_err_D": [float("%.3g" % x) for x in ed]}
+            json.dump(rec, open(path, "w"), indent=1)
+        if variant == "wgp":
+            # WGAN-GP's critic loss is a DISCONTINUOUS function of the hidden pre-activations: the penalty's gradient norm
+            # ||sum_u [pre_u > 0] w2_u W1[u, :]|| (w_gp_gan.py:207-214) jumps when a unit of ONE sample changes sides, and
+            # the loss with it by 10 / B * delta((n - 1)^2) ~ 1e-4 -- in THAT step only; the trajectory is unaffected to
+            # first order (the generator's losses stay within 4e-6 over all 50 steps).  Measured: isolated single-step
+            # spikes at steps 22 / 30 / 37 (2.2e-5 / 1.5e-5 / 1.9e-5), every other step of the 50 below 1e-5.  Asserted:
+            # every spike is isolated (the next step is back under 1e-5), below 1e-4, happens where the ORACLE'S OWN
+            # critic has a hidden pre-activation within 2e-6 of the kink in that step (the two trajectories are ~1e-6
+            # apart by then), and there are at most 5 of them; everything else holds north_star's 1e-5 over all 50 steps.
+            kink = _oracle_min_hidden_preact("wgp", meta)
+            spikes = [i for i in range(len(ed)) if ed[i] > TOL]
+            assert eg.max() <= TOL, eg.max()
+            assert len(spikes) <= 5, spikes
+            for i in spikes:
+                assert ed[i] <= 1e-4 and kink[i] <= 2e-6, (i, ed[i], kink[i])
+                assert i + 1 >= len(ed) or ed[i + 1] <= TOL, (i, ed[i], ed[i + 1])
+        else:
+            assert max(eg[:24].max(), ed[:24].max()) <= TOL, (eg[:24].max(), ed[:24].max())
+            assert max(eg.max(), ed.max()) <= max(10 * LONG_MEASURED[name], 2e-6), (eg.max(), ed.max())
     else:
         lclose(p_tr.Glosses, z["Glosses"], name + " Glosses")
         lclose(p_tr.Dlosses, z["Dlosses"], name + " Dlosses")
@@ -642,9 +690,11 @@ def test_vae_engine_vs_oracle(cfg, n_train):
         assert (a.cpu() - b).abs().max().item() <= 5e-5, k
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_full_b512", "vae_full_b512_ragged", "vae_full_b512_epoch98"])
 def test_vae_engine_vs_reference_golden(name):
-    """vae_full_b512_ragged: 3 full batches of 512 + the ragged 336 (= 50 000 mod 512), 2 epochs."""
+    """vae_full_b512_ragged: 3 full batches of 512 + the ragged 336 (= 50 000 mod 512), 2 epochs.
+    vae_full_b512_epoch98 (round 6): ONE WHOLE EPOCH of the unmodified reference over 50 000 images -- 97 batches of 512,
+    the ragged 336 and the validation pass (vae.py:127-191): the epoch bench.py times, every batch's losses at 1e-5."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     cfg = meta["cfg"]
@@ -659,6 +709,13 @@ def test_vae_engine_vs_reference_golden(name):
     ref, got = z["kl_loss"], np.array(p.kl_loss)
     assert np.max(np.abs(got - ref) / np.maximum(1, np.abs(ref))) <= 1e-5, (got[:4], ref[:4])
     assert abs(p.best_val_loss - float(z["best_val_loss"])) <= 1e-5 * abs(float(z["best_val_loss"]))
+    if name.endswith("epoch98"):
+        from oracle.gen_golden import digest
+        _record("vae_epoch98_vs_reference", recon_err=_loss_err(p.recon_loss, z["recon_loss"]),
+                kl_err=_loss_err(p.kl_loss, z["kl_loss"]),
+                best_val_rel_err=abs(p.best_val_loss - float(z["best_val_loss"])) / abs(float(z["best_val_loss"])))
+        for k, v in p_model.state_dict().items():
+            np.testing.assert_allclose(digest(v), z["digest:" + k], rtol=2e-4, atol=2e-4)
 
 
 # ---------------------------------------------------------------------------------------------
