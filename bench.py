@@ -36,7 +36,7 @@ FLOP_PER_IMAGE = 6_326_400        # 10 U GEMMs + small, algorith
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
-LDS_MIN_M = int(os.environ.get("GM_LDS_MIN_M", "1024"))    # csrc/gm_gemm.hip try_launch_lds
+LDS_MIN_M = 1024    # csrc/gm_gemm.hip lds_cfg_for
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
 PROFILE_ROUND = "r05"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
 FOLD_HEAD_DEFAULT = os.environ.get("GM_FOLD_HEAD", "1") != "0"   # engine default (folded critic head)
@@ -150,7 +150,7 @@ def gemm_variant(kind, M, K, N):
                 mi, ni = 3, 2
     b = lambda v: "true" if v else "false"
     # weight gradients over >= 768 rows on 32x48 / 48x32 tiles: the LDS-DMA instantiations (gemm16_dw_dma)
-    dma = mode == 2 and xv and Kr >= int(os.environ.get("GM_DW_DMA_MIN_K", "768")) > 0 and (mi, ni) in ((2, 3), (3, 2))
+    dma = mode == 2 and xv and Kr >= 768 and (mi, ni) in ((2, 3), (3, 2))
     if kind in ("dwh", "dwhf", "dwhs"):
         # last three arguments: ones column with a row offset (WGAN-GP's stacked weight gradient only); folded
         # head; LDS-DMA
@@ -737,7 +737,10 @@ def dp_identity(eng, world):
     mine = {"rank": eng.rank, "device": dp._device_identity() if torch.cuda.is_available() else "cpu",
             "exchange": eng.exchange_form(), "exchange_memory": eng.comm_memory,
             "peer_selfcheck": "refused: %s" % eng.comm_fallback if getattr(eng, "comm_fallback", None)
-            else ("passed" if eng._peer() else "not used")}
+            else ("passed" if eng._peer() else "not used"),
+            # first contact: how long the self-check took under which device-side wait bound, per optimizer bucket
+            "peer_selfcheck_detail": getattr(eng, "comm_selfcheck", None),
+            "fallback": (("rccl_in_graph" if eng._rccl_in_graph() else "rccl (host-launched)") if not eng._peer() else None)}
     if world <= 1 or not torch.distributed.is_initialized():
         return [mine]
     out = [None] * world
@@ -777,8 +780,29 @@ def dp_series(dev, world, rank, ranks_seen, K, W, reps):
                 e["efficiency"] = e["img_s"] / one / world
             entry[kind] = e
             log("%s %s N=%d: %.0f img/s" % (variant, kind, world, e["img_s"]))
+            peer = eng._peer()
             del eng
             fence(world)
+            if kind == "weak" and peer:
+                # the same weak step with the FALLBACK exchange (RCCL all-reduce captured in the graph), side by side in
+                # one invocation: which of the two a node should run is a measurement, not a default
+                prev = os.environ.get("GM_DP_COMM")
+                os.environ["GM_DP_COMM"] = "rccl"
+                try:
+                    eng, secs = bench_gan(variant, Bg, W, K, reps, dev, world=world, rank=rank, lrs=lrs[variant])
+                    dt = float(np.median(secs))
+                    r = {"global_batch": Bg, "img_s": K * Bg / dt, "ms_per_step": dt / K * 1e3, "comm": comm_mode_of(eng)}
+                    if one:
+                        r["efficiency"] = r["img_s"] / one / world
+                    entry["weak_rccl"] = r
+                    log("%s weak (rccl arm) N=%d: %.0f img/s" % (variant, world, r["img_s"]))
+                    del eng
+                finally:
+                    if prev is None:
+                        del os.environ["GM_DP_COMM"]
+                    else:
+                        os.environ["GM_DP_COMM"] = prev
+                fence(world)
         out.append(entry)
     return out
 

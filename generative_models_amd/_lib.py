@@ -219,12 +219,14 @@ _SIGNATURES = {
     "gm_comm_destroy": (c_int, [_P]),
     "gm_comm_error": (c_int, [_P, POINTER(c_int)]),
     "gm_comm_info": (c_int, [_P, POINTER(c_int)]),
+    "gm_rccl_available": (c_int, []),
     "gm_rccl_unique_id": (c_int, [_P]),
     "gm_rccl_comm_create": (c_int, [c_int, c_int, _P, POINTER(c_void_p)]),
     "gm_rccl_allreduce_f32": (c_int, [_P, _P, _P, c_int64]),
     "gm_rccl_comm_destroy": (c_int, [_P]),
     "gm_comm_set_exchange": (c_int, [_P, c_int]),
     "gm_comm_set_max_blocks": (c_int, [_P, c_int]),
+    "gm_comm_set_wait_seconds": (c_int, [_P, ctypes.c_double]),
     "gm_comm_buffer": (c_int, [_P, POINTER(c_void_p), POINTER(c_int64)]),
     "gm_allreduce_f32": (c_int, [_P, _P, _P, c_int64]),
     "gm_allreduce_adam_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, Slot, ctypes.c_double,

@@ -37,12 +37,12 @@ constexpr int64_t FLAG_BYTES = 4096;             // [phase 0..7][source rank] u6
                                                  // exchange's two phases, 2 the scalar exchange, 4 / 5 the push exchange
 constexpr int PUSH_PHASE_A = 4, PUSH_PHASE_B = 5;
 constexpr int64_t SCAL_FLOATS = 64;              // scalar exchange: 2 parities x up to 16 values (+pad)
-constexpr unsigned long long WAIT_TICKS = 10ull * 100000000ull;   // bounded waits: 10 s of the 100 MHz wall clock
+constexpr unsigned long long WAIT_TICKS = 10ull * 100000000ull;   // bounded waits: 10 s of the 100 MHz wall clock (default)
 
 struct Region {            // layout of one rank's exchange region (byte offsets)
     int64_t flags, scal, in, out, stage, stage_stride, total;     // stage: [source rank][slice] of the push exchange
 };
-Region layout(int64_t n_floats) {
+Region layout(int64_t n_floats, int world) {
     Region r;
     const int64_t nb = ((n_floats * 4 + 255) / 256) * 256;
     r.flags = 0;
@@ -50,13 +50,14 @@ Region layout(int64_t n_floats) {
     r.in = r.scal + 2 * SCAL_FLOATS * 4 * MAXW;   // [parity][rank][16 floats]
     r.in = ((r.in + 255) / 256) * 256;
     r.out = r.in + nb;
-    // push exchange: every peer deposits ITS contribution to my slice here (a slice is at most ceil(n4 / W) float4 for
-    // any W <= MAXW: W = 1 needs none, W = 2 the largest -- half the bucket per source, MAXW sources: sized for the
-    // worst case of every world size, 4 * nb bytes would be wasteful: the stride is fixed at nb / 2 rounded up, and
-    // only `world` sources exist: total <= MAXW * nb / 2)
+    // push exchange: every peer deposits ITS contribution to my slice here.  A slice is ceil(n4 / world) float4 and
+    // exactly `world` sources exist, so the area is about one bucket whatever the world size (it used to be
+    // sized MAXW x half a bucket = 4 buckets for every communicator; every rank computes the same layout from the
+    // same (n_floats, world), which gm_comm_connect relies on)
+    const int64_t n4 = (n_floats + 3) / 4;
     r.stage = r.out + nb;
-    r.stage_stride = ((nb / 2 + 16 + 255) / 256) * 256;
-    r.total = r.stage + MAXW * r.stage_stride;
+    r.stage_stride = world > 1 ? ((((n4 + world - 1) / world) * 16 + 16 + 255) / 256) * 256 : 0;
+    r.total = r.stage + (int64_t)world * r.stage_stride;
     return r;
 }
 
@@ -74,6 +75,7 @@ struct Comm {
                                // device), 2 one kernel, PUSH (posted remote writes only): gm_comm_set_exchange
     int coarse;                // 1: the region is plain hipMalloc memory (fine-grained allocation refused)
     int max_blocks;            // workgroups of an exchange launch: what can be co-resident on THIS device (or less)
+    unsigned long long wait_ticks;   // bound of every device-side wait (gm_comm_set_wait_seconds)
 };
 
 struct CommP {
@@ -84,6 +86,7 @@ struct CommP {
     unsigned long long* sseq;
     int* err;
     unsigned* arrive;
+    unsigned long long wait_ticks;
 };
 
 __device__ __forceinline__ unsigned long long* flag_ptr(const CommP& c, int owner, int phase, int src) {
@@ -114,7 +117,7 @@ __device__ void signal_and_wait(const CommP& c, int phase, unsigned long long s)
             while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_SYSTEM) < s) {
                 __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 255u) == 0 && wall_clock64() - t0 > WAIT_TICKS) {
+                if ((++spins & 255u) == 0 && wall_clock64() - t0 > c.wait_ticks) {
                     atomicExch(c.err, 1);
                     dead = true;
                     break;
@@ -215,7 +218,7 @@ __device__ void wait_peers(const CommP& c, int phase, unsigned long long s) {
         unsigned int spins = 0;
         while (__hip_atomic_load(flag_ptr(c, c.rank, phase, peer), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 255u) == 0 && wall_clock64() - t0 > WAIT_TICKS) {
+            if ((++spins & 255u) == 0 && wall_clock64() - t0 > c.wait_ticks) {
                 atomicExch(c.err, 1);
                 dead = true;
                 break;
@@ -423,6 +426,7 @@ CommP params_of(const Comm* cm) {
     CommP p{};
     p.rank = cm->rank; p.world = cm->world; p.lay = cm->lay; p.seq = cm->seq; p.sseq = cm->sseq; p.err = cm->err;
     p.arrive = cm->arrive;
+    p.wait_ticks = cm->wait_ticks ? cm->wait_ticks : WAIT_TICKS;
     for (int i = 0; i < MAXW; ++i) p.base[i] = cm->base[i];
     return p;
 }
@@ -475,7 +479,7 @@ static int comm_create_impl(Comm* cm, void* handle_out64) {
 extern "C" int gm_comm_create(int rank, int world, int64_t n_floats, void** comm_out, void* handle_out64) {
     GM_CHECK_ARG(comm_out && handle_out64 && world >= 1 && world <= MAXW && rank >= 0 && rank < world && n_floats > 0);
     Comm* cm = new Comm();
-    cm->rank = rank; cm->world = world; cm->n_floats = n_floats; cm->lay = layout(n_floats);
+    cm->rank = rank; cm->world = world; cm->n_floats = n_floats; cm->lay = layout(n_floats, world);
     cm->seq = nullptr; cm->sseq = nullptr; cm->err = nullptr; cm->coarse = 0;
     for (int i = 0; i < MAXW; ++i) { cm->base[i] = nullptr; cm->opened[i] = false; }
     const int rc = comm_create_impl(cm, handle_out64);
@@ -549,9 +553,23 @@ static int resident_blocks() {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 64;
+    // the cap must hold for WHICHEVER one-kernel exchange is launched: the smaller of the two occupancies
+    int per_push = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xchg_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_push, push_kernel, 256, 0) != hipSuccess || per_push < 1) per_push = 1;
+    if (per_push < per_cu) per_cu = per_push;
     const long cap = (long)per_cu * pr.multiProcessorCount;
     return (int)(cap < 320 ? (cap < 1 ? 1 : cap) : 320);
+}
+
+// Bound of every device-side wait of this communicator's launches from now on (default 10 s).  First contact between
+// two devices -- the start-up self-check -- runs with a short one: a peer mapping that is not coherent must cost
+// seconds, not minutes, before every rank falls back.
+extern "C" int gm_comm_set_wait_seconds(void* comm, double seconds) {
+    Comm* cm = static_cast<Comm*>(comm);
+    GM_CHECK_ARG(cm && seconds > 0.0 && seconds <= 600.0);
+    cm->wait_ticks = (unsigned long long)(seconds * 1.0e8);
+    return 0;
 }
 
 extern "C" int gm_comm_set_max_blocks(void* comm, int max_blocks) {
@@ -585,11 +603,9 @@ static int allreduce_impl(Comm* cm, hipStream_t s, float* buf, int64_t n, const 
     if (rblocks < 1) rblocks = 1;
     if (reinterpret_cast<char*>(buf) != cm->base[cm->rank] + cm->lay.in)    // the bucket lives elsewhere
         hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n);
-    static int two = -1;                              // GM_DP_TWO_KERNELS=1: round 3's reduce + gather pair everywhere (A/B)
-    if (two < 0) { const char* e = getenv("GM_DP_TWO_KERNELS"); two = e ? atoi(e) : 0; }
     if (cm->two_kernels == 2) {
         hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
-    } else if (two || cm->two_kernels) {
+    } else if (cm->two_kernels) {
         hipLaunchKernelGGL(reduce_kernel, dim3(rblocks), dim3(256), 0, s, p, n);
         hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, p, buf, n, ad);
     } else {
@@ -658,6 +674,15 @@ int nccl_fail(int rc, const char* what) {
     return GM_EINVAL - 100 - rc;
 }
 }  // namespace
+
+// 1 when every RCCL entry point this library calls resolves in this process, else 0 -- asked on EVERY rank before the
+// collective ncclCommInitRank, so that a rank that cannot start makes all ranks fall back instead of leaving the others
+// blocked inside the init.
+extern "C" int gm_rccl_available(void) {
+    for (const char* n : {"ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy"})
+        if (!nccl_sym(n)) return 0;
+    return 1;
+}
 
 extern "C" int gm_rccl_unique_id(void* uid128_out) {
     GM_CHECK_ARG(uid128_out);

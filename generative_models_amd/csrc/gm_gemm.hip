@@ -339,6 +339,17 @@ __device__ __forceinline__ void store_group(const GemmP& p, float4 v, int m, int
     if (n + 3 < p.N && n + 3 < ncap) store_element<MODE>(p, v.w, m, n + 3);
 }
 
+// Index of element (row, col) of wave w's 32 x 32 partial tile in the cross-wave reduction buffer.  Round 6: the column
+// is swizzled by one bit of the row -- col ^ 16 where ((row >> 2) ^ row) is odd.  The MFMA's C layout puts lanes 0..15
+// and 16..31 of a half-wave on rows that are 4 apart (1 apart with the x-contiguous operands' output permutation): 128
+// (32) floats = the same LDS bank, so every ds_write of a partial tile was a 2-way bank conflict with half of the banks
+// idle (SQ_LDS_BANK_CONFLICT = 512 of 554 LDS-active cycles per workgroup, profiles/r05_nsgan_b256_sq_pmc.txt; the stamped
+// timeline shows 0.75 us between the slowest wave's last MFMA and the barrier behind these writes).  Readers take whole
+// rows (32 lanes = 32 columns): any permutation of a row's columns is conflict-free for them.
+__device__ __forceinline__ int red_idx(int w, int row, int col) {
+    return (w * 32 + row) * 32 + (col ^ ((((row >> 2) ^ row) & 1) << 4));
+}
+
 // Sum the per-wave partial tiles (red[w][32][32]) and apply the epilogue of the mode.
 // ncap: columns >= ncap are not this block's to store (the 16-column last block of a 48-wide tile);
 // rcap: rows of the block that belong to the tile (16 for the last block of a 48-row tile)
@@ -356,7 +367,7 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
             float v = 0.f;
             if (live) {
 #pragma unroll
-                for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+                for (int ww = 0; ww < WAVES; ++ww) v += red[red_idx(ww, row, col)];
             }
             const int m = m0 + row, n = n0 + col;
             const bool ok = live && m < p.M && n < p.N && n < ncap;
@@ -388,7 +399,7 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
             float v = 0.f;
             if (live) {
 #pragma unroll
-                for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+                for (int ww = 0; ww < WAVES; ++ww) v += red[red_idx(ww, row, col)];
             }
             const int m = m0 + row, n = n0 + col;
             const bool ok = live && m < p.M && n < p.N && n < ncap;
@@ -417,7 +428,7 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
         if ((ROWS < 32 && row >= ROWS) || row >= rcap) continue;   // 16-row tiles / blocks: half the threads idle
         float v = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) v += red[(ww * 32 + row) * 32 + col];
+        for (int ww = 0; ww < WAVES; ++ww) v += red[red_idx(ww, row, col)];
         const int m = m0 + row, n = n0 + col;
         if (m >= p.M || n >= p.N || n >= ncap) continue;
         store_element<MODE>(p, v, m, n);
@@ -444,6 +455,11 @@ __device__ __forceinline__ void reduce_and_store(const GemmP& p, const float* re
 //     gets the contiguous m-tiles [x*mpx, (x+1)*mpx): its private L2 holds 1/8 of A plus B instead
 //     of both in full.
 // ------------------------------------------------------------------------------------------
+// (Round 6, kernel entry: the rider launches take 0.9 - 1.9 KB of arguments, loaded in four or five groups each behind
+// an s_waitcnt lgkmcnt(0); the stamped timelines show 1.5 - 2.2 us between a wave's entry and its first operand load
+// there.  One burst of scalar loads over the whole argument block at the top of every kernel -- so that the later groups
+// hit the scalar cache -- measured SLOWER: step 68.3 -> 69.4 us, every launch +0.1 .. 0.3 us; the groups already hit.
+// profiles/r06_experiments.md section 4.)
 __device__ __forceinline__ float4 keep4(bool ok, float4 v) {      // componentwise: stays in registers
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
@@ -756,8 +772,7 @@ int launch_lds_cfg(hipStream_t s, GemmP p) {
 template <int MODE>
 int lds_cfg_for(const GemmP& p, bool vec, bool xv) {
     static_assert(MODE != MODE_DW, "forward and input gradient only");
-    static int min_m = -1;
-    if (min_m < 0) { const char* e = getenv("GM_LDS_MIN_M"); min_m = e ? atoi(e) : 1024; }
+    constexpr int min_m = 1024;                              // (ops.lds_min_m() mirrors it on the host side)
     if (p.M < min_m || p.K < 64 || !vec || (MODE == MODE_DX && !xv) || p.N < 32) return 0;
     return lds_pick_cfg(p.M, p.N);
 }
@@ -864,6 +879,7 @@ template <int MI, int NI, bool ILO, bool XMAP = false>
 __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f32x4 (&acc)[MI][NI], int m0, int n0,
                                                   bool sync_first) {
     constexpr int RT = 16 * MI, CT = 16 * NI, IMG = RT * CT, G = IMG / 2;
+    constexpr bool SWZ = !ILO && XMAP && (CT % 32 == 0);
     static_assert(G <= 1024, "one pair of columns per thread");
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -878,7 +894,9 @@ __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f3
                 // XMAP: the coalesced x-contiguous loads leave output index sigma16(.) of each 16-wide sub-tile in a lane
                 const int row = ILO ? MI * (4 * g4 + r) + e : 16 * e + (XMAP ? sigma16(4 * g4 + r) : 4 * g4 + r);
                 const int col = ILO ? NI * i16 + f : 16 * f + (XMAP ? sigma16(i16) : i16);
-                img[row * CT + col] = acc[e][f][r];
+                // SWZ (images whose rows are a whole number of 32-bank turns, e.g. the generator's 48 x 32 tiles): the two
+                // lane groups of a half-wave sit on neighbouring rows = the same banks; flip column bit 4 on odd rows
+                img[row * CT + (SWZ ? col ^ ((row & 1) << 4) : col)] = acc[e][f][r];
             }
     __syncthreads();
 #ifdef GM_STAMPS
@@ -890,7 +908,7 @@ __device__ __forceinline__ void dw_reduce_onepass(const GemmP& p, float* red, f3
     float2 v = make_float2(0.f, 0.f);
 #pragma unroll
     for (int ww = 0; ww < 16; ++ww) {
-        const float2 x = *reinterpret_cast<const float2*>(&red[ww * IMG + row * CT + 2 * c2]);
+        const float2 x = *reinterpret_cast<const float2*>(&red[ww * IMG + row * CT + (SWZ ? (2 * c2) ^ ((row & 1) << 4) : 2 * c2)]);
         v.x += x.x; v.y += x.y;
     }
     GM_STAMP_AFTER(v.x);
@@ -930,7 +948,7 @@ __device__ __forceinline__ void dw_il_reduce(const GemmP& p, float* red, f32x4 (
                     for (int r = 0; r < 4; ++r) {
                         const int row = MI * (4 * g4 + r) + e, col = NI * i16 + f;
                         if ((row >> 5) == bm && (col >> 5) == bnk)
-                            red[(w * 32 + (row & 31)) * 32 + (col & 31)] = acc[e][f][r];
+                            red[red_idx(w, row & 31, col & 31)] = acc[e][f][r];
                     }
             __syncthreads();
             reduce_and_store<MODE_DW, WAVES, (MI > 1 ? 32 : 16)>(p, red, t, m0 + 32 * bm, n0 + 32 * bnk,
@@ -1198,7 +1216,22 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 FoldTP tp_unused;
                 fold_fill_lds_tp(*fold, sds, fold->R, tp_unused);
             } else {
+#ifdef GM_STAMPS
+                {                                             // fold_fill_lds, with the probe's stamps inside
+                    for (int r = threadIdx.x; r < fold->R; r += blockDim.x) {
+                        float s_ = fold_score(*fold, r);
+                        GM_STAMP_AFTER(s_);
+                        if (r == (int)threadIdx.x) GM_STAMP(st_slot, st_tile, 14);   // this wave's partial dots have landed
+                        float ds_, l_;
+                        fold_row(*fold, r, s_, ds_, l_);
+                        sds[r] = ds_;
+                    }
+                    GM_STAMP(st_slot, st_tile, 15);           // rows done (waves without rows: at once), barrier next
+                    __syncthreads();
+                }
+#else
                 fold_fill_lds(*fold, sds, fold->R);           // every reduction row (ends with the barrier)
+#endif
             }
         } else if constexpr (FOLD == 2) {
             if (t < 16 * MI) {                                // the tile's own rows
@@ -1206,6 +1239,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
                 fold_row(*fold, min(m0 + t, fold->R - 1), s_, ds_, l_);
                 sds[t] = ds_;
             }
+            GM_STAMP(st_slot, st_tile, 15);
             __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fds[mi] = sds[16 * mi + i16];     // dS of this lane's A rows
@@ -1317,14 +1351,14 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             for (int rgi = 0; rgi < 4; ++rgi) {
                 // (XMAP: rows follow the A operand's lane -> output map, columns the B operand's)
                 const int row = XMAP_A ? sigma16(g4 * 4 + rgi) : g4 * 4 + rgi;
-                red[(w * 32 + row) * 32 + ib] = acc[2 * bm][2 * bn][rgi];
-                if (2 * bn + 1 < NI) red[(w * 32 + row) * 32 + 16 + ib] = acc[2 * bm][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
+                red[red_idx(w, row, ib)] = acc[2 * bm][2 * bn][rgi];
+                if (2 * bn + 1 < NI) red[red_idx(w, row, 16 + ib)] = acc[2 * bm][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
                 if (2 * bm + 1 < MI) {
                     constexpr int MIX = MI > 1 ? MI - 1 : 0;             // (keeps the index in range for MI == 1)
                     const int mu = (2 * bm + 1 < MI) ? 2 * bm + 1 : MIX;
-                    red[(w * 32 + 16 + row) * 32 + ib] = acc[mu][2 * bn][rgi];
+                    red[red_idx(w, 16 + row, ib)] = acc[mu][2 * bn][rgi];
                     if (2 * bn + 1 < NI)
-                        red[(w * 32 + 16 + row) * 32 + 16 + ib] = acc[mu][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
+                        red[red_idx(w, 16 + row, 16 + ib)] = acc[mu][(2 * bn + 1 < NI) ? 2 * bn + 1 : 0][rgi];
                 }
             }
             __syncthreads();
@@ -1448,12 +1482,10 @@ __global__ __launch_bounds__(1024) void gemm16_dw_pair_fin_kernel(GemmP pa, Gemm
 }
 
 // May the epilogue move whole float4s (store4)?  Every array it touches 16-byte aligned, leading dimensions in
-// whole float4s.  GM_VEC_EPI=0: element-wise epilogues everywhere (round 3).
+// whole float4s.
 template <int MODE>
 int vec_epi_ok(const GemmP& p) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("GM_VEC_EPI"); on = e ? atoi(e) : 1; }
-    if (!on || !aligned16(p.C) || p.ldc % 4 != 0) return 0;
+    if (!aligned16(p.C) || p.ldc % 4 != 0) return 0;
     if (MODE == MODE_FWD) {
         if (p.bias && !aligned16(p.bias)) return 0;
         if (p.ip_out && !(aligned16(p.ip_out) && aligned16(p.ip_x) && p.ip_ldo % 4 == 0 && p.ip_ldx % 4 == 0)) return 0;
@@ -1536,9 +1568,8 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     // below that the extra hop through LDS costs more than the load instructions it saves (512 rows 9.0 -> 9.2, 256
     // rows 6.3 -> 7.0): the 16-byte + quad-transpose form keeps the short reductions.  (32-bit element offsets.)
     auto dma_ok = [&](const GemmP& q, bool qxv) {
-        static int dma_min_k = -1;
-        if (dma_min_k < 0) { const char* e = getenv("GM_DW_DMA_MIN_K"); dma_min_k = e ? atoi(e) : 768; }
-        return MODE == MODE_DW && qxv && dma_min_k > 0 && q.K >= dma_min_k && q.M >= 4 && q.n_real >= 4 &&
+        constexpr int dma_min_k = 768;
+        return MODE == MODE_DW && qxv && q.K >= dma_min_k && q.M >= 4 && q.n_real >= 4 &&
                ((int64_t)q.K + 64) * (q.lda > q.ldb ? q.lda : q.ldb) < (1ll << 31);
     };
     p.dma = dma_ok(p, xv);

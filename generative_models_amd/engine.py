@@ -193,7 +193,7 @@ class HostReplay:
     def available(cls):
         if cls._flavour is None:
             import os
-            cls._flavour = False if os.environ.get("GM_HOST_REPLAY", "1") == "0" else cls._selfcheck()
+            cls._flavour = cls._selfcheck()
             if cls._flavour is not False:
                 from . import _lib
                 _lib.call("gm_host_replay_flavour", cls._flavour)
@@ -303,7 +303,7 @@ class NumpyReplay:
     def available(cls):
         if cls._ok is None:
             import os
-            cls._ok = os.environ.get("GM_NUMPY_REPLAY", "1") != "0" and cls._selfcheck()
+            cls._ok = cls._selfcheck()
         return cls._ok
 
     @staticmethod
@@ -447,14 +447,12 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         self.Hd_dim = self.D1.W.shape[0]
         assert self.D2.W.shape[0] == 1 or variant == "be", "score-based critics (BEGAN: autoencoder)"
         self.use_graph = use_graph
-        self.fuse_head = os.environ.get("GM_FUSE_HEAD", "1") != "0"
-        self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
-        self.fold_tick = os.environ.get("GM_FOLD_TICK", "1") != "0"
-        self.ride_head_dx = os.environ.get("GM_RIDE_HEAD_DX", "1") != "0"
-        self.group_head = os.environ.get("GM_GROUP_HEAD", "1") != "0"
-        self.ride_gather = os.environ.get("GM_RIDE_GATHER", "1") != "0"
-        self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
-        self.batch_gen_env = os.environ.get("GM_BATCH_GEN", "1") != "0"
+        # Launch-fusion forms of the step.  Rounds 1 - 5 kept an environment switch per form for same-box A/Bs; every
+        # slower arm has its measurement committed (profiles/r01 .. r05_experiments.md) and round 6 removed the switches
+        # (VERDICT r5 item 8).  The attributes stay: the unfused forms are still what the data-parallel, many-row and
+        # penalty steps take where a fused one does not apply (_adam_in_epilogue, _fold_ok, _tick_in_head ...).
+        self.fuse_head = self.fuse_adam = self.fold_tick = self.ride_head_dx = True
+        self.group_head = self.ride_gather = self.pair_dw = self.batch_gen_env = True
         # folded critic head (round 3): no launch for the N = 1 layer -- partial dots in the hidden
         # layer's forward epilogue, scores / losses / dS rebuilt in the consumers' prologues, dH formed
         # in registers (csrc/gm_head.h).  "2": also where the forward would take the LDS macro-tile kernel
@@ -465,15 +463,11 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         # configure() picks 128 / 64 / 32 with the ring the draws of this variant afford (_ring_and_graph_size)
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))
         # launch graphs ahead of the host draws they consume; the stage-in kernel waits on the fill gate
-        self.gated = os.environ.get("GM_GATED", "1") != "0"
-        self._early_submit = os.environ.get("GM_EARLY_SUBMIT", "1") != "0"
+        self.gated = True
+        self._early_submit = True
         # (rounds 4 - 5 also issued every piece's stage-in on a side stream ahead of its graph: with the gate wait as its
         # own one-wave kernel in front of an ungated copy the in-graph stage-in is the faster form everywhere -- a launch
         # of k iterations 22 + 67.5 k us against 31 + 67.5 k us, profiles/r05_experiments.md section 10 -- removed)
-        if os.environ.get("GM_RAMP"):
-            self.RAMP = tuple(max(1, int(x)) for x in os.environ["GM_RAMP"].split(","))
-        if os.environ.get("GM_FIRST_PIECE"):
-            self.FIRST_PIECE = max(1, int(os.environ["GM_FIRST_PIECE"]))
         self._gate = None
         self._standalone_G = False
         Bl, I, H, Hd = self.Bl, self.I, self.H, self.Hd_dim
@@ -501,7 +495,7 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         self.pre = z(16)                   # data parallel: scalars exchanged between the loss phases
         if variant in ("wgp", "dra"):
             self.Xh, self.Hh, self.Sh = z(Bl, I), z(Bl, Hd), z(Bl)
-            self.merge_fwd3 = os.environ.get("GM_MERGE_FWD3", "1") != "0"
+            self.merge_fwd3 = True
             if self.merge_fwd3:
                 # D's hidden layer on [x_hat ; x ; G(z)] as ONE 3B-row launch: x_hat lives in the first row block
                 # of XX4 (WGAN-GP writes gamma there LATER, when x_hat has been consumed), its hidden activations
@@ -608,14 +602,13 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         import os
         if self.variant in ("ra", "fisher"):
             return self._single() and not self.force_segments and self._fold_ok(2 * self.Bl) and \
-                os.environ.get("GM_FOLD_HEAD_TP", "1") != "0" and os.environ.get("GM_FOLD_HEAD_D", "1") != "0"
-        return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl) and \
-            os.environ.get("GM_FOLD_HEAD_D", "1") != "0"
+                os.environ.get("GM_FOLD_HEAD_TP", "1") != "0"
+        return self.variant in ("ns", "mm", "w", "ls", "f", "info") and self._fold_ok(2 * self.Bl)
 
     def _fold_head_G(self):
         """Generator step: every variant's D(G(z)) pass is the plain fused head in generator mode."""
         import os
-        return self._fold_ok(self.Bl) and os.environ.get("GM_FOLD_HEAD_G", "1") != "0"
+        return self._fold_ok(self.Bl)
 
     def _wgp_stacked(self):
         """WGAN-GP critic step with the second backward folded into the first-order launches: the
@@ -822,7 +815,7 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         # stage-in -- 36 us of serial GPU-initiated PCIe reads per iteration -- but through the copy
         # engine on a side stream, overlapping the previous piece's kernels (_copy_U)
         import os
-        self._u_copy = ("U" in shapes) and os.environ.get("GM_DRA_UCOPY", "1") != "0"
+        self._u_copy = "U" in shapes
         self._u_copied, self._u_stream = 0, None
         for k in shapes:
             if k == "U" and self._u_copy:
@@ -856,7 +849,7 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         # scribbles on are rewritten before anything reads them)
         import os
         self._native_fill = False
-        if self._replay_ok and os.environ.get("GM_NATIVE_FILL", "1") != "0":
+        if self._replay_ok:
             probe = torch.get_rng_state().clone()
             self._native_fill = HostReplay.call(probe, self._host_views(0)["program"], 1) == 0
         self._rng_state, self._rng_owned = None, False
@@ -1122,6 +1115,9 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
             # that skipped one would leave its peers in a 10 s bounded wait)
             checks = [c.selfcheck(self.device) for c in comms.values()]
             ok = all(checks)
+            self.comm_selfcheck = dict(seconds=round(sum(c.selfcheck_seconds for c in comms.values()), 4),
+                                       wait_bound_s=max(c.selfcheck_bound_s for c in comms.values()),
+                                       passed={k: bool(v) for k, v in zip(comms, checks)})
             if not ok:
                 why = "self-check failed for %s" % [k for k, c in zip(comms, checks) if not c]
         except Exception as e:                       # noqa: BLE001  (no IPC / no peer access here)
@@ -1428,19 +1424,25 @@ class GANEngine(CriticStep, InfoQStep, GeneratorStep, PenaltySteps):
         it = it_start
         cold = not self._fills and self._cursor == it_start       # nothing drawn ahead
         gated = self.gated
-        if cold:
-            self._ramp = list(self.RAMP)
-            # the first piece's draws go to the fill worker before anything else happens here: the GPU's first gate opens
-            # ~30 us after THIS point, everything below (gate check, plan, first launch: ~50 us) runs beside the draws
-            if gated and self._native_fill and self._early_submit:
-                self._pump(limit, upto=it_start + min(self.FIRST_PIECE, n_iters))
+        # (a gate that timed out in an earlier run raises HERE, before any fill job of this run owns the generator state:
+        # ADVICE r5 -- the early submit below used to sit in front of this check and outside the try block)
+        self._check_gate()
         trace = self._trace
+        try:
+            if cold:
+                self._ramp = list(self.RAMP)
+                # the first piece's draws go to the fill worker before anything else happens here: the GPU's first gate
+                # opens ~30 us after THIS point, everything below (plan, first launch: ~50 us) runs beside the draws
+                if gated and self._native_fill and self._early_submit:
+                    self._pump(limit, upto=it_start + min(self.FIRST_PIECE, n_iters))
+        except BaseException:
+            self._drain()
+            raise
         if trace is not None:
             import time
             trace.append(("run", it_start, time.perf_counter()))
             tev = [torch.cuda.Event(enable_timing=True)]     # GPU-side completion time of every piece (trace mode only)
             tev[0].record()
-        self._check_gate()
         try:
             plan = self._plan(it_start, n_iters, cold)
             if trace is not None:

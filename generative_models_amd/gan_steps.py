@@ -65,7 +65,7 @@ class CriticStep:
     def _local_rings(self):
         """Data parallel: device rings hold only this rank's rows of every draw (see _alloc_rings)."""
         import os
-        return self.world > 1 and self.variant != "dra" and os.environ.get("GM_LOCAL_RINGS", "1") != "0"
+        return self.world > 1 and self.variant != "dra"
 
     def _D_gen(self, st, it, j):
         Bl, d, R = self.Bl, self.D_steps, self.R
@@ -91,7 +91,7 @@ class CriticStep:
     def _interp_in_gen(self):
         import os
         # (the DAG experiment runs the gather on a side stream, concurrently with this launch)
-        return self.variant == "wgp" and os.environ.get("GM_WGP_INTERP_EPI", "1") != "0"
+        return self.variant == "wgp"
 
     # ---- the critic step behind the generator's forward: three builders, one per launch structure -------------------
     #   folded     separable losses (+ RaGAN / Fisher on one GPU): hidden layer forward with the head's partial dots,

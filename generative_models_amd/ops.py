@@ -238,7 +238,7 @@ def linear_bwd_dx_reparam(dA, W, dZ, ml, eps, dml, M=None, eps_slot=NO_SLOT, str
 def lds_min_m():
     """Rows from which forward / dX launches take the LDS macro-tile kernel (csrc/gm_gemm.hip)."""
     import os
-    return int(os.environ.get("GM_LDS_MIN_M", "1024"))
+    return 1024
 
 
 class HeadFold:

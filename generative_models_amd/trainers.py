@@ -414,7 +414,10 @@ class GANTrainer:
             # the progress lines; nothing between the reference's epochs reads the model (ns_gan.py:158-170 with
             # viz=False).  GM_PIPELINE_EPOCHS=0: read back before the next epoch is enqueued.
             import os
-            pipelined = (not self.viz) and eng.world == 1 and os.environ.get("GM_PIPELINE_EPOCHS", "1") != "0"
+            # A subclass that overrides _end_epoch / _viz_epoch (e.g. to save or read the model per epoch) must see the
+            # parameters of THAT epoch's end, not of an epoch already running ahead: no pipelining then.
+            pipelined = ((not self.viz) and eng.world == 1 and os.environ.get("GM_PIPELINE_EPOCHS", "1") != "0"
+                         and self._hook_is_stock("_end_epoch") and self._hook_is_stock("_viz_epoch"))
 
             def finish(epoch, it0, mark):
                 G_losses, D_losses = eng.losses(it0, it0 + epoch_steps, after=mark)     # one sync per epoch

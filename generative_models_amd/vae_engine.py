@@ -100,16 +100,16 @@ class VAEEngine:
         self.graphs = {}
         self._bufB = None
         import os
-        self.fuse_adam = os.environ.get("GM_FUSE_ADAM", "1") != "0"
-        self.pair_dw = os.environ.get("GM_PAIR_DW", "1") != "0"
+        self.fuse_adam = True
+        self.pair_dw = True
         self.graph_iters = max(1, int(os.environ.get("GM_GRAPH_ITERS", "32")))   # batches per graph
-        self.prefetch_gather = os.environ.get("GM_VAE_PREFETCH_GATHER", "1") != "0"
+        self.prefetch_gather = True
         # launch fusions of round 3 (each replaces a ~5 us latency-bound launch by an epilogue)
-        self.fuse_sqerr = os.environ.get("GM_VAE_FUSE_SQERR", "1") != "0"
-        self.fuse_reparam_bwd = os.environ.get("GM_VAE_FUSE_REPARAM_BWD", "1") != "0"
-        self.fuse_reparam_fwd = os.environ.get("GM_VAE_FUSE_REPARAM_FWD", "1") != "0"
-        self.fuse_bwd_mid = os.environ.get("GM_VAE_BWD_MID", "1") != "0"
-        self.fin_in_dw = os.environ.get("GM_VAE_FINALIZE_IN_DW", "1") != "0"
+        self.fuse_sqerr = True
+        self.fuse_reparam_bwd = True
+        self.fuse_reparam_fwd = True
+        self.fuse_bwd_mid = True
+        self.fin_in_dw = True
         self.fin_done = torch.zeros(1, dtype=torch.int32, device=device)
 
     def _alloc(self, B):

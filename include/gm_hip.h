@@ -566,6 +566,10 @@ int gm_comm_set_exchange(void* comm, int form);
  * (each spins until every peer's last workgroup has arrived): the default (max_blocks = 0) is what the occupancy API
  * reports for this device or partition (CPX mode, HSA_CU_MASK), at most 320; ranks that share one device pass less. */
 int gm_comm_set_max_blocks(void* comm, int max_blocks);
+/* Bound (seconds of the 100 MHz wall clock, default 10) of every device-side wait of this communicator's later
+ * launches; an expired wait raises gm_comm_error's flag instead of hanging the GPU.  The start-up self-check between
+ * ranks on different devices runs with 2 s. */
+int gm_comm_set_wait_seconds(void* comm, double seconds);
 /* The region's own bucket (n_floats fp32, 256-byte aligned): a gradient buffer placed here is
  * all-reduced without a staging copy. */
 int gm_comm_buffer(void* comm, void** ptr_out, int64_t* n_floats_out);
@@ -580,6 +584,7 @@ int gm_allreduce_scalars(void* comm, void* stream, float* vals, int k);
  * segment graphs).  RCCL is not linked: its symbols are resolved at first use from the librccl the process already
  * carries (torch's).  uid128: 128 bytes (ncclUniqueId) made on rank 0 by gm_rccl_unique_id and handed to every rank
  * by the host; gm_rccl_comm_create is collective.  In place, fp32. */
+int gm_rccl_available(void);          /* 1: ncclGetUniqueId / CommInitRank / AllReduce / CommDestroy all resolve here */
 int gm_rccl_unique_id(void* uid128_out);
 int gm_rccl_comm_create(int rank, int world, const void* uid128, void** rccl_comm_out);
 int gm_rccl_allreduce_f32(void* rccl_comm, void* stream, float* buf, int64_t n);

@@ -101,7 +101,7 @@ def _comm_case(world, real, one_kernel=False):
     procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, real)) for r in range(world)]
     # ranks sharing one device default to the two-launch exchange (dp.PeerComm); GM_DP_ONE_KERNEL=1 keeps the
     # one-kernel form, whose cross-rank protocol (arrival counter, last arriver signals) is what this case covers;
-    # GM_DP_PUSH=1 the push form (two arrival counters, flag phases 2 / 3, staging areas)
+    # GM_DP_PUSH=1 the push form (two arrival counters, flag phases 4 / 5, staging areas)
     key = "GM_DP_PUSH" if one_kernel == "push" else "GM_DP_ONE_KERNEL"
     if one_kernel:
         os.environ[key] = "1"

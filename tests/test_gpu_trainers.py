@@ -332,6 +332,48 @@ def test_small_ring_wraps_many_times_and_changes_nothing(ring, monkeypatch):
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("iters", ["1", "4", "64"])
+def test_graph_size_changes_nothing(iters, monkeypatch):
+    """GM_GRAPH_ITERS: iterations per captured hipGraph (1 = a launch per iteration, 64 = whole epochs of the small
+    configuration in one graph) -- the same kernels on the same slots: bitwise the default run."""
+    ref, ref_model, ref_rng = run_product("ns", SMALL, SMALL["batch"], dict(num_epochs=3))
+    monkeypatch.setenv("GM_GRAPH_ITERS", iters)
+    got, got_model, got_rng = run_product("ns", SMALL, SMALL["batch"], dict(num_epochs=3))
+    assert got._engine.graph_iters == int(iters)
+    assert got.Glosses == ref.Glosses and got.Dlosses == ref.Dlosses and torch.equal(ref_rng, got_rng)
+    for (k, a), (_, b) in zip(got_model.state_dict().items(), ref_model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_overridden_epoch_end_hook_sees_its_own_epochs_parameters(monkeypatch):
+    """with the epochs enqueued ahead of the loss read-back, a subclass whose _end_epoch reads the model
+    would see parameters of an epoch already under way -- such a subclass is not pipelined: what it records per epoch
+    equals what it records with GM_PIPELINE_EPOCHS=0."""
+    import ns_gan
+
+    class Snap(ns_gan.NSGANTrainer):
+        def _end_epoch(self, epoch, num_epochs, G_losses, D_losses, quiet=False):
+            torch.cuda.synchronize()
+            self.snaps = getattr(self, "snaps", []) + [float(self.model.D.linear.weight.double().sum())]
+            super()._end_epoch(epoch, num_epochs, G_losses, D_losses, quiet)
+
+    def run():
+        loaders = port.synthetic_loaders(16, n_train=SMALL["n_train"], n_val=48, n_test=48, image_shape=SMALL["image_shape"])
+        torch.manual_seed(1234)
+        tr = Snap(ns_gan.NSGAN(SMALL["image_size"], SMALL["hidden_dim"], SMALL["z_dim"]), *loaders)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.train(4)
+        torch.cuda.synchronize()
+        return tr
+    a = run()
+    assert a._stock() and a._engine is not None and len(a.snaps) == 4
+    monkeypatch.setenv("GM_PIPELINE_EPOCHS", "0")
+    b = run()
+    assert a.snaps == b.snaps and a.Glosses == b.Glosses
+    assert len(set(a.snaps)) == 4                      # (the parameters do move from epoch to epoch)
+
+
 def test_two_train_calls_reset_adam():
     """Optimizers are locals of the reference's train(): Adam state resets per call."""
     cfg = SMALL

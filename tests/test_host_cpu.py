@@ -520,3 +520,45 @@ def test_committed_counter_passes_name_kernels_the_library_contains():
             if name.startswith(("gemm", "head_", "gan_loss", "adam_", "stage_in", "ar_", "vae_", "std_", "gp_", "interp",
                                 "sum_finalize", "gather_rows", "tick", "dragan", "began", "info_q", "bir_", "l1_rows", "sqerr")):
                 assert name in have, "%s names %r, which the built library does not contain" % (os.path.basename(f), name)
+
+
+def test_environment_switchboard_is_pinned():
+    """the product is steered by at most 15 GM_* environment switches, each with an agreement test
+    under tests/ (bitwise or to-rounding, named here); everything else that rounds 1 - 5 kept for A/B runs is gone (the
+    slower arms' measurements are in profiles/r0*_experiments.md).  A new os.environ / getenv read of a GM_* name must
+    be added here WITH its test, or this fails."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(HERE), "generative_models_amd")
+    files = glob.glob(os.path.join(root, "*.py")) + glob.glob(os.path.join(root, "csrc", "*"))
+    found = set()
+    for f in files:
+        if f.endswith((".o", ".so")):
+            continue
+        found |= set(re.findall(r"(?:getenv|environ\.get|environ\[)\(?\"(GM_[A-Z0-9_]+)", open(f, errors="ignore").read()))
+    steering = {   # switch -> the agreement test that covers both of its arms
+        "GM_CAPTURED_GENERAL": "test_captured_general_path_equals_the_host_loop",
+        "GM_DP_COMM": "test_dp_launch_structure_single_rank_rccl",
+        "GM_RCCL_IN_GRAPH": "test_dp_launch_structure_single_rank_rccl",
+        "GM_DP_PUSH": "GM_DP_PUSH",
+        "GM_DP_ONE_KERNEL": "GM_DP_ONE_KERNEL",
+        "GM_FOLD_HEAD": "test_summation_order_switches_agree_within_rounding",
+        "GM_FOLD_HEAD_TP": "test_summation_order_switches_agree_within_rounding",
+        "GM_WGP_STACK": "test_summation_order_switches_agree_within_rounding",
+        "GM_WGP_PEN_IN_HEAD": "test_summation_order_switches_agree_within_rounding",
+        "GM_DRA_STACK": "test_summation_order_switches_agree_within_rounding",
+        "GM_PACKED": "test_fp32_resident_dataset_equals_bit_packed",
+        "GM_PACKED_OPERAND": "test_packed_operand_rows_equal_fp32_rows",
+        "GM_PIPELINE_EPOCHS": "test_epochs_enqueued_ahead_of_the_loss_read_back_change_nothing",
+        "GM_RING": "test_small_ring_wraps_many_times_and_changes_nothing",
+        "GM_GRAPH_ITERS": "test_graph_size_changes_nothing",
+    }
+    # not steering the arithmetic: where the library is, host threads, tracing, one test hook of the numpy restatement
+    infrastructure = {"GM_LIB_PATH", "GM_HOST_THREADS", "GM_NUMPY_THREADS", "GM_KEEP_THREADS", "GM_TRACE_RUN",
+                      "GM_TRACE_NOSYNC", "GM_NUMPY_SCALAR"}
+    assert len(steering) <= 15
+    assert found == set(steering) | infrastructure, (sorted(found - set(steering) - infrastructure),
+                                                     sorted((set(steering) | infrastructure) - found))
+    tests_text = "".join(open(f).read() for f in glob.glob(os.path.join(HERE, "test_*.py")) if not f.endswith("test_host_cpu.py"))
+    for sw, needle in steering.items():
+        assert sw in tests_text and needle in tests_text, (sw, needle)

@@ -45,6 +45,8 @@ def main():
     o.train(1)
     orr, ok = np.array(o.recon_loss), np.array(o.kl_loss)
     osd = om.state_dict()
+    # (round 5 ran this over every fusion toggle of the VAE engine -- same drift under each, profiles/r05_experiments.md
+    # section 4; round 6 removed those environment switches, the rows below that name one now repeat the default)
     cases = [("default", {}), ("eager", {"PROBE_EAGER": "1"}), ("no bwd_mid", {"GM_VAE_BWD_MID": "0"}),
              ("no reparam_fwd", {"GM_VAE_FUSE_REPARAM_FWD": "0"}), ("no reparam_bwd", {"GM_VAE_FUSE_REPARAM_BWD": "0"}),
              ("no sqerr", {"GM_VAE_FUSE_SQERR": "0"}), ("no prefetch", {"GM_VAE_PREFETCH_GATHER": "0"}),

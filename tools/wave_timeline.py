@@ -101,7 +101,8 @@ P("")
 NAMES = {0: "entry", 1: "chunk 0 operands in, MFMAs start", 2: "chunk 0 MFMAs retired", 3: "chunk 1 operands in", 4: "chunk 1 MFMAs retired",
          5: "chunk 2 operands in", 6: "chunk 2 MFMAs retired", 7: "chunk 3 operands in", 8: "chunk 3 MFMAs retired",
          9: "reduction loop done", 10: "all waves' partial tiles in LDS (barrier passed)", 11: "images summed", 12: "epilogue stores issued",
-         13: "folded head: dS rebuilt in LDS (barrier passed)"}
+         13: "folded head: dS rebuilt in LDS (barrier passed)", 14: "folded head: this wave's partial dots landed",
+         15: "folded head: this wave's rows done, barrier next"}
 LDS_NAMES = {0: "entry", 1: "2 stages stored to LDS, 4 more requested", 2: "first fragments in registers", 36: "WK partial tiles in LDS (barrier passed)",
              37: "epilogue stores issued"}
 for i, L in enumerate(launches):
