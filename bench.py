@@ -107,7 +107,7 @@ def gemm_shapes_vae(B):
 def gemm_variant(kind, M, K, N):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
-    load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI."""
+    load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI, DMA, SL."""
     if kind == "fwdz":
         return "vae_reparam_fwd_kernel"
     if kind == "bmid":
@@ -165,7 +165,9 @@ def gemm_variant(kind, M, K, N):
     if kind == "dwp":
         assert xv and (mi, ni) != (1, 2)
         return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s>" % (g, mi, ni, b(dma))
-    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(dma))
+    # (last argument, round 6: the instantiation that resolves ring slots on its operands -- false for every launch this
+    # function names, only the generator's first layer reads through one and it rides in the gather / pair kernels)
+    return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s, false>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(dma))
 
 
 def clock_probe():

@@ -155,6 +155,21 @@ struct GemmP {
 #endif
 };
 
+// Operand base behind an optional ring slot.  Round 6: almost every launch passes NO_SLOT for both operands (only the
+// generator's first layer reads its input -- the noise ring -- through one), and the general resolution -- the
+// counter's load behind the argument loads (a third serial scalar-memory trip), a 64-bit multiply-add, the modulo's
+// fast-path test, a 64-bit multiply -- sat in front of every kernel's FIRST operand loads: ~40 scalar instructions that
+// each of a SIMD's four waves issues in turn (16 cycles apiece by the time the fourth wave is through).  Compiled out,
+// the forward launches run 0.33 - 0.40 us shorter (8.07 -> 7.70 us; a run-time test for "no slot" did not keep the gain:
+// hipcc scheduled one shape 0.7 us slower around the branch -- profiles/r06_experiments.md section 5).  SL is a template
+// argument of the kernels: the host picks the slot-free instantiation whenever both operands come without one.
+template <bool SL>
+__device__ __forceinline__ const float* slot_base(const float* P, const gm_slot& s) {
+    if constexpr (SL) return P + gm_slot_offset(s);
+    return P;
+}
+inline bool has_slot(const gm_slot& s) { return s.ctr != nullptr || s.add != 0; }
+
 // elements e .. e+3 (e % 4 == 0) of a packed row from the word that holds them; expanded where the fragment is consumed
 __device__ __forceinline__ float4 pk_expand(uint32_t word, int e) {
     const uint32_t v = word >> (e & 31);
@@ -530,8 +545,8 @@ __global__ __launch_bounds__(64 * (BM / WTM) * (BN / WTN) * WK) void gemm_lds_ke
     const int tile_m = xcd * p.lds_mpx + l / p.tn, tile_n = l % p.tn;
     if (tile_m >= p.lds_tm) return;                               // workgroup-uniform
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float* A = p.A + gm_slot_offset(p.a_slot);
-    const float* B = p.B + gm_slot_offset(p.b_slot);
+    const float* A = p.A;                                    // (launches with a ring slot take the 16-wave kernels)
+    const float* B = p.B;
 #ifdef GM_STAMPS
     const gm_stamps::Ctx st_slot = p.stamp; const int st_tile = (int)blockIdx.x;
 #endif
@@ -974,7 +989,7 @@ __device__ __forceinline__ void dw_il_reduce(const GemmP& p, float* red, f32x4 (
 // group never holds a real column) and only feed outputs nobody stores; the virtual ones column and rows past K are
 // selects on the fragment, compiled into their own copy of the loop for the (workgroup-uniform) tiles that need them.
 // ------------------------------------------------------------------------------------------
-template <int MI, int NI, bool OF, int FOLD>
+template <int MI, int NI, bool OF, int FOLD, bool SL>
 __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx, int by, float* sds,
                                               const FoldP* fold) {
     constexpr int WAVES = 16, NP = MI + NI, CH = NP * 256;   // pieces / floats of a wave's chunk buffer
@@ -998,7 +1013,7 @@ __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx
         const int row = isA ? idx / (4 * MI) : idx / (4 * NI);
         const int c4 = isA ? idx % (4 * MI) : idx % (4 * NI);
         const int col = isA ? min(m0 + 4 * c4, p.M - 4) : min(n0 + 4 * c4, b_cols - 4);
-        src[j] = (isA ? p.A + gm_slot_offset(p.a_slot) : p.B + gm_slot_offset(p.b_slot)) + col;
+        src[j] = (isA ? slot_base<SL>(p.A, p.a_slot) : slot_base<SL>(p.B, p.b_slot)) + col;
         sld[j] = isA ? (int)p.lda : (int)p.ldb;
         srow[j] = row;
     }
@@ -1094,7 +1109,7 @@ template <int MODE, bool DMA, int MI, int NI> struct RedSize {
 // formed from h[m][k], sds[m - m0] and w2[k].  sds: the workgroup's LDS copy of dS.
 // TP (with FOLD == 1): the rows' dS come from the two-phase prologue (RaGAN / Fisher critic steps, gm_head.h).
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool DMA = false,
-          bool TP = false, bool PK = false>
+          bool TP = false, bool PK = false, bool SL = true>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
                                             float* sds = nullptr, const FoldP* fold = nullptr) {
     static_assert(!TP || (FOLD == 1 && !DMA), "two-phase losses: folded weight gradient, operands through registers");
@@ -1106,7 +1121,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // DMA: the launch chose the LDS-DMA weight gradient (its own kernel instantiations: as a run-time branch inside the
     // shared kernels a second body cost the bs=256 step 1.5 us in registers and code it never runs)
     if constexpr (DMA && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
-        gemm16_dw_dma<MI, NI, OF, FOLD>(p, red, bx, by, sds, fold);
+        gemm16_dw_dma<MI, NI, OF, FOLD, SL>(p, red, bx, by, sds, fold);
         return;
     }
     const int t = threadIdx.x;
@@ -1119,11 +1134,13 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     GM_STAMP_EDGE(p, false, st_tile, MODE);
     GM_STAMP(st_slot, st_tile, 0);                            // entry
 
-    const float* A = p.A + gm_slot_offset(p.a_slot);
-    const float* B = p.B + gm_slot_offset(p.b_slot);
+    const float* A = slot_base<SL>(p.A, p.a_slot);
+    const float* B = slot_base<SL>(p.B, p.b_slot);
     const int b_cols = (MODE == MODE_DW) ? p.n_real : p.N;
     const int ones_col = (MODE == MODE_DW && p.db) ? p.n_real : -1;
     const int nchunks = (p.K + 15) >> 4;
+    GM_STAMP_AFTER(A); GM_STAMP_AFTER(B); GM_STAMP_AFTER(nchunks);
+    GM_STAMP(st_slot, st_tile, 16);                           // operand bases resolved (kernel arguments + slot counters read)
 
     // folded head: what stays fixed per lane across the reduction
     float4 fw[FOLD == 1 ? MI : 1];
@@ -1168,6 +1185,10 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         return fix_xc(XV ? lane48_transpose(v, lane) : v, x, b_cols, kb, p.K, ones_col, OF ? p.ones_from : 0);
     };
 
+    // (Round 6: NOT zeroing the accumulators up front -- the first chunk's MFMAs taking 0 as their C operand, that chunk
+    // peeled in front of the loop so that its loads are the kernel's first work -- removed 16 - 32 v_mov from in front of
+    // the first operand loads and measured mixed: 256-row launches -0.1 us, 512-row forwards +0.2 us, step 65.85 ->
+    // 66.1 us.  Not kept.  profiles/r06_experiments.md section 5.)
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1312,6 +1333,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             for (int ni = 0; ni < NI; ++ni) rb[ni] = load_b(w, ni);
             wk = load_wk(w);
         }
+        GM_STAMP(st_slot, st_tile, 17);                       // first chunk's operand loads issued
         fold_prologue();
         GM_STAMP(st_slot, st_tile, 13);                       // folded head: dS of every reduction row rebuilt in LDS
         if (have) consume(ra, rb, wk, 0);
@@ -1371,10 +1393,10 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     GM_STAMP_EDGE(p, true, st_tile, MODE);
 }
 
-template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool DMA = false>
+template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool DMA = false, bool SL = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) float red[(WAVES == 16) ? RedSize<MODE, DMA, MI, NI>::value : WAVES * 32 * 32];
-    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI, false, 0, DMA>(p, red, blockIdx.x, blockIdx.y);
+    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI, false, 0, DMA, false, false, SL>(p, red, blockIdx.x, blockIdx.y);
 }
 
 // The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
@@ -1394,7 +1416,7 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body<TP>(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP, PK>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP, PK, false>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
 }
 
 template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false>
@@ -1407,7 +1429,7 @@ __global__ __launch_bounds__(1024) void gemm16_dw_head_kernel(GemmP p, HeadBwdP 
 // each -- the shapes pick_tile gives the MNIST critic (32x32 forward tiles, 32x48 weight-gradient tiles).
 __global__ __launch_bounds__(1024) void gemm16_fwd_bits_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_FWD, false, 2, 2>::value];
-    gemm16_body<MODE_FWD, true, 16, 1, false, 2, 2, false, 0, false, false, true>(p, red, blockIdx.x, blockIdx.y);
+    gemm16_body<MODE_FWD, true, 16, 1, false, 2, 2, false, 0, false, false, true, false>(p, red, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(1024) void gemm16_dw_head_bits_kernel(GemmP p, HeadBwdP hp, int hrows, int hblocks) {
     gemm16_with_head<MODE_DW, false, 1, true, 2, 3, false, true, false, false, true>(p, hp, hrows, hblocks);
@@ -1563,6 +1585,14 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     p.stamp.tile = gm_stamps::host_tile;
 #endif
     const bool xv = xvec && MODE != MODE_FWD;
+    // ring slots on the operands (the generator's first layer on the noise ring): the slot-resolving instantiations of
+    // the plain / gather / pair kernels; the head-riding, bit-packed and LDS macro-tile kernels are compiled without
+    const bool slots = has_slot(p.a_slot) || has_slot(p.b_slot);
+    if (slots && (folded || p.pk_bits)) {
+        gm_set_error("ring slots on the operands of a folded-head / bit-packed launch are not supported");
+        return GM_EINVAL;
+    }
+    const bool ride_head = head && !slots;                   // (else the head workgroups get their own launch below)
     // weight gradients over >= GM_DW_DMA_MIN_K rows on 16-byte aligned operands: chunks by LDS-DMA (gemm16_dw_dma).
     // Measured (profiles/r04_experiments.md): 2048 rows 26.0 -> 24.2 us, 1024 rows 15.3 -> 15.2, 768 rows 12.2 -> 11.9;
     // below that the extra hop through LDS costs more than the load instructions it saves (512 rows 9.0 -> 9.2, 256
@@ -1605,7 +1635,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     // many-row forward / input-gradient launches: LDS-staged macro tiles.  Riders get their own launch first (a head /
     // gather workgroup set is microseconds next to a >= 1024-row GEMM).
     if constexpr (MODE != MODE_DW) {
-        if (!rider.pair && !folded && !p.hd_part && !p.sq_part) {
+        if (!rider.pair && !folded && !p.hd_part && !p.sq_part && !slots) {
             const int cfg = lds_cfg_for<MODE>(p, vec, xv);
             if (cfg) {
                 if (head) hipLaunchKernelGGL(head_bwd_kernel, dim3(gm_head_bwd_blocks(*head)), dim3(1024), 0, s, *head);
@@ -1619,7 +1649,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
     const int mi = tile_mi(tile), ni = tile_ni(tile);
     const dim3 grid((p.N + 16 * ni - 1) / (16 * ni), (p.M + 16 * mi - 1) / (16 * mi));
     if constexpr (MODE == MODE_DW) {
-        if (head) {                      // the critic head's backward workgroups ride in rows [0, hrows) of the grid
+        if (ride_head) {                 // the critic head's backward workgroups ride in rows [0, hrows) of the grid
             const int hblocks = gm_head_bwd_blocks(*head);
             const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
             const dim3 hgrid(grid.x, grid.y + hrows);
@@ -1657,7 +1687,7 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
     }
     if constexpr (MODE == MODE_DX) {
-        if (head && vec && xv && (tile == T22 || tile == T12)) {   // the generator-mode head's scalar workgroup rides along
+        if (ride_head && vec && xv && (tile == T22 || tile == T12)) {   // the generator-mode head's scalar workgroup rides along
             const int hblocks = gm_head_bwd_blocks(*head);
             const int hrows = (hblocks + (int)grid.x - 1) / (int)grid.x;
             const dim3 hgrid(grid.x, grid.y + hrows);
@@ -1722,7 +1752,15 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
         }
     }
     // template arguments: MODE, VEC, waves, G, XV, MI, NI, DMA
-#define GM_L16K(V, X, MI_, NI_, D_) hipLaunchKernelGGL((gemm16_kernel<MODE, V, 16, 1, X, MI_, NI_, (MODE == MODE_DW && (X) && (D_))>), grid, dim3(1024), 0, s, p)
+    // (ring slots exist on the batch-row operand of forward and weight-gradient launches only: gm_hip.h)
+    if (MODE == MODE_DX && slots) { gm_set_error("ring slots: forward and weight-gradient operands only"); return GM_EINVAL; }
+#define GM_L16K(V, X, MI_, NI_, D_)                                                                                          \
+    do {                                                                                                                     \
+        if (MODE != MODE_DX && slots)                                                                                        \
+            hipLaunchKernelGGL((gemm16_kernel<MODE, V, 16, 1, X, MI_, NI_, (MODE == MODE_DW && (X) && (D_)), MODE != MODE_DX>), grid, dim3(1024), 0, s, p); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm16_kernel<MODE, V, 16, 1, X, MI_, NI_, (MODE == MODE_DW && (X) && (D_)), false>), grid, dim3(1024), 0, s, p); \
+    } while (0)
 #define GM_L16_tt(MI_, NI_, D_) GM_L16K(true, true, MI_, NI_, D_)
 #define GM_L16_tf(MI_, NI_, D_) GM_L16K(true, false, MI_, NI_, D_)
 #define GM_L16_ft(MI_, NI_, D_) GM_L16K(false, true, MI_, NI_, D_)

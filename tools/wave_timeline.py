@@ -102,7 +102,8 @@ NAMES = {0: "entry", 1: "chunk 0 operands in, MFMAs start", 2: "chunk 0 MFMAs re
          5: "chunk 2 operands in", 6: "chunk 2 MFMAs retired", 7: "chunk 3 operands in", 8: "chunk 3 MFMAs retired",
          9: "reduction loop done", 10: "all waves' partial tiles in LDS (barrier passed)", 11: "images summed", 12: "epilogue stores issued",
          13: "folded head: dS rebuilt in LDS (barrier passed)", 14: "folded head: this wave's partial dots landed",
-         15: "folded head: this wave's rows done, barrier next"}
+         15: "folded head: this wave's rows done, barrier next", 16: "operand bases resolved (arguments, slot counters)",
+         17: "first chunk's operand loads issued"}
 LDS_NAMES = {0: "entry", 1: "2 stages stored to LDS, 4 more requested", 2: "first fragments in registers", 36: "WK partial tiles in LDS (barrier passed)",
              37: "epilogue stores issued"}
 for i, L in enumerate(launches):
