@@ -104,7 +104,7 @@ def gemm_shapes_vae(B):
             ("dwp", B, IMG, HID, (2 * Z, HID))]
 
 
-def gemm_variant(kind, M, K, N):
+def gemm_variant(kind, M, K, N, extra=None):
     """Name of the kernel instantiation csrc/gm_gemm.hip launches for this layer shape with the
     default settings (mirrors launch<MODE>(): v_mfma_f32_16x16x4_f32 kernel, 16 waves, per-chunk
     load/consume schedule, 16-byte paths by alignment, tile shape from the tile count) -- the name rocprofv3 reports.  Template order: MODE, VEC, WAVES, G, XV, MI, NI, DMA, SL."""
@@ -164,7 +164,9 @@ def gemm_variant(kind, M, K, N):
         return "gemm16_fwd_gather_kernel<true, %d, %d, %d>" % (g, mi, ni)
     if kind == "dwp":
         assert xv and (mi, ni) != (1, 2)
-        return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s>" % (g, mi, ni, b(dma))
+        # last two arguments (round 6): which of the pair resolves ring slots on its operands -- the generator's second
+        # GEMM reads its X from the noise ring (extra is None), the VAE's pairs (extra = the second layer's shape) neither
+        return "gemm16_dw_pair_kernel<%d, true, %d, %d, %s, false, %s>" % (g, mi, ni, b(dma), b(extra is None))
     # (last argument, round 6: the instantiation that resolves ring slots on its operands -- false for every launch this
     # function names, only the generator's first layer reads through one and it rides in the gather / pair kernels)
     return "gemm16_kernel<%d, %s, %d, %d, %s, %d, %d, %s, false>" % (mode, b(vec), nw, g, b(xv), mi, ni, b(dma))
@@ -273,8 +275,11 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
             dH2, zz = torch.randn(M, N2, device=dev), torch.randn(M, K2, device=dev)
             sched = torch.from_numpy(ops.adam_schedule(2e-4, 4)).to(dev)
             ad = dict(sched=sched, sched_slot=ops.slot(0, 0, 1, 0, 1), clamp=0.0) if fused_adam else None
+            # the generator's pair reads the second GEMM's X through a ring slot (the noise ring), as the step does
+            zctr = torch.zeros(1, dtype=torch.int64, device=dev)         # (captured by the lambda: stays alive)
+            zslot = {} if extra is not None else dict(x_slot=ops.slot(zctr.data_ptr(), 1, 0, 1, 0))
             fn = lambda: ops.linear_bwd_dw_adam_pair(dict(dA=dA, X=x, lin=L2, adam=ad),
-                                                     dict(dA=dH2, X=zz, lin=L1, adam=ad), stream=st)
+                                                     dict(dA=dH2, X=zz, lin=L1, adam=ad, keep=zctr, **zslot), stream=st)
             flop += 2.0 * M * N2 * K2
         elif kind == "dx":
             fn = lambda: ops.linear_bwd_dx(dA, W, dX, below=x, epi="relu", stream=st)
@@ -318,7 +323,7 @@ def time_kernels_isolated(B, reps=100, fused_head=True, batch_gen=True, group_he
         e1.sync()
         us = e0.elapsed_ms(e1) * 1e3 / reps
         log('  %-4s M=%4d K=%4d N=%4d : %7.2f us  %6.2f TFLOP/s' % (kind, M, K, N, us, flop / us / 1e6))
-        name = gemm_variant(kind, M, K, N)
+        name = gemm_variant(kind, M, K, N, extra)
         t, f, n = out.get(name, (0.0, 0.0, 0))
         out[name] = (t + us, f + flop, n + 1)
     return out
@@ -600,7 +605,7 @@ def dominant_gemm_roofline(shapes, B, pmc_tag=None, reps=50):
     ach = flop / (us * 1e-6) / 1e12
     e = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": us / n,
          "us_per_step": us, "shapes": ["%s %dx%dx%d" % tuple(sh[:4]) for sh in shapes
-                                       if gemm_variant(*sh[:4]) == name],
+                                       if gemm_variant(*sh[:5]) == name],
          "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
          "per_kernel_us_per_step": {k: round(v[0], 2) for k, v in kt.items()}}
     e["traffic"], e["traffic_source"] = pmc_traffic(name, pmc_tag)

@@ -1471,13 +1471,15 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
-template <int G, bool XV, int MI, int NI, bool DMA = false>
+// SLA / SLB: which of the two resolves ring slots on its operands (the generator's pair: only the second, whose X is the
+// noise ring; the VAE's pairs: neither)
+template <int G, bool XV, int MI, int NI, bool DMA = false, bool SLA = true, bool SLB = true>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb, int na, int tna,
                                                               int tnb) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, DMA, MI, NI>::value];
     const int id = blockIdx.x;
-    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
-    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
+    if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA, false, false, SLA>(pa, red, id % tna, id / tna);
+    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA, false, false, SLB>(pb, red, (id - na) % tnb, (id - na) / tnb);
 }
 
 // The same launch closing a VAE batch (round 4): workgroup 0 adds up the batch's reconstruction and KL partials
@@ -1485,14 +1487,14 @@ __global__ __launch_bounds__(1024) void gemm16_dw_pair_kernel(GemmP pa, GemmP pb
 // launches ago), the others are the pair's tiles.  The device step counter may only advance once every workgroup has
 // resolved its slots (Adam's schedule slot in the tiles' epilogues, the loss slot in workgroup 0): each workgroup
 // arrives on f.done when it is finished and the LAST arriver ticks and re-arms the counter.
-template <int G, bool XV, int MI, int NI, bool DMA = false>
+template <int G, bool XV, int MI, int NI, bool DMA = false, bool SLA = true, bool SLB = true>
 __global__ __launch_bounds__(1024) void gemm16_dw_pair_fin_kernel(GemmP pa, GemmP pb, int na, int tna, int tnb,
                                                                   gm_fin2 f) {
     __shared__ __attribute__((aligned(16))) float red[RedSize<MODE_DW, DMA, MI, NI>::value];
     const int id = (int)blockIdx.x - 1;
     if (id < 0) gm_fin2_sums(f, reinterpret_cast<double*>(red));
-    else if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pa, red, id % tna, id / tna);
-    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA>(pb, red, (id - na) % tnb, (id - na) / tnb);
+    else if (id < na) gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA, false, false, SLA>(pa, red, id % tna, id / tna);
+    else gemm16_body<MODE_DW, false, 16, G, XV, MI, NI, false, 0, DMA, false, false, SLB>(pb, red, (id - na) % tnb, (id - na) / tnb);
     __syncthreads();                                         // every thread's slot reads are behind it
     if (threadIdx.x == 0) {
         const unsigned int arrived = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1733,10 +1735,18 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                 const int tna = (int)grid.x, na = (int)(grid.x * grid.y);
                 const int tnb = (pb.N + 16 * ni - 1) / (16 * ni), tmb = (pb.M + 16 * mi - 1) / (16 * mi);
                 const dim3 pgrid(na + tnb * tmb);
-#define GM_LP(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_kernel<1, true, MI_, NI_, D_>), pgrid, dim3(1024), 0, s, p, pb, na, tna, tnb)
-#define GM_LPF(MI_, NI_, D_) hipLaunchKernelGGL((gemm16_dw_pair_fin_kernel<1, true, MI_, NI_, D_>), dim3(pgrid.x + 1), dim3(1024), 0, s, p, pb, na, tna, tnb, *rider.fin)
+                const bool sl_b = has_slot(pb.a_slot) || has_slot(pb.b_slot);
+#define GM_LP2(K_, GRID_, MI_, NI_, D_, ...)                                                                              \
+    do {                                                                                                                  \
+        if (slots) hipLaunchKernelGGL((K_<1, true, MI_, NI_, D_, true, true>), GRID_, dim3(1024), 0, s, __VA_ARGS__);     \
+        else if (sl_b) hipLaunchKernelGGL((K_<1, true, MI_, NI_, D_, false, true>), GRID_, dim3(1024), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((K_<1, true, MI_, NI_, D_, false, false>), GRID_, dim3(1024), 0, s, __VA_ARGS__);         \
+    } while (0)
+#define GM_LP(MI_, NI_, D_) GM_LP2(gemm16_dw_pair_kernel, pgrid, MI_, NI_, D_, p, pb, na, tna, tnb)
+#define GM_LPF(MI_, NI_, D_) GM_LP2(gemm16_dw_pair_fin_kernel, dim3(pgrid.x + 1), MI_, NI_, D_, p, pb, na, tna, tnb, *rider.fin)
                 if (rider.fin) GM_TILE_SWITCH(tile, dma, GM_LPF);
                 else GM_TILE_SWITCH(tile, dma, GM_LP);
+#undef GM_LP2
 #undef GM_LPF
 #undef GM_LP
                 GM_LAUNCH_RET();
