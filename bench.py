@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md:35 (spec)
 B_PER_GPU = 256
 LDS_MIN_M = 1024    # csrc/gm_gemm.hip lds_cfg_for
 IMG, HID, Z, N_TRAIN = 784, 400, 20, 50000
-PROFILE_ROUND = "r05"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
+PROFILE_ROUND = "r06"             # profiles/<round>_* hold the rocprofv3 / PMC passes of the kernels named below
 FOLD_HEAD_DEFAULT = os.environ.get("GM_FOLD_HEAD", "1") != "0"   # engine default (folded critic head)
 
 
@@ -703,9 +703,17 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
         dt = float(np.median(secs))
         out.append({"workload": "DRAGAN MNIST bs=256 D_steps=1 (dra_gan.py; host draws 256 x 784 uniforms per step)",
                     "img_s": K * 256 / dt, "ms_per_step": dt / K * 1e3, "steps": K,
-                    "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs]})
+                    "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
+                    "step_mfma_frac": K * 256 / dt * VARIANT_FLOP["dra"][0] / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                    "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "flop_per_image": VARIANT_FLOP["dra"][0], "flop_derivation": VARIANT_FLOP["dra"][1],
+                                 "step_frac": K * 256 / dt * VARIANT_FLOP["dra"][0] / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                                 "profile": "profiles/%s_dra_b256_summary.md" % PROFILE_ROUND}})
         log("DRAGAN bs=256: %.0f img/s" % (K * 256 / dt))
         del eng
+    for v in ("info", "be"):
+        if want(v + "_b256"):
+            out.append(bench_variant_trainer(v))
     for with_eval in ((False, True) if want("vae_b512") else ()):
         img_s, ms, n = bench_vae(512, dev, with_eval)
         e = {"workload": "VAE MNIST bs=512 full epochs incl. the ragged 336 batch, %s "
@@ -722,6 +730,56 @@ def other_configs(dev, steps, warmup, reps, cpu=True, only=None):
     for e, fn in deferred:
         e["cpu_baseline"] = fn()
     return out
+
+
+# Algorithmic FLOP per real image of one D+G iteration at D_steps = 1 for the variants outside BASELINE.json (2 m n k per
+# GEMM; U = one 784 x 400 contraction = 627 200 FLOP per row; the reference's wasted backprops -- G's gradients during the
+# critic step, D's during the generator step -- are not counted)
+VARIANT_FLOP = {
+    "dra": (8_836_000, "NSGAN's 10 U + small layers (6 326 400) + the penalty path's D(x_hat) forward, grad wrt x_hat and "
+                       "the two second-backward GEMMs = 4 U: as WGAN-GP (SURVEY.md 8d), dra_gan.py:198-223"),
+    "info": (10_249_600, "critic step 5 U + 36 800, generator step 5 U + 65 600 (G's first layer is 40 wide: 32 000 per "
+                         "pass), MI step (info_gan.py:269-304) G forward, Q forward, Q dW1, Q dX, dH through G's output "
+                         "layer, G dW2 = 6 U + 112 000 (G's first layer forward and dW, Q's 400 x 20 head forward / dW / "
+                         "dX): 16 U + 214 400"),
+    "be": (11_337_600, "the critic is an autoencoder 784-400-784 (be_gan.py:63-76): critic step G 1 U + D forward on "
+                       "[x ; G(z)] 4 U + decoder dW 2 U + dH 2 U + encoder dW 2 U = 11 U + 16 000; generator step G 1 U + "
+                       "D forward 2 U + dX through decoder and encoder 2 U + dH through G 1 U + G dW2 1 U = 7 U + 32 000: "
+                       "18 U + 48 000"),
+}
+
+
+def bench_variant_trainer(v, epochs=2):
+    """InfoGAN / BEGAN at bs=256 through their drop-in Trainer.train (default arguments), warm: us per D+G iteration,
+    images/s and the step's fraction of the FP32-MFMA roofline from VARIANT_FLOP."""
+    import importlib
+    mod_name, cls = {"info": ("info_gan", "InfoGAN"), "be": ("be_gan", "BEGAN")}[v]
+    mod = importlib.import_module(mod_name)
+    ds = synthetic_dataset()
+    torch.manual_seed(1234)
+    kw = dict(image_size=IMG, hidden_dim=HID, z_dim=Z)
+    if v == "info":
+        kw.update(disc_dim=10, cont_dim=10)
+    model = getattr(mod, cls)(**kw)
+    tr = getattr(mod, cls + "Trainer")(model, torch.utils.data.DataLoader(ds, batch_size=B_PER_GPU, shuffle=True), None, None, viz=False)
+    steps = len(tr.train_iter)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train(epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert np.isfinite(tr.Glosses).all() and tr._engine is not None
+    img_s = epochs * steps * B_PER_GPU / dt
+    flop, why = VARIANT_FLOP[v]
+    frac = img_s * flop / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    log("%s bs=256: %.0f img/s" % (cls, img_s))
+    return {"workload": "%s MNIST bs=256 (%s.py defaults) through %sTrainer.train, warm" % (cls, mod_name, cls),
+            "img_s": img_s, "ms_per_step": dt / (epochs * steps) * 1e3, "steps": epochs * steps, "step_mfma_frac": frac,
+            "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "flop_per_image": flop,
+                         "flop_derivation": why, "step_frac": frac,
+                         "profile": "profiles/%s_variant_%s_summary.md" % (PROFILE_ROUND, v)}}
 
 
 def comm_mode_of(eng):
@@ -923,7 +981,7 @@ def main():
                     help="seconds of ONE uninterrupted window of the headline step behind the timed regions (0: skip)")
     ap.add_argument("--general-path", action="store_true", help="run only the README-override leg and print its entry")
     ap.add_argument("--only", default=None, help="profiling: run ONE of the extra configs (wgp_b256, ns_b1024, "
-                    "ls_b1024, dra_b256, vae_b512) and print its entry instead of the contract line")
+                    "ls_b1024, dra_b256, info_b256, be_b256, vae_b512) and print its entry instead of the contract line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

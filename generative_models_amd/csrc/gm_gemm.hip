@@ -991,12 +991,30 @@ __device__ __forceinline__ void dw_il_reduce(const GemmP& p, float* red, f32x4 (
 // ------------------------------------------------------------------------------------------
 template <int MI, int NI, bool OF, int FOLD, bool SL>
 __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx, int by, float* sds,
-                                              const FoldP* fold) {
+                                              const FoldP* fold, int gx) {
     constexpr int WAVES = 16, NP = MI + NI, CH = NP * 256;   // pieces / floats of a wave's chunk buffer
+    // XCD-aware tile map (round 6).  Workgroups go to the eight XCDs round-robin by their linear id, and each XCD has
+    // its own L2: with tile = linear id every L2 pulls the WHOLE of both operands over the fabric -- at 2048 rows 8 x
+    // (3.3 + 6.4) MB = 78 MB per launch, 3.9 TB/s of fabric reads for the launch's 20 us (profiles/r05_ns_b1024_pmc_*).
+    // Here the workgroups that share an XCD (same id mod 8) take CONSECUTIVE tiles in m-fastest order: ~28 tiles = two or
+    // three 48-column strips of X, so an L2 fetches all of dH but only its strips of X.  (gx: n-tiles of this GEMM; a
+    // rotation of the XCD numbering -- the head workgroups in front of the tiles -- does not matter.)
+    if (gx > 0) {
+        const int gy = (p.M + 16 * MI - 1) / (16 * MI), total = gx * gy;
+        const int L = by * gx + bx, x = L & 7, k = L >> 3;
+        const int base = total >> 3, rem = total & 7;
+        const int T = x * base + min(x, rem) + k;            // XCD x owns tiles [x * base + min(x, rem), + base + (x < rem))
+        by = T % gy; bx = T / gy;                            // m fastest: neighbours share their X columns
+    }
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
     const int m0 = by * (16 * MI), n0 = bx * (16 * NI);
+#ifdef GM_STAMPS
+    const gm_stamps::Ctx st_slot = p.stamp; const int st_tile = by * max(gx, 1) + bx;
+#endif
+    GM_STAMP_EDGE(p, false, st_tile, MODE_DW + 20);
+    GM_STAMP(st_slot, st_tile, 0);
     const int b_cols = p.n_real;
     const int ones_col = p.db ? p.n_real : -1;
     const int nchunks = (p.K + 15) >> 4;
@@ -1042,10 +1060,12 @@ __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx
     auto run = [&](auto special_tag) {
         constexpr bool SPECIAL = decltype(special_tag)::value;
         if (nq > 0) issue(w);
+        GM_STAMP(st_slot, st_tile, 17);
         if constexpr (FOLD == 1) fold_fill_lds(*fold, sds, fold->R);   // behind the first chunk's loads; ends with a barrier
         for (int q = 0; q < nq; ++q) {
             const int c = w + q * WAVES;
             slab::wait_vm<0>();                              // this wave's pieces have landed
+            if (q < 8) GM_STAMP(st_slot, st_tile, 20 + 2 * q);   // chunk q: pieces landed in LDS
             ILV<MI> ra[4]; ILV<NI> rb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -1082,10 +1102,15 @@ __device__ __forceinline__ void gemm16_dw_dma(const GemmP& p, float* red, int bx
                     for (int f = 0; f < NI; ++f)
                         acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[f], acc[e][f], 0, 0, 0);
             }
+            GM_STAMP_AFTER(acc[MI - 1][NI - 1][0]);
+            if (q < 8) GM_STAMP(st_slot, st_tile, 21 + 2 * q);   // chunk q: MFMAs retired
         }
     };
     if (special) run(std::true_type{}); else run(std::false_type{});
+    GM_STAMP(st_slot, st_tile, 9);
     dw_il_reduce<MI, NI>(p, red, acc, m0, n0, true);         // the ring shares `red`: everybody out of the loop first
+    GM_STAMP(st_slot, st_tile, 12);
+    GM_STAMP_EDGE(p, true, st_tile, MODE_DW + 20);
 }
 
 // LDS floats of the 16-wave kernels: the 64 KB block-by-block reduction buffer; for weight gradients of multi-block
@@ -1111,7 +1136,7 @@ template <int MODE, bool DMA, int MI, int NI> struct RedSize {
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool OF = false, int FOLD = 0, bool DMA = false,
           bool TP = false, bool PK = false, bool SL = true>
 __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, int by,
-                                            float* sds = nullptr, const FoldP* fold = nullptr) {
+                                            float* sds = nullptr, const FoldP* fold = nullptr, int gx = 0) {
     static_assert(!TP || (FOLD == 1 && !DMA), "two-phase losses: folded weight gradient, operands through registers");
     static_assert(FOLD == 0 || (FOLD == 1 && MODE == MODE_DW && XV) || (FOLD == 2 && MODE == MODE_DX && VEC),
                   "folded head: 16-byte operand paths only");
@@ -1121,7 +1146,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
     // DMA: the launch chose the LDS-DMA weight gradient (its own kernel instantiations: as a run-time branch inside the
     // shared kernels a second body cost the bs=256 step 1.5 us in registers and code it never runs)
     if constexpr (DMA && MODE == MODE_DW && XV && WAVES == 16 && FOLD != 2) {
-        gemm16_dw_dma<MI, NI, OF, FOLD, SL>(p, red, bx, by, sds, fold);
+        gemm16_dw_dma<MI, NI, OF, FOLD, SL>(p, red, bx, by, sds, fold, gx);
         return;
     }
     const int t = threadIdx.x;
@@ -1396,7 +1421,8 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
 template <int MODE, bool VEC, int WAVES, int G, bool XV, int MI, int NI, bool DMA = false, bool SL = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm16_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) float red[(WAVES == 16) ? RedSize<MODE, DMA, MI, NI>::value : WAVES * 32 * 32];
-    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI, false, 0, DMA, false, false, SL>(p, red, blockIdx.x, blockIdx.y);
+    gemm16_body<MODE, VEC, WAVES, G, XV, MI, NI, false, 0, DMA, false, false, SL>(p, red, blockIdx.x, blockIdx.y, nullptr, nullptr,
+                                                                                  (int)gridDim.x);
 }
 
 // The weight-gradient GEMM with the critic head's backward workgroups riding in the same grid:
@@ -1416,7 +1442,8 @@ __device__ __forceinline__ void gemm16_with_head(const GemmP& p, const HeadBwdP&
         if (bid < hblocks) head_bwd_body<TP>(hp, bid, sds);
         return;
     }
-    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP, PK, false>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold);
+    gemm16_body<MODE, VEC, 16, G, XV, MI, NI, OF, FOLD, DMA, TP, PK, false>(p, red, blockIdx.x, blockIdx.y - hrows, sds, &hp.fold,
+                                                                            (int)gridDim.x);
 }
 
 template <bool VEC, int G, bool XV, int MI, int NI, bool OF = false, bool FOLDED = false, bool DMA = false>

@@ -69,7 +69,7 @@ eng.run(k, it_start=32 * k, horizon=total)
 e1.record()
 torch.cuda.synchronize()
 raw, us_iter = buf.cpu().numpy().astype(np.uint64).reshape(SLOTS, SLOT_WORDS), e0.elapsed_time(e1) * 1e3 / k
-MODE = {0: "fwd", 1: "dx", 2: "dw", 10: "fwd (LDS tiles)", 11: "dx (LDS tiles)"}
+MODE = {0: "fwd", 1: "dx", 2: "dw", 10: "fwd (LDS tiles)", 11: "dx (LDS tiles)", 22: "dw (LDS-DMA chunks)"}
 launches = []
 for s in range(SLOTS):
     h = raw[s, :HDR]
@@ -126,7 +126,10 @@ for i, L in enumerate(launches):
     P("| stamp | " + " | ".join("w%d" % w for w in waves) + " |")
     P("|---|" + "---|" * len(waves))
     for j in ids:
-        nm = (("stage %d done (barrier passed)" % (j - 3)) if (lds and 3 <= j < 36) else (LDS_NAMES if lds else NAMES).get(j, str(j)))
+        if "DMA" in L["mode"] and 20 <= j < 36:
+            nm = "chunk %d %s" % ((j - 20) // 2, "pieces landed in LDS" if j % 2 == 0 else "MFMAs retired")
+        else:
+            nm = (("stage %d done (barrier passed)" % (j - 3)) if (lds and 3 <= j < 36) else (LDS_NAMES if lds else NAMES).get(j, str(j)))
         row = []
         for w in waves:
             if not st[w, j, 1]:
