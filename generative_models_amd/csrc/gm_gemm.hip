@@ -1351,6 +1351,11 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
         float4 ra[MI], rb[NI];
         float4 wk = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool have = nq > 0;
+        // folded weight gradient: this thread's row of partial dots is requested FIRST (gm_head.h fold_part_load)
+        float4 pv[4];
+        if constexpr (FOLD == 1 && !TP) {
+            if (t < fold->R) fold_part_load(*fold, t, pv);
+        }
         if (have) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) ra[mi] = load_a(w, mi);
@@ -1359,7 +1364,8 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p, float* red, int bx, 
             wk = load_wk(w);
         }
         GM_STAMP(st_slot, st_tile, 17);                       // first chunk's operand loads issued
-        fold_prologue();
+        if constexpr (FOLD == 1 && !TP) fold_fill_lds_pre(*fold, sds, fold->R, pv);
+        else fold_prologue();
         GM_STAMP(st_slot, st_tile, 13);                       // folded head: dS of every reduction row rebuilt in LDS
         if (have) consume(ra, rb, wk, 0);
         q_first = 1;

@@ -29,12 +29,17 @@ struct FoldP {
 // independent 16-byte loads, one memory round trip -- a loop of dependent-in-order scalar loads cost 13
 // serial trips to the fabric per row when the partials were fresh from another XCD (measured: the folded
 // step was 3 us SLOWER than the unfolded one until this changed).
-static __device__ __forceinline__ float fold_score(const FoldP& f, int r) {
+// (round 6: the loads and the arithmetic are separate functions -- the folded weight gradient requests its rows' partial
+// dots BEFORE its first operand loads: vector-memory results return in issue order, and behind 80 KB of operand
+// fragments per CU the partial dots landed ~1 us later than they had to)
+static __device__ __forceinline__ void fold_part_load(const FoldP& f, int r, float4 (&v)[4]) {
     const float4* q = reinterpret_cast<const float4*>(f.part + (int64_t)r * f.ldp);
     const int n4 = (f.nparts + 3) >> 2;
-    float4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = q[min(j, n4 - 1)];
+}
+static __device__ __forceinline__ float fold_score_of(const FoldP& f, const float4 (&v)[4]) {
+    const int n4 = (f.nparts + 3) >> 2;
     const float bias = f.snap[f.Hd];
     float a2 = 0.f;
 #pragma unroll
@@ -46,16 +51,29 @@ static __device__ __forceinline__ float fold_score(const FoldP& f, int r) {
     else if (f.out_act == GM_ACT_RELU) s = fmaxf(a2, 0.f);
     return s;
 }
+static __device__ __forceinline__ float fold_score(const FoldP& f, int r) {
+    float4 v[4];
+    fold_part_load(f, r, v);
+    return fold_score_of(f, v);
+}
 
+static __device__ __forceinline__ void fold_row_of(const FoldP& f, int r, float s_in, float& s, float& ds, float& l);
 static __device__ __forceinline__ void fold_row(const FoldP& f, int r, float& s, float& ds, float& l) {
-    s = fold_score(f, r);
+    fold_row_of(f, r, fold_score(f, r), s, ds, l);
+}
+static __device__ __forceinline__ void fold_row_of(const FoldP& f, int r, float s_in, float& s, float& ds, float& l) {
+    s = s_in;
     const bool D = !f.gen_mode;
     const bool is_x = D && r < f.B;
+    // (round 6: evaluating only the row's own branch -- one log and one division instead of two -- measured 0.4 us
+    // per step SLOWER than computing both on a dummy and selecting, same box, three alternations: 65.71 / 65.87 / 65.80
+    // against 65.40 / 65.34 / 65.46 us; the variant switch in front of it costs more than the arithmetic it saves)
     float lx, lg, dx, dg;
     sample_terms(f.variant, D, is_x ? s : 0.5f, is_x ? 0.5f : s, f.inv_b, f.hyper, lx, lg, dx, dg);
     l = is_x ? lx : lg;
+    const float dsel = is_x ? dx : dg;
     if (is_x && f.pen) l += f.hyper[7] * f.pen[r];
-    ds = act_grad(is_x ? dx : dg, s, f.out_act);
+    ds = act_grad(dsel, s, f.out_act);
 }
 
 // dH of four consecutive columns from h, the row's dS and the columns' w2
@@ -93,6 +111,23 @@ constexpr int HB_COLS = 16, HB_RG = 64;
 // the workgroup's LDS copy of dS for rows [0, R): every thread strides over the rows
 static __device__ __forceinline__ void fold_fill_lds(const FoldP& f, float* sds, int R) {
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float s, ds, l;
+        fold_row(f, r, s, ds, l);
+        sds[r] = ds;
+    }
+    __syncthreads();
+}
+// the same with this thread's FIRST row's partial dots already requested (fold_part_load(f, threadIdx.x, v) if
+// threadIdx.x < R): same arithmetic on the same values
+static __device__ __forceinline__ void fold_fill_lds_pre(const FoldP& f, float* sds, int R, const float4 (&v)[4]) {
+    int r = threadIdx.x;
+    if (r < R) {
+        float s, ds, l;
+        fold_row_of(f, r, fold_score_of(f, v), s, ds, l);
+        sds[r] = ds;
+        r += blockDim.x;
+    }
+    for (; r < R; r += blockDim.x) {
         float s, ds, l;
         fold_row(f, r, s, ds, l);
         sds[r] = ds;
