@@ -1075,6 +1075,10 @@ def main():
                        "gradient_exchange": comm_mode_of(eng),
                        "ranks": ranks_info,
                        "timing": "median of %d repetitions of the %d-step timed region" % (reps, K),
+                       # a short timed region is COLD-START-INCLUSIVE: every repetition starts with no draws ahead of it
+                       # (the host's first two iterations of draws, two graph hand-offs and the final synchronisation
+                       # sit inside it: run_fixed_cost_us); the steady step is steady_us_per_step
+                       "cold_start_inclusive": bool(K <= 200),
                        "reps_ms_per_step": [round(x / K * 1e3, 5) for x in secs],
                        "host_rng": "C replay (gm_host_replay)" if eng._replay_ok else "torch per-draw",
                        "host_threads": __import__("generative_models_amd").host_thread_plan(),
