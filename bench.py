@@ -392,7 +392,7 @@ def cpu_baseline_gan(variant="ns", B=B_PER_GPU, seconds_target=12.0, compute_onl
                          else "as-written incl. DataLoader reshuffle", dt) +
                       "; kind 'port' = the oracle's restatement, pinned bit for bit to the unmodified reference "
                       "(tests/test_oracle_pin.py), used where the reference is not mounted (the GPU box); the two timed "
-                      "side by side on one host: profiles/r05_cpu_reference_vs_port.json"}
+                      "side by side on one host: profiles/r06_cpu_reference_vs_port.json"}
 
 
 def cpu_baseline_reference(B=B_PER_GPU, seconds_target=12.0, cores=None):
