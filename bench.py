@@ -126,6 +126,10 @@ def gemm_variant(kind, M, K, N, extra=None):
         best = min(cands, key=lambda c: (cost(c), -c[0] * c[1]))
         ns = -(-Kr // 32)
         return "gemm_lds_kernel<%d, %s, %d>" % (mode, best[2], ns if Kr in (784, 400) else 0)
+    if kind in ("fwd", "fwdg") and Kr <= 32 and vec:
+        # forwards over a reduction of at most 32 (the generator's first layer): one wave per 16 x 32 piece, no cross-wave
+        # reduction.  Arguments: ring slot on the operand (the noise ring: true in the engines), gather riders
+        return "gemm16_k32_fwd_kernel<true, %s>" % ("true" if kind == "fwdg" else "false")
     nw = 16
     chunks = -(-Kr // 16)
     g = 1                                  # per-chunk load/consume schedule

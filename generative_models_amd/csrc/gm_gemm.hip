@@ -1501,6 +1501,118 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
     gemm16_body<MODE_FWD, VEC, 16, G, false, MI, NI>(p, red, blockIdx.x, blockIdx.y - grows);
 }
 
+// Forward GEMM whose reduction is at most 32 long (the generator's / the VAE decoder's first layer: K = z_dim = 20), round 6.
+// The 16-wave kernels give such a launch 16 waves per 32 x 32 tile of which two have a chunk; the other fourteen resolve
+// their arguments, zero accumulators, write zero partial tiles and sit in the barrier in front of a 16-image sum --
+// 2.1 us of workgroup residence for 0.4 us of loads and MFMAs (profiles/r06_ns_b256_wave_timeline.md, launch 0).  Here
+// a WAVE owns a 16 x 32 piece outright: both chunks' fragments requested up front (6 loads), 16 MFMAs, no LDS, no
+// barrier, the epilogue straight from the accumulators; 4 waves = a 32 x 64 workgroup tile.
+// Bit-identical to the 16-wave form: chunk c's four MFMAs start from a zero accumulator exactly as wave c's did, and
+// the two partial tiles are added in wave order onto 0.f (reduce_and_store: v = 0; v += image[w], the other fourteen
+// images being zeros); fragments and fix-ups are the same functions.  The batch gather's workgroups ride in rows
+// [0, grows) of the grid as in gemm16_fwd_gather_kernel (4 image rows per workgroup here).
+template <bool SL, bool GATHER>
+__global__ __launch_bounds__(256) void gemm16_k32_fwd_kernel(GemmP p, GatherP gp, int grows, int gblocks) {
+    if constexpr (GATHER) {
+        if ((int)blockIdx.y < grows) {                       // workgroup-uniform
+            const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+            if (bid < gblocks) gather_body(gp, bid);
+            return;
+        }
+    }
+    const int by = (int)blockIdx.y - (GATHER ? grows : 0), bx = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int m0 = 32 * by + 16 * (w >> 1), n0 = 64 * bx + 32 * (w & 1);
+#ifdef GM_STAMPS
+    const gm_stamps::Ctx st_slot = p.stamp; const int st_tile = by * (int)gridDim.x + bx;
+#endif
+    GM_STAMP_EDGE(p, false, st_tile, MODE_FWD);
+    GM_STAMP(st_slot, st_tile, 0);                            // entry
+    if (m0 >= p.M || n0 >= p.N) { GM_STAMP_EDGE(p, true, st_tile, MODE_FWD); return; }   // wave-uniform (no barrier in this kernel)
+    const float* A = slot_base<SL>(p.A, p.a_slot);
+    const float* B = slot_base<SL>(p.B, p.b_slot);
+    float4 ra[2], rb[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                            // (K <= 16: chunk 1 is clamped and fixed to zeros)
+        const int kb = 16 * c + 4 * g4;
+        ra[c] = raw_kc<true>(A, p.lda, m0 + i16, p.M, kb, p.K);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) rb[c][ni] = raw_kc<true>(B, p.ldb, n0 + 16 * ni + i16, p.N, kb, p.K);
+    }
+    f32x4 part[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int kb = 16 * c + 4 * g4;
+        const float4 fa = fix_kc(ra[c], m0 + i16, p.M, kb, p.K);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float4 fb = fix_kc(rb[c][ni], n0 + 16 * ni + i16, p.N, kb, p.K);
+            f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, c4, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, c4, 0, 0, 0);
+            part[c][ni] = c4;
+            if (c == 0 && ni == 0) { GM_STAMP_AFTER(fa.x); GM_STAMP_AFTER(fb.x); GM_STAMP(st_slot, st_tile, 1); }   // first operands in
+        }
+    }
+    GM_STAMP_AFTER(part[1][1][0]);
+    GM_STAMP(st_slot, st_tile, 2);                            // MFMAs retired
+    // store_element<MODE_FWD>'s arithmetic per element (bias, activation, the interpolation rider), with the
+    // kernel-argument-uniform branches outside the eight elements
+    float v[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = min(n0 + 16 * ni + i16, p.N - 1);
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = 0.f;
+            x += part[0][ni][r];
+            x += part[1][ni][r];
+            if (p.bias) x += bv;
+            v[ni][r] = x;
+        }
+    }
+    if (p.epi == GM_ACT_RELU) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[ni][r] = fmaxf(v[ni][r], 0.f);
+    } else if (p.epi == GM_ACT_SIGMOID) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[ni][r] = gm_sigmoid(v[ni][r]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + 16 * ni + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * g4 + r;
+            if (m < p.M && n < p.N) p.C[(int64_t)m * p.ldc + n] = v[ni][r];
+        }
+    }
+    if (p.ip_out) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + 16 * ni + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * g4 + r;
+                if (m < p.M && n < p.N && m < p.ip_rows) {
+                    const float ev = (p.ip_eps + gm_slot_offset(p.ip_slot))[m];
+                    p.ip_out[(int64_t)m * p.ip_ldo + n] = gm_interp_unfused(ev, p.ip_x[(int64_t)m * p.ip_ldx + n], v[ni][r]);
+                }
+            }
+        }
+    }
+    GM_STAMP(st_slot, st_tile, 12);                           // stores issued
+    GM_STAMP_EDGE(p, true, st_tile, MODE_FWD);
+}
+
 // Two weight-gradient GEMMs over the same batch rows (same reduction length, same tile shape) as
 // ONE launch: workgroups [0, na) are tiles of the first, the rest tiles of the second.  The
 // generator step's dW2 (784x401) and dW1 (400x21) are independent once dH is known.
@@ -1678,6 +1790,24 @@ int launch(hipStream_t s, const GemmP& p_in, bool vec, bool xvec = false, const 
                     hipLaunchKernelGGL(gather_rows_kernel, dim3(gm_gather_blocks(*rider.gather, 4)), dim3(256), 0, s, *rider.gather);
                 return launch_lds<MODE>(s, p, cfg);
             }
+        }
+    }
+    // forwards over a reduction of at most 32: one wave per 16 x 32 piece, no cross-wave reduction (gemm16_k32_fwd_kernel)
+    if constexpr (MODE == MODE_FWD) {
+        if (vec && p.K <= 32 && !head && !p.hd_part && !p.sq_part) {
+            const dim3 kgrid((p.N + 63) / 64, (p.M + 31) / 32);
+            if (rider.gather) {
+                const GatherP& gp = *rider.gather;
+                const int gblocks = gm_gather_blocks(gp, 4);
+                const int grows = (gblocks + (int)kgrid.x - 1) / (int)kgrid.x;
+                const dim3 ggrid(kgrid.x, kgrid.y + grows);
+                if (slots) hipLaunchKernelGGL((gemm16_k32_fwd_kernel<true, true>), ggrid, dim3(256), 0, s, p, gp, grows, gblocks);
+                else hipLaunchKernelGGL((gemm16_k32_fwd_kernel<false, true>), ggrid, dim3(256), 0, s, p, gp, grows, gblocks);
+            } else {
+                if (slots) hipLaunchKernelGGL((gemm16_k32_fwd_kernel<true, false>), kgrid, dim3(256), 0, s, p, GatherP{}, 0, 0);
+                else hipLaunchKernelGGL((gemm16_k32_fwd_kernel<false, false>), kgrid, dim3(256), 0, s, p, GatherP{}, 0, 0);
+            }
+            GM_LAUNCH_RET();
         }
     }
     const int tile = pick_tile<MODE>(p);

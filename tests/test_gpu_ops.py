@@ -493,6 +493,38 @@ def test_dw_adam_with_head_in_one_launch(B, I, Hd):
     assert a[1].abs().sum().item() > 0 and torch.isfinite(a[0]).all()
 
 
+@pytest.mark.parametrize("M,K,N", [(512, 20, 400), (256, 20, 400), (2048, 20, 400), (37, 20, 50), (100, 16, 400),
+                                   (336, 32, 404), (64, 4, 32), (1, 20, 400), (512, 28, 784)])
+@pytest.mark.parametrize("act", ["id", "relu", "sigmoid"])
+def test_short_reduction_forward_equals_the_16_wave_kernel_bit_for_bit(M, K, N, act):
+    """K <= 32 on 16-byte aligned operands runs gemm16_k32_fwd_kernel (one wave per 16 x 32 piece, no cross-wave
+    reduction); the same rows at a row stride that is not a multiple of 4 floats take the 16-wave split-reduction
+    kernel.  Same fragments, same MFMA chains per chunk, partial tiles added in wave order onto 0: the same bits
+    (also through a ring slot on the operand, and with the x_hat rider of WGAN-GP)."""
+    torch.manual_seed(M + 31 * K + N)
+    x, W, b = torch.randn(M, K), torch.randn(N, K) * 0.3, torch.randn(N) * 0.1
+    xa = x.to(DEV)
+    wide = torch.zeros(M, K + 1, device=DEV)
+    wide[:, :K] = xa
+    xu = wide[:, :K]                                             # ld = K + 1: not the 16-byte path
+    Wd, bd = W.to(DEV), b.to(DEV)
+    for bias in (bd, None):
+        y1, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        ops.linear_fwd(xa, Wd, bias, y1, act)
+        ops.linear_fwd(xu, Wd, bias, y2, act)
+        assert torch.equal(y1, y2)
+        ref = act_cpu(F.linear(x.double(), W.double(), b.double() if bias is not None else None), act)
+        assert (y1.cpu().double() - ref).abs().max().item() < 1e-4
+    # ring slot on the operand (the generator's noise ring): slot 2 of 3
+    ring = torch.randn(3, M, K, device=DEV)
+    ctr = torch.full((1,), 2, dtype=torch.int64, device=DEV)
+    slot = ops.slot(ctr.data_ptr(), 1, 0, 3, M * K)
+    y3, y4 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.linear_fwd(ring.view(-1, K), Wd, bd, y3, act, M=M, x_slot=slot)
+    ops.linear_fwd(ring[2].contiguous(), Wd, bd, y4, act)
+    assert torch.equal(y3, y4)
+
+
 @pytest.mark.parametrize("M,K,N,B,I", [(512, 20, 400, 256, 784), (256, 20, 400, 256, 784),
                                        (33, 13, 31, 7, 10), (64, 20, 400, 100, 36)])
 def test_linear_fwd_with_gather_riding(M, K, N, B, I):
