@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(1024) void gemm16_fwd_gather_kernel(GemmP p, Gather
 // Forward GEMM whose reduction is at most 32 long (the generator's / the VAE decoder's first layer: K = z_dim = 20), round 6.
 // The 16-wave kernels give such a launch 16 waves per 32 x 32 tile of which two have a chunk; the other fourteen resolve
 // their arguments, zero accumulators, write zero partial tiles and sit in the barrier in front of a 16-image sum --
-// 2.1 us of workgroup residence for 0.4 us of loads and MFMAs (profiles/r06_ns_b256_wave_timeline.md, launch 0).  Here
+// 2.1 us of workgroup residence for 0.4 us of loads and MFMAs (stamped; profiles/r06_experiments.md section 15).  Here
 // a WAVE owns a 16 x 32 piece outright: both chunks' fragments requested up front (6 loads), 16 MFMAs, no LDS, no
 // barrier, the epilogue straight from the accumulators; 4 waves = a 32 x 64 workgroup tile.
 // Bit-identical to the 16-wave form: chunk c's four MFMAs start from a zero accumulator exactly as wave c's did, and
